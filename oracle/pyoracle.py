@@ -1,0 +1,121 @@
+"""ORACLE loader (test infrastructure only): ctypes bindings of oracle/liboracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (unidom_amd) must never import anything from oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oc_cloth_create.restype = C.c_void_p
+        if hasattr(_LIB, "oc_mpm_create"):
+            _LIB.oc_mpm_create.restype = C.c_void_p
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _suf(dtype):
+    return "f32" if np.dtype(dtype) == np.float32 else "f64"
+
+
+def damp_factor(damping, dt, dtype):
+    """jnp.exp(-damping*dt): python-float product, evaluated in the array dtype (cloth_simulator.py:309)."""
+    if np.dtype(dtype) == np.float32:
+        return float(np.exp(np.float32(-damping * dt)))
+    return float(np.exp(-damping * dt))
+
+
+class ClothOracle:
+    """CPU restatement of ClothSimulator's robot_step rollout + adjoint (cloth_simulator.py:163-337)."""
+
+    def __init__(self, mask, N=80, gravity=0.5, damping=2, dt=2e-3, max_v=2.0, small_num=1e-8, substeps=50):
+        self.N, self.S = N, substeps
+        self.mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        L = lib()
+        self.h = C.c_void_p(L.oc_cloth_create(
+            C.c_int(N), _p(self.mask), C.c_double(gravity), C.c_double(dt),
+            C.c_double(damp_factor(damping, dt, np.float32)), C.c_double(damp_factor(damping, dt, np.float64)),
+            C.c_double(max_v), C.c_double(small_num), C.c_int(substeps)))
+        self.P = L.oc_cloth_num_particles(self.h)
+
+    def __del__(self):
+        try:
+            lib().oc_cloth_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        nbr = np.zeros((self.P, 8), np.int32)
+        L0 = np.zeros((self.P, 8), np.float32)
+        lib().oc_cloth_tables(self.h, _p(nbr), _p(L0))
+        return nbr, L0
+
+    def rollout_fwd(self, x0, v0, prim0, k, mu, actions, want_lists=False, want_grasp=False, want_ckpt=False,
+                    nthreads=1):
+        dt = x0.dtype
+        B, P = x0.shape[0], self.P
+        T = actions.shape[0]
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        x0, v0, prim0, k, mu, actions = map(c, (x0, v0, prim0, k, mu, actions))
+        assert x0.shape == (B, P, 3) and prim0.shape == (B, 2, 4) and actions.shape == (T, B, 8)
+        xo, vo, po = np.empty_like(x0), np.empty_like(v0), np.empty_like(prim0)
+        xl = np.empty((T, B, P, 3), dt) if want_lists else None
+        vl = np.empty((T, B, P, 3), dt) if want_lists else None
+        pl = np.empty((T, B, 2, 4), dt) if want_lists else None
+        gr = np.zeros((T, self.S, B, 2, P), np.uint8) if want_grasp else None
+        ck = np.empty((B, T, self.S, P * 6 + 8), dt) if want_ckpt else None
+        getattr(lib(), "oc_cloth_rollout_fwd_" + _suf(dt))(
+            self.h, C.c_int(B), C.c_int(T), _p(x0), _p(v0), _p(prim0), _p(k), _p(mu), _p(actions),
+            _p(xo), _p(vo), _p(po), _p(xl), _p(vl), _p(pl), _p(gr), _p(ck), C.c_int(nthreads))
+        out = dict(x=xo, v=vo, prim=po)
+        if want_lists:
+            out.update(x_list=xl, v_list=vl, prim_list=pl)
+        if want_grasp:
+            out["grasp"] = gr
+        if want_ckpt:
+            out["ckpt"] = ck
+        return out
+
+    def rollout_bwd(self, x0, v0, prim0, k, mu, actions, gx, gv, gprim, gx_list=None, gv_list=None,
+                    gprim_list=None, normalize=True, nthreads=1):
+        dt = x0.dtype
+        B, P = x0.shape[0], self.P
+        T = actions.shape[0]
+        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=dt)
+        x0, v0, prim0, k, mu, actions, gx, gv, gprim, gx_list, gv_list, gprim_list = map(
+            c, (x0, v0, prim0, k, mu, actions, gx, gv, gprim, gx_list, gv_list, gprim_list))
+        gx0, gv0, gp0 = np.empty_like(x0), np.empty_like(v0), np.empty_like(prim0)
+        ga = np.empty((T, B, 8), dt)
+        gk, gmu = np.empty((B,), dt), np.empty((B,), dt)
+        getattr(lib(), "oc_cloth_rollout_bwd_" + _suf(dt))(
+            self.h, C.c_int(B), C.c_int(T), _p(x0), _p(v0), _p(prim0), _p(k), _p(mu), _p(actions),
+            _p(gx), _p(gv), _p(gprim), _p(gx_list), _p(gv_list), _p(gprim_list), C.c_int(int(normalize)),
+            _p(gx0), _p(gv0), _p(gp0), _p(ga), _p(gk), _p(gmu), C.c_int(nthreads))
+        return dict(gx=gx0, gv=gv0, gprim=gp0, gactions=ga, gk=gk, gmu=gmu)
