@@ -1,0 +1,95 @@
+/*
+ * unidom_hip.h -- C ABI of libunidom_hip.so: MI355X (gfx950) kernels for the differentiable-physics
+ * hot path of Kuroki1931/UniDOM (the substep that APG training drives through env.step_diff).
+ *
+ * The reference has no FFI for this path: it sits behind a Python/JAX functional API
+ *     simulator.step_jax(state, action) -> (state, state)
+ * consumed by lax.scan in step_diff and differentiated by jax.grad.  Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference/DaXBench/daxbench/).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (HBM) unless marked "host"; float32, C-contiguous, AoS at the
+ *     boundary ([B,P,3] etc., the reference's own layouts); the library transposes to SoA internally.
+ *   - purely functional like the reference (NamedTuple._replace): inputs are never written, the caller owns
+ *     every state / gradient / checkpoint buffer; a handle owns only constant tables.
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside.
+ *   - return value: 0 = ok, negative = ud_status; ud_last_error() gives the text (thread-local).
+ *   - a handle is bound to the device current at create time; not thread-safe per handle.
+ */
+#ifndef UNIDOM_HIP_H
+#define UNIDOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  UD_OK = 0,
+  UD_ERR_INVALID = -1,      /* bad argument (null pointer, size out of range) */
+  UD_ERR_UNSUPPORTED = -2,  /* configuration the kernels do not cover (stated in the message) */
+  UD_ERR_HIP = -3,          /* a HIP runtime call failed (no device, launch error, ...) */
+  UD_ERR_OVERFLOW = -4      /* a device-side capacity (MPM LDS cell table) was exceeded */
+} ud_status;
+
+const char* ud_last_error(void);
+/* 3-part version + the gfx arch the code object was built for, e.g. "0.1.0 gfx950" */
+const char* ud_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cloth (mass-spring) -- replaces ClothSimulator.step_jax = vmap(jit(robot_step_wrapper))
+ *   core/engine/cloth_simulator.py:26-70 (tables), :163-180 (robot_step), :257-337 (step),
+ *   :198-226 (gripper), :182-196 (norm_grad), :228-255 (what is differentiated)
+ * driven by lax.scan over the 40 macro actions of one step_diff (core/envs/basic/cloth_env.py:211).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ud_cloth ud_cloth;
+
+typedef struct {
+  int N;           /* lattice size (80)                    fold_cloth1_env.py:17 */
+  float gravity;   /* 0.5                                  :19 */
+  float damping;   /* 2                                    :21 */
+  float dt;        /* 2e-3                                 :22 */
+  float max_v;     /* 2.0                                  :23 */
+  float small_num; /* 1e-8                                 :24 */
+  int substeps;    /* 50 = fori_loop bound                 cloth_simulator.py:176 */
+} ud_cloth_conf;
+
+/* mask: host pointer, N*N bytes, row-major, non-zero = cloth particle (create_cloth_mask,
+ * fold_cloth1_env.py:48-53).  Particle order = row-major nonzero(mask) (cloth_simulator.py:52).
+ * Limits: 1 <= P <= 1024; the mask must not touch the lattice border (UD_ERR_UNSUPPORTED otherwise). */
+int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** out);
+void ud_cloth_destroy(ud_cloth* h);
+int ud_cloth_num_particles(const ud_cloth* h);
+/* bytes of the per-substep checkpoint arena a forward rollout of T macro steps x B envs writes */
+size_t ud_cloth_ckpt_bytes(const ud_cloth* h, int B, int T);
+
+/* Forward: T macro steps (robot_step) of `substeps` substeps each, for B independent envs.
+ *   x, v [B,P,3]; prim [B,2,4] = (primitive0, primitive1) = (pos xyz, radius); stiffness, mu [B];
+ *   actions [T,B,8] (the scan xs: get_pnp_actions output, cloth_env.py:134-173).
+ * Outputs: final x_out, v_out [B,P,3], prim_out [B,2,4]; optional per-macro-step state_list
+ *   x_list, v_list [T,B,P,3], prim_list [T,B,2,4] (the scan ys, may be NULL);
+ *   ckpt (may be NULL = no backward): ud_cloth_ckpt_bytes() bytes, opaque, consumed by ud_cloth_rollout_bwd;
+ *   grasp (may be NULL, debug/tests): [T,substeps,B,2,P] bytes, 1 where the gripper mask was true (Q3). */
+int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float* v, const float* prim,
+                         const float* stiffness, const float* mu, const float* actions, float* x_out,
+                         float* v_out, float* prim_out, float* x_list, float* v_list, float* prim_list,
+                         void* ckpt, uint8_t* grasp, void* stream);
+
+/* Backward: the adjoint jax.grad produces through robot_step_wrapper / step_wrapper
+ * (cloth_simulator.py:107-145, :228-255) including the per-substep norm_grad rescaling (:189-194) when
+ * normalize != 0.  g_x, g_v [B,P,3], g_prim [B,2,4]: cotangents of the final state;
+ * g_*_list (may be NULL): cotangents of the scan ys.  Outputs: cotangents of the initial state,
+ * of actions [T,B,8] and the contributions to stiffness / mu [B] (the identity pass-through of those two
+ * state fields is the caller's to add). */
+int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const float* stiffness, const float* mu,
+                         const float* actions, const float* g_x, const float* g_v, const float* g_prim,
+                         const float* g_x_list, const float* g_v_list, const float* g_prim_list, int normalize,
+                         float* g_x0, float* g_v0, float* g_prim0, float* g_actions, float* g_stiffness,
+                         float* g_mu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIDOM_HIP_H */

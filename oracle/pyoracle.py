@@ -48,7 +48,8 @@ def _suf(dtype):
 def damp_factor(damping, dt, dtype):
     """jnp.exp(-damping*dt): python-float product, evaluated in the array dtype (cloth_simulator.py:309)."""
     if np.dtype(dtype) == np.float32:
-        return float(np.exp(np.float32(-damping * dt)))
+        # correctly rounded f32 exp of the f32 argument (numpy's own f32 exp is 1 ulp off here)
+        return float(np.float32(np.exp(np.float64(np.float32(-damping * dt)))))
     return float(np.exp(-damping * dt))
 
 

@@ -185,7 +185,7 @@ class ClothTwin:
 
         v = v + force * c.dt                                                                       # :308
         v = v * math.exp(-c.damping * c.dt) if self.dtype == torch.float64 else \
-            v * float(np.exp(np.float32(-c.damping * c.dt)))                                       # :309
+            v * float(np.float32(np.exp(np.float64(np.float32(-c.damping * c.dt)))))                                       # :309
         # :312 collision_func is the identity (cloth_env.py:239-243)
         x, v, m0 = self.gripper(x, v, st.action0, st.primitive0)                                   # :313
         x, v, m1 = self.gripper(x, v, st.action1, st.primitive1)                                   # :314

@@ -1,0 +1,126 @@
+"""GPU parity: HIP cloth rollout (through the C ABI, via ClothSimulator) vs the CPU oracle.
+
+Forward: bit-exact (same f32 operation order, correctly rounded div/sqrt, no FMA contraction) and the
+set of grasped particles per substep identical.  Backward: tolerance (reduction orders
+differ), the tolerance is written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import fold_cloth1_mask, make_cloth_case
+
+pytestmark = pytest.mark.gpu
+
+
+class Conf:  # fold_cloth1_env.py:15-33
+    N = 80
+    gravity = 0.5
+    stiffness = 900
+    damping = 2
+    dt = 2e-3
+    max_v = 2.0
+    small_num = 1e-8
+    mu = 0.5
+    seed = 1
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    return ClothSimulator(Conf(), 4, lambda x, v, i, j: v, fold_cloth1_mask())
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle.pyoracle import ClothOracle
+    return ClothOracle(fold_cloth1_mask())
+
+
+def _run_hip(sim, x, v, prim, k, mu, actions, g=None, want_lists=True, normalize=True):
+    from unidom_amd.engine.cloth_simulator import _Rollout
+    dev = sim.device
+    t = lambda a, rg=False: torch.tensor(a, device=dev, requires_grad=rg)
+    rg = g is not None
+    X, V, PR, K, MU, A = t(x, rg), t(v, rg), t(prim, rg), t(k, rg), t(mu, rg), t(actions, rg)
+    sim.record_grasp = True
+    sim.normalize_grad = normalize
+    out = _Rollout.apply(sim, X, V, PR, K, MU, A, want_lists)
+    res = dict(x=out[0].detach().cpu().numpy(), v=out[1].detach().cpu().numpy(), prim=out[2].detach().cpu().numpy(),
+               grasp=sim.last_grasp.cpu().numpy())
+    if want_lists:
+        res.update(x_list=out[3].detach().cpu().numpy(), v_list=out[4].detach().cpu().numpy(),
+                   prim_list=out[5].detach().cpu().numpy())
+    if rg:
+        loss = (out[0] * t(g["gx"])).sum() + (out[1] * t(g["gv"])).sum() + (out[2] * t(g["gprim"])).sum()
+        if "gx_list" in g:
+            loss = loss + (out[3] * t(g["gx_list"])).sum() + (out[4] * t(g["gv_list"])).sum() + (out[5] * t(g["gprim_list"])).sum()
+        loss.backward()
+        res.update(gx=X.grad.cpu().numpy(), gv=V.grad.cpu().numpy(), gprim=PR.grad.cpu().numpy(),
+                   gk=K.grad.cpu().numpy(), gmu=MU.grad.cpu().numpy(), gactions=A.grad.cpu().numpy())
+    sim.record_grasp = False
+    sim.normalize_grad = True
+    return res
+
+
+@pytest.mark.parametrize("B,T,seed", [(1, 1, 0), (3, 2, 1), (4, 5, 2)])
+def test_fwd_bit_exact_short(sim, oracle, B, T, seed):
+    rng = np.random.default_rng(seed)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    o = oracle.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    h = _run_hip(sim, x, v, prim, k, mu, actions)
+    assert o["grasp"].sum() > 0, "test case must exercise the grasp"
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+
+
+def test_fwd_bit_exact_full_step_diff(sim, oracle):
+    """fold_cloth1 size: 40 macro steps x 50 substeps = 2000 substeps, B=4 (BASELINE config 2)."""
+    rng = np.random.default_rng(7)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, 4, 40, deform=0.0005, v_scale=0.01)
+    actions *= 0.2
+    o = oracle.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True, nthreads=4)
+    h = _run_hip(sim, x, v, prim, k, mu, actions)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    assert np.isfinite(h["x"]).all()
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("B,T,seed", [(1, 1, 0), (3, 2, 1)])
+def test_bwd_matches_oracle_short(sim, oracle, B, T, seed, normalize):
+    rng = np.random.default_rng(100 + seed)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    P = x.shape[1]
+    g = dict(gx=rng.normal(size=(B, P, 3)).astype(np.float32), gv=rng.normal(size=(B, P, 3)).astype(np.float32),
+             gprim=rng.normal(size=(B, 2, 4)).astype(np.float32),
+             gx_list=rng.normal(size=(T, B, P, 3)).astype(np.float32), gv_list=rng.normal(size=(T, B, P, 3)).astype(np.float32),
+             gprim_list=rng.normal(size=(T, B, 2, 4)).astype(np.float32))
+    o = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"],
+                           g["gprim_list"], normalize=normalize)
+    h = _run_hip(sim, x, v, prim, k, mu, actions, g=g, normalize=normalize)
+    # f32 adjoint, different reduction orders -> 2e-4 relative (max-norm) on every output
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert _rel(h[key], o[key]) < 2e-4, (key, _rel(h[key], o[key]))
+
+
+def test_bwd_matches_oracle_full_step_diff(sim, oracle):
+    rng = np.random.default_rng(11)
+    B, T = 2, 40
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T, deform=0.0005, v_scale=0.01)
+    actions *= 0.2
+    P = x.shape[1]
+    g = dict(gx=rng.normal(size=(B, P, 3)).astype(np.float32), gv=rng.normal(size=(B, P, 3)).astype(np.float32),
+             gprim=rng.normal(size=(B, 2, 4)).astype(np.float32))
+    o = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], normalize=True, nthreads=2)
+    h = _run_hip(sim, x, v, prim, k, mu, actions, g=g, want_lists=False)
+    # 2000 normalised reverse substeps in f32: 1e-3 relative (max-norm)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert np.isfinite(h[key]).all(), key
+        assert _rel(h[key], o[key]) < 1e-3, (key, _rel(h[key], o[key]))

@@ -1,0 +1,74 @@
+"""ctypes binding of libunidom_hip.so (the C ABI declared in include/unidom_hip.h).
+
+The HIP library IS the product path: there is no CPU or eager-PyTorch fallback. If the shared object is
+missing or a call fails, an exception is raised (UnidomError) -- nothing silently routes elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libunidom_hip.so")
+
+# every symbol include/unidom_hip.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "ud_last_error", "ud_version",
+    "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes",
+    "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
+]
+
+
+class UnidomError(RuntimeError):
+    pass
+
+
+class ud_cloth_conf(C.Structure):
+    _fields_ = [("N", C.c_int), ("gravity", C.c_float), ("damping", C.c_float), ("dt", C.c_float),
+                ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libunidom_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "unidom_hip.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "libunidom_hip.so"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise UnidomError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C {CSRC}`). There is no fallback path.")
+        L = C.CDLL(SO_PATH)
+        L.ud_last_error.restype = C.c_char_p
+        L.ud_version.restype = C.c_char_p
+        L.ud_cloth_ckpt_bytes.restype = C.c_size_t
+        for name in SYMBOLS:
+            if not hasattr(L, name):
+                raise UnidomError(f"{SO_PATH} does not export {name}")
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise UnidomError(f"{what} failed (status {rc}): {lib().ud_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/uint8 CUDA(HIP) tensor, or NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "libunidom_hip takes contiguous device tensors"
+    return C.c_void_p(t.data_ptr())

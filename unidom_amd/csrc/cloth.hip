@@ -1,0 +1,613 @@
+// Mass-spring cloth rollout for gfx950: one workgroup per environment, one particle per lane.
+//
+// What it replaces (reference, /root/reference/DaXBench/daxbench/core/engine/cloth_simulator.py):
+//   forward  = lax.scan over macro actions of robot_step (:163-180) = fori_loop(50) of step (:257-337)
+//   backward = jax.grad through robot_step_wrapper / step_wrapper (:107-145, :228-255) with the live
+//              norm_grad rescaling (:182-196).  The reference rematerialises (3 forwards + 1 adjoint per
+//              substep at mem_saving_level 2); here the forward writes one (x,v,primitives) checkpoint per
+//              substep into HBM (6*Ppad+8 floats, SoA) and the backward streams them back in reverse, so
+//              fwd+bwd costs one forward and one adjoint.
+//
+// Mapping: the whole T x substeps rollout of one env runs inside ONE launch.  x lives double-buffered in LDS
+// (2 x 3 x Ppad floats) for the 8-neighbour stencil, v / cotangents / link tables live in registers, there
+// is one s_barrier per forward substep.  The kernel is latency/occupancy bound:
+// at num_envs=4 only 4 of 256 CUs have work.
+//
+// Forward arithmetic keeps the reference's operation order and is compiled with -ffp-contract=off and
+// correctly rounded f32 divide/sqrt, so it is bit-identical to the CPU restatement (the grasp test
+// |x - pos| <= radius is a discrete event).
+#include "common.h"
+
+namespace ud {
+
+struct ClothConst {
+  float gdt;      // float(gravity*dt)        :259
+  float g;        // gravity                  :278
+  float dt;
+  float damp;     // exp(-damping*dt) in f32  :309
+  float max_v;
+  float eps;      // small_num
+  float n_mask;   // cloth_mask.sum()         :192
+  int P, Pp, S;
+};
+
+struct ClothFwdArgs {
+  ClothConst c;
+  const int* nbr;      // [8][Pp]
+  const float* L0;     // [8][Pp]
+  int B, T;
+  const float *x, *v, *prim, *k, *mu, *actions;
+  float *x_out, *v_out, *prim_out, *x_list, *v_list, *prim_list;
+  float* ckpt;
+  uint8_t* grasp;
+};
+
+struct ClothBwdArgs {
+  ClothConst c;
+  const int* nbr;
+  const float* L0;
+  int B, T;
+  const float* ckpt;
+  const float *k, *mu, *actions;
+  const float *g_x, *g_v, *g_prim, *g_x_list, *g_v_list, *g_prim_list;
+  int normalize;
+  float *g_x0, *g_v0, *g_prim0, *g_actions, *g_k, *g_mu;
+};
+
+// per-particle intermediates of one forward substep that the adjoint needs
+struct Inter {
+  float F1, cF, muF, xV, yV, sV, dm, Ax, Az, sF, zm, nz, R;
+  float v3[3], v4[3], x2[3], v5[3];
+  bool m0, m1;
+};
+
+__device__ __forceinline__ void macro_action(const float* a8, float* act) {  // :168-169
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    act[g * 4 + 3] = a8[g * 4 + 3];
+  }
+}
+
+// One forward substep for particle `i` (own x,v in registers, neighbours' x in LDS plane X).
+// Same operation order as oracle/csrc/cloth_oracle.hpp::cloth_substep_fwd (= the reference's).
+template <bool KEEP>
+__device__ __forceinline__ void substep_fwd(const ClothConst& c, int i, const int* nb, const float* L0,
+                                            const float* X, float k, float mu, const float* x, const float* v,
+                                            const float* ps, const float* act, float* xo, float* vo, Inter* in) {
+  const int Pp = c.Pp;
+  const float INF = INFINITY;
+  float v1[3] = {v[0], v[1] - c.gdt, v[2]};
+  float F[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const int j = nb[l];
+    const bool ok = j >= 0;
+    const int jj = ok ? j : i;
+    float r0 = X[jj] - x[0], r1 = X[Pp + jj] - x[1], r2 = X[2 * Pp + jj] - x[2];
+    float s = r0 * r0 + r1 * r1 + r2 * r2;
+    float len = sqrtf(clipf(s, 1e-12f, INF));
+    float L = L0[l];
+    float f0 = k * r0 / len * (len - L) / L;
+    float f1 = k * r1 / len * (len - L) / L;
+    float f2 = k * r2 / len * (len - L) / L;
+    F[0] += ok ? f0 : 0.f;
+    F[1] += ok ? f1 : 0.f;
+    F[2] += ok ? f2 : 0.f;
+  }
+  F[1] += -c.g;
+  const bool fm = x[1] <= c.eps;
+  float cF = clipf(F[1], -INF, 0.f);
+  float muF = mu * cF * -1.0f;
+  float xV = v1[0], yV = v1[2];
+  float sV = sqrtf(xV * xV + yV * yV + c.eps);
+  float dm = (fm && sV > c.eps) ? 1.f : 0.f;
+  float Ax = F[0] - dm * muF * xV / sV;
+  float Az = F[2] - dm * muF * yV / sV;
+  const bool st = fm && (sV <= c.eps);
+  float sF = sqrtf(Ax * Ax + Az * Az + c.eps);
+  float zm = (st && muF > sF) ? 1.f : 0.f;
+  float Bx = 0.f + (1.f - zm) * Ax, Bz = 0.f + (1.f - zm) * Az;
+  float nz = (st && muF <= sF) ? 1.f : 0.f;
+  float R = 1.f - muF / sF;
+  float Cx = (R * Ax) * nz + Bx * (1.f - nz);
+  float Cz = (R * Az) * nz + Bz * (1.f - nz);
+  float Ff[3] = {Cx, F[1], Cz};
+  float vv[3], xx[3] = {x[0], x[1], x[2]};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) vv[a] = (v1[a] + Ff[a] * c.dt) * c.damp;
+  if (KEEP) {
+    in->F1 = F[1]; in->cF = cF; in->muF = muF; in->xV = xV; in->yV = yV; in->sV = sV; in->dm = dm;
+    in->Ax = Ax; in->Az = Az; in->sF = sF; in->zm = zm; in->nz = nz; in->R = R;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) in->v3[a] = vv[a];
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float* p = ps + g * 4;
+    const float* ac = act + g * 4;
+    float d0 = xx[0] - p[0], d1 = xx[1] - p[1], d2 = xx[2] - p[2];
+    float dist = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const bool m = dist <= p[3];
+    const float suction = ac[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float vs = suction * vv[a];
+      float xs = xx[a] + ac[a] * (1.f - suction);
+      vv[a] = m ? vs : vv[a];
+      xx[a] = m ? xs : xx[a];
+    }
+    if (KEEP) {
+      if (g == 0) { in->m0 = m;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) in->v4[a] = vv[a];
+      } else { in->m1 = m; }
+    } else {
+      if (g == 0) in->m0 = m; else in->m1 = m;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (KEEP) { in->x2[a] = xx[a]; in->v5[a] = vv[a]; }
+    float xc = clipf(xx[a], 0.f, 1.f);
+    float vc = clipf(vv[a], -c.max_v, c.max_v);
+    xo[a] = xc + c.dt * vc;
+    vo[a] = vc;
+  }
+}
+
+__device__ __forceinline__ void prim_update(const float* ps, const float* act, float* po) {  // :322-323
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) po[g * 4 + a] = clipf(ps[g * 4 + a] + (a < 3 ? act[g * 4 + a] : 0.f), 0.f, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) cloth_rollout_fwd_kernel(ClothFwdArgs a) {
+  extern __shared__ float lds[];  // [2][3][Pp]
+  const ClothConst c = a.c;
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const bool live = i < P;
+  int nb[8];
+  float L0[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = a.x[((size_t)b * P + i) * 3 + d]; v[d] = a.v[((size_t)b * P + i) * 3 + d]; }
+  }
+  float ps[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  const size_t rec = (size_t)6 * Pp + 8;
+  unsigned step = 0;
+  for (int t = 0; t < T; ++t) {
+    float act[8];
+    macro_action(a.actions + ((size_t)t * B + b) * 8, act);
+    for (int s = 0; s < S; ++s, ++step) {
+      float* X = lds + (step & 1u) * 3 * Pp;
+      X[i] = x[0]; X[Pp + i] = x[1]; X[2 * Pp + i] = x[2];
+      if (a.ckpt) {
+        float* r = a.ckpt + (((size_t)b * T + t) * S + s) * rec;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+        if (i == 0) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+        }
+      }
+      __syncthreads();
+      float xo[3], vo[3], po[8];
+      Inter in;
+      substep_fwd<false>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
+      if (a.grasp && live) {
+        uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
+        g[i] = in.m0; g[P + i] = in.m1;
+      }
+      prim_update(ps, act, po);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = xo[d]; v[d] = vo[d]; }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ps[d] = po[d];
+    }
+    if (live) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.x_list) { a.x_list[o] = x[0]; a.x_list[o + 1] = x[1]; a.x_list[o + 2] = x[2]; }
+      if (a.v_list) { a.v_list[o] = v[0]; a.v_list[o + 1] = v[1]; a.v_list[o + 2] = v[2]; }
+    }
+    if (a.prim_list && i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) a.prim_list[((size_t)t * B + b) * 8 + d] = ps[d];
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.x_out[o + d] = x[d]; a.v_out[o + d] = v[d]; }
+  }
+  if (i == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.prim_out[b * 8 + d] = ps[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// block-wide sums of two values; red points at a private [2*16] LDS slot for this round
+__device__ __forceinline__ void block_sum2(float& s0, float& s1, float* red, int nw) {
+  float a = wave_sum(s0), b = wave_sum(s1);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+  __syncthreads();
+  float t0 = 0.f, t1 = 0.f;
+  for (int q = 0; q < nw; ++q) { t0 += red[2 * q]; t1 += red[2 * q + 1]; }
+  s0 = t0; s1 = t1;
+}
+
+__device__ __forceinline__ void norm3(float* g, float nrm2, float n_mask) {  // :189-194
+  float nrm = sqrtf(nrm2);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) g[a] = nan_to_num(g[a] / nrm) / n_mask;
+}
+
+__device__ __forceinline__ void norm4(float* g, float n_mask) {
+  float nrm = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3]);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) g[a] = nan_to_num(g[a] / nrm) / n_mask;
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a) {
+  extern __shared__ float lds[];  // X [3][Pp] | G [3][Pp] | red [6][32]
+  const ClothConst c = a.c;
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const int nw = Pp >> 6;
+  const bool live = i < P;
+  const bool norm = a.normalize != 0;
+  float* X = lds;
+  float* G = lds + 3 * Pp;
+  float* red = lds + 6 * Pp;
+  int nb[8];
+  float L0[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = a.g_x[((size_t)b * P + i) * 3 + d]; gv[d] = a.g_v[((size_t)b * P + i) * 3 + d]; }
+  }
+  float gp[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) gp[d] = a.g_prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  float gk = 0.f, gmu = 0.f;
+  const size_t rec = (size_t)6 * Pp + 8;
+  const float* ck = a.ckpt + (size_t)b * T * S * rec;
+  // prefetch the last record
+  float nx[3], nv[3], nps[8];
+  {
+    const float* r = ck + ((size_t)T * S - 1) * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+  }
+  unsigned step = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    if (live) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.g_x_list) { gx[0] += a.g_x_list[o]; gx[1] += a.g_x_list[o + 1]; gx[2] += a.g_x_list[o + 2]; }
+      if (a.g_v_list) { gv[0] += a.g_v_list[o]; gv[1] += a.g_v_list[o + 1]; gv[2] += a.g_v_list[o + 2]; }
+    }
+    if (a.g_prim_list) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) gp[d] += a.g_prim_list[((size_t)t * B + b) * 8 + d];
+    }
+    const float* a8 = a.actions + ((size_t)t * B + b) * 8;
+    float act[8], ga[8];
+    macro_action(a8, act);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ga[d] = 0.f;
+    for (int s = S - 1; s >= 0; --s, ++step) {
+      float x[3], v[3], ps[8];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = nx[d]; v[d] = nv[d]; }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ps[d] = nps[d];
+      {  // prefetch the previous substep's record (the next one this loop consumes)
+        const long q = (long)t * S + s - 1;
+        const float* r = ck + (size_t)(q < 0 ? 0 : q) * rec;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+      }
+      float* rd = red + (step & 1u) * 96;
+      // -- stage x for the stencil; (G of the previous substep has been consumed before its last barrier)
+      X[i] = x[0]; X[Pp + i] = x[1]; X[2 * Pp + i] = x[2];
+      // -- reduction round 1: |g_x|, |g_v| (:331-332) -- its barrier also publishes X
+      float n0 = gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2];
+      float n1 = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2];
+      block_sum2(n0, n1, rd, nw);
+      if (norm) {
+        norm3(gx, n0, c.n_mask);
+        norm3(gv, n1, c.n_mask);
+        norm4(gp, c.n_mask);      // :333-334
+        norm4(gp + 4, c.n_mask);
+      }
+      float xo[3], vo[3];
+      Inter in;
+      substep_fwd<true>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
+      // x_out = clip(x2) + dt*clip(v5)   (:326-329)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float gxc = gx[d];
+        float gvc = gv[d] + c.dt * gx[d];
+        gx[d] = gxc * clip_grad(in.x2[d], 0.f, 1.f);
+        gv[d] = gvc * clip_grad(in.v5[d], -c.max_v, c.max_v);
+      }
+      // primitives (:322-323); uniform across lanes, counted once (lane 0) in the action accumulators
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          float add = d < 3 ? act[g * 4 + d] : 0.f;
+          float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
+          gp[g * 4 + d] = tt;
+          if (d < 3) ga[g * 4 + d] += (i == 0) ? tt : 0.f;
+        }
+      // grippers in reverse order (:313-314, :198-226)
+#pragma unroll
+      for (int g = 1; g >= 0; --g) {
+        n0 = gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2];
+        n1 = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2];
+        block_sum2(n0, n1, rd + 32 * (2 - g), nw);
+        if (norm) { norm3(gx, n0, c.n_mask); norm3(gv, n1, c.n_mask); }  // :223-224
+        const bool m = (g ? in.m1 : in.m0) && live;
+        const float* vin = g ? in.v4 : in.v3;
+        const float suction = act[g * 4 + 3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          float gvo = gv[d], gxo = gx[d];
+          ga[g * 4 + 3] += m ? (vin[d] * gvo - gxo * act[g * 4 + d]) : 0.f;
+          ga[g * 4 + d] += m ? gxo * (1.f - suction) : 0.f;
+          gv[d] = m ? suction * gvo : gvo;
+        }
+      }
+      // v3 = (v1 + F*dt)*damp (:308-309); friction block (:281-306)
+      float gF[3];
+      {
+        float gv2[3], gFf[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { gv2[d] = gv[d] * c.damp; gFf[d] = gv2[d] * c.dt; }
+        float gCx = gFf[0], gCz = gFf[2];
+        float gBx = gCx * (1.f - in.nz), gBz = gCz * (1.f - in.nz);
+        float gR = gCx * in.nz * in.Ax + gCz * in.nz * in.Az;
+        float gAx = gCx * in.nz * in.R + gBx * (1.f - in.zm);
+        float gAz = gCz * in.nz * in.R + gBz * (1.f - in.zm);
+        float gmuF = -gR / in.sF;
+        float gsF = gR * in.muF / (in.sF * in.sF);
+        gAx += gsF * in.Ax / in.sF;
+        gAz += gsF * in.Az / in.sF;
+        gmuF += -(gAx * in.dm * in.xV / in.sV + gAz * in.dm * in.yV / in.sV);
+        float gxV = -gAx * in.dm * in.muF / in.sV, gyV = -gAz * in.dm * in.muF / in.sV;
+        float gsV = (gAx * in.dm * in.muF * in.xV + gAz * in.dm * in.muF * in.yV) / (in.sV * in.sV);
+        gxV += gsV * in.xV / in.sV;
+        gyV += gsV * in.yV / in.sV;
+        gmu += live ? -gmuF * in.cF : 0.f;
+        float gcF = -gmuF * mu;
+        gF[0] = gAx;
+        gF[1] = gFf[1] + gcF * clip_grad(in.F1, -INFINITY, 0.f);
+        gF[2] = gAz;
+        gv[0] = gv2[0] + gxV;
+        gv[1] = gv2[1];
+        gv[2] = gv2[2] + gyV;
+        if (!live) { gF[0] = gF[1] = gF[2] = 0.f; }
+      }
+      // spring forces (:262-277), gather form: g_x_i += sum_l J_il (gF_j - gF_i)
+      G[i] = gF[0]; G[Pp + i] = gF[1]; G[2 * Pp + i] = gF[2];
+      __syncthreads();
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const int j = nb[l];
+        const bool ok = j >= 0;
+        const int jj = ok ? j : i;
+        float r0 = X[jj] - x[0], r1 = X[Pp + jj] - x[1], r2 = X[2 * Pp + jj] - x[2];
+        float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+        float cf = clip_grad(s2, 1e-12f, INFINITY);
+        float len = sqrtf(clipf(s2, 1e-12f, INFINITY));
+        float L = L0[l];
+        float d0 = G[jj] - gF[0], d1 = G[Pp + jj] - gF[1], d2 = G[2 * Pp + jj] - gF[2];
+        float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
+        float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
+        float c1 = (k / L) * (1.f - L / len);
+        float c2 = (k / L) * cf * L / (len * len * len) * rd_;
+        gk += ok ? rg / len * (len - L) / L : 0.f;
+        gx[0] += ok ? c1 * d0 + c2 * r0 : 0.f;
+        gx[1] += ok ? c1 * d1 + c2 * r1 : 0.f;
+        gx[2] += ok ? c1 * d2 + c2 * r2 : 0.f;
+      }
+      // the next substep overwrites X before its first barrier and G after it; a trailing barrier keeps
+      // slow lanes' stencil reads of X/G ahead of those writes
+      __syncthreads();
+    }
+    // macro-step boundary: robot_step's action transform (:168-169)
+    {
+      float* rd = red + 192;
+      float part[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) part[d] = wave_sum(ga[d]);
+      const int lane = i & 63, w = i >> 6;
+      if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) rd[w * 8 + d] = part[d];
+      }
+      __syncthreads();
+      if (i < 8) {
+        float tot = 0.f;
+        for (int q = 0; q < nw; ++q) tot += rd[q * 8 + i];
+        const int d = i & 3;
+        float out = (d < 3) ? tot / 50.0f * clip_grad(a8[i], -2.0f, 2.0f) : tot;
+        a.g_actions[((size_t)t * B + b) * 8 + i] = out;
+      }
+      __syncthreads();
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.g_x0[o + d] = gx[d]; a.g_v0[o + d] = gv[d]; }
+  }
+  float rk = gk, rmu = gmu;
+  block_sum2(rk, rmu, red + 192, nw);
+  if (i == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.g_prim0[b * 8 + d] = gp[d];
+    a.g_k[b] = rk;
+    a.g_mu[b] = rmu;
+  }
+}
+
+}  // namespace ud
+
+// ------------------------------------------------------------------------------------------------
+// host side: handle + C ABI
+// ------------------------------------------------------------------------------------------------
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+struct ud_cloth {
+  ud::ClothConst c;
+  int device = 0;
+  int* d_nbr = nullptr;
+  float* d_L0 = nullptr;
+};
+
+extern "C" {
+
+int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** out) {
+  if (!conf || !mask || !out) { ud::set_error("ud_cloth_create: null argument"); return UD_ERR_INVALID; }
+  const int N = conf->N;
+  if (N < 3 || conf->substeps < 1) { ud::set_error("ud_cloth_create: bad N/substeps"); return UD_ERR_INVALID; }
+  static const int links[8][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};  // :48
+  std::vector<int> pid((size_t)N * N, -1), gi, gj;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j)
+      if (mask[i * N + j]) {
+        if (i == 0 || j == 0 || i == N - 1 || j == N - 1) {
+          ud::set_error("ud_cloth_create: cloth mask touches the lattice border (clipped links, cloth_simulator.py:58) -- unsupported");
+          return UD_ERR_UNSUPPORTED;
+        }
+        pid[i * N + j] = (int)gi.size(); gi.push_back(i); gj.push_back(j);
+      }
+  const int P = (int)gi.size();
+  if (P < 1 || P > 1024) { ud::set_error("ud_cloth_create: P=%d outside 1..1024 (one workgroup per env)", P); return UD_ERR_UNSUPPORTED; }
+  const int Pp = (P + 63) / 64 * 64;
+  std::vector<int> nbr((size_t)8 * Pp, -1);
+  std::vector<float> L0((size_t)8 * Pp, 1.0f);
+  for (int p = 0; p < P; ++p)
+    for (int l = 0; l < 8; ++l) {
+      const int ji = gi[p] + links[l][0], jj = gj[p] + links[l][1];
+      const int di = links[l][0], dj = links[l][1];
+      const float ol = (float)(1.0 / N) * sqrtf((float)(di * di + dj * dj));  // :61 (f32)
+      L0[(size_t)l * Pp + p] = fmaxf(ol, 1e-12f);                               // :63
+      nbr[(size_t)l * Pp + p] = mask[ji * N + jj] ? pid[ji * N + jj] : -1;      // :276
+    }
+  auto* h = new ud_cloth;
+  h->c.gdt = (float)((double)conf->gravity * (double)conf->dt);
+  h->c.g = conf->gravity;
+  h->c.dt = conf->dt;
+  h->c.damp = expf(-(float)((double)conf->damping * (double)conf->dt));
+  h->c.max_v = conf->max_v;
+  h->c.eps = conf->small_num;
+  h->c.n_mask = (float)P;
+  h->c.P = P; h->c.Pp = Pp; h->c.S = conf->substeps;
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_nbr, nbr.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_L0, L0.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_L0, L0.data(), L0.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ud::set_error("ud_cloth_create: %s", hipGetErrorString(e));
+    if (h->d_nbr) (void)hipFree(h->d_nbr);
+    if (h->d_L0) (void)hipFree(h->d_L0);
+    delete h;
+    return UD_ERR_HIP;
+  }
+  *out = h;
+  return UD_OK;
+}
+
+void ud_cloth_destroy(ud_cloth* h) {
+  if (!h) return;
+  (void)hipFree(h->d_nbr);
+  (void)hipFree(h->d_L0);
+  delete h;
+}
+
+int ud_cloth_num_particles(const ud_cloth* h) { return h ? h->c.P : UD_ERR_INVALID; }
+
+size_t ud_cloth_ckpt_bytes(const ud_cloth* h, int B, int T) {
+  if (!h || B < 0 || T < 0) return 0;
+  return (size_t)B * T * h->c.S * ((size_t)6 * h->c.Pp + 8) * sizeof(float);
+}
+
+int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float* v, const float* prim,
+                         const float* stiffness, const float* mu, const float* actions, float* x_out,
+                         float* v_out, float* prim_out, float* x_list, float* v_list, float* prim_list,
+                         void* ckpt, uint8_t* grasp, void* stream) {
+  if (!h || !x || !v || !prim || !stiffness || !mu || !actions || !x_out || !v_out || !prim_out) {
+    ud::set_error("ud_cloth_rollout_fwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1 || T < 1) { ud::set_error("ud_cloth_rollout_fwd: B=%d T=%d", B, T); return UD_ERR_INVALID; }
+  ud::ClothFwdArgs a;
+  a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
+  a.x = x; a.v = v; a.prim = prim; a.k = stiffness; a.mu = mu; a.actions = actions;
+  a.x_out = x_out; a.v_out = v_out; a.prim_out = prim_out; a.x_list = x_list; a.v_list = v_list;
+  a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
+  const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
+  if (h->c.Pp <= 512)
+    hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<1024>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const float* stiffness, const float* mu,
+                         const float* actions, const float* g_x, const float* g_v, const float* g_prim,
+                         const float* g_x_list, const float* g_v_list, const float* g_prim_list, int normalize,
+                         float* g_x0, float* g_v0, float* g_prim0, float* g_actions, float* g_stiffness,
+                         float* g_mu, void* stream) {
+  if (!h || !ckpt || !stiffness || !mu || !actions || !g_x || !g_v || !g_prim || !g_x0 || !g_v0 || !g_prim0 ||
+      !g_actions || !g_stiffness || !g_mu) {
+    ud::set_error("ud_cloth_rollout_bwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1 || T < 1) { ud::set_error("ud_cloth_rollout_bwd: B=%d T=%d", B, T); return UD_ERR_INVALID; }
+  ud::ClothBwdArgs a;
+  a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
+  a.ckpt = (const float*)ckpt; a.k = stiffness; a.mu = mu; a.actions = actions;
+  a.g_x = g_x; a.g_v = g_v; a.g_prim = g_prim; a.g_x_list = g_x_list; a.g_v_list = g_v_list;
+  a.g_prim_list = g_prim_list; a.normalize = normalize;
+  a.g_x0 = g_x0; a.g_v0 = g_v0; a.g_prim0 = g_prim0; a.g_actions = g_actions; a.g_k = g_stiffness; a.g_mu = g_mu;
+  const size_t shmem = ((size_t)6 * h->c.Pp + 192 + 128) * sizeof(float);
+  if (h->c.Pp <= 512)
+    hipLaunchKernelGGL(ud::cloth_rollout_bwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(ud::cloth_rollout_bwd_kernel<1024>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+}  // extern "C"
