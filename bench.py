@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+Metric (BASELINE.json): differentiable-physics substeps/sec, forward + backward, on `fold_cloth1` with
+num_envs=4 per GPU, ep_len=3 (the reference's `apg_no_para --env fold_cloth1 --ep_len 3 --num_envs 4` iteration;
+fold_cloth1 is the mass-spring cloth simulator).  One "step" = one full APG update:
+policy forward, 3 x env.step_diff (each 40 macro actions x 50 substeps inside ONE kernel launch), loss,
+backward through everything (the adjoint kernel streams the per-substep checkpoints back), gradient
+nan_to_num + clip, the RCCL all-reduce of the flat policy gradient when N > 1, and the Adam step.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Weak scaling: every rank owns 4 envs; `value` is the whole-job aggregate.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NUM_ENVS_PER_GPU = 4
+EP_LEN = 3
+MACRO, SUBSTEPS, P = 40, 50, 512
+# algorithmic bytes per env-substep (recompute passes not counted)
+BYTES_FWD = 48 * P     # read x,v + write x,v
+BYTES_BWD = 72 * P     # read saved x,v + read g_x,g_v + write g_x,g_v
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
+    """Oracle (CPU restatement, NOT JAX-CPU) timed on the host cores: fwd + adjoint of the same workload.
+    The oracle is only the thing timed/compared here, never the product path."""
+    from oracle.pyoracle import ClothOracle
+    from tests.conftest import fold_cloth1_mask, make_cloth_case
+    orc = ClothOracle(fold_cloth1_mask())
+    rng = np.random.default_rng(0)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, sample_envs, MACRO, deform=0.0005, v_scale=0.01)
+    actions *= 0.2
+    g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
+    threads = min(sample_envs, os.cpu_count() or 1)
+    t0 = time.time()
+    for _ in range(ep_len):
+        orc.rollout_fwd(x, v, prim, k, mu, actions, nthreads=threads)
+    t_f = time.time() - t0
+    t0 = time.time()
+    for _ in range(ep_len):
+        orc.rollout_bwd(x, v, prim, k, mu, actions, g[0], g[1], g[2], normalize=True, nthreads=threads)
+    t_b = time.time() - t0
+    n = sample_envs * ep_len * MACRO * SUBSTEPS
+    return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
+            "sample": f"CPU restatement (C++ -O2, f32, reference op order; not JAX-CPU): {sample_envs} envs x "
+                      f"{ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint (with its "
+                      f"own state recompute) {t_b:.2f}s, OpenMP over envs ({threads} threads; substeps are sequential)",
+            "fwd_only_value": n / t_f}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from unidom_amd.algorithms.apg.core import APG, init_distributed
+    from unidom_amd.envs.registration import env_functions
+    from unidom_amd.utils import prng
+
+    rank, world, device = init_distributed(args.gpus)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, seed=0, aux_reward=True, device=device)
+    learner = APG(env, EP_LEN, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
+    key_env = prng.split(prng.PRNGKey(0), world)[rank]
+    _, state = env.reset(key_env)
+    env.simulator.profile = None
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        learner.minimize(state)
+    env.simulator.profile = {"fwd": [], "bwd": []}   # HIP events around every kernel launch, on its stream
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        learner.minimize(state)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = env.simulator.profile
+    env.simulator.profile = None
+
+    # forward-only rate (BASELINE config 2), untimed region of the main metric
+    with torch.no_grad():
+        sync()
+        tf0 = time.perf_counter()
+        for _ in range(args.steps):
+            learner.evaluate(state, EP_LEN)
+        sync()
+        dt_fwd = time.perf_counter() - tf0
+
+    t_max = torch.tensor([dt, dt_fwd], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt, dt_fwd = float(t_max[0]), float(t_max[1])
+
+    if rank == 0:
+        units = world * NUM_ENVS_PER_GPU * EP_LEN * MACRO * SUBSTEPS * args.steps
+        k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
+        dom = max(k_ms, key=k_ms.get)
+        per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
+        achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tj):
+            traffic = json.load(open(tj)).get("cloth_rollout_%s_kernel" % dom, {}).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "fold_cloth1 (mass-spring cloth, P=512) APG loss+grad+update: num_envs=4 per GPU, "
+                                   "ep_len=3, 40 macro x 50 substeps per step_diff",
+                       "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
+                       "parallelism": f"env-sharded dp{world}, 1 RCCL all-reduce of {learner.n_params} f32 per update"},
+            "fwd_only_substeps_per_sec": units / dt_fwd,
+            "roofline": {"bound": "hbm", "kernel": f"cloth_rollout_{dom}_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
+                         "note": "latency/occupancy bound: 4 envs = 4 workgroups on 256 CUs, 2000 sequential substeps"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

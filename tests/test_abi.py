@@ -1,0 +1,49 @@
+"""CPU: the C-ABI library loads and exports every symbol include/unidom_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "unidom_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ud_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from unidom_amd import _lib
+    so = _lib.build()
+    L = ctypes.CDLL(so)
+    declared = _header_symbols()
+    assert declared, "no symbols parsed from the header"
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, f"declared in include/unidom_hip.h but not exported: {missing}"
+    assert sorted(_lib.SYMBOLS) == declared, (sorted(_lib.SYMBOLS), declared)
+    L.ud_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.ud_version()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under unidom_amd/ may reference it."""
+    bad = []
+    for dp, _, fns in os.walk(os.path.join(ROOT, "unidom_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+\"[^\"]*oracle", txt, flags=re.M):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from unidom_amd import _lib
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    try:
+        _lib.lib()
+    except _lib.UnidomError as e:
+        assert "no fallback" in str(e).lower()
+    else:
+        raise AssertionError("expected UnidomError")

@@ -1,0 +1,144 @@
+"""`python -m unidom_amd.algorithms.apg.apg --env fold_cloth1 ...` -- same flags and update rule as the
+reference entry point /root/reference/DaXBench/daxbench/algorithms/apg/apg.py:384-443 (train(): :39-350).
+
+Differences that are host-side only: logging goes to stdout + a JSON-lines file under --logdir (tensorboardX,
+wandb, imageio and pyrender are not part of the hot path), parameters are saved with torch.save, and multi-GPU
+runs are launched one process per GPU (torch.distributed.run) instead of jax.pmap.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from ...envs.basic.cloth_env import ClothEnv
+from ...envs.registration import env_functions
+from ...utils import prng
+from .core import APG, init_distributed
+
+
+def build_parser(para: bool):
+    p = argparse.ArgumentParser()
+    p.add_argument("--env", default="fold_cloth1", help="name of the environment (default: %(default)s)")
+    p.add_argument("--ep_len", default=10, type=int, help="length of each episode (default: %(default)s)")
+    p.add_argument("--num_envs", default=4, type=int, help="number of environments used in training (default: %(default)s)")
+    p.add_argument("--lr", default=1e-4, type=float, help="learning rate (default: %(default)s)")
+    p.add_argument("--max_it", default=2000, type=int, help="maximum number of iterations (default: %(default)s)")
+    p.add_argument("--max_grad_norm", default=0.3, type=float, help="maximum norm to perform gradient clip (default: %(default)s)")
+    p.add_argument("--seed", default=1, type=int, help="random seed (default: %(default)s)")
+    p.add_argument("--gpus", default=1, type=int, help="number of GPUs (default: %(default)s)")
+    p.add_argument("--eval_freq", default=20, type=int, help="number of iterations for each evaluation (default: %(default)s)")
+    p.add_argument("--logdir", default=None, help="where logs / parameters go (default: ./logs/apg/<env>/...)")
+    if para:  # apg_para.py:540-563
+        p.add_argument("--train_min_stiff", default=200, type=float)
+        p.add_argument("--train_max_stiff", default=1800, type=float)
+        p.add_argument("--eval_min_stiff", default=100, type=float)
+        p.add_argument("--eval_max_stiff", default=2000, type=float)
+    return p
+
+
+def _with_stiffness(state, value):
+    return state._replace(stiffness=torch.full_like(state.stiffness, value, dtype=torch.float32))
+
+
+def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_eval_envs: int = 20):
+    rank, world, device = init_distributed(args.gpus)
+    xt = time.time()
+    tag = "apg_para" if para_obs else "apg"
+    logdir = args.logdir or (f"./logs/{tag}/{args.env}/{args.env}_ep_len{args.ep_len}_num_envs{args.num_envs}"
+                             f"_lr{args.lr}_max_it{args.max_it}_max_grad_norm{args.max_grad_norm}/seed{args.seed}")
+    if rank == 0:
+        os.makedirs(logdir, exist_ok=True)
+    log = open(os.path.join(logdir, "log.jsonl"), "a") if rank == 0 else None
+
+    # seeds (apg.py:75-80)
+    key = prng.PRNGKey(args.seed)
+    key, key_models, key_env = prng.split(key, 3)
+    key_eval = prng.PRNGKey(args.seed + 666)
+
+    env_kwargs = dict(batch_size=args.num_envs // world, seed=args.seed, aux_reward=True, device=device)
+    eval_kwargs = dict(batch_size=num_eval_envs, seed=args.seed + 666, device=device)
+    if para_obs:
+        mm = [args.eval_min_stiff, args.eval_max_stiff]
+        env_kwargs["eval_min_max_stiff"] = mm
+        eval_kwargs["eval_min_max_stiff"] = mm
+    environment_fn = env_functions[args.env]
+    core_env = environment_fn(**env_kwargs)
+    eval_env = environment_fn(**eval_kwargs) if rank == 0 else None
+    is_cloth = isinstance(core_env, ClothEnv)
+
+    learner = APG(core_env, args.ep_len, learning_rate=args.lr, max_gradient_norm=args.max_grad_norm, seed=args.seed)
+    evaluator = None
+    if rank == 0:
+        evaluator = APG(eval_env, args.ep_len, seed=args.seed + 666)
+        evaluator.policy = learner.policy
+
+    _, first_state = core_env.reset(key_env)
+    _, eval_first_state = eval_env.reset(key_eval) if rank == 0 else (None, None)
+
+    for it in range(args.max_it + 1):
+        stiff = None
+        if randomize_stiffness:                                   # apg_para.py:324-329
+            np.random.seed(it)
+            stiff = np.random.uniform(args.train_min_stiff, args.train_max_stiff)
+        if is_cloth:
+            # key_env is never advanced on the cloth branch (apg.py:297-300): same initial state every iteration;
+            # every device draws its own shift from split(key_env, devices)[rank]
+            key_envs = prng.split(key_env, world)
+            _, train_first_state = core_env.reset(key_envs[rank])
+        else:
+            key_env = prng.split(key_env, 1)[0]                   # apg.py:302-307
+            key_envs = prng.split(key_env, args.num_envs).reshape(world, args.num_envs // world, 2)
+            train_first_state = core_env.auto_reset(first_state, first_state, key_envs[rank])
+        if stiff is not None:
+            train_first_state = _with_stiffness(train_first_state, stiff)
+
+        # the reference re-creates optax.adam(actor_lr) every iteration, but jit keeps the optimizer captured at
+        # the first trace, so the effective learning rate stays args.lr ("Hidden facts")
+        actor_lr = (1e-5 - args.lr) * float(it / max(args.max_it, 1)) + args.lr
+        if rank == 0:
+            print("actor_lr: ", actor_lr)
+
+        test = {}
+        if rank == 0 and it % args.eval_freq == 0:
+            if randomize_stiffness:                               # apg_para.py:376-404
+                for test_step in range(10):
+                    np.random.seed((it * test_step) + test_step)
+                    es = np.random.uniform(args.eval_min_stiff, args.eval_max_stiff)
+                    r = evaluator.evaluate(_with_stiffness(eval_first_state, es), eval_env.max_steps)
+                    test[f"eval_env_stiffness_{test_step}"] = float(es)
+                    test[f"test_reward_{test_step}"] = float(r.sum(0).mean())
+            else:
+                r = evaluator.evaluate(eval_first_state, eval_env.max_steps)
+                test["test_reward"] = float(r.sum(0).mean())
+                test["last_reward"] = float(r[-1].mean())
+            print(f"[it {it}] Test reward {test}")
+            torch.save(learner.policy.state_dict(), os.path.join(logdir, f"apg_{args.env}_{it}.pt"))
+
+        t = time.time()
+        metrics = learner.minimize(train_first_state)
+        train_reward = float(metrics["reward"].sum(0).mean())     # host sync, like block_until_ready (apg.py:337)
+        dt_it = time.time() - t
+        if rank == 0:
+            rec = {"iter": it, "train_reward": train_reward, "grad_norm": float(metrics["grad_norm"]),
+                   "sps": args.ep_len * args.num_envs / dt_it, "wall": time.time() - xt}
+            if stiff is not None:
+                rec["core_env_stiffness"] = float(stiff)
+            rec.update(test)
+            print(f"[it {it}] Training reward {train_reward:.5f} grad_norm {rec['grad_norm']:.4g} ({dt_it * 1e3:.1f} ms)")
+            log.write(json.dumps(rec) + "\n")
+            log.flush()
+    return learner
+
+
+def main(argv=None):
+    args = build_parser(para=False).parse_args(argv)
+    return train(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -62,10 +62,12 @@ class _Rollout(torch.autograd.Function):
             ckpt = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
         grasp = torch.zeros((T, sim.substeps, B, 2, P), dtype=torch.uint8, device=dev) if sim.record_grasp else None
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ev = sim._prof_begin("fwd")
         _lib.check(L.ud_cloth_rollout_fwd(
             sim._h, C.c_int(B), C.c_int(T), _lib.ptr(x), _lib.ptr(v), _lib.ptr(prim), _lib.ptr(stiffness),
             _lib.ptr(mu), _lib.ptr(actions), _lib.ptr(xo), _lib.ptr(vo), _lib.ptr(po), _lib.ptr(xl),
             _lib.ptr(vl), _lib.ptr(pl), _lib.ptr(ckpt), _lib.ptr(grasp), stream), "ud_cloth_rollout_fwd")
+        sim._prof_end(ev)
         sim.last_grasp = grasp
         ctx.sim, ctx.B, ctx.T, ctx.want_lists = sim, B, T, want_lists
         ctx.save_for_backward(ckpt, stiffness, mu, actions)
@@ -89,11 +91,13 @@ class _Rollout(torch.autograd.Function):
         ga = torch.empty((T, B, 8), device=dev)
         gk, gmu = torch.empty((B,), device=dev), torch.empty((B,), device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ev = sim._prof_begin("bwd")
         _lib.check(L.ud_cloth_rollout_bwd(
             sim._h, C.c_int(B), C.c_int(T), _lib.ptr(ckpt), _lib.ptr(stiffness), _lib.ptr(mu), _lib.ptr(actions),
             _lib.ptr(gx), _lib.ptr(gv), _lib.ptr(gp), _lib.ptr(gxl), _lib.ptr(gvl), _lib.ptr(gpl),
             C.c_int(1 if sim.normalize_grad else 0), _lib.ptr(gx0), _lib.ptr(gv0), _lib.ptr(gp0), _lib.ptr(ga),
             _lib.ptr(gk), _lib.ptr(gmu), stream), "ud_cloth_rollout_bwd")
+        sim._prof_end(ev)
         return None, gx0, gv0, gp0, gk, gmu, ga, None
 
 
@@ -122,6 +126,7 @@ class ClothSimulator:
         self.normalize_grad = True           # live norm_grad, :182-196
         self.record_grasp = False            # tests: capture the gripper masks (Q3)
         self.last_grasp = None
+        self.profile = None                  # bench.py: {"fwd": [...], "bwd": [...]} lists of (start, end) events
 
         self.num_triangles = (self.N - 1) * (self.N - 1) * 2
         idx_i, idx_j = np.nonzero(self.cloth_mask)            # :52 (row-major)
@@ -158,6 +163,18 @@ class ClothSimulator:
                     sq.append((a, b_, c))
                     sq.append((d, c, b_))
         self.indices = np.asarray(sq, dtype=np.float32).reshape(-1, 3)
+
+    def _prof_begin(self, kind):
+        if self.profile is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(self.device))   # same stream the kernel is launched on
+        return (kind, a, b)
+
+    def _prof_end(self, ev):
+        if ev is not None:
+            ev[2].record(torch.cuda.current_stream(self.device))
+            self.profile[ev[0]].append((ev[1], ev[2]))
 
     # -- state helpers -------------------------------------------------------------------------------
     def reset_jax(self) -> ClothState:  # :339-364

@@ -60,3 +60,29 @@ def split_first(key: np.ndarray, times: int = 1) -> np.ndarray:
     for _ in range(times):
         key = split(key, 2)[..., 0, :]
     return key
+
+
+def random_bits(key: np.ndarray, n: int) -> np.ndarray:
+    """threefry_random_bits for 32-bit words: hash iota(n) (padded to even), halves as x0/x1 lanes."""
+    key = np.asarray(key, dtype=np.uint32)
+    m = n + (n % 2)
+    cnt = np.arange(m, dtype=np.uint32)
+    y0, y1 = threefry2x32(key, cnt[: m // 2], cnt[m // 2:])
+    return np.concatenate([y0, y1])[:n]
+
+
+def uniform(key: np.ndarray, n: int, minval=0.0, maxval=1.0) -> np.ndarray:
+    """jax.random.uniform (f32): mantissa bits -> [1,2) - 1, scaled; recalled semantics, NOT pinned by data."""
+    bits = random_bits(key, n)
+    f = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+    lo, hi = np.float32(minval), np.float32(maxval)
+    return np.maximum(lo, f * (hi - lo) + lo).astype(np.float32)
+
+
+def normal(key: np.ndarray, n: int) -> np.ndarray:
+    """jax.random.normal (f32) = sqrt(2) * erfinv(uniform(-1+ulp, 1)).  erfinv is evaluated in f64 here
+    (XLA uses an f32 polynomial), so values agree with JAX to f32 round-off, not bit for bit."""
+    from scipy.special import erfinv
+    lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
+    u = uniform(key, n, lo, 1.0)
+    return (np.float32(np.sqrt(2)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
