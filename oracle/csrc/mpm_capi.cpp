@@ -1,0 +1,185 @@
+// ORACLE -- test infrastructure only. C ABI over mpm_oracle.hpp for ctypes (tests/, smoke(), bench cpu_baseline).
+// `step` structure follows mpm_simulator.py:413-429 (norm_grad_state / norm_grad :375-411, set_action
+// primitives.py:212-229, fori_loop of substep, copy_frame :365-373).
+#include <omp.h>
+
+#include "mpm_oracle.hpp"
+
+using namespace oracle;
+
+struct OcMpm {
+  MpmParams<float> pf;
+  MpmParams<double> pd;
+};
+template <class T> static const MpmParams<T>& P(const OcMpm* h);
+template <> const MpmParams<float>& P<float>(const OcMpm* h) { return h->pf; }
+template <> const MpmParams<double>& P<double>(const OcMpm* h) { return h->pd; }
+
+template <class T>
+static void fill_params(MpmParams<T>& p, int N, int n_grid, const int* res, int steps, double dt, double p_mass,
+                        double p_vol, const double* gravity, int position_control, const int* material, const double* hard) {
+  p.N = N; p.n_grid = n_grid; p.steps = steps;
+  for (int d = 0; d < 3; ++d) p.res[d] = res[d];
+  const double dx = 1.0 / n_grid;
+  p.dt = (T)dt; p.dx = (T)dx; p.inv_dx = (T)(double)n_grid; p.p_mass = (T)p_mass; p.p_vol = (T)p_vol;
+  p.stress_c = (T)(-dt * p_vol * 4);
+  p.dx2 = (T)(dx * dx);
+  for (int d = 0; d < 3; ++d) p.dtg[d] = (T)dt * (T)gravity[d];
+  p.position_control = position_control;
+  p.material.assign(material, material + N);
+  p.h.resize(N);
+  for (int i = 0; i < N; ++i) p.h[i] = (T)hard[i];
+}
+
+template <class T>
+struct StepIO {
+  const T *x, *v, *C, *F, *J, *ppos, *prot, *psize, *friction, *mu, *lamda, *action;
+};
+
+template <class T>
+static void load_state(const MpmParams<T>& pr, const StepIO<T>& io, int b, MpmState<T>& st, T a_clipped[6]) {
+  const int N = pr.N, S = pr.steps;
+  st.alloc(N, S);
+  for (int i = 0; i < N * 3; ++i) { st.x[i] = nan_to_num(io.x[(size_t)b * N * 3 + i]); st.v[i] = nan_to_num(io.v[(size_t)b * N * 3 + i]); }
+  for (int i = 0; i < N * 9; ++i) { st.C[i] = nan_to_num(io.C[(size_t)b * N * 9 + i]); st.F[i] = nan_to_num(io.F[(size_t)b * N * 9 + i]); }
+  for (int i = 0; i < N; ++i) st.J[i] = nan_to_num(io.J[(size_t)b * N + i]);
+  for (int i = 0; i < S * 3; ++i) st.ppos[i] = io.ppos[(size_t)b * S * 3 + i];
+  for (int i = 0; i < S * 4; ++i) st.prot[i] = io.prot[(size_t)b * S * 4 + i];
+  for (int a = 0; a < 3; ++a) st.psize[a] = io.psize[b * 3 + a];
+  st.friction = io.friction[b]; st.mu = io.mu[b]; st.lamda = io.lamda[b];
+  for (int c = 0; c < 6; ++c) a_clipped[c] = clipf(io.action[b * 6 + c], T(-1), T(1));  // :419
+  for (int j = 0; j < S; ++j)                                                            // set_velocity
+    for (int c = 0; c < 3; ++c) { st.pv[j * 3 + c] = a_clipped[c] * T(1) / (T)S; st.pw[j * 3 + c] = a_clipped[3 + c] * T(1) / (T)S; }
+}
+
+template <class T>
+static void copy_frame(const MpmParams<T>& pr, MpmState<T>& st) {  // copy_frame(steps, 0): source index clamps (Q5)
+  const int src = pr.steps - 1;
+  for (int a = 0; a < 3; ++a) st.ppos[a] = st.ppos[src * 3 + a];
+  for (int a = 0; a < 4; ++a) st.prot[a] = st.prot[src * 4 + a];
+}
+
+template <class T>
+static void step_fwd(const OcMpm* h, int B, StepIO<T> io, T* xo, T* vo, T* Co, T* Fo, T* Jo, T* ppos_o, T* prot_o,
+                     T* pv_o, T* pw_o, int nthreads) {
+  const auto& pr = P<T>(h);
+  const int N = pr.N, S = pr.steps;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int b = 0; b < B; ++b) {
+    MpmState<T> a, c;
+    T ac[6];
+    load_state(pr, io, b, a, ac);
+    std::vector<T> gm, gv;
+    for (int f = 0; f < S; ++f) { mpm_substep_fwd(pr, f, a, c, gm, gv); std::swap(a, c); }
+    copy_frame(pr, a);
+    std::memcpy(xo + (size_t)b * N * 3, a.x.data(), sizeof(T) * N * 3);
+    std::memcpy(vo + (size_t)b * N * 3, a.v.data(), sizeof(T) * N * 3);
+    std::memcpy(Co + (size_t)b * N * 9, a.C.data(), sizeof(T) * N * 9);
+    std::memcpy(Fo + (size_t)b * N * 9, a.F.data(), sizeof(T) * N * 9);
+    std::memcpy(Jo + (size_t)b * N, a.J.data(), sizeof(T) * N);
+    std::memcpy(ppos_o + (size_t)b * S * 3, a.ppos.data(), sizeof(T) * S * 3);
+    std::memcpy(prot_o + (size_t)b * S * 4, a.prot.data(), sizeof(T) * S * 4);
+    if (pv_o) std::memcpy(pv_o + (size_t)b * S * 3, a.pv.data(), sizeof(T) * S * 3);
+    if (pw_o) std::memcpy(pw_o + (size_t)b * S * 3, a.pw.data(), sizeof(T) * S * 3);
+  }
+}
+
+template <class T>
+static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* gv, const T* gC, const T* gF,
+                     const T* gppos, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0, T* gfric, T* gmu, T* glam,
+                     T* gaction, int nthreads) {
+  const auto& pr = P<T>(h);
+  const int N = pr.N, S = pr.steps;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int b = 0; b < B; ++b) {
+    std::vector<MpmState<T>> states(S + 1);
+    T ac[6];
+    load_state(pr, io, b, states[0], ac);
+    std::vector<T> gm, gvv;
+    for (int f = 0; f < S; ++f) mpm_substep_fwd(pr, f, states[f], states[f + 1], gm, gvv);
+    MpmGrad<T> g;
+    g.alloc(N, S);
+    for (int i = 0; i < N * 3; ++i) { g.x[i] = gx[(size_t)b * N * 3 + i]; g.v[i] = gv[(size_t)b * N * 3 + i]; }
+    for (int i = 0; i < N * 9; ++i) { g.C[i] = gC[(size_t)b * N * 9 + i]; g.F[i] = gF[(size_t)b * N * 9 + i]; }
+    for (int i = 0; i < S * 3; ++i) g.ppos[i] = gppos[(size_t)b * S * 3 + i];
+    // copy_frame adjoint: position[0] <- position[steps-1]
+    if (S - 1 != 0) for (int a = 0; a < 3; ++a) { g.ppos[(S - 1) * 3 + a] += g.ppos[a]; g.ppos[a] = 0; }
+    for (int f = S - 1; f >= 0; --f) mpm_substep_bwd(pr, f, states[f], g);
+    // set_action adjoint (primitives.py:212-229); action_scale = 1 is a state leaf (its cotangent only enters the norm)
+    T ga[6] = {0, 0, 0, 0, 0, 0}, gscale[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < S; ++j)
+      for (int c = 0; c < 3; ++c) { ga[c] += g.pv[j * 3 + c] * T(1) / (T)S; gscale[c] += g.pv[j * 3 + c] * ac[c] / (T)S; }
+    // rotation path: d|w|/dw at w = 0 is NaN in the reference and is zeroed by nan_to_num at this boundary -> 0
+    for (int c = 0; c < 6; ++c) ga[c] *= clip_grad(io.action[b * 6 + c], T(-1), T(1));
+    if (clip) {  // norm_grad_bwd / norm_grad_state_bwd (:389-394, :403-408)
+      T n2 = 0;
+      for (int c = 0; c < 6; ++c) { ga[c] = nan_to_num(ga[c] + T(0)); n2 += ga[c] * ga[c]; }
+      T nrm = std::sqrt(n2);
+      if (!(nrm < T(1))) for (int c = 0; c < 6; ++c) ga[c] = ga[c] / nrm;
+      T s2 = 0;
+      auto acc = [&](std::vector<T>& a) { for (auto& q : a) { q = nan_to_num(q + T(0)); s2 += q * q; } };
+      acc(g.x); acc(g.v); acc(g.C); acc(g.F); acc(g.ppos);
+      g.friction = nan_to_num(g.friction); g.mu = nan_to_num(g.mu); g.lamda = nan_to_num(g.lamda);
+      s2 += g.friction * g.friction + g.mu * g.mu + g.lamda * g.lamda;
+      for (int c = 0; c < 3; ++c) { gscale[c] = nan_to_num(gscale[c]); s2 += gscale[c] * gscale[c]; }
+      T sn = std::sqrt(s2);
+      if (!(sn < T(1))) {
+        auto sc = [&](std::vector<T>& a) { for (auto& q : a) q = q / sn; };
+        sc(g.x); sc(g.v); sc(g.C); sc(g.F); sc(g.ppos);
+        g.friction /= sn; g.mu /= sn; g.lamda /= sn;
+      }
+    }
+    std::memcpy(gx0 + (size_t)b * N * 3, g.x.data(), sizeof(T) * N * 3);
+    std::memcpy(gv0 + (size_t)b * N * 3, g.v.data(), sizeof(T) * N * 3);
+    std::memcpy(gC0 + (size_t)b * N * 9, g.C.data(), sizeof(T) * N * 9);
+    std::memcpy(gF0 + (size_t)b * N * 9, g.F.data(), sizeof(T) * N * 9);
+    std::memcpy(gppos0 + (size_t)b * S * 3, g.ppos.data(), sizeof(T) * S * 3);
+    gfric[b] = g.friction; gmu[b] = g.mu; glam[b] = g.lamda;
+    for (int c = 0; c < 6; ++c) gaction[b * 6 + c] = ga[c];
+  }
+}
+
+extern "C" {
+
+void* oc_mpm_create(int N, int n_grid, const int* res, int steps, double dt, double p_mass, double p_vol,
+                    const double* gravity, int position_control, const int* material, const double* hardness) {
+  auto* h = new OcMpm;
+  fill_params(h->pf, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness);
+  fill_params(h->pd, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness);
+  return h;
+}
+void oc_mpm_destroy(void* h) { delete (OcMpm*)h; }
+
+void oc_svd3_f32(const float* A, float* U, float* S, float* Vh) {
+  M3<float> a = load9(A), u, vh;
+  svd3(a, u, S, vh);
+  store9(U, u); store9(Vh, vh);
+}
+void oc_svd3_f64(const double* A, double* U, double* S, double* Vh) {
+  M3<double> a = load9(A), u, vh;
+  svd3(a, u, S, vh);
+  store9(U, u); store9(Vh, vh);
+}
+
+#define DEFINE(SUF, T)                                                                                              \
+  void oc_mpm_step_fwd_##SUF(void* h, int B, const T* x, const T* v, const T* C, const T* F, const T* J,             \
+                             const T* ppos, const T* prot, const T* psize, const T* friction, const T* mu,           \
+                             const T* lamda, const T* action, T* xo, T* vo, T* Co, T* Fo, T* Jo, T* ppos_o,         \
+                             T* prot_o, T* pv_o, T* pw_o, int nthreads) {                                            \
+    StepIO<T> io{x, v, C, F, J, ppos, prot, psize, friction, mu, lamda, action};                                     \
+    step_fwd<T>((OcMpm*)h, B, io, xo, vo, Co, Fo, Jo, ppos_o, prot_o, pv_o, pw_o, nthreads);                         \
+  }                                                                                                                  \
+  void oc_mpm_step_bwd_##SUF(void* h, int B, const T* x, const T* v, const T* C, const T* F, const T* J,             \
+                             const T* ppos, const T* prot, const T* psize, const T* friction, const T* mu,           \
+                             const T* lamda, const T* action, const T* gx, const T* gv, const T* gC, const T* gF,   \
+                             const T* gppos, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0, T* gfric, T* gmu, \
+                             T* glam, T* gaction, int nthreads) {                                                    \
+    StepIO<T> io{x, v, C, F, J, ppos, prot, psize, friction, mu, lamda, action};                                     \
+    step_bwd<T>((OcMpm*)h, B, io, gx, gv, gC, gF, gppos, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam,         \
+                gaction, nthreads);                                                                                  \
+  }
+DEFINE(f32, float)
+DEFINE(f64, double)
+#undef DEFINE
+
+}  // extern "C"

@@ -120,3 +120,67 @@ class ClothOracle:
             _p(gx), _p(gv), _p(gprim), _p(gx_list), _p(gv_list), _p(gprim_list), C.c_int(int(normalize)),
             _p(gx0), _p(gv0), _p(gp0), _p(ga), _p(gk), _p(gmu), C.c_int(nthreads))
         return dict(gx=gx0, gv=gv0, gprim=gp0, gactions=ga, gk=gk, gmu=gmu)
+
+
+class MpmOracle:
+    """CPU restatement of SimpleMPMSimulator.step (mpm_simulator.py:413-429) + adjoint, dense grid."""
+
+    def __init__(self, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0),
+                 position_control=True, material=None, hardness=None):
+        self.N, self.steps, self.res, self.n_grid = N, steps, tuple(res), n_grid
+        dx = 1 / n_grid
+        p_vol = (dx * 0.5) ** 2
+        p_mass = p_vol * p_rho
+        mat = np.ascontiguousarray(np.full(N, 1) if material is None else material, dtype=np.int32)
+        hd = np.ascontiguousarray(np.full(N, 1.0) if hardness is None else hardness, dtype=np.float64)
+        r = np.ascontiguousarray(res, dtype=np.int32)
+        g = np.ascontiguousarray(gravity, dtype=np.float64)
+        self.h = C.c_void_p(lib().oc_mpm_create(
+            C.c_int(N), C.c_int(n_grid), _p(r), C.c_int(steps), C.c_double(dt), C.c_double(p_mass), C.c_double(p_vol),
+            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd)))
+
+    def __del__(self):
+        try:
+            lib().oc_mpm_destroy(self.h)
+        except Exception:
+            pass
+
+    def _prep(self, st, dt):
+        c = lambda a: np.ascontiguousarray(a, dtype=dt)
+        return [c(st[k]) for k in ("x", "v", "C", "F", "J", "ppos", "prot", "psize", "friction", "mu", "lamda", "action")]
+
+    def step_fwd(self, st, nthreads=1):
+        """st: dict x[B,N,3] v C[B,N,3,3] F J[B,N] ppos[B,steps,3] prot[B,steps,4] psize[B,3] friction mu lamda[B] action[B,6]"""
+        dt = st["x"].dtype
+        a = self._prep(st, dt)
+        B, N, S = a[0].shape[0], self.N, self.steps
+        o = dict(x=np.empty((B, N, 3), dt), v=np.empty((B, N, 3), dt), C=np.empty((B, N, 3, 3), dt),
+                 F=np.empty((B, N, 3, 3), dt), J=np.empty((B, N), dt), ppos=np.empty((B, S, 3), dt),
+                 prot=np.empty((B, S, 4), dt), pv=np.empty((B, S, 3), dt), pw=np.empty((B, S, 3), dt))
+        getattr(lib(), "oc_mpm_step_fwd_" + _suf(dt))(
+            self.h, C.c_int(B), *[_p(q) for q in a],
+            *[_p(o[k]) for k in ("x", "v", "C", "F", "J", "ppos", "prot", "pv", "pw")], C.c_int(nthreads))
+        return o
+
+    def step_bwd(self, st, g, clip=True, nthreads=1):
+        """g: dict gx gv gC gF gppos (cotangents of the step outputs)."""
+        dt = st["x"].dtype
+        a = self._prep(st, dt)
+        B, N, S = a[0].shape[0], self.N, self.steps
+        c = lambda q: np.ascontiguousarray(q, dtype=dt)
+        gin = [c(g[k]) for k in ("gx", "gv", "gC", "gF", "gppos")]
+        o = dict(gx=np.empty((B, N, 3), dt), gv=np.empty((B, N, 3), dt), gC=np.empty((B, N, 3, 3), dt),
+                 gF=np.empty((B, N, 3, 3), dt), gppos=np.empty((B, S, 3), dt), gfriction=np.empty((B,), dt),
+                 gmu=np.empty((B,), dt), glamda=np.empty((B,), dt), gaction=np.empty((B, 6), dt))
+        getattr(lib(), "oc_mpm_step_bwd_" + _suf(dt))(
+            self.h, C.c_int(B), *[_p(q) for q in a], *[_p(q) for q in gin], C.c_int(int(clip)),
+            *[_p(o[k]) for k in ("gx", "gv", "gC", "gF", "gppos", "gfriction", "gmu", "glamda", "gaction")],
+            C.c_int(nthreads))
+        return o
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A)
+    U, S, Vh = np.empty_like(A), np.empty(3, A.dtype), np.empty_like(A)
+    getattr(lib(), "oc_svd3_" + _suf(A.dtype))(_p(A), _p(U), _p(S), _p(Vh))
+    return U, S, Vh

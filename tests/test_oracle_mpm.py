@@ -1,0 +1,187 @@
+"""CPU: pin the MPM oracle.
+
+Primary pin = the reference's OWN recorded trajectory expert_demo/whip_rope/demo_0.pkl (re-packed as data in
+tests/golden/whip_rope_demo0.npz): 69 (state, action) -> state' transitions = 3450 substeps, replayed with the
+legacy parameter overrides found in SURVEY.md F3 (steps=50, gripper size (.02,.06,.02), Lame parameters from
+E=100, nu=0.2, ground friction 0.1, recorded action fed to simulator.step unchanged, position control, focus shift).
+It pins the forward substep (M1-M5, M8, E3 focus shift).  Not pinned by reference data (-> validated against
+torch.autograd on the line-by-line twin + f64 finite differences): every adjoint, the plastic branch.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle.pyoracle import MpmOracle, svd3
+from oracle.twin import mpm_twin as tw
+
+torch.set_num_threads(2)
+E, NU = 100, 0.2
+MU0, LA0 = E / (2 * (1 + NU)), E * NU / ((1 + NU) * (1 - 2 * NU))
+S_LEGACY = 50
+
+
+@pytest.fixture(scope="module")
+def demo():
+    return np.load(os.path.join(GOLDEN, "whip_rope_demo0.npz"))
+
+
+def legacy_state(d, k, dt=np.float32, S=S_LEGACY):
+    """demo state k -> step input with the focus shift of mpm_env.py:99-114 applied."""
+    x = d["x"][k].astype(dt)
+    target = np.array([32, 32, 32], dt) * dt(0.5) / dt(64)
+    shift = (target - x.mean(0, dtype=dt)).astype(dt)
+    shift[1] = 0
+    ppos = np.zeros((S, 3), dt)
+    ppos[0] = d["prim_position"][k, 0]
+    ppos = ppos + shift
+    prot = np.zeros((S, 4), dt)
+    prot[:, 0] = 1
+    st = dict(x=(x + shift)[None], v=d["v"][k][None].astype(dt), C=d["C"][k][None].astype(dt), F=d["F"][k][None].astype(dt),
+              J=d["J"][k][None].astype(dt), ppos=ppos[None], prot=prot[None], psize=np.array([[0.02, 0.06, 0.02]], dt),
+              friction=np.array([0.1], dt), mu=np.array([MU0], dt), lamda=np.array([LA0], dt),
+              action=d["action"][k][None].astype(dt))
+    return st, shift
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_golden_all_transitions_cpp(demo):
+    """All 69 recorded transitions, one step (50 substeps) ahead."""
+    d = demo
+    orc = MpmOracle(67, steps=S_LEGACY)
+    for k in range(69):
+        st, shift = legacy_state(d, k)
+        o = orc.step_fwd(st)
+        assert np.abs(o["x"][0] - shift - d["x"][k + 1]).max() < 5e-7          # measured 1.2e-7
+        assert _rel(o["v"][0], d["v"][k + 1]) < 3e-5                            # measured 7.4e-6
+        assert _rel(o["C"][0], d["C"][k + 1]) < 1e-4                            # measured 2.7e-5
+        assert np.abs(o["F"][0] - d["F"][k + 1]).max() < 2e-5                   # measured 4.6e-6
+        np.testing.assert_array_equal(o["ppos"][0, 0] - shift, d["prim_position"][k + 1, 0])   # Q5: steps-1 increments
+        np.testing.assert_array_equal(o["J"][0], d["J"][k + 1])
+
+
+def test_golden_chained_rollout_cpp(demo):
+    """20 chained steps = 1000 substeps from state 0 (errors may accumulate)."""
+    d = demo
+    orc = MpmOracle(67, steps=S_LEGACY)
+    st, _ = legacy_state(d, 0)
+    cur = {k: st[k] for k in ("v", "C", "F", "J")}
+    cur["x"] = d["x"][0][None].astype(np.float32)
+    ppos0 = d["prim_position"][0, 0].astype(np.float32)
+    for k in range(20):
+        x = cur["x"][0]
+        shift = (np.float32([0.25, 0, 0.25]) - x.mean(0, dtype=np.float32)).astype(np.float32)
+        shift[1] = 0
+        ppos = np.zeros((S_LEGACY, 3), np.float32)
+        ppos[0] = ppos0
+        s = dict(st, x=(x + shift)[None], v=cur["v"], C=cur["C"], F=cur["F"], J=cur["J"], ppos=(ppos + shift)[None],
+                 action=d["action"][k][None])
+        o = orc.step_fwd(s)
+        cur = dict(x=o["x"] - shift, v=o["v"], C=o["C"], F=o["F"], J=o["J"])
+        ppos0 = o["ppos"][0, 0] - shift
+    assert np.abs(cur["x"][0] - d["x"][20]).max() < 2e-6                        # measured 4e-7
+    assert _rel(cur["v"][0], d["v"][20]) < 5e-5
+    assert np.abs(ppos0 - d["prim_position"][20, 0]).max() < 1e-6
+
+
+def test_golden_twin(demo):
+    """The literal torch twin (dense jnp-style code, LAPACK svd) reproduces the recording too."""
+    d = demo
+    conf = tw.MPMConf(steps=S_LEGACY)
+    sim = tw.MPMTwin(conf, 67, clip_grads=False)
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    with torch.no_grad():
+        for k in (1, 40):
+            p = tw.make_prim(conf, [0.02, 0.06, 0.02], d["prim_position"][k, 0])
+            st = tw.MPMState(t(d["x"][k]), t(d["v"][k]), t(d["C"][k]), t(d["F"][k]), t(d["J"][k]), [p], t([0.1]), t([MU0]), t([LA0]))
+            shift = tw.focus_shift(conf, st.x)
+            st = st._replace(x=st.x + shift, primitives=[p._replace(position=p.position + shift)])
+            st = sim.step(st, t(d["action"][k]))
+            assert np.abs((st.x - shift).numpy() - d["x"][k + 1]).max() < 5e-7
+            assert _rel(st.v.numpy(), d["v"][k + 1]) < 3e-5
+            assert _rel(st.C.numpy(), d["C"][k + 1]) < 1e-4
+
+
+def test_svd3_properties():
+    rng = np.random.default_rng(0)
+    for dt, tol in ((np.float64, 1e-13), (np.float32, 5e-6)):
+        for _ in range(50):
+            A = (np.eye(3) + rng.normal(size=(3, 3)) * 0.3).astype(dt)
+            U, S, Vh = svd3(A)
+            assert np.abs(U @ np.diag(S) @ Vh - A).max() < tol
+            assert np.abs(U.T @ U - np.eye(3)).max() < tol and np.abs(Vh @ Vh.T - np.eye(3)).max() < tol
+            assert S[0] >= S[1] >= S[2] >= 0
+            np.testing.assert_allclose(S, np.linalg.svd(A.astype(np.float64), compute_uv=False), rtol=0, atol=tol * 10)
+    U, S, Vh = svd3(np.eye(3, dtype=np.float32))   # degenerate: triple singular value
+    np.testing.assert_array_equal(S, [1, 1, 1])
+    np.testing.assert_array_equal(U @ Vh, np.eye(3, dtype=np.float32))
+
+
+def _adjoint_case(d, S, k, material, seed, dtn=np.float64):
+    rng = np.random.default_rng(seed)
+    st, shift = legacy_state(d, k, dtn, S)
+    st["ppos"][0, 0] = st["x"][0, 5]                     # gripper on the rope: control touches occupied cells
+    st["F"] = st["F"] + rng.normal(size=st["F"].shape) * 0.05
+    st["action"] = np.array([[0.3, -0.2, 0.5, 0, 0, 0]], dtn)
+    g = dict(gx=rng.normal(size=(1, 67, 3)), gv=rng.normal(size=(1, 67, 3)), gC=rng.normal(size=(1, 67, 3, 3)) * 0.01,
+             gF=rng.normal(size=(1, 67, 3, 3)) * 0.1, gppos=rng.normal(size=(1, S, 3)))
+    return st, {kk: v.astype(dtn) for kk, v in g.items()}
+
+
+@pytest.mark.parametrize("clip,material,S,k", [(False, 1, 3, 40), (True, 1, 3, 40), (False, 2, 3, 20)])
+def test_adjoint_matches_autograd_through_twin_f64(demo, clip, material, S, k):
+    """Hand-derived adjoint (incl. _svd_bwd, friction/boundary/control masks, set_action, copy_frame, the
+    step-boundary nan_to_num + global-norm clip) == torch.autograd through the literal twin, f64."""
+    st, g = _adjoint_case(demo, S, k, material, 0)
+    orc = MpmOracle(67, steps=S, material=np.full(67, material))
+    of, ob = orc.step_fwd(st), orc.step_bwd(st, g, clip=clip)
+    conf = tw.MPMConf(steps=S)
+    sim = tw.MPMTwin(conf, 67, material=material, dtype=torch.float64, clip_grads=clip)
+    L = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    xt, vt, Ct, Ft, pp = L(st["x"][0]), L(st["v"][0]), L(st["C"][0]), L(st["F"][0]), L(st["ppos"][0])
+    fr, mu, la, ac = L(st["friction"]), L(st["mu"]), L(st["lamda"]), L(st["action"][0])
+    p = tw.make_prim(conf, [0.02, 0.06, 0.02], [0, 0, 0], torch.float64)._replace(position=pp)
+    s2 = sim.step(tw.MPMState(xt, vt, Ct, Ft, torch.tensor(st["J"][0]), [p], fr, mu, la), ac)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    loss = (s2.x * T(g["gx"][0])).sum() + (s2.v * T(g["gv"][0])).sum() + (s2.C * T(g["gC"][0])).sum() + \
+        (s2.F * T(g["gF"][0])).sum() + (s2.primitives[0].position * T(g["gppos"][0])).sum()
+    loss.backward()
+    for key, ref in (("x", s2.x), ("v", s2.v), ("C", s2.C), ("F", s2.F)):
+        assert _rel(of[key][0], ref.detach().numpy()) < 1e-12
+    for key, ref in (("gx", xt), ("gv", vt), ("gC", Ct), ("gF", Ft), ("gppos", pp)):
+        assert _rel(ob[key][0], ref.grad.numpy()) < 1e-10, key
+    for key, ref in (("gfriction", fr), ("gmu", mu), ("glamda", la)):
+        assert _rel(ob[key], ref.grad.numpy()) < 1e-9, key
+    assert _rel(ob["gaction"][0], ac.grad.numpy()) < 1e-10
+    assert np.abs(ob["gaction"][0, :3]).max() > 0
+
+
+def test_adjoint_vs_finite_differences_f64(demo):
+    S = 2
+    st, g = _adjoint_case(demo, S, 40, 1, 3)
+    orc = MpmOracle(67, steps=S)
+
+    def Lf(s):
+        o = orc.step_fwd(s)
+        return (o["x"] * g["gx"]).sum() + (o["v"] * g["gv"]).sum() + (o["C"] * g["gC"]).sum() + \
+            (o["F"] * g["gF"]).sum() + (o["ppos"] * g["gppos"]).sum()
+
+    b = orc.step_bwd(st, g, clip=False)
+    rng = np.random.default_rng(0)
+    for name, gname in (("x", "gx"), ("v", "gv"), ("C", "gC"), ("F", "gF"), ("mu", "gmu"), ("lamda", "glamda"), ("friction", "gfriction")):
+        for _ in range(4):
+            a = st[name]
+            idx = tuple(rng.integers(0, s) for s in a.shape)
+            h = 1e-6 * max(1.0, abs(a[idx]))
+            sp, sm = dict(st), dict(st)
+            sp[name], sm[name] = a.copy(), a.copy()
+            sp[name][idx] += h
+            sm[name][idx] -= h
+            fd = (Lf(sp) - Lf(sm)) / (2 * h)
+            an = b[gname][idx]
+            assert abs(fd - an) <= 2e-5 * max(1.0, abs(fd), abs(an)), (name, idx, fd, an)
