@@ -89,6 +89,60 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
                          float* g_x0, float* g_v0, float* g_prim0, float* g_actions, float* g_stiffness,
                          float* g_mu, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MLS-MPM -- replaces SimpleMPMSimulator.step_jax = vmap(jit(step))
+ *   core/engine/mpm_simulator.py:27-63 (constructor), :413-429 (step), :223-330 (substep),
+ *   :178-221 (p2g_micro / g2p_micro), :365-373 (copy_frame), :375-411 (norm_grad_state / norm_grad),
+ *   core/engine/svd_safe_batch.py:19-102 (svd + safe VJP),
+ *   core/engine/primitives/primitives.py:185-239 (forward_kinematics, set_action, position_control_batch),
+ *   core/engine/primitives/box.py:6-18 (box SDF)
+ * driven by lax.scan over the macro actions of one step_diff (core/envs/basic/mpm_env.py:141).
+ * One call = one `simulator.step` = conf.steps substeps for B independent envs, ONE kernel launch.
+ * Scope this round: one box primitive in position-control mode (whip_rope); N <= 128 particles per env
+ * (one workgroup per env, the touched part of the `res` grid lives in an LDS cell table); materials 1
+ * (elastic), 2 (plastic clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ud_mpm ud_mpm;
+
+typedef struct {
+  int n_particles;
+  int n_grid;                /* conf.n_grid (dx = 1/n_grid)                 whip_rope_env.py:47 */
+  int res[3];                /* conf.res: allocated grid (index wrap/clamp)  :59 */
+  int steps;                 /* conf.steps substeps per step                :51 */
+  float dt;                  /* :48 */
+  float p_mass, p_vol;       /* :62-63 */
+  float gravity[3];          /* :64 */
+  int use_position_control;  /* 1: position_control_batch (only mode supported) */
+} ud_mpm_conf;
+
+/* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */
+int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* hardness, ud_mpm** out);
+void ud_mpm_destroy(ud_mpm* h);
+size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B);
+
+/* Forward `step`: state (x,v [B,N,3]; C,F [B,N,3,3]; J [B,N]), primitive 0 (position [B,steps,3], rotation
+ * [B,steps,4] (w,x,y,z), size [B,3]), friction/mu/lamda [B], action [B,6] -> new state, primitive position /
+ * rotation after copy_frame(steps,0) and the v,w [B,steps,3] written by set_action.
+ * ckpt (may be NULL = no backward): ud_mpm_ckpt_bytes() bytes. status [B] int32: 0 ok, 1 = LDS cell table
+ * overflow in that env (outputs invalid; the caller checks it when it next synchronises). */
+int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
+                    const float* prim_position, const float* prim_rotation, const float* prim_size,
+                    const float* friction, const float* mu, const float* lamda, const float* action, float* x_out,
+                    float* v_out, float* C_out, float* F_out, float* J_out, float* prim_position_out,
+                    float* prim_rotation_out, float* prim_v_out, float* prim_w_out, void* ckpt, int* status,
+                    void* stream);
+
+/* Backward `step`: cotangents of (x,v,C,F, primitive position) at the step output -> cotangents at the step
+ * input plus friction/mu/lamda [B] and action [B,6].  J receives no gradient (excluded from the reference's
+ * substep loss, mpm_simulator.py:343-350); action[3:6] (rotation) is 0: the reference yields NaN there for
+ * w = 0 and launders it with nan_to_num at this boundary.  clip != 0 applies norm_grad_state / norm_grad
+ * (nan_to_num + global-norm clip to 1, :389-408). */
+int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, const float* friction,
+                    const float* mu, const float* lamda, const float* action, const float* g_x, const float* g_v,
+                    const float* g_C, const float* g_F, const float* g_prim_position, int clip, float* g_x0,
+                    float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_friction, float* g_mu,
+                    float* g_lamda, float* g_action, int* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ SYMBOLS = [
     "ud_last_error", "ud_version",
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
+    "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
 ]
 
 
@@ -28,6 +29,12 @@ class UnidomError(RuntimeError):
 class ud_cloth_conf(C.Structure):
     _fields_ = [("N", C.c_int), ("gravity", C.c_float), ("damping", C.c_float), ("dt", C.c_float),
                 ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int)]
+
+
+class ud_mpm_conf(C.Structure):
+    _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("res", C.c_int * 3), ("steps", C.c_int),
+                ("dt", C.c_float), ("p_mass", C.c_float), ("p_vol", C.c_float), ("gravity", C.c_float * 3),
+                ("use_position_control", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -54,6 +61,7 @@ def lib():
         L.ud_last_error.restype = C.c_char_p
         L.ud_version.restype = C.c_char_p
         L.ud_cloth_ckpt_bytes.restype = C.c_size_t
+        L.ud_mpm_ckpt_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if not hasattr(L, name):
                 raise UnidomError(f"{SO_PATH} does not export {name}")

@@ -1,0 +1,1103 @@
+// MLS-MPM `step` (conf.steps substeps) for gfx950: one workgroup per environment, 4 lanes (a DPP quad) per
+// particle, the touched part of the `res` grid in an LDS open-addressing cell table.
+//
+// What it replaces (reference, /root/reference/DaXBench/daxbench/core/engine/):
+//   mpm_simulator.py  substep :223-330, p2g_micro :178-194, g2p_micro :196-221, step :413-429,
+//                     copy_frame :365-373, norm_grad_state / norm_grad :375-411, bwd loss leaves :343-354
+//   svd_safe_batch.py svd :19-51, _svd_bwd :65-102
+//   primitives/primitives.py forward_kinematics :185-194, set_action :212-229, position_control_batch :232-239,
+//                     sdf_batch :112-114, inv_trans_batch :105-109, qrot_batch :95-102, qmul :73-81, w2quat :84-92
+//   primitives/box.py _sdf_batch :6-18
+//
+// Why a cell table instead of the dense res grid: g2p only reads cells inside some particle's 3x3x3 support,
+// and every grid-op input of such a cell is (m, mv) scattered by particles, so cells no particle touches can
+// never influence x, v, C, F or any cotangent (their cotangent is 0, or NaN that nothing gathers -- Q7).
+// The reference spends its time on ~10 dense 32^3 temporaries per substep; here only the few hundred touched
+// cells exist, in LDS.  The whole `steps`-substep loop runs in one launch; the backward streams per-substep
+// particle checkpoints (24 floats/particle, SoA) from HBM in reverse.
+//
+// Lane mapping: lane = 4*particle + q.  The four lanes of a quad compute the particle pre-pass (F update, 3x3
+// Jacobi SVD, stress) redundantly -- there are far fewer particles than lanes on a CU -- and split the 27
+// stencil cells (7/7/7/6); quad sums go through DPP quad_perm.  No MFMA: stencil / scatter work.
+#include "common.h"
+
+namespace ud {
+
+struct MpmConst {
+  int N, Np, n_grid, res[3], steps;
+  float dt, dx, inv_dx, p_mass, p_vol, stress_c, dx2, dtg[3];
+  int H, logH, nthreads;
+};
+
+struct MpmFwdArgs {
+  MpmConst c;
+  const int* material;
+  const float* hard;
+  int B;
+  const float *x, *v, *C, *F, *J, *ppos, *prot, *psize, *friction, *mu, *lamda, *action;
+  float *xo, *vo, *Co, *Fo, *Jo, *ppos_o, *prot_o, *pv_o, *pw_o;
+  float* ckpt;
+  int* status;
+};
+
+struct MpmBwdArgs {
+  MpmConst c;
+  const int* material;
+  const float* hard;
+  int B;
+  const float* ckpt;
+  const float *psize, *friction, *mu, *lamda, *action;
+  const float *gx, *gv, *gC, *gF, *gppos;
+  int clip;
+  float *gx0, *gv0, *gC0, *gF0, *gppos0, *gfric, *gmu, *glam, *gaction;
+  int* status;
+};
+
+// ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------
+__device__ __forceinline__ void m_mul(const float* A, const float* B, float* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void m_mul_bt(const float* A, const float* B, float* R) {  // A * B^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* R) {  // A^T * B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+#define UD_JROT(p, q)                                                                                       \
+  {                                                                                                         \
+    float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
+    float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
+    float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
+    const bool rot = fabsf(ga) > 1.5e-8f * sqrtf(al * be);                                                   \
+    float zeta = (be - al) / (2.f * (rot ? ga : 1.f));                                                       \
+    float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));                               \
+    float cs = 1.f / sqrtf(1.f + t * t), sn = cs * t;                                                        \
+    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
+      float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \
+      a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                                    \
+      float vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                                          \
+      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                                  \
+    }                                                                                                        \
+  }
+
+#define UD_CSWAP(p, q)                                                                  \
+  if (sv[p] < sv[q]) {                                                                  \
+    float ts = sv[p]; sv[p] = sv[q]; sv[q] = ts;                                        \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                     \
+      float t1 = a[i * 3 + p]; a[i * 3 + p] = a[i * 3 + q]; a[i * 3 + q] = t1;          \
+      float t2 = vv[i * 3 + p]; vv[i * 3 + p] = vv[i * 3 + q]; vv[i * 3 + q] = t2;      \
+    }                                                                                   \
+  }
+
+// One-sided Jacobi (Hestenes) SVD of a 3x3: A = U diag(S) Vh, S descending >= 0.  The reference calls LAPACK
+// (third party); only U S Vh, U Vh and S -- gauge-invariant -- enter the dynamics.
+__device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* Vh) {
+  float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = A[i];
+#pragma unroll 1
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    UD_JROT(0, 1)
+    UD_JROT(0, 2)
+    UD_JROT(1, 2)
+  }
+  float sv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrtf(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+  UD_CSWAP(0, 1)
+  UD_CSWAP(1, 2)
+  UD_CSWAP(0, 1)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S[j] = sv[j];
+    float inv = sv[j] > FLT_MIN ? 1.f / sv[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
+  }
+}
+
+__device__ __forceinline__ float safe_inv(float x) { return x / (x * x + 1e-12f); }
+
+// svd_safe_batch.py:65-102 (real 3x3): cotangents (dU, dS, dVh) -> dA
+__device__ __forceinline__ void svd3_bwd(const float* U, const float* S, const float* Vh, const float* dU,
+                                         const float* dS, const float* dVh, float* dA) {
+  float UtdU[9], VtdV[9];
+  m_mul_at(U, dU, UtdU);     // Ut @ dU
+  m_mul_bt(Vh, dVh, VtdV);   // Vt @ Hc(dVh),  Vt = Cc(Vh) = Vh
+  float S2[3] = {S[0] * S[0], S[1] * S[1], S[2] * S[2]};
+  float Si[3] = {safe_inv(S[0]), safe_inv(S[1]), safe_inv(S[2])};
+  float JJ[9], KK[9];        // (J + J^H) * S  and  S * (K + K^H) handled below
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float Fij = (i == j) ? 0.f : safe_inv(S2[j] - S2[i]);
+      JJ[i * 3 + j] = Fij * UtdU[i * 3 + j];
+      KK[i * 3 + j] = Fij * VtdV[i * 3 + j];
+    }
+  // M = dS(diag) + (J+J^T) colscale S + rowscale S (K+K^T)   (the L - L^H term vanishes: L is a real diagonal)
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float t = (JJ[i * 3 + j] + JJ[j * 3 + i]) * S[j] + S[i] * (KK[i * 3 + j] + KK[j * 3 + i]);
+      M[i * 3 + j] = t + ((i == j) ? dS[i] : 0.f);
+    }
+  float UM[9];
+  m_mul(U, M, UM);
+  m_mul(UM, Vh, dA);
+  // projector terms: Pc_U_perp @ (dU * S_inv) @ Vt + (Uc * S_inv) @ dVh @ Pc_V_perp
+  float Pu[9], Pv[9], T1[9], T2[9], T3[9];
+  m_mul_bt(U, U, Pu);
+  m_mul_at(Vh, Vh, Pv);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Pu[i] = ((i % 4 == 0) ? 1.f : 0.f) - Pu[i]; Pv[i] = ((i % 4 == 0) ? 1.f : 0.f) - Pv[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { T1[i * 3 + j] = dU[i * 3 + j] * Si[j]; T2[i * 3 + j] = U[i * 3 + j] * Si[j]; }
+  m_mul(Pu, T1, T3);
+  m_mul(T3, Vh, T1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dA[i] += T1[i];
+  m_mul(T2, dVh, T3);
+  m_mul(T3, Pv, T1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dA[i] += T1[i];
+}
+
+// ---- primitive helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void qrot(const float* q, const float* v, float* o) {  // :95-102
+  float uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
+  float w0 = q[2] * uv2 - q[3] * uv1, w1 = q[3] * uv0 - q[1] * uv2, w2 = q[1] * uv1 - q[2] * uv0;
+  o[0] = v[0] + 2.f * (q[0] * uv0 + w0);
+  o[1] = v[1] + 2.f * (q[0] * uv1 + w1);
+  o[2] = v[2] + 2.f * (q[0] * uv2 + w2);
+}
+
+struct PrimF {          // primitive 0 at substep f (uniform)
+  float pos[3], iq[4], size[3], pv[3];
+  float friction;       // state.friction (ground), not the primitive's own
+};
+
+__device__ __forceinline__ float box_sdf(const float* size, const float* gp) {  // box.py:6-18
+  float q0 = clipf(fabsf(gp[0]) - size[0], 0.f, INFINITY);
+  float q1 = clipf(fabsf(gp[1]) - size[1], 0.f, INFINITY);
+  float q2 = clipf(fabsf(gp[2]) - size[2], 0.f, INFINITY);
+  float out = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + 1e-12f);
+  float tmp = q1 > q2 ? q1 : q2;
+  tmp = q0 > tmp ? q0 : tmp;
+  tmp = clipf(tmp, -INFINITY, 0.f);
+  return out + tmp;
+}
+
+struct CellRec {
+  float v1[3];
+  bool ctrl, fric, bnd[3];
+};
+
+// grid op of one cell (:283-313): (m, mv) -> v.  REC: keep what the adjoint needs.
+template <bool REC>
+__device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int ci, int cj, int ck, float m,
+                                        const float* mv, float* vo, CellRec* rec) {
+  float v[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = ((m > 0.f) ? mv[a] / m : mv[a]) + c.dtg[a];
+  float gp[3] = {(float)ci * c.dx, (float)cj * c.dx, (float)ck * c.dx};
+  float d[3] = {gp[0] - pf.pos[0], gp[1] - pf.pos[1], gp[2] - pf.pos[2]}, loc[3];
+  qrot(pf.iq, d, loc);
+  const bool ctrl = box_sdf(pf.size, loc) < pf.size[0] * 1.5f;   // :232-239
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = ctrl ? pf.pv[a] / c.dt : v[a];
+  if (REC) { rec->ctrl = ctrl; rec->v1[0] = v[0]; rec->v1[1] = v[1]; rec->v1[2] = v[2]; }
+  const bool fric = (cj < 3) && (v[1] <= 0.f);                    // :297-307
+  {
+    float g0 = (float)ci, g1 = (float)cj, g2 = (float)ck;
+    float lin = v[1] + 1e-30f;
+    float vit0 = v[0] - lin * 0.f - g0 * 1e-30f, vit1 = v[1] - lin * 1.f - g1 * 1e-30f, vit2 = v[2] - lin * 0.f - g2 * 1e-30f;
+    float e0 = vit0 + 1e-12f, e1 = vit1 + 1e-12f, e2 = vit2 + 1e-12f;
+    float lit = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    float s = clipf(1.f + pf.friction * lin / lit, 0.f, INFINITY);
+    float f0 = s * (vit0 + g0 * 1e-30f), f2 = s * (vit2 + g2 * 1e-30f);
+    v[0] = fric ? f0 : v[0];
+    v[1] = fric ? 0.f : v[1];
+    v[2] = fric ? f2 : v[2];
+  }
+  if (REC) rec->fric = fric;
+  const int id[3] = {ci, cj, ck};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {                                    // :310-313 (Q8: n_grid, not res)
+    const bool b = (id[a] < 3 && v[a] < 0.f) || (id[a] > c.n_grid - 3 && v[a] > 0.f);
+    if (REC) rec->bnd[a] = b;
+    vo[a] = b ? 0.f : v[a];
+  }
+}
+
+// ---- LDS cell table --------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cell_hash(int cell, int logH) { return ((unsigned)cell * 2654435761u) >> (32 - logH); }
+
+__device__ __forceinline__ int table_insert(int* key, int H, int logH, int cell) {
+  unsigned s = cell_hash(cell, logH);
+  for (int probe = 0; probe < H; ++probe) {
+    int old = atomicCAS(&key[s], -1, cell);
+    if (old == -1 || old == cell) return (int)s;
+    s = (s + 1) & (unsigned)(H - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// scatter index rule (Q5/Q9): negative wraps, out-of-range dropped (-1); gather rule: negative wraps, clamp
+__device__ __forceinline__ int cell_scatter(const MpmConst& c, int i, int j, int k) {
+  i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
+  if (i < 0 || i >= c.res[0] || j < 0 || j >= c.res[1] || k < 0 || k >= c.res[2]) return -1;
+  return (i * c.res[1] + j) * c.res[2] + k;
+}
+__device__ __forceinline__ int cell_gather(const MpmConst& c, int i, int j, int k) {
+  i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
+  i = min(max(i, 0), c.res[0] - 1); j = min(max(j, 0), c.res[1] - 1); k = min(max(k, 0), c.res[2] - 1);
+  return (i * c.res[1] + j) * c.res[2] + k;
+}
+
+// quad (4-lane) all-reduce through DPP quad_perm
+__device__ __forceinline__ float quad_sum(float v) {
+  v += dpp_f<0xB1>(v);  // [1,0,3,2]
+  v += dpp_f<0x4E>(v);  // [2,3,0,1]
+  return v;
+}
+
+// ---- particle pre-pass (:233-268) ---------------------------------------------------------------------
+struct Pre {
+  int base[3];
+  float fx[3], w[9];           // w[k*3+d]
+  float Fn[9], affine[9];
+};
+struct PreB {                   // extras the adjoint needs
+  float U[9], Vh[9], sig_raw[3], sig[3], Jd, mu, la, A[9];
+};
+
+template <bool KEEP>
+__device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, const float* Cm, const float* F,
+                                             float mu_s, float la_s, int material, float hard, Pre& q, PreB* kb) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    q.base[d] = (int)(x[d] * c.inv_dx - 0.5f);   // truncation (:233)
+    float f = x[d] * c.inv_dx - (float)q.base[d];
+    q.fx[d] = f;
+    q.w[0 * 3 + d] = 0.5f * ((1.5f - f) * (1.5f - f));
+    q.w[1 * 3 + d] = 0.75f - (f - 1.f) * (f - 1.f);
+    q.w[2 * 3 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+  }
+  float IC[9], Fu[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[i];
+  m_mul(IC, F, Fu);                                              // :238
+  float h = clipf(hard, 0.1f, 5.f);
+  float mu = mu_s * h, la = la_s * h;
+  if (material == 0) { mu = 0.f; la = 1.f; }                     // Q10
+  float U[9], Vh[9], sr[3], sg[3];
+  svd3(Fu, U, sr, Vh);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sg[i] = sr[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q.Fn[i] = Fu[i];
+  if (material == 2) {                                           // :250-258
+    float US[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sg[i] = clipf(sr[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) US[i * 3 + j] = U[i * 3 + j] * sg[j];
+    m_mul(US, Vh, q.Fn);
+  }
+  float Jd = sg[0] * sg[1] * sg[2];
+  float R[9], A[9], St[9];
+  m_mul(U, Vh, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) A[i] = q.Fn[i] - R[i];
+  m_mul_bt(A, q.Fn, St);
+  float vol = la * Jd * (Jd - 1.f);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float s = 2.f * mu * St[i] + ((i % 4 == 0) ? vol : 0.f);
+    q.affine[i] = c.stress_c * s / c.dx2 + c.p_mass * Cm[i];
+  }
+  if (KEEP) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { kb->U[i] = U[i]; kb->Vh[i] = Vh[i]; kb->A[i] = A[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { kb->sig_raw[i] = sr[i]; kb->sig[i] = sg[i]; }
+    kb->Jd = Jd; kb->mu = mu; kb->la = la;
+  }
+}
+
+// lane q of a quad owns stencil cells cidx = q, q+4, ..., < 27
+#define UD_NCELL 7
+__device__ __forceinline__ float sel3(const float* w, int d, int i) {  // w[i*3+d] without dynamic register indexing
+  return (i == 0) ? w[d] : ((i == 1) ? w[3 + d] : w[6 + d]);
+}
+__device__ __forceinline__ bool cell_of(int q, int t, int& i, int& j, int& k) {
+  const int cidx = q + 4 * t;
+  i = cidx / 9; j = (cidx / 3) % 3; k = cidx % 3;
+  return cidx < 27;
+}
+
+// LDS layout helpers
+struct Lds {
+  int* key; float* m; float* mv;    // [H], [H], [3H]  (fwd: mv becomes the grid velocity after the grid op)
+  float* vel; float* gacc; float* gmm;  // bwd only: [3H], [3H], [H]
+  float* ppos; float* prot;          // [S*3], [S*4]
+  float* ppin; float* gppos; float* gpv;  // bwd only: [S*3] each
+  float* scr;                        // [64] scratch
+};
+
+__device__ __forceinline__ void prim_at(const Lds& L, int f, int S, const float* psize, const float* pv, float friction, PrimF& pf) {
+  const int fc = min(max(f, 0), S - 1);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { pf.pos[a] = L.ppos[fc * 3 + a]; pf.size[a] = psize[a]; pf.pv[a] = pv[a]; }
+  float r0 = L.prot[fc * 4], r1 = -L.prot[fc * 4 + 1], r2 = -L.prot[fc * 4 + 2], r3 = -L.prot[fc * 4 + 3];
+  float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;   // :105-109
+  pf.iq[0] = r0 / n; pf.iq[1] = r1 / n; pf.iq[2] = r2 / n; pf.iq[3] = r3 / n;
+  pf.friction = friction;
+}
+
+// forward kinematics writes (:185-194): called by every thread between two barriers
+__device__ __forceinline__ void fk_read(const Lds& L, int f, int S, const float* pv, int tid, float& pending) {
+  // entry e = tid: value the array holds after `set(f+1, pos[f]+v[f])`, before the whole-array clip
+  if (tid < S * 3) {
+    const int row = tid / 3, a = tid - row * 3;
+    const int fc = min(max(f, 0), S - 1);
+    const float pva = (a == 0) ? pv[0] : ((a == 1) ? pv[1] : pv[2]);
+    pending = (row == f + 1) ? (L.ppos[fc * 3 + a] + pva) : L.ppos[tid];
+  }
+}
+__device__ __forceinline__ void fk_write(const Lds& L, int f, int S, const float* pw, int tid, float pending) {
+  if (tid < S * 3) L.ppos[tid] = clipf(pending, -2.f, 2.f);
+  if (tid == 0 && f + 1 < S) {   // rotation[f+1] = qmul(w2quat(w[f]), rotation[f])  (:73-92)
+    float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;
+    float sn = sinf(ang / 2.f);
+    float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
+    const float* r = L.prot + f * 4;
+    float o0 = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    float o1 = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+    float o2 = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+    float o3 = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+    float nn = clipf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3), 1e-12f, INFINITY);
+    float* w = L.prot + (f + 1) * 4;
+    w[0] = o0 / nn; w[1] = o1 / nn; w[2] = o2 / nn; w[3] = o3 / nn;
+  }
+}
+
+// p2g of one quad lane: insert its cells, scatter mass / momentum.  slots[t] = (scatter_slot+1) << 16 | gather_slot
+__device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const Pre& q, const float* v, int qi, int* slots) {
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < UD_NCELL; ++t) {
+    int i, j, k;
+    slots[t] = 0;
+    if (!cell_of(qi, t, i, j, k)) continue;
+    const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+    const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    int ss = -1;
+    if (sc >= 0) {
+      ss = table_insert(L.key, c.H, c.logH, sc);
+      ok = ok && (ss >= 0);
+      if (ss >= 0) {
+        const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+        lds_add(&L.m[ss], weight * c.p_mass);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float ad = q.affine[a * 3] * dp0 + q.affine[a * 3 + 1] * dp1 + q.affine[a * 3 + 2] * dp2;
+          lds_add(&L.mv[ss * 3 + a], weight * (c.p_mass * v[a] + ad));
+        }
+      }
+    }
+    int gs = ss;
+    if (gc != sc) { gs = table_insert(L.key, c.H, c.logH, gc); ok = ok && (gs >= 0); }
+    slots[t] = ((ss + 1) << 16) | (max(gs, 0) & 0xffff);
+  }
+  return ok;
+}
+
+__device__ __forceinline__ void decode_cell(const MpmConst& c, int cell, int& ci, int& cj, int& ck) {
+  ck = cell % c.res[2];
+  const int t = cell / c.res[2];
+  cj = t % c.res[1];
+  ci = t / c.res[1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
+  extern __shared__ float smem[];
+  const MpmConst c = a.c;
+  const int tid = threadIdx.x, b = blockIdx.x, nt = blockDim.x;
+  const int N = c.N, S = c.steps, H = c.H;
+  Lds L;
+  L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H;
+  L.ppos = smem + 5 * H; L.prot = L.ppos + S * 3; L.scr = L.prot + S * 4;
+  const int p = tid >> 2, qi = tid & 3;
+  const bool live = p < N;
+  const int pc = live ? p : 0;
+  float x[3], v[3], Cm[9], F[9], Jp;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[d] = nan_to_num(a.x[((size_t)b * N + pc) * 3 + d]); v[d] = nan_to_num(a.v[((size_t)b * N + pc) * 3 + d]); }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { Cm[d] = nan_to_num(a.C[((size_t)b * N + pc) * 9 + d]); F[d] = nan_to_num(a.F[((size_t)b * N + pc) * 9 + d]); }
+  Jp = nan_to_num(a.J[(size_t)b * N + pc]);                      // norm_grad_state fwd (:377-381)
+  const int material = a.material[pc];
+  const float hard = a.hard[pc];
+  for (int e = tid; e < S * 3; e += nt) L.ppos[e] = a.ppos[(size_t)b * S * 3 + e];
+  for (int e = tid; e < S * 4; e += nt) L.prot[e] = a.prot[(size_t)b * S * 4 + e];
+  float pv[3], pw[3], psize[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {                                   // clip + set_action (:419-423, primitives.py:212-229)
+    pv[d] = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+    pw[d] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+    psize[d] = a.psize[b * 3 + d];
+  }
+  const float friction = a.friction[b], mu_s = a.mu[b], la_s = a.lamda[b];
+  bool ok = true;
+  const size_t ck_env = ((size_t)S * 24 * c.Np + (size_t)S * 10);
+  float* ck = a.ckpt ? a.ckpt + (size_t)b * ck_env : nullptr;
+  __syncthreads();
+  for (int f = 0; f < S; ++f) {
+    // ---- A: clear the cell table, read for FK, checkpoint ----
+    for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f; }
+    float pending = 0.f;
+    fk_read(L, f, S, pv, tid, pending);
+    if (ck && live && qi == 0) {
+      float* r = ck + (size_t)f * 24 * c.Np + p;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { r[d * c.Np] = x[d]; r[(3 + d) * c.Np] = v[d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { r[(6 + d) * c.Np] = Cm[d]; r[(15 + d) * c.Np] = F[d]; }
+    }
+    if (f > 0) {  // J of the previous substep (:327, Q6): one scalar shared by all particles
+      float trq = L.scr[0] + L.scr[1] + L.scr[2];
+      Jp = Jp * (1.f + c.dt * trq);
+    }
+    __syncthreads();
+    // ---- B: FK write, particle pre-pass, p2g ----
+    fk_write(L, f, S, pw, tid, pending);
+    Pre q;
+    int slots[UD_NCELL];
+    particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
+    if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
+    __syncthreads();
+    // ---- C: grid op on the occupied slots ----
+    {
+      PrimF pf;
+      prim_at(L, f, S, psize, pv, friction, pf);
+      for (int s = tid; s < H; s += nt) {
+        const int cell = L.key[s];
+        if (cell >= 0) {
+          int ci, cj, ckk;
+          decode_cell(c, cell, ci, cj, ckk);
+          float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
+          grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
+          L.mv[s * 3] = vo[0]; L.mv[s * 3 + 1] = vo[1]; L.mv[s * 3 + 2] = vo[2];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- D: g2p (:196-221), advect ----
+    float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < UD_NCELL; ++t) {
+        int i, j, k;
+        if (!cell_of(qi, t, i, j, k)) continue;
+        const int gs = slots[t] & 0xffff;
+        const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+        const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
+        const float g[3] = {L.mv[gs * 3], L.mv[gs * 3 + 1], L.mv[gs * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * g[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nv[d] = quad_sum(nv[d]);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) nC[d] = quad_sum(nC[d]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { v[d] = nv[d]; x[d] = x[d] + c.dt * nv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = q.Fn[d]; }
+    if (live && qi == 0 && p < 3) {   // row p of particle p (Q6)
+      const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
+      L.scr[p] = (p == 0) ? r0 : ((p == 1) ? r1 : r2);
+    }
+    if (tid == 0 && N < 3) { for (int e = N; e < 3; ++e) L.scr[e] = 0.f; }
+    __syncthreads();
+  }
+  {
+    float trq = L.scr[0] + L.scr[1] + L.scr[2];
+    Jp = Jp * (1.f + c.dt * trq);
+  }
+  if (live && qi == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.xo[((size_t)b * N + p) * 3 + d] = x[d]; a.vo[((size_t)b * N + p) * 3 + d] = v[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { a.Co[((size_t)b * N + p) * 9 + d] = Cm[d]; a.Fo[((size_t)b * N + p) * 9 + d] = F[d]; }
+    a.Jo[(size_t)b * N + p] = Jp;
+  }
+  // checkpoint tail: primitive arrays before copy_frame (position | rotation)
+  if (ck) {
+    float* tail = ck + (size_t)S * 24 * c.Np;
+    for (int e = tid; e < S * 3; e += nt) tail[e] = L.ppos[e];
+    for (int e = tid; e < S * 4; e += nt) tail[S * 3 + e] = L.prot[e];
+    for (int e = tid; e < S * 3; e += nt) tail[S * 7 + e] = a.ppos[(size_t)b * S * 3 + e];
+  }
+  // copy_frame(steps, 0): source index clamps to steps-1 (Q5)
+  for (int e = tid; e < S * 3; e += nt) {
+    const int row = e / 3, d = e - row * 3;
+    a.ppos_o[(size_t)b * S * 3 + e] = (row == 0) ? L.ppos[(S - 1) * 3 + d] : L.ppos[e];
+    a.pv_o[(size_t)b * S * 3 + e] = (d == 0) ? pv[0] : ((d == 1) ? pv[1] : pv[2]);
+    a.pw_o[(size_t)b * S * 3 + e] = (d == 0) ? pw[0] : ((d == 1) ? pw[1] : pw[2]);
+  }
+  for (int e = tid; e < S * 4; e += nt) {
+    const int row = e / 4, d = e - row * 4;
+    a.prot_o[(size_t)b * S * 4 + e] = (row == 0) ? L.prot[(S - 1) * 4 + d] : L.prot[e];
+  }
+  const int bad = __syncthreads_or(ok ? 0 : 1);
+  if (tid == 0 && a.status) a.status[b] = bad ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum1(float v, float* red, int nw) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int q = 0; q < nw; ++q) t += red[q];
+  return t;
+}
+
+// pre-clip value of primitive position entry (row j, component a) at substep f (see forward_kinematics :185-187)
+__device__ __forceinline__ float ppos_preclip(const Lds& L, int f, int S, int j, int a, float pva) {
+  if (j == f + 1) return L.ppos[f * 3 + a] + pva;
+  if (j <= f) return (f == 0) ? L.ppin[j * 3 + a] : L.ppos[j * 3 + a];
+  return (f == 0) ? L.ppin[j * 3 + a] : clipf(L.ppin[j * 3 + a], -2.f, 2.f);
+}
+
+__global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
+  extern __shared__ float smem[];
+  const MpmConst c = a.c;
+  const int tid = threadIdx.x, b = blockIdx.x, nt = blockDim.x;
+  const int N = c.N, S = c.steps, H = c.H;
+  const int nw = nt >> 6;
+  Lds L;
+  L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H; L.vel = smem + 5 * H; L.gacc = smem + 8 * H; L.gmm = smem + 11 * H;
+  L.ppos = smem + 12 * H; L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3; L.gpv = L.gppos + S * 3;
+  L.scr = L.gpv + S * 3;
+  const int p = tid >> 2, qi = tid & 3;
+  const bool live = p < N;
+  const int pc = live ? p : 0;
+  const int material = a.material[pc];
+  const float hard = a.hard[pc];
+  const size_t ck_env = ((size_t)S * 24 * c.Np + (size_t)S * 10);
+  const float* ck = a.ckpt + (size_t)b * ck_env;
+  {
+    const float* tail = ck + (size_t)S * 24 * c.Np;
+    for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.f; }
+    for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
+    // copy_frame adjoint: position[0] <- position[steps-1]
+    for (int e = tid; e < S * 3; e += nt) {
+      const int row = e / 3, d = e - row * 3;
+      float g = a.gppos[(size_t)b * S * 3 + e];
+      if (S > 1) {
+        if (row == 0) g = 0.f;
+        if (row == S - 1) g += a.gppos[(size_t)b * S * 3 + d];
+      }
+      L.gppos[e] = g;
+    }
+  }
+  float gx[3], gv[3], gC[9], gF[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gx[d] = a.gx[((size_t)b * N + pc) * 3 + d]; gv[d] = a.gv[((size_t)b * N + pc) * 3 + d]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = a.gC[((size_t)b * N + pc) * 9 + d]; gF[d] = a.gF[((size_t)b * N + pc) * 9 + d]; }
+  float ac[6], pv[3], pw[3], psize[3];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ac[d] = clipf(a.action[b * 6 + d], -1.f, 1.f);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { pv[d] = ac[d] * 1.f / (float)S; pw[d] = ac[3 + d] * 1.f / (float)S; psize[d] = a.psize[b * 3 + d]; }
+  const float friction = a.friction[b], mu_s = a.mu[b], la_s = a.lamda[b];
+  float acc_fric = 0.f, acc_mu = 0.f, acc_la = 0.f;
+  bool ok = true;
+  float pend_val = 0.f, pend_pv = 0.f;   // FK-adjoint values computed in phase F, written at the top of the next iteration
+  bool pend = false;
+  __syncthreads();
+  for (int f = S - 1; f >= 0; --f) {
+    float x[3], v[3], Cm[9], F[9];
+    {
+      const float* r = ck + (size_t)f * 24 * c.Np + pc;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = r[d * c.Np]; v[d] = r[(3 + d) * c.Np]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { Cm[d] = r[(6 + d) * c.Np]; F[d] = r[(15 + d) * c.Np]; }
+    }
+    // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
+    for (int s = tid; s < H; s += nt) {
+      L.key[s] = -1; L.m[s] = 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { L.mv[s * 3 + d] = 0.f; L.gacc[s * 3 + d] = 0.f; }
+    }
+    if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += pend_pv; }
+    __syncthreads();
+    // ---- B: particle pre-pass, p2g ----
+    Pre q;
+    PreB kb;
+    int slots[UD_NCELL];
+    particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
+    if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
+    __syncthreads();
+    // ---- C: grid op forward -> vel ----
+    PrimF pf;
+    prim_at(L, f, S, psize, pv, friction, pf);
+    for (int s = tid; s < H; s += nt) {
+      const int cell = L.key[s];
+      if (cell >= 0) {
+        int ci, cj, ckk;
+        decode_cell(c, cell, ci, cj, ckk);
+        float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
+        grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
+        L.vel[s * 3] = vo[0]; L.vel[s * 3 + 1] = vo[1]; L.vel[s * 3 + 2] = vo[2];
+      }
+    }
+    __syncthreads();
+    // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
+    float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];       // x_out = x + dt*v_new
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < UD_NCELL; ++t) {
+        int i, j, k;
+        if (!cell_of(qi, t, i, j, k)) continue;
+        const int gs = slots[t] & 0xffff;
+        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+        const float weight = wi * wj * wk;
+        const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
+        float gwt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+          const float vel = L.vel[gs * 3 + r];
+          lds_add(&L.gacc[gs * 3 + r], weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
+          gwt += vel * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vel;
+        }
+        // gw[k*3+d]: select-accumulate (i, j, k are compile-time after unrolling only through cidx = q + 4t)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+          gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- E: grid-op adjoint per occupied slot ----
+    for (int s = tid; s < H; s += nt) {
+      const int cell = L.key[s];
+      if (cell < 0) continue;
+      int ci, cj, ckk;
+      decode_cell(c, cell, ci, cj, ckk);
+      const float m = L.m[s];
+      float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
+      CellRec rec;
+      grid_op<true>(c, pf, ci, cj, ckk, m, mvv, vo, &rec);
+      float g[3] = {L.gacc[s * 3], L.gacc[s * 3 + 1], L.gacc[s * 3 + 2]};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[d] = rec.bnd[d] ? 0.f : g[d];
+      if (rec.fric) {
+        const float g0 = (float)ci, g1 = (float)cj, g2 = (float)ckk;
+        const float* vv = rec.v1;
+        float lin = vv[1] + 1e-30f;
+        float vit[3] = {vv[0] - g0 * 1e-30f, vv[1] - lin - g1 * 1e-30f, vv[2] - g2 * 1e-30f};
+        float e[3] = {vit[0] + 1e-12f, vit[1] + 1e-12f, vit[2] + 1e-12f};
+        float lit = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        float arg = 1.f + friction * lin / lit;
+        float sc = clipf(arg, 0.f, INFINITY);
+        float qv0 = vit[0] + g0 * 1e-30f, qv2 = vit[2] + g2 * 1e-30f;
+        float gs_ = g[0] * qv0 + g[2] * qv2;
+        float gvit[3] = {sc * g[0], 0.f, sc * g[2]};
+        float garg = gs_ * clip_grad(arg, 0.f, INFINITY);
+        acc_fric += garg * lin / lit;
+        float glin = garg * friction / lit;
+        float glit = -garg * friction * lin / (lit * lit);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gvit[d] += glit * e[d] / lit;
+        glin -= gvit[1];
+        g[0] = gvit[0]; g[1] = gvit[1] + glin; g[2] = gvit[2];
+      }
+      if (rec.ctrl) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { lds_add(&L.gpv[f * 3 + d], g[d] / c.dt); g[d] = 0.f; }
+      }
+      float gmm;
+      if (m > 0.f) {
+        gmm = 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { float vn = mvv[d] / m; gmm -= g[d] * vn / m; g[d] = g[d] / m; }
+      } else if (m == 0.f) {   // Q7: the mv/m branch sees cotangent 0 and 0/0 -> NaN
+        g[0] = g[1] = g[2] = NAN; gmm = NAN;
+      } else {                 // m < 0 (negative quadratic weights below dx/2): pass-through branch
+        gmm = 0.f;
+      }
+      L.gacc[s * 3] = g[0]; L.gacc[s * 3 + 1] = g[1]; L.gacc[s * 3 + 2] = g[2];
+      L.gmm[s] = gmm;
+    }
+    __syncthreads();
+    // ---- F: p2g adjoint (gather) + particle pre-pass adjoint + FK adjoint ----
+    float gaff[9], gvp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gaff[d] = 0.f;
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < UD_NCELL; ++t) {
+        int i, j, k;
+        if (!cell_of(qi, t, i, j, k)) continue;
+        const int ss = (slots[t] >> 16) - 1;
+        if (ss < 0) continue;
+        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+        const float weight = wi * wj * wk;
+        const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
+        float gwt = c.p_mass * L.gmm[ss];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gc = L.gacc[ss * 3 + r];
+          const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+          gwt += gc * (c.p_mass * v[r] + ad);
+          gvp[r] += weight * c.p_mass * gc;
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) {
+            gaff[r * 3 + s2] += weight * gc * dpos[s2];
+            gfx[s2] -= c.dx * weight * gc * q.affine[r * 3 + s2];
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+          gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gw[d] = quad_sum(gw[d]); gaff[d] = quad_sum(gaff[d]); }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gfx[d] = quad_sum(gfx[d]); gvp[d] = quad_sum(gvp[d]); }
+    {
+      // weights -> fx
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float fxd = q.fx[d];
+        gfx[d] += gw[0 * 3 + d] * (-(1.5f - fxd)) + gw[1 * 3 + d] * (-2.f * (fxd - 1.f)) + gw[2 * 3 + d] * (fxd - 0.5f);
+      }
+      float gS[9], gCn[9];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gCn[d] = gaff[d] * c.p_mass; gS[d] = gaff[d] / c.dx2 * c.stress_c; }
+      // stress = 2 mu A Fn^T + la J (J-1) I
+      float AFt[9], T1[9], gA[9], gFn[9];
+      m_mul_bt(kb.A, q.Fn, AFt);
+      float gmu_p = 0.f;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gmu_p += gS[d] * 2.f * AFt[d];
+      m_mul(gS, q.Fn, gA);
+      m_mul_at(gS, kb.A, T1);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gA[d] *= 2.f * kb.mu; gFn[d] = gF[d] + 2.f * kb.mu * T1[d] + gA[d]; }
+      const float trg = gS[0] + gS[4] + gS[8];
+      const float gJ = kb.la * (2.f * kb.Jd - 1.f) * trg;
+      const float gla_p = kb.Jd * (kb.Jd - 1.f) * trg;
+      float gU[9], gVh[9], gR[9];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gR[d] = -gA[d];
+      m_mul_bt(gR, kb.Vh, gU);
+      m_mul_at(kb.U, gR, gVh);
+      float gsig[3] = {gJ * kb.sig[1] * kb.sig[2], gJ * kb.sig[0] * kb.sig[2], gJ * kb.sig[0] * kb.sig[1]};
+      float gFu[9];
+      if (material == 2) {
+        float US[9], SV[9], T2[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) { US[i * 3 + j] = kb.U[i * 3 + j] * kb.sig[j]; SV[i * 3 + j] = kb.Vh[i * 3 + j] * kb.sig[i]; }
+        m_mul_bt(gFn, SV, T1);
+#pragma unroll
+        for (int d = 0; d < 9; ++d) gU[d] += T1[d];
+        m_mul_at(US, gFn, T1);
+#pragma unroll
+        for (int d = 0; d < 9; ++d) gVh[d] += T1[d];
+        m_mul_at(kb.U, gFn, T1);
+        m_mul_bt(T1, kb.Vh, T2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          gsig[i] += T2[i * 4];
+          gsig[i] *= clip_grad(kb.sig_raw[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
+        }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) gFu[d] = 0.f;
+      } else {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) gFu[d] = gFn[d];
+      }
+      float dA[9];
+      svd3_bwd(kb.U, kb.sig_raw, kb.Vh, gU, gsig, gVh, dA);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gFu[d] += dA[d];
+      // Fu = (I + dt C) F
+      float IC[9];
+      m_mul_bt(gFu, F, T1);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gC[d] = gCn[d] + c.dt * T1[d]; IC[d] = ((d % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[d]; }
+      m_mul_at(IC, gFu, gF);
+      const float h = clipf(hard, 0.1f, 5.f);
+      if (live && qi == 0 && material != 0) { acc_mu += gmu_p * h; acc_la += gla_p * h; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gx[d] = gx[d] + gfx[d] * c.inv_dx; gv[d] = gvp[d]; }
+    }
+    // FK adjoint (:185-187): position' = clip(set(position, f+1, position[f] + v[f])); reads now, writes in A
+    pend = true;
+    pend_val = 0.f; pend_pv = 0.f;
+    if (tid < S * 3) {
+      const int row = tid / 3, d = tid - row * 3;
+      const float pva = (d == 0) ? pv[0] : ((d == 1) ? pv[1] : pv[2]);
+      const float mine = L.gppos[tid] * clip_grad(ppos_preclip(L, f, S, row, d, pva), -2.f, 2.f);
+      float val = mine;
+      if (f + 1 < S) {
+        if (row == f + 1) val = 0.f;
+        if (row == f) {
+          const float t = L.gppos[tid + 3] * clip_grad(ppos_preclip(L, f, S, f + 1, d, pva), -2.f, 2.f);
+          val += t;
+          pend_pv = t;
+        }
+      }
+      pend_val = val;
+    }
+    __syncthreads();
+  }
+  if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += pend_pv; }
+  __syncthreads();
+  // ---- step boundary: set_action adjoint, action clip, norm_grad(_state) (:375-411, :419-423) ----
+  float* red = L.scr;
+  float tot_fric = block_sum1(acc_fric, red, nw);
+  float tot_mu = block_sum1(acc_mu, red, nw);
+  float tot_la = block_sum1(acc_la, red, nw);
+  float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < S; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float t = L.gpv[j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
+  // rotation path (action[3:6]): the reference's d|w|/dw at w = 0 is NaN and nan_to_num zeroes it here -> 0
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
+  if (a.clip) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { ga[d] = nan_to_num(ga[d] + 0.f); n2 += ga[d] * ga[d]; }
+    const float nrm = sqrtf(n2);
+    if (!(nrm < 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) ga[d] = ga[d] / nrm;
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = nan_to_num(gx[d] + 0.f); gv[d] = nan_to_num(gv[d] + 0.f); }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = nan_to_num(gC[d] + 0.f); gF[d] = nan_to_num(gF[d] + 0.f); }
+    if (live && qi == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) s2 += gx[d] * gx[d] + gv[d] * gv[d];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) s2 += gC[d] * gC[d] + gF[d] * gF[d];
+    }
+    if (tid < S * 3) { const float t = nan_to_num(L.gppos[tid] + 0.f); L.gppos[tid] = t; s2 += t * t; }
+    tot_fric = nan_to_num(tot_fric); tot_mu = nan_to_num(tot_mu); tot_la = nan_to_num(tot_la);
+    if (tid == 0) {
+      s2 += tot_fric * tot_fric + tot_mu * tot_mu + tot_la * tot_la;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+    }
+    const float sn = sqrtf(block_sum1(s2, red, nw));
+    if (!(sn < 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gx[d] = gx[d] / sn; gv[d] = gv[d] / sn; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gC[d] = gC[d] / sn; gF[d] = gF[d] / sn; }
+      if (tid < S * 3) L.gppos[tid] = L.gppos[tid] / sn;
+      tot_fric = tot_fric / sn; tot_mu = tot_mu / sn; tot_la = tot_la / sn;
+    }
+  }
+  if (live && qi == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.gx0[((size_t)b * N + p) * 3 + d] = gx[d]; a.gv0[((size_t)b * N + p) * 3 + d] = gv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { a.gC0[((size_t)b * N + p) * 9 + d] = gC[d]; a.gF0[((size_t)b * N + p) * 9 + d] = gF[d]; }
+  }
+  if (tid < S * 3) a.gppos0[(size_t)b * S * 3 + tid] = L.gppos[tid];
+  if (tid == 0) {
+    a.gfric[b] = tot_fric; a.gmu[b] = tot_mu; a.glam[b] = tot_la;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a.gaction[b * 6 + d] = ga[d];
+  }
+  const int bad = __syncthreads_or(ok ? 0 : 1);
+  if (tid == 0 && a.status) a.status[b] = bad ? 1 : 0;
+}
+
+}  // namespace ud
+
+// ------------------------------------------------------------------------------------------------
+// host side: handle + C ABI
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+
+struct ud_mpm {
+  ud::MpmConst c;
+  int device = 0;
+  int* d_material = nullptr;
+  float* d_hard = nullptr;
+  size_t lds_fwd = 0, lds_bwd = 0;
+};
+
+extern "C" {
+
+int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* hardness, ud_mpm** out) {
+  if (!conf || !material || !hardness || !out) { ud::set_error("ud_mpm_create: null argument"); return UD_ERR_INVALID; }
+  const int N = conf->n_particles, S = conf->steps;
+  if (N < 1 || S < 1 || conf->n_grid < 4 || conf->res[0] < 4 || conf->res[1] < 4 || conf->res[2] < 4) {
+    ud::set_error("ud_mpm_create: bad sizes (N=%d steps=%d n_grid=%d)", N, S, conf->n_grid); return UD_ERR_INVALID;
+  }
+  if (!conf->use_position_control) {
+    ud::set_error("ud_mpm_create: only position-control primitives are implemented (collide_batch is a next row)");
+    return UD_ERR_UNSUPPORTED;
+  }
+  if (N > 128) {
+    ud::set_error("ud_mpm_create: N=%d > 128 particles per env needs the multi-workgroup path (not built yet)", N);
+    return UD_ERR_UNSUPPORTED;
+  }
+  if (S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
+  auto* h = new ud_mpm;
+  ud::MpmConst& c = h->c;
+  c.N = N; c.Np = (N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.steps = S;
+  for (int d = 0; d < 3; ++d) c.res[d] = conf->res[d];
+  const double dx = 1.0 / conf->n_grid;
+  c.dt = conf->dt; c.dx = (float)dx; c.inv_dx = (float)(double)conf->n_grid;
+  c.p_mass = conf->p_mass; c.p_vol = conf->p_vol;
+  c.stress_c = (float)(-(double)conf->dt * (double)conf->p_vol * 4.0);   // :267
+  c.dx2 = (float)(dx * dx);
+  for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
+  int Hh = 1024, lg = 10;
+  while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
+  c.H = Hh; c.logH = lg;
+  c.nthreads = std::max(256, (4 * N + 63) / 64 * 64);
+  h->lds_fwd = ((size_t)5 * Hh + (size_t)S * 7 + 64) * sizeof(float);
+  h->lds_bwd = ((size_t)12 * Hh + (size_t)S * 16 + 64) * sizeof(float);
+  if (h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_material, N * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_hard, N * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->d_material, material, N * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_hard, hardness, N * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::mpm_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fwd);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::mpm_step_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bwd);
+  if (e != hipSuccess) {
+    ud::set_error("ud_mpm_create: %s", hipGetErrorString(e));
+    if (h->d_material) (void)hipFree(h->d_material);
+    if (h->d_hard) (void)hipFree(h->d_hard);
+    delete h;
+    return UD_ERR_HIP;
+  }
+  *out = h;
+  return UD_OK;
+}
+
+void ud_mpm_destroy(ud_mpm* h) {
+  if (!h) return;
+  (void)hipFree(h->d_material);
+  (void)hipFree(h->d_hard);
+  delete h;
+}
+
+size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B) {
+  if (!h || B < 0) return 0;
+  return (size_t)B * ((size_t)h->c.steps * 24 * h->c.Np + (size_t)h->c.steps * 10) * sizeof(float);
+}
+
+int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
+                    const float* prim_position, const float* prim_rotation, const float* prim_size,
+                    const float* friction, const float* mu, const float* lamda, const float* action, float* x_out,
+                    float* v_out, float* C_out, float* F_out, float* J_out, float* prim_position_out,
+                    float* prim_rotation_out, float* prim_v_out, float* prim_w_out, void* ckpt, int* status,
+                    void* stream) {
+  if (!h || !x || !v || !C || !F || !J || !prim_position || !prim_rotation || !prim_size || !friction || !mu || !lamda ||
+      !action || !x_out || !v_out || !C_out || !F_out || !J_out || !prim_position_out || !prim_rotation_out ||
+      !prim_v_out || !prim_w_out) {
+    ud::set_error("ud_mpm_step_fwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1) { ud::set_error("ud_mpm_step_fwd: B=%d", B); return UD_ERR_INVALID; }
+  ud::MpmFwdArgs a;
+  a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B;
+  a.x = x; a.v = v; a.C = C; a.F = F; a.J = J; a.ppos = prim_position; a.prot = prim_rotation; a.psize = prim_size;
+  a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
+  a.xo = x_out; a.vo = v_out; a.Co = C_out; a.Fo = F_out; a.Jo = J_out; a.ppos_o = prim_position_out;
+  a.prot_o = prim_rotation_out; a.pv_o = prim_v_out; a.pw_o = prim_w_out; a.ckpt = (float*)ckpt; a.status = status;
+  hipLaunchKernelGGL(ud::mpm_step_fwd_kernel, dim3(B), dim3(h->c.nthreads), h->lds_fwd, (hipStream_t)stream, a);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, const float* friction,
+                    const float* mu, const float* lamda, const float* action, const float* g_x, const float* g_v,
+                    const float* g_C, const float* g_F, const float* g_prim_position, int clip, float* g_x0,
+                    float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_friction, float* g_mu,
+                    float* g_lamda, float* g_action, int* status, void* stream) {
+  if (!h || !ckpt || !prim_size || !friction || !mu || !lamda || !action || !g_x || !g_v || !g_C || !g_F ||
+      !g_prim_position || !g_x0 || !g_v0 || !g_C0 || !g_F0 || !g_prim_position0 || !g_friction || !g_mu || !g_lamda ||
+      !g_action) {
+    ud::set_error("ud_mpm_step_bwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1) { ud::set_error("ud_mpm_step_bwd: B=%d", B); return UD_ERR_INVALID; }
+  ud::MpmBwdArgs a;
+  a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B; a.ckpt = (const float*)ckpt;
+  a.psize = prim_size; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
+  a.gx = g_x; a.gv = g_v; a.gC = g_C; a.gF = g_F; a.gppos = g_prim_position; a.clip = clip;
+  a.gx0 = g_x0; a.gv0 = g_v0; a.gC0 = g_C0; a.gF0 = g_F0; a.gppos0 = g_prim_position0; a.gfric = g_friction;
+  a.gmu = g_mu; a.glam = g_lamda; a.gaction = g_action; a.status = status;
+  hipLaunchKernelGGL(ud::mpm_step_bwd_kernel, dim3(B), dim3(h->c.nthreads), h->lds_bwd, (hipStream_t)stream, a);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+"""SimpleMPMSimulator -- host-side mirror of the reference's MLS-MPM simulator over the HIP kernels.
+
+Mirrors /root/reference/DaXBench/daxbench/core/engine/mpm_simulator.py:
+    MPMState                        :13-24
+    SimpleMPMSimulator.__init__     :27-63   (same arguments / attributes: material, h, n_particles, key_global)
+    add_box / add_box_from_points   :65-145  (lattice seeding for material != 0; liquids use uniform sampling)
+    reset_jax(state)                :152-172
+    step_jax(state, action)         :61-63, :413-429  one `step` = conf.steps substeps for the whole batch
+All physics runs in libunidom_hip.so (csrc/mpm.hip), one launch per `step`; torch provides device memory,
+streams and the autograd hook (forward kernel + adjoint kernel as one torch.autograd.Function).
+The reference's mutable attributes material / h / n_particles (set during add_box / reset) become constants of
+the kernel handle, which is created at reset_jax().
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, NamedTuple
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..utils import prng
+from .primitives.primitives import PrimitiveState
+
+
+class MPMState(NamedTuple):  # mpm_simulator.py:13-24
+    x: torch.Tensor = None
+    v: torch.Tensor = None
+    C: torch.Tensor = None
+    F: torch.Tensor = None
+    J: torch.Tensor = None
+    cur_step: torch.Tensor = None
+    primitives: List[PrimitiveState] = []
+    key: np.ndarray = None
+    friction: torch.Tensor = None
+    mu: torch.Tensor = None
+    lamda: torch.Tensor = None
+
+
+class _Step(torch.autograd.Function):
+    """forward = ud_mpm_step_fwd, backward = ud_mpm_step_bwd (include/unidom_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, sim, x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action):
+        L = _lib.lib()
+        B, N, S = x.shape[0], sim.n_particles, sim.conf.steps
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action = map(
+            f32, (x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action))
+        assert x.shape == (B, N, 3) and Cm.shape == (B, N, 3, 3) and J.shape == (B, N)
+        assert ppos.shape == (B, S, 3) and prot.shape == (B, S, 4) and psize.shape == (B, 3) and action.shape == (B, 6)
+        ctx.pshape = (tuple(friction.shape), tuple(mu.shape), tuple(lamda.shape))
+        friction, mu, lamda = friction.reshape(B).contiguous(), mu.reshape(B).contiguous(), lamda.reshape(B).contiguous()
+        dev = x.device
+        xo, vo, Co, Fo, Jo = (torch.empty_like(t) for t in (x, v, Cm, F, J))
+        ppo, pro = torch.empty_like(ppos), torch.empty_like(prot)
+        pvo, pwo = torch.empty((B, S, 3), device=dev), torch.empty((B, S, 3), device=dev)
+        ckpt = None
+        if any(ctx.needs_input_grad):
+            ckpt = torch.empty((L.ud_mpm_ckpt_bytes(sim._h, C.c_int(B)) // 4,), dtype=torch.float32, device=dev)
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ev = sim._prof_begin("fwd")
+        _lib.check(L.ud_mpm_step_fwd(
+            sim._h, C.c_int(B), *[_lib.ptr(t) for t in (x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action)],
+            *[_lib.ptr(t) for t in (xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo)], _lib.ptr(ckpt), _lib.ptr(status), stream),
+            "ud_mpm_step_fwd")
+        sim._prof_end(ev)
+        sim.status_log.append(status)
+        ctx.sim, ctx.B = sim, B
+        ctx.save_for_backward(ckpt, psize, friction, mu, lamda, action)
+        ctx.mark_non_differentiable(Jo, pro, pvo, pwo)
+        return xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo
+
+    @staticmethod
+    def backward(ctx, gx, gv, gC, gF, gJ, gppos, gprot, gpv, gpw):
+        L = _lib.lib()
+        sim, B = ctx.sim, ctx.B
+        ckpt, psize, friction, mu, lamda, action = ctx.saved_tensors
+        if ckpt is None:
+            raise _lib.UnidomError("MPM step backward without a checkpoint (forward ran under no_grad)")
+        N, S, dev = sim.n_particles, sim.conf.steps, psize.device
+        z = lambda t, shape: (torch.zeros(shape, device=dev) if t is None else t.to(torch.float32).contiguous())
+        gx, gv, gC, gF = z(gx, (B, N, 3)), z(gv, (B, N, 3)), z(gC, (B, N, 3, 3)), z(gF, (B, N, 3, 3))
+        gppos = z(gppos, (B, S, 3))
+        ox, ov, oC, oF, opp = (torch.empty_like(t) for t in (gx, gv, gC, gF, gppos))
+        ofr, omu, ola = (torch.empty((B,), device=dev) for _ in range(3))
+        oa = torch.empty((B, 6), device=dev)
+        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ev = sim._prof_begin("bwd")
+        _lib.check(L.ud_mpm_step_bwd(
+            sim._h, C.c_int(B), _lib.ptr(ckpt), *[_lib.ptr(t) for t in (psize, friction, mu, lamda, action)],
+            *[_lib.ptr(t) for t in (gx, gv, gC, gF, gppos)], C.c_int(1 if sim.clip_grad else 0),
+            *[_lib.ptr(t) for t in (ox, ov, oC, oF, opp, ofr, omu, ola, oa)], _lib.ptr(status), stream), "ud_mpm_step_bwd")
+        sim._prof_end(ev)
+        sim.status_log.append(status)
+        fs, ms, ls = ctx.pshape
+        return (None, ox, ov, oC, oF, None, opp, None, None, ofr.reshape(fs), omu.reshape(ms), ola.reshape(ls), oa)
+
+
+class SimpleMPMSimulator:
+    def __init__(self, conf, batch_size, use_position_control=False, device="cuda"):
+        self.conf = conf
+        self.key_global = None
+        self.batch_size = batch_size
+        self.ground_friction = conf.ground_friction
+        self.res = tuple(conf.res)
+        self.dt = conf.dt
+        self.dx = conf.dx
+        self.inv_dx = conf.inv_dx
+        self.p_mass = conf.p_mass
+        self.p_vol = conf.p_vol
+        self.gravity = conf.gravity
+        self.key = getattr(conf, "key", None)
+        self.n_particles = 0
+        self.n_grid = conf.n_grid
+        self.use_position_control = use_position_control
+        self.device = torch.device(device)
+        self.material = None
+        self.h = None
+        self.clip_grad = True            # norm_grad_state / norm_grad (:375-411)
+        self.profile = None
+        self.status_log = []
+        self._h = None
+
+    # -- particle seeding (:65-145) ----------------------------------------------------------------------
+    def add_box(self, conf, state, size, init_pos, hardness=1, z_rotation_angle=0, material=0, density=1):
+        assert density >= 1
+        size, init_pos = np.asarray(size, np.float32), np.asarray(init_pos, np.float32)
+        c, s = np.float32(np.cos(z_rotation_angle)), np.float32(np.sin(z_rotation_angle))
+        rot = np.array([[c, -s], [s, c]], np.float32)
+        if material == 0:                                            # :87-91 (uniform; jax sampler: utils/prng.uniform)
+            n_points = int(size.prod() * conf.n_grid ** 3 * density)
+            u = prng.uniform(np.asarray(conf.key, np.uint32), n_points * 3).reshape(n_points, 3)
+            x_ = (u * 2 - 1) * (np.float32(0.5) * size)
+        else:                                                        # :94-109 lattice
+            n_grid = int(conf.n_grid * density)
+            center = np.array([0.5, 0.01, 0.5], np.float32)
+            lower = (np.zeros(3, np.float32) * 2 - 1) * (np.float32(0.5) * size) + center
+            upper = (np.ones(3, np.float32) * 2 - 1) * (np.float32(0.5) * size) + center
+            a, b, cc = np.indices((n_grid, n_grid, n_grid))
+            grid_idx = np.stack([a, b, cc], -1).astype(np.float32) * np.float32(1.0) / np.float32(n_grid)
+            mask = ((grid_idx <= upper) & (grid_idx >= lower)).all(-1)
+            x_ = grid_idx[mask] - center
+        x_ = x_.astype(np.float32)
+        x_[:, [0, 2]] = x_[:, [0, 2]] @ rot.T
+        x_ = x_ + init_pos
+        return self._append(state, torch.tensor(x_, device=self.device), material, hardness)
+
+    def add_box_from_points(self, conf, state, points, hardness=1, material=0):
+        return self._append(state, torch.as_tensor(points, dtype=torch.float32, device=self.device), material, hardness)
+
+    def _append(self, state, x_, material, hardness):
+        n = x_.shape[0]
+        mat, hh = np.full((n,), material, np.int32), np.full((n,), hardness, np.float32)
+        if state is None:
+            self.material, self.h = mat, hh
+        else:
+            x_ = torch.cat((state.x, x_), 0)
+            self.material, self.h = np.concatenate((self.material, mat)), np.concatenate((self.h, hh))
+        return MPMState(x=x_, primitives=[] if state is None else list(state.primitives))
+
+    # -- reset (:152-172): also the point where the kernel handle is built ---------------------------------
+    def reset_jax(self, state: MPMState) -> MPMState:
+        self.n_particles = N = state.x.shape[0]
+        B, dev = self.batch_size, self.device
+        conf = self.conf
+        E, nu = conf.E, conf.nu
+        mu_0, lambda_0 = E / (2 * (1 + nu)), E * nu / ((1 + nu) * (1 - 2 * nu))
+        rep = lambda t: t[None].repeat((B,) + (1,) * t.dim()).contiguous()
+        prims = [PrimitiveState(*[rep(torch.as_tensor(f).to(dev)) for f in p]) for p in state.primitives]
+        key_global = self.key_global if self.key_global is not None else prng.PRNGKey(0)
+        out = MPMState(
+            x=rep(state.x.to(dev)), v=torch.zeros((B, N, 3), device=dev), C=torch.zeros((B, N, 3, 3), device=dev),
+            F=rep(torch.eye(3, device=dev)[None].repeat(N, 1, 1)), J=torch.ones((B, N), device=dev),
+            cur_step=torch.zeros((B,), dtype=torch.int32, device=dev), primitives=prims,
+            key=prng.split(key_global, B),
+            friction=torch.full((B, 1), float(conf.ground_friction), device=dev),
+            mu=torch.full((B, 1), float(mu_0), device=dev), lamda=torch.full((B, 1), float(lambda_0), device=dev))
+        self._make_handle()
+        return out
+
+    def _make_handle(self):
+        if self._h is not None:
+            _lib.lib().ud_mpm_destroy(self._h)
+        conf = self.conf
+        g = [float(v) for v in np.asarray(conf.gravity, dtype=np.float64).reshape(3)]
+        cc = _lib.ud_mpm_conf(n_particles=self.n_particles, n_grid=int(conf.n_grid), res=(C.c_int * 3)(*self.res),
+                              steps=int(conf.steps), dt=float(conf.dt), p_mass=float(conf.p_mass), p_vol=float(conf.p_vol),
+                              gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)))
+        mat = np.ascontiguousarray(self.material, dtype=np.int32)
+        hh = np.ascontiguousarray(self.h, dtype=np.float32)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ud_mpm_create(C.byref(cc), mat.ctypes.data_as(C.c_void_p),
+                                                hh.ctypes.data_as(C.c_void_p), C.byref(self._h)), "ud_mpm_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().ud_mpm_destroy(self._h)
+        except Exception:
+            pass
+
+    def _prof_begin(self, kind):
+        if self.profile is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(self.device))
+        return (kind, a, b)
+
+    def _prof_end(self, ev):
+        if ev is not None:
+            ev[2].record(torch.cuda.current_stream(self.device))
+            self.profile[ev[0]].append((ev[1], ev[2]))
+
+    def check_status(self):
+        """Host sync: raise if any launch since the last check overflowed its LDS cell table."""
+        if self.status_log:
+            bad = torch.stack(self.status_log).sum().item()
+            self.status_log = []
+            if bad:
+                raise _lib.UnidomError("MPM LDS cell table overflow (UD_ERR_OVERFLOW): particle cloud too spread out")
+
+    # -- the hot path --------------------------------------------------------------------------------------
+    def step_jax(self, state: MPMState, action):
+        """One `step` for the batch: (state, action[B, 6*n_primitive]) -> (state, state)   (:413-429)."""
+        if self._h is None:
+            raise _lib.UnidomError("reset_jax() must run before step_jax() (it fixes n_particles / material / h)")
+        if len(state.primitives) != 1:
+            raise NotImplementedError("exactly one primitive is supported this round")
+        p = state.primitives[0]
+        if len(self.status_log) > 256:
+            self.status_log = self.status_log[-8:]
+        xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo = _Step.apply(
+            self, state.x, state.v, state.C, state.F, state.J, p.position, p.rotation, p.size, state.friction,
+            state.mu, state.lamda, action[:, :6])
+        a = action[:, :6].clamp(-1, 1)
+        p2 = p._replace(position=ppo, rotation=pro, v=pvo, w=pwo, action_buffer=a)
+        new = state._replace(x=xo, v=vo, C=Co, F=Fo, J=Jo, primitives=[p2])
+        return new, new
