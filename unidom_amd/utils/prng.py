@@ -86,3 +86,8 @@ def normal(key: np.ndarray, n: int) -> np.ndarray:
     lo = np.nextafter(np.float32(-1.0), np.float32(0.0))
     u = uniform(key, n, lo, 1.0)
     return (np.float32(np.sqrt(2)) * erfinv(u.astype(np.float64)).astype(np.float32)).astype(np.float32)
+
+
+def normal_batch(keys: np.ndarray, n: int) -> np.ndarray:
+    """vmap(lambda k: normal(k, (n,)))(keys): keys [B,2] -> [B,n]."""
+    return np.stack([normal(k, n) for k in np.asarray(keys, dtype=np.uint32)])
