@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-mode", type=int, default=0,
+                    help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
     args = ap.parse_args()
 
     from unidom_amd.algorithms.apg.core import APG, init_distributed
@@ -80,7 +82,10 @@ def main():
     rank, world, device = init_distributed(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, seed=0, aux_reward=True, device=device)
+    from unidom_amd.envs.fold_cloth1_env import DefaultConf
+    conf = DefaultConf()
+    conf.kernel_mode = args.kernel_mode
+    env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, conf=conf, seed=0, aux_reward=True, device=device)
     learner = APG(env, EP_LEN, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
     key_env = prng.split(prng.PRNGKey(0), world)[rank]
     _, state = env.reset(key_env)
@@ -122,22 +127,24 @@ def main():
         units = world * NUM_ENVS_PER_GPU * EP_LEN * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
+        kname = {"fwd": "cloth_rollout_fwd_fast_kernel" if args.kernel_mode == 2 else "cloth_rollout_fwd_kernel",
+                 "bwd": "cloth_rollout_bwd_kernel" if args.kernel_mode == 1 else "cloth_rollout_bwd_fast_kernel"}[dom]
         per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
-            traffic = json.load(open(tj)).get("cloth_rollout_%s_kernel" % dom, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tj)).get(kname, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "fold_cloth1 (mass-spring cloth, P=512) APG loss+grad+update: num_envs=4 per GPU, "
                                    "ep_len=3, 40 macro x 50 substeps per step_diff",
-                       "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
+                       "kernel_mode": args.kernel_mode, "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
                        "parallelism": f"env-sharded dp{world}, 1 RCCL all-reduce of {learner.n_params} f32 per update"},
             "fwd_only_substeps_per_sec": units / dt_fwd,
-            "roofline": {"bound": "hbm", "kernel": f"cloth_rollout_{dom}_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
                          "note": "latency/occupancy bound: 4 envs = 4 workgroups on 256 CUs, 2000 sequential substeps"},

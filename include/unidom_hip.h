@@ -54,6 +54,11 @@ typedef struct {
   float max_v;     /* 2.0                                  :23 */
   float small_num; /* 1e-8                                 :24 */
   int substeps;    /* 50 = fori_loop bound                 cloth_simulator.py:176 */
+  int mode;        /* 0 (default): forward in the reference's f32 operation order (bit-identical to the CPU
+                    *    restatement) + restructured adjoint kernel (one reduction round per substep);
+                    * 1: reference-order forward AND reference-order adjoint (six reductions per substep);
+                    * 2: restructured fast-math forward + restructured adjoint (f32 round-off differences,
+                    *    which this stiff system amplifies over long rollouts -- see DESIGN.md) */
 } ud_cloth_conf;
 
 /* mask: host pointer, N*N bytes, row-major, non-zero = cloth particle (create_cloth_mask,

@@ -28,7 +28,7 @@ class UnidomError(RuntimeError):
 
 class ud_cloth_conf(C.Structure):
     _fields_ = [("N", C.c_int), ("gravity", C.c_float), ("damping", C.c_float), ("dt", C.c_float),
-                ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int)]
+                ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int), ("mode", C.c_int)]
 
 
 class ud_mpm_conf(C.Structure):

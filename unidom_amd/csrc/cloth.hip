@@ -16,43 +16,9 @@
 // Forward arithmetic keeps the reference's operation order and is compiled with -ffp-contract=off and
 // correctly rounded f32 divide/sqrt, so it is bit-identical to the CPU restatement (the grasp test
 // |x - pos| <= radius is a discrete event).
-#include "common.h"
+#include "cloth_common.h"
 
 namespace ud {
-
-struct ClothConst {
-  float gdt;      // float(gravity*dt)        :259
-  float g;        // gravity                  :278
-  float dt;
-  float damp;     // exp(-damping*dt) in f32  :309
-  float max_v;
-  float eps;      // small_num
-  float n_mask;   // cloth_mask.sum()         :192
-  int P, Pp, S;
-};
-
-struct ClothFwdArgs {
-  ClothConst c;
-  const int* nbr;      // [8][Pp]
-  const float* L0;     // [8][Pp]
-  int B, T;
-  const float *x, *v, *prim, *k, *mu, *actions;
-  float *x_out, *v_out, *prim_out, *x_list, *v_list, *prim_list;
-  float* ckpt;
-  uint8_t* grasp;
-};
-
-struct ClothBwdArgs {
-  ClothConst c;
-  const int* nbr;
-  const float* L0;
-  int B, T;
-  const float* ckpt;
-  const float *k, *mu, *actions;
-  const float *g_x, *g_v, *g_prim, *g_x_list, *g_v_list, *g_prim_list;
-  int normalize;
-  float *g_x0, *g_v0, *g_prim0, *g_actions, *g_k, *g_mu;
-};
 
 // per-particle intermediates of one forward substep that the adjoint needs
 struct Inter {
@@ -196,7 +162,7 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_fwd_kernel(ClothFwdArgs a)
       float* X = lds + (step & 1u) * 3 * Pp;
       X[i] = x[0]; X[Pp + i] = x[1]; X[2 * Pp + i] = x[2];
       if (a.ckpt) {
-        float* r = a.ckpt + (((size_t)b * T + t) * S + s) * rec;
+        float* r = a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)t * S + s) * rec;
 #pragma unroll
         for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
         if (i == 0) {
@@ -236,6 +202,15 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_fwd_kernel(ClothFwdArgs a)
   if (i == 0) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) a.prim_out[b * 8 + d] = ps[d];
+  }
+  if (a.ckpt) {  // final record (the fast backward derives the velocity-clip mask of the last substep from it)
+    float* r = a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)T * S) * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+    if (i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+    }
   }
 }
 
@@ -292,7 +267,7 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a)
   const float k = a.k[b], mu = a.mu[b];
   float gk = 0.f, gmu = 0.f;
   const size_t rec = (size_t)6 * Pp + 8;
-  const float* ck = a.ckpt + (size_t)b * T * S * rec;
+  const float* ck = a.ckpt + (size_t)b * ((size_t)T * S + 1) * rec;
   // prefetch the last record
   float nx[3], nv[3], nps[8];
   {
@@ -489,6 +464,7 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a)
 
 struct ud_cloth {
   ud::ClothConst c;
+  int mode = 0;   // ud_cloth_conf.mode
   int device = 0;
   int* d_nbr = nullptr;
   float* d_L0 = nullptr;
@@ -533,6 +509,9 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   h->c.eps = conf->small_num;
   h->c.n_mask = (float)P;
   h->c.P = P; h->c.Pp = Pp; h->c.S = conf->substeps;
+  h->c.cell = (float)(1.0 / N);
+  h->mode = conf->mode;
+  if (h->mode < 0 || h->mode > 2) { ud::set_error("ud_cloth_create: mode must be 0, 1 or 2"); delete h; return UD_ERR_INVALID; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_nbr, nbr.size() * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_L0, L0.size() * sizeof(float));
@@ -560,7 +539,7 @@ int ud_cloth_num_particles(const ud_cloth* h) { return h ? h->c.P : UD_ERR_INVAL
 
 size_t ud_cloth_ckpt_bytes(const ud_cloth* h, int B, int T) {
   if (!h || B < 0 || T < 0) return 0;
-  return (size_t)B * T * h->c.S * ((size_t)6 * h->c.Pp + 8) * sizeof(float);
+  return (size_t)B * ud::cloth_env_records(T, h->c.S) * ud::cloth_rec_floats(h->c.Pp) * sizeof(float);
 }
 
 int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float* v, const float* prim,
@@ -577,7 +556,9 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   a.x_out = x_out; a.v_out = v_out; a.prim_out = prim_out; a.x_list = x_list; a.v_list = v_list;
   a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
-  if (h->c.Pp <= 512)
+  if (h->mode == 2 && h->c.Pp <= 512)
+    ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
+  else if (h->c.Pp <= 512)
     hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<1024>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
@@ -602,7 +583,9 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
   a.g_prim_list = g_prim_list; a.normalize = normalize;
   a.g_x0 = g_x0; a.g_v0 = g_v0; a.g_prim0 = g_prim0; a.g_actions = g_actions; a.g_k = g_stiffness; a.g_mu = g_mu;
   const size_t shmem = ((size_t)6 * h->c.Pp + 192 + 128) * sizeof(float);
-  if (h->c.Pp <= 512)
+  if (h->mode != 1 && h->c.Pp <= 512)
+    ud::cloth_launch_bwd_fast(a, (hipStream_t)stream);
+  else if (h->c.Pp <= 512)
     hipLaunchKernelGGL(ud::cloth_rollout_bwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(ud::cloth_rollout_bwd_kernel<1024>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);

@@ -1,0 +1,480 @@
+// Fast cloth rollout kernels for gfx950 (the default path; the reference-operation-order kernels are in cloth.hip).
+//
+// Same mapping as cloth.hip (one workgroup per env, one particle per lane, whole T x substeps rollout in one
+// launch, per-substep checkpoints in HBM) but the arithmetic is restructured for the CU, not for bit-identity:
+//   forward   the spring force is evaluated as  f = r * (k/L0 - k/|r|)  (= k r/|r| (|r|-L0)/L0 of
+//             cloth_simulator.py:267-268) with v_rsq_f32, i.e. 1 transcendental + 4 FMAs per link and component
+//             triple instead of 6 IEEE divisions + 1 IEEE sqrt; x is staged as float4 in LDS (one ds_read_b128
+//             per neighbour); the dead static-friction branch (:293-306, never taken because
+//             sqrt(.+small_num) > small_num) is dropped; FMA contraction is on.
+//   backward  the reference normalises cotangents six times per substep (norm_grad, :189-194, applied at
+//             :223-224 twice and :331-334).  Every map between two normalisations is linear, so all six norms
+//             are functions of NINE block-wide sums of the incoming cotangent that can be taken BEFORE the
+//             stencil barrier: |gx|^2, |gv|^2, |Dx gx|^2, |Dv gv|^2, <Dv gv, Dv gx>, |Dv gx|^2 and the last three
+//             restricted to the particles gripper 1 holds (Dx, Dv = the clip masks of :326-327; Dv is read off
+//             the NEXT checkpoint record, whose v is clip(v5)).  That turns 3 dependent reduction rounds + 6
+//             barriers per substep into 1 round + 2 barriers.
+// Results agree with the reference-order kernels / the CPU oracle to f32 round-off (tests/test_cloth_gpu.py,
+// tolerances written there); the discrete grasp test |x - pos| <= radius keeps its exact form.
+#include "cloth_common.h"
+
+namespace ud {
+
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  // cloth_simulator.py:168-169
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    act[g * 4 + 3] = a8[g * 4 + 3];
+  }
+}
+
+struct FastInter {
+  float F1, cF, muF, xV, yV, isV, tf;   // friction block
+  float v3[3], v4[3];
+};
+
+// grippers, own-particle part only (:198-226): masks and displaced positions
+__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, bool& m0, bool& m1, float* x2) {
+  float d0 = x[0] - ps[0], d1 = x[1] - ps[1], d2 = x[2] - ps[2];
+  m0 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[3];
+  float x1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x1[a] = m0 ? x[a] + act[a] * (1.f - act[3]) : x[a];
+  d0 = x1[0] - ps[4]; d1 = x1[1] - ps[5]; d2 = x1[2] - ps[6];
+  m1 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[7];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x2[a] = m1 ? x1[a] + act[4 + a] * (1.f - act[7]) : x1[a];
+}
+
+// spring + gravity + ground friction + damping: (x, v, neighbours in X4) -> v3 ; keeps the adjoint's inputs
+template <bool KEEP>
+__device__ __forceinline__ void force_fast(const ClothConst& c, int i, const int* nb, const float4* X4, float k, float kLs,
+                                           float kLd, float mu, const float* x, const float* v, float* v3, FastInter* in) {
+  float F0 = 0.f, F1 = 0.f, F2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const int j = nb[l];
+    const bool ok = j >= 0;
+    const float4 xj = X4[ok ? j : i];
+    const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
+    const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+    const float inv = rsq(fmaxf(s2, 1e-12f));
+    float coef = ((l < 4) ? kLs : kLd) - k * inv;
+    coef = ok ? coef : 0.f;
+    F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
+  }
+  F1 -= c.g;                                        // :278
+  const float v1y = v[1] - c.gdt;                   // :259
+  const bool fm = x[1] <= c.eps;                    // :281
+  const float cF = fminf(F1, 0.f);
+  const float muF = -(mu * cF);                     // :282
+  const float xV = v[0], yV = v[2];
+  const float isV = rsq(xV * xV + yV * yV + c.eps); // :285
+  const float tf = fm ? muF * isV : 0.f;            // :288-290 (sV > small_num always holds)
+  const float Ax = F0 - tf * xV, Az = F2 - tf * yV;
+  v3[0] = (xV + Ax * c.dt) * c.damp;                // :308-309
+  v3[1] = (v1y + F1 * c.dt) * c.damp;
+  v3[2] = (yV + Az * c.dt) * c.damp;
+  if (KEEP) { in->F1 = F1; in->cF = cF; in->muF = muF; in->xV = xV; in->yV = yV; in->isV = isV; in->tf = tf; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArgs a) {
+  extern __shared__ float4 lds4[];  // [2][Pp]
+  const ClothConst c = a.c;
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const bool live = i < P;
+  int nb[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = a.x[((size_t)b * P + i) * 3 + d]; v[d] = a.v[((size_t)b * P + i) * 3 + d]; }
+  }
+  float ps[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  const float kLs = k / c.cell, kLd = k / (c.cell * sqrtf(2.0f));
+  const size_t rec = cloth_rec_floats(Pp);
+  float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
+  unsigned step = 0;
+  for (int t = 0; t < T; ++t) {
+    float act[8];
+    macro_action_f(a.actions + ((size_t)t * B + b) * 8, act);
+    for (int s = 0; s < S; ++s, ++step) {
+      float4* X4 = lds4 + (step & 1u) * Pp;
+      X4[i] = make_float4(x[0], x[1], x[2], 0.f);
+      if (ckb) {
+        float* r = ckb + (size_t)step * rec;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+        if (i == 0) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+        }
+      }
+      __syncthreads();
+      float vv[3], x2[3];
+      bool m0, m1;
+      FastInter dummy;
+      force_fast<false>(c, i, nb, X4, k, kLs, kLd, mu, x, v, vv, &dummy);
+      grip_own(x, ps, act, m0, m1, x2);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        vv[d] = m0 ? act[3] * vv[d] : vv[d];
+        vv[d] = m1 ? act[7] * vv[d] : vv[d];
+      }
+      if (a.grasp && live) {
+        uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
+        g[i] = m0; g[P + i] = m1;
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ps[g * 4 + d] = clipf(ps[g * 4 + d] + (d < 3 ? act[g * 4 + d] : 0.f), 0.f, 1.f);  // :322-323
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {   // :326-329
+        const float vc = clipf(vv[d], -c.max_v, c.max_v);
+        x[d] = clipf(x2[d], 0.f, 1.f) + c.dt * vc;
+        v[d] = vc;
+      }
+    }
+    if (live) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.x_list) { a.x_list[o] = x[0]; a.x_list[o + 1] = x[1]; a.x_list[o + 2] = x[2]; }
+      if (a.v_list) { a.v_list[o] = v[0]; a.v_list[o + 1] = v[1]; a.v_list[o + 2] = v[2]; }
+    }
+    if (a.prim_list && i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) a.prim_list[((size_t)t * B + b) * 8 + d] = ps[d];
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.x_out[o + d] = x[d]; a.v_out[o + d] = v[d]; }
+  }
+  if (i == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.prim_out[b * 8 + d] = ps[d];
+  }
+  if (ckb) {
+    float* r = ckb + (size_t)T * S * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+    if (i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// wave-wide sum that leaves the total in lane 63 (row butterflies + row_bcast15 / row_bcast31)
+__device__ __forceinline__ float wave_sum_l63(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return v;
+}
+
+// 1 / (n_mask * sqrt(n2)) with norm_grad's nan_to_num semantics: a zero (or non-finite) norm zeroes the cotangent
+__device__ __forceinline__ float inv_norm(float n2, float n_mask) {
+  const bool okv = (n2 > 0.f) && (n2 < INFINITY);
+  return okv ? rsq(n2) / n_mask : 0.f;
+}
+
+#define UD_NSUM 9
+
+__global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArgs a) {
+  extern __shared__ float4 lds4[];  // X4[2][Pp] | G4[2][Pp] | red[2][16*UD_NSUM] | mac[16*8]
+  const ClothConst c = a.c;
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const int nw = Pp >> 6, lane = i & 63, wv = i >> 6;
+  const bool live = i < P;
+  const bool norm = a.normalize != 0;
+  float4* Xb = lds4;
+  float4* Gb = lds4 + 2 * Pp;
+  float* red = (float*)(lds4 + 4 * Pp);
+  float* mac = red + 2 * 16 * UD_NSUM;
+  int nb[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = a.g_x[((size_t)b * P + i) * 3 + d]; gv[d] = a.g_v[((size_t)b * P + i) * 3 + d]; }
+  }
+  float gp[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) gp[d] = a.g_prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  const float Ls = c.cell, Ld = c.cell * sqrtf(2.0f);
+  const float kLs = k / Ls, kLd = k / Ld, iLs = 1.f / Ls, iLd = 1.f / Ld;
+  float gk = 0.f, gmu = 0.f;
+  const size_t rec = cloth_rec_floats(Pp);
+  const float* ck = a.ckpt + (size_t)b * cloth_env_records(T, S) * rec;
+  // records: `cur` = input of the substep being reversed, `vnext` = v of the record after it (= clip(v5))
+  float vnext[3], nx[3], nv[3], nps[8];
+  {
+    const float* r = ck + (size_t)T * S * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) vnext[d] = r[(3 + d) * Pp + i];
+    r = ck + ((size_t)T * S - 1) * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+  }
+  unsigned step = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    if (live) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.g_x_list) { gx[0] += a.g_x_list[o]; gx[1] += a.g_x_list[o + 1]; gx[2] += a.g_x_list[o + 2]; }
+      if (a.g_v_list) { gv[0] += a.g_v_list[o]; gv[1] += a.g_v_list[o + 1]; gv[2] += a.g_v_list[o + 2]; }
+    }
+    if (a.g_prim_list) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) gp[d] += a.g_prim_list[((size_t)t * B + b) * 8 + d];
+    }
+    const float* a8 = a.actions + ((size_t)t * B + b) * 8;
+    float act[8], ga[8];
+    macro_action_f(a8, act);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ga[d] = 0.f;
+    for (int s = S - 1; s >= 0; --s, ++step) {
+      float x[3], v[3], ps[8];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = nx[d]; v[d] = nv[d]; }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ps[d] = nps[d];
+      {  // prefetch the record this loop consumes next
+        const long q = (long)t * S + s - 1;
+        const float* r = ck + (size_t)(q < 0 ? 0 : q) * rec;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+      }
+      const unsigned par = step & 1u;
+      float4* X4 = Xb + par * Pp;
+      float4* G4 = Gb + par * Pp;
+      float* rd = red + par * 16 * UD_NSUM;
+      X4[i] = make_float4(x[0], x[1], x[2], 0.f);
+      // ---- own-particle forward pieces and the nine sums (no neighbour data needed) ----
+      bool m0, m1;
+      float x2[3];
+      grip_own(x, ps, act, m0, m1, x2);
+      m0 = m0 && live; m1 = m1 && live;
+      float av[3], bv[3], bx[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float Dx = clip_grad(x2[d], 0.f, 1.f);
+        const float Dv = (fabsf(vnext[d]) < c.max_v) ? 1.f : 0.f;
+        av[d] = Dx * gx[d]; bv[d] = Dv * gv[d]; bx[d] = Dv * gx[d];
+      }
+      float sm[UD_NSUM];
+      sm[0] = gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2];
+      sm[1] = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2];
+      sm[2] = av[0] * av[0] + av[1] * av[1] + av[2] * av[2];
+      sm[3] = bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2];
+      sm[4] = bv[0] * bx[0] + bv[1] * bx[1] + bv[2] * bx[2];
+      sm[5] = bx[0] * bx[0] + bx[1] * bx[1] + bx[2] * bx[2];
+      sm[6] = m1 ? sm[3] : 0.f; sm[7] = m1 ? sm[4] : 0.f; sm[8] = m1 ? sm[5] : 0.f;
+      if (norm) {
+#pragma unroll
+        for (int q = 0; q < UD_NSUM; ++q) {
+          const float w = wave_sum_l63(sm[q]);
+          if (lane == 63) rd[wv * UD_NSUM + q] = w;
+        }
+      }
+      __syncthreads();   // barrier 1: X4 and the wave partials are visible
+      float sx = 1.f, sv = 1.f, sA = 1.f, sB = 1.f, s3x = 1.f, s3v = 1.f;   // cumulative scale factors
+      if (norm) {
+        float tot = 0.f;
+        if (lane < UD_NSUM) for (int q = 0; q < nw; ++q) tot += rd[q * UD_NSUM + lane];
+        float T_[UD_NSUM];
+#pragma unroll
+        for (int q = 0; q < UD_NSUM; ++q) T_[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), q));
+        sx = inv_norm(T_[0], c.n_mask);                                   // :331
+        sv = inv_norm(T_[1], c.n_mask);                                   // :332
+        const float cx = c.dt * sx;
+        const float n2x = sx * sx * T_[2];                                // |g_x2|^2
+        const float n2v = sv * sv * T_[3] + 2.f * sv * cx * T_[4] + cx * cx * T_[5];
+        sA = inv_norm(n2x, c.n_mask);                                     // :223 (gripper 1)
+        sB = inv_norm(n2v, c.n_mask);                                     // :224
+        const float n3x = sA * sA * n2x;
+        const float s1 = act[7];
+        const float nm = sv * sv * T_[6] + 2.f * sv * cx * T_[7] + cx * cx * T_[8];
+        const float n3v = sB * sB * (n2v - (1.f - s1 * s1) * nm);
+        s3x = inv_norm(n3x, c.n_mask);                                    // :223 (gripper 0)
+        s3v = inv_norm(fmaxf(n3v, 0.f), c.n_mask);                        // :224
+        // primitives (:333-334): 4-vector norms, uniform
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const float n2 = gp[g * 4] * gp[g * 4] + gp[g * 4 + 1] * gp[g * 4 + 1] + gp[g * 4 + 2] * gp[g * 4 + 2] + gp[g * 4 + 3] * gp[g * 4 + 3];
+          const float sc = inv_norm(n2, c.n_mask);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) gp[g * 4 + d] *= sc;
+        }
+      }
+      // ---- neighbour-dependent forward recompute ----
+      float v3[3], v4[3];
+      FastInter in;
+      force_fast<true>(c, i, nb, X4, k, kLs, kLd, mu, x, v, v3, &in);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v4[d] = m0 ? act[3] * v3[d] : v3[d];
+      // ---- reverse: clip (:326-329) and the two grippers (:313-314) with their normalisations folded in ----
+      float gx2n[3], gv5n[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        gx2n[d] = sA * (sx * av[d]);
+        gv5n[d] = sB * (sv * bv[d] + (c.dt * sx) * bx[d]);
+      }
+      {  // gripper 1
+        const float s1 = act[7];
+        float dotv = v4[0] * gv5n[0] + v4[1] * gv5n[1] + v4[2] * gv5n[2];
+        float dotx = gx2n[0] * act[4] + gx2n[1] * act[5] + gx2n[2] * act[6];
+        ga[7] += m1 ? (dotv - dotx) : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          ga[4 + d] += m1 ? gx2n[d] * (1.f - s1) : 0.f;
+          gv5n[d] = m1 ? s1 * gv5n[d] : gv5n[d];
+        }
+      }
+      float gxd[3], gv3[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gxd[d] = s3x * gx2n[d]; gv3[d] = s3v * gv5n[d]; }
+      {  // gripper 0
+        const float s0 = act[3];
+        float dotv = v3[0] * gv3[0] + v3[1] * gv3[1] + v3[2] * gv3[2];
+        float dotx = gxd[0] * act[0] + gxd[1] * act[1] + gxd[2] * act[2];
+        ga[3] += m0 ? (dotv - dotx) : 0.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          ga[d] += m0 ? gxd[d] * (1.f - s0) : 0.f;
+          gv3[d] = m0 ? s0 * gv3[d] : gv3[d];
+        }
+      }
+      // primitives (:322-323), uniform; counted once (lane 0) in the action accumulators
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float add = d < 3 ? act[g * 4 + d] : 0.f;
+          const float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
+          gp[g * 4 + d] = tt;
+          if (d < 3) ga[g * 4 + d] += (i == 0) ? tt : 0.f;
+        }
+      // ---- v3 = (v1 + F dt) damp ; ground friction (:281-290) ----
+      float gF[3];
+      {
+        const float g2x = gv3[0] * c.damp, g2y = gv3[1] * c.damp, g2z = gv3[2] * c.damp;
+        const float gAx = g2x * c.dt, gFy = g2y * c.dt, gAz = g2z * c.dt;
+        const float gt = -(gAx * in.xV + gAz * in.yV);
+        float gxV = -gAx * in.tf, gyV = -gAz * in.tf;
+        const bool fm = x[1] <= c.eps;
+        const float gmuF = fm ? gt * in.isV : 0.f;
+        const float gisV = fm ? gt * in.muF : 0.f;
+        const float gq = -0.5f * in.isV * in.isV * in.isV * gisV;
+        gxV += 2.f * in.xV * gq; gyV += 2.f * in.yV * gq;
+        gmu += live ? -gmuF * in.cF : 0.f;
+        const float gcF = -gmuF * mu;
+        const float cfm = (in.F1 < 0.f) ? 1.f : ((in.F1 == 0.f) ? 0.5f : 0.f);
+        gF[0] = live ? gAx : 0.f;
+        gF[1] = live ? gFy + gcF * cfm : 0.f;
+        gF[2] = live ? gAz : 0.f;
+        gv[0] = g2x + gxV; gv[1] = g2y; gv[2] = g2z + gyV;   // v1 = v - (0, g dt, 0)
+      }
+      G4[i] = make_float4(gF[0], gF[1], gF[2], 0.f);
+      __syncthreads();   // barrier 2: G4 visible
+      // ---- spring adjoint, gather form: g_x_i = gxd + sum_l J_il (gF_j - gF_i) ----
+      float ax0 = gxd[0], ax1 = gxd[1], ax2 = gxd[2];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+        const int j = nb[l];
+        const bool ok = j >= 0;
+        const int jj = ok ? j : i;
+        const float4 xj = X4[jj];
+        const float4 gj = G4[jj];
+        const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
+        const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+        const bool big = s2 > 1e-12f;
+        const float inv = rsq(fmaxf(s2, 1e-12f));
+        const float d0 = gj.x - gF[0], d1 = gj.y - gF[1], d2 = gj.z - gF[2];
+        const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
+        const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
+        float c1 = ((l < 4) ? kLs : kLd) - k * inv;
+        float c2 = big ? k * inv * inv * inv * rd_ : 0.f;
+        c1 = ok ? c1 : 0.f; c2 = ok ? c2 : 0.f;
+        gk += ok ? rg * (((l < 4) ? iLs : iLd) - inv) : 0.f;
+        ax0 += c1 * d0 + c2 * r0; ax1 += c1 * d1 + c2 * r1; ax2 += c1 * d2 + c2 * r2;
+      }
+      gx[0] = ax0; gx[1] = ax1; gx[2] = ax2;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) vnext[d] = v[d];   // this substep's input v is the previous substep's clip(v5)
+    }
+    // macro-step boundary: robot_step's action transform (:168-169)
+    {
+      __syncthreads();
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const float w = wave_sum_l63(ga[d]);
+        if (lane == 63) mac[wv * 8 + d] = w;
+      }
+      __syncthreads();
+      if (i < 8) {
+        float tot = 0.f;
+        for (int q = 0; q < nw; ++q) tot += mac[q * 8 + i];
+        const int d = i & 3;
+        a.g_actions[((size_t)t * B + b) * 8 + i] = (d < 3) ? tot / 50.0f * clip_grad(a8[i], -2.0f, 2.0f) : tot;
+      }
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.g_x0[o + d] = gx[d]; a.g_v0[o + d] = gv[d]; }
+  }
+  __syncthreads();
+  {
+    const float w0 = wave_sum_l63(gk), w1 = wave_sum_l63(gmu);
+    if (lane == 63) { mac[wv * 2] = w0; mac[wv * 2 + 1] = w1; }
+  }
+  __syncthreads();
+  if (i == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int q = 0; q < nw; ++q) { t0 += mac[q * 2]; t1 += mac[q * 2 + 1]; }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.g_prim0[b * 8 + d] = gp[d];
+    a.g_k[b] = t0;
+    a.g_mu[b] = t1;
+  }
+}
+
+void cloth_launch_fwd_fast(const ClothFwdArgs& a, hipStream_t stream) {
+  const size_t shmem = (size_t)2 * a.c.Pp * sizeof(float4);
+  hipLaunchKernelGGL(cloth_rollout_fwd_fast_kernel, dim3(a.B), dim3(a.c.Pp), shmem, stream, a);
+}
+
+void cloth_launch_bwd_fast(const ClothBwdArgs& a, hipStream_t stream) {
+  const size_t shmem = (size_t)4 * a.c.Pp * sizeof(float4) + (2 * 16 * UD_NSUM + 16 * 8) * sizeof(float);
+  hipLaunchKernelGGL(cloth_rollout_bwd_fast_kernel, dim3(a.B), dim3(a.c.Pp), shmem, stream, a);
+}
+
+}  // namespace ud
