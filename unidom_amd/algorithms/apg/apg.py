@@ -18,7 +18,7 @@ import torch
 from ...envs.basic.cloth_env import ClothEnv
 from ...envs.registration import env_functions
 from ...utils import prng
-from .core import APG, init_distributed
+from .core import APG, init_distributed, shard_envs
 
 
 def build_parser(para: bool):
@@ -60,7 +60,7 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
     key, key_models, key_env = prng.split(key, 3)
     key_eval = prng.PRNGKey(args.seed + 666)
 
-    env_kwargs = dict(batch_size=args.num_envs // world, seed=args.seed, aux_reward=True, device=device)
+    env_kwargs = dict(batch_size=shard_envs(args.num_envs, world), seed=args.seed, aux_reward=True, device=device)
     eval_kwargs = dict(batch_size=num_eval_envs, seed=args.seed + 666, device=device)
     if para_obs:
         mm = [args.eval_min_stiff, args.eval_max_stiff]

@@ -51,6 +51,58 @@ def sample_action(logits, eps, min_std=0.001):
     return torch.tanh(loc + (Fn.softplus(raw) + min_std) * eps)
 
 
+class GradSync:
+    """The data-parallel half of the APG update (apg.py:233-258), device-agnostic:
+    nan_to_num -> per-device global-norm clip -> ONE mean all-reduce of the flat gradient -> Adam.
+    All parameter gradients are views into one flat buffer, so the collective is a single bucket."""
+
+    def __init__(self, module, learning_rate, max_gradient_norm):
+        self.params = [p for p in module.parameters()]
+        self.n_params = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat_grad = torch.zeros(self.n_params, device=dev)
+        self._bind()
+        self.max_gradient_norm = max_gradient_norm
+        self.optimizer = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+
+    def _bind(self):
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def step(self):
+        off = 0
+        for p in self.params:   # autograd accumulates in place; re-bind defensively if it ever replaced a .grad
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad[off:off + 1].data_ptr():
+                if p.grad is not None:
+                    self.flat_grad[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        g = self.flat_grad
+        torch.nan_to_num_(g)                                                 # apg.py:233
+        g_norm = torch.linalg.vector_norm(g)
+        raw_norm = g_norm.clone()
+        scale = torch.where(g_norm < self.max_gradient_norm, torch.ones_like(g_norm),
+                            self.max_gradient_norm / g_norm)                 # apg.py:260-267 (per device, BEFORE the mean)
+        g.mul_(scale)
+        if dist.is_initialized() and dist.get_world_size() > 1:              # apg.py:235 lax.pmean
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            g.div_(dist.get_world_size())
+        self.optimizer.step()
+        return raw_norm
+
+
+def shard_envs(num_envs: int, world: int) -> int:
+    """Environments per rank (apg.py:83-85)."""
+    if num_envs % world:
+        raise ValueError(f"num_envs={num_envs} is not divisible by the number of GPUs {world}")
+    return num_envs // world
+
+
 class APG:
     def __init__(self, env, episode_length, learning_rate=1e-4, max_gradient_norm=1e9, seed=0, truncation_length=None):
         self.env = env
@@ -62,15 +114,9 @@ class APG:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.policy = Policy(env.observation_size, env.action_size, seed=seed).to(self.device)
-        self.params = [p for p in self.policy.parameters()]
-        self.n_params = sum(p.numel() for p in self.params)
-        # one flat gradient bucket = one all-reduce (925 452 f32 = 3.7 MB for fold_cloth1)
-        self.flat_grad = torch.zeros(self.n_params, device=self.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        self.optimizer = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+        self.sync = GradSync(self.policy, learning_rate, max_gradient_norm)
+        self.params, self.n_params, self.flat_grad, self.optimizer = (
+            self.sync.params, self.sync.n_params, self.sync.flat_grad, self.sync.optimizer)
         self.gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + self.rank)
         self.want_lists = False   # the loss never reads obs_list/state_list (XLA dead-code-eliminates them)
 
@@ -107,20 +153,10 @@ class APG:
 
     def minimize(self, state, deterministic_noise=None):
         """One APG update (apg.py:217-258). Returns metrics dict (tensors; no host sync here)."""
-        self.flat_grad.zero_()
+        self.sync.zero_grad()
         loss, (rewards, _, _) = self.loss(state, deterministic_noise)
         loss.backward()
-        g = self.flat_grad
-        torch.nan_to_num_(g)                                                 # apg.py:233
-        g_norm = torch.linalg.vector_norm(g)
-        scale = torch.where(g_norm < self.max_gradient_norm, torch.ones_like(g_norm),
-                            self.max_gradient_norm / g_norm)                 # apg.py:260-267 (per device)
-        raw_norm = g_norm.clone()
-        g.mul_(scale)
-        if self.world > 1:                                                   # apg.py:235 lax.pmean
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            g.div_(self.world)
-        self.optimizer.step()
+        raw_norm = self.sync.step()
         return {"grad_norm": raw_norm, "reward": rewards.detach(), "loss": loss.detach()}
 
     @torch.no_grad()
