@@ -9,6 +9,7 @@
 using namespace oracle;
 
 struct OcCloth {
+  int order = 1;   // 1: reference operation order, 2: re-associated IEEE order ("v2")
   ClothTables<float> tf;
   ClothTables<double> td;
   ClothParams<float> pf;
@@ -55,7 +56,10 @@ static void rollout_fwd(const OcCloth* h, int B, int TT, const T* x0, const T* v
         }
         uint8_t* g0 = grasp ? grasp + ((((size_t)t * S + s) * B + b) * 2 + 0) * P : nullptr;
         uint8_t* g1 = grasp ? g0 + P : nullptr;
-        cloth_substep_fwd(tb, pr, k[b], mu[b], xa.data(), va.data(), pa, act, xb.data(), vb.data(), pb, g0, g1);
+        if (h->order == 2)
+          cloth_substep_fwd_v2(tb, pr, k[b], mu[b], xa.data(), va.data(), pa, act, xb.data(), vb.data(), pb, g0, g1);
+        else
+          cloth_substep_fwd(tb, pr, k[b], mu[b], xa.data(), va.data(), pa, act, xb.data(), vb.data(), pb, g0, g1);
         xa.swap(xb); va.swap(vb);
         std::memcpy(pa, pb, sizeof(pa));
       }
@@ -136,6 +140,7 @@ void* oc_cloth_create(int N, const uint8_t* mask, double gravity, double dt, dou
   return h;
 }
 void oc_cloth_destroy(void* h) { delete (OcCloth*)h; }
+void oc_cloth_set_order(void* h, int order) { ((OcCloth*)h)->order = order; }
 int oc_cloth_num_particles(void* h) { return ((OcCloth*)h)->tf.P; }
 void oc_cloth_tables(void* h, int* nbr, float* L0) {
   auto* c = (OcCloth*)h;

@@ -164,6 +164,69 @@ void cloth_substep_fwd(const ClothTables<T>& tb, const ClothParams<T>& pr, T k, 
   }
 }
 
+// Forward substep, operation order "v2": the same formulas re-associated into far fewer IEEE operations
+//   spring      f = r * (k/L0 - k * (1/|r|))     instead of  k*r/|r|*(|r|-L0)/L0   (6 divisions + sqrt -> 1 + sqrt)
+//   friction    t = dm*muF / sV ; A = F - t*V     instead of  F - dm*muF*V/sV
+//   the static-friction block (:293-306) is dropped: sV = sqrt(.+small_num) > small_num always (small_num < 1)
+// Only +,-,*,/,sqrt, no FMA: a CPU and a GPU build of this order agree bit for bit (the default HIP forward,
+// csrc/cloth.hip::substep_fwd_v2).  Against the reference order it differs by f32 round-off per substep
+// (tests/test_oracle_cloth.py::test_order_v2_matches_reference_order_short_horizon).
+template <class T>
+void cloth_substep_fwd_v2(const ClothTables<T>& tb, const ClothParams<T>& pr, T k, T mu, const T* x, const T* v,
+                          const T* prim, const T* act, T* xo, T* vo, T* primo, uint8_t* grasp0, uint8_t* grasp1) {
+  const int P = tb.P;
+  const T eps = pr.small_num;
+  for (int i = 0; i < P; ++i) {
+    const T xi[3] = {x[i * 3], x[i * 3 + 1], x[i * 3 + 2]};
+    T v1[3] = {v[i * 3], v[i * 3 + 1] - pr.gravity_dt, v[i * 3 + 2]};
+    T F[3] = {0, 0, 0};
+    for (int l = 0; l < 8; ++l) {
+      int j = tb.nbr[i * 8 + l];
+      if (j < 0) continue;
+      T r[3] = {x[j * 3] - xi[0], x[j * 3 + 1] - xi[1], x[j * 3 + 2] - xi[2]};
+      T s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      T len = std::sqrt(std::max(s, T(1e-12)));
+      T inv = T(1) / len;
+      T coef = k / tb.L0[i * 8 + l] - k * inv;
+      for (int a = 0; a < 3; ++a) F[a] += coef * r[a];
+    }
+    F[1] += -pr.gravity;
+    bool fm = xi[1] <= eps;
+    T cF = std::min(F[1], T(0));
+    T muF = mu * cF * T(-1);
+    T xV = v1[0], yV = v1[2];
+    T sV = std::sqrt(xV * xV + yV * yV + eps);
+    T tf = fm ? muF / sV : T(0);
+    T Ff[3] = {F[0] - tf * xV, F[1], F[2] - tf * yV};
+    T vv[3], xx[3] = {xi[0], xi[1], xi[2]};
+    for (int a = 0; a < 3; ++a) vv[a] = (v1[a] + Ff[a] * pr.dt) * pr.damp;
+    for (int g = 0; g < 2; ++g) {
+      const T* ps = prim + g * 4;
+      const T* ac = act + g * 4;
+      T d[3] = {xx[0] - ps[0], xx[1] - ps[1], xx[2] - ps[2]};
+      T dist = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      bool m = dist <= ps[3];
+      if (g == 0 && grasp0) grasp0[i] = m;
+      if (g == 1 && grasp1) grasp1[i] = m;
+      if (m) {
+        T suction = ac[3];
+        for (int a = 0; a < 3; ++a) { vv[a] = suction * vv[a]; xx[a] = xx[a] + ac[a] * (T(1) - suction); }
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      T xc = clipf(xx[a], T(0), T(1));
+      T vc = clipf(vv[a], -pr.max_v, pr.max_v);
+      xo[i * 3 + a] = xc + pr.dt * vc;
+      vo[i * 3 + a] = vc;
+    }
+  }
+  for (int g = 0; g < 2; ++g)
+    for (int a = 0; a < 4; ++a) {
+      T add = (a < 3) ? act[g * 4 + a] : T(0);
+      primo[g * 4 + a] = clipf(prim[g * 4 + a] + add, T(0), T(1));
+    }
+}
+
 template <class T>
 inline void norm_grad_bwd(T* g, int n, T n_mask) {  // :189-194
   T s = 0;

@@ -56,7 +56,8 @@ def damp_factor(damping, dt, dtype):
 class ClothOracle:
     """CPU restatement of ClothSimulator's robot_step rollout + adjoint (cloth_simulator.py:163-337)."""
 
-    def __init__(self, mask, N=80, gravity=0.5, damping=2, dt=2e-3, max_v=2.0, small_num=1e-8, substeps=50):
+    def __init__(self, mask, N=80, gravity=0.5, damping=2, dt=2e-3, max_v=2.0, small_num=1e-8, substeps=50, order=1):
+        """order=1: the reference's operation order; order=2: the re-associated IEEE order of the default HIP forward."""
         self.N, self.S = N, substeps
         self.mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
         L = lib()
@@ -65,6 +66,7 @@ class ClothOracle:
             C.c_double(damp_factor(damping, dt, np.float32)), C.c_double(damp_factor(damping, dt, np.float64)),
             C.c_double(max_v), C.c_double(small_num), C.c_int(substeps)))
         self.P = L.oc_cloth_num_particles(self.h)
+        L.oc_cloth_set_order(self.h, C.c_int(order))
 
     def __del__(self):
         try:

@@ -50,8 +50,16 @@ def dsim():
 
 @pytest.fixture(scope="module")
 def oracle():
+    """reference operation order"""
     from oracle.pyoracle import ClothOracle
     return ClothOracle(fold_cloth1_mask())
+
+
+@pytest.fixture(scope="module")
+def oracle2():
+    """re-associated IEEE order "v2" (the default HIP forward is bit-identical to it)"""
+    from oracle.pyoracle import ClothOracle
+    return ClothOracle(fold_cloth1_mask(), order=2)
 
 
 def _run_hip(sim, x, v, prim, k, mu, actions, g=None, want_lists=True, normalize=True):
@@ -144,7 +152,8 @@ def test_bwd_matches_oracle_full_step_diff(sim, oracle):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# default mode 0: reference-order forward (bit-exact, same kernel as above) + restructured adjoint kernel
+# default mode 0: forward in the re-associated IEEE order "v2" (bit-exact vs the oracle in the same order)
+# + restructured adjoint kernel
 # ---------------------------------------------------------------------------------------------------------
 def _grads(rng, B, T, P, lists=True):
     g = dict(gx=rng.normal(size=(B, P, 3)).astype(np.float32), gv=rng.normal(size=(B, P, 3)).astype(np.float32),
@@ -155,11 +164,23 @@ def _grads(rng, B, T, P, lists=True):
     return g
 
 
-def test_default_fwd_bit_exact_full_step_diff(dsim, oracle):
+@pytest.mark.parametrize("B,T,seed", [(1, 1, 0), (4, 5, 2)])
+def test_default_fwd_bit_exact_short(dsim, oracle2, B, T, seed):
+    rng = np.random.default_rng(seed)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    o = oracle2.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    h = _run_hip(dsim, x, v, prim, k, mu, actions)
+    assert o["grasp"].sum() > 0
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+
+
+def test_default_fwd_bit_exact_full_step_diff(dsim, oracle2):
     rng = np.random.default_rng(8)
     x, v, prim, k, mu, actions = make_cloth_case(rng, 4, 40, deform=0.0005, v_scale=0.01)
     actions *= 0.2
-    o = oracle.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True, nthreads=4)
+    o = oracle2.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True, nthreads=4)
     h = _run_hip(dsim, x, v, prim, k, mu, actions)
     np.testing.assert_array_equal(h["grasp"], o["grasp"])
     for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
@@ -168,11 +189,11 @@ def test_default_fwd_bit_exact_full_step_diff(dsim, oracle):
 
 @pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("B,T,seed", [(1, 1, 0), (3, 2, 1)])
-def test_default_bwd_matches_oracle_short(dsim, oracle, B, T, seed, normalize):
+def test_default_bwd_matches_oracle_short(dsim, oracle2, B, T, seed, normalize):
     rng = np.random.default_rng(100 + seed)
     x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
     g = _grads(rng, B, T, x.shape[1])
-    o = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"],
+    o = oracle2.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"],
                            g["gprim_list"], normalize=normalize)
     h = _run_hip(dsim, x, v, prim, k, mu, actions, g=g, normalize=normalize)
     # identical forward states (bit-exact checkpoints); restructured f32 adjoint (folded norm_grad, v_rsq/v_rcp):
@@ -181,13 +202,13 @@ def test_default_bwd_matches_oracle_short(dsim, oracle, B, T, seed, normalize):
         assert _rel(h[key], o[key]) < 1e-3, (key, _rel(h[key], o[key]))
 
 
-def test_default_bwd_matches_oracle_full_step_diff(dsim, oracle):
+def test_default_bwd_matches_oracle_full_step_diff(dsim, oracle2):
     rng = np.random.default_rng(11)
     B, T = 2, 40
     x, v, prim, k, mu, actions = make_cloth_case(rng, B, T, deform=0.0005, v_scale=0.01)
     actions *= 0.2
     g = _grads(rng, B, T, x.shape[1], lists=False)
-    o = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], normalize=True, nthreads=2)
+    o = oracle2.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], normalize=True, nthreads=2)
     h = _run_hip(dsim, x, v, prim, k, mu, actions, g=g, want_lists=False)
     # 2000 normalised reverse substeps in f32: 5e-3 relative (max-norm)
     for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):

@@ -510,6 +510,8 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   h->c.n_mask = (float)P;
   h->c.P = P; h->c.Pp = Pp; h->c.S = conf->substeps;
   h->c.cell = (float)(1.0 / N);
+  h->c.Ls = fmaxf((float)(1.0 / N) * sqrtf(1.0f), 1e-12f);
+  h->c.Ld = fmaxf((float)(1.0 / N) * sqrtf(2.0f), 1e-12f);
   h->mode = conf->mode;
   if (h->mode < 0 || h->mode > 2) { ud::set_error("ud_cloth_create: mode must be 0, 1 or 2"); delete h; return UD_ERR_INVALID; }
   hipError_t e = hipGetDevice(&h->device);
@@ -558,6 +560,8 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
   if (h->mode == 2 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
+  else if (h->mode == 0 && h->c.Pp <= 512)
+    ud::cloth_launch_fwd_v2(a, (hipStream_t)stream);
   else if (h->c.Pp <= 512)
     hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
   else

@@ -13,7 +13,8 @@ struct ClothConst {
   float eps;      // small_num
   float n_mask;   // cloth_mask.sum()         :192
   int P, Pp, S;
-  float cell;     // 1/N: rest lengths are cell (links 0-3) and cell*sqrt(2) (links 4-7) for interior masks
+  float cell;     // 1/N
+  float Ls, Ld;   // rest lengths of the straight (links 0-3) / diagonal (4-7) springs, f32 as cloth_simulator.py:61-63
 };
 
 struct ClothFwdArgs {
@@ -46,6 +47,7 @@ struct ClothBwdArgs {
 __host__ __device__ inline size_t cloth_rec_floats(int Pp) { return (size_t)6 * Pp + 8; }
 __host__ __device__ inline size_t cloth_env_records(int T, int S) { return (size_t)T * S + 1; }
 
+void cloth_launch_fwd_v2(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_fwd_fast(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_bwd_fast(const ClothBwdArgs& a, hipStream_t stream);
 

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
 #pragma unroll
   for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
   const float k = a.k[b], mu = a.mu[b];
-  const float kLs = k / c.cell, kLd = k / (c.cell * sqrtf(2.0f));
+  const float kLs = k / c.Ls, kLd = k / c.Ld;
   const size_t rec = cloth_rec_floats(Pp);
   float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
   unsigned step = 0;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
 #pragma unroll
   for (int d = 0; d < 8; ++d) gp[d] = a.g_prim[b * 8 + d];
   const float k = a.k[b], mu = a.mu[b];
-  const float Ls = c.cell, Ld = c.cell * sqrtf(2.0f);
+  const float Ls = c.Ls, Ld = c.Ld;
   const float kLs = k / Ls, kLd = k / Ld, iLs = 1.f / Ls, iLd = 1.f / Ld;
   float gk = 0.f, gmu = 0.f;
   const size_t rec = cloth_rec_floats(Pp);

@@ -1,0 +1,166 @@
+// Default cloth forward for gfx950: operation order "v2" -- the reference's formulas re-associated into far fewer
+// IEEE operations (1 division + 1 sqrt per link instead of 6 + 1) and compiled WITHOUT FMA contraction, so that
+// it is bit-identical to the CPU restatement of the same order (oracle/csrc/cloth_oracle.hpp::cloth_substep_fwd_v2)
+// over a whole 2000-substep step_diff, including the discrete grasp sets.  Against the reference's
+// literal order (cloth.hip, mode 1) it differs by f32 round-off per substep -- see DESIGN.md "Numerical sensitivity".
+// Same mapping as the other cloth kernels: one workgroup per env, one particle per lane, float4 positions
+// double-buffered in LDS, one barrier per substep, per-substep checkpoints to HBM.
+#include "cloth_common.h"
+
+namespace ud {
+
+__device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  // cloth_simulator.py:168-169
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    act[g * 4 + 3] = a8[g * 4 + 3];
+  }
+}
+
+// grippers, own-particle part only (:198-226): masks and displaced positions
+__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, bool& m0, bool& m1, float* x2) {
+  float d0 = x[0] - ps[0], d1 = x[1] - ps[1], d2 = x[2] - ps[2];
+  m0 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[3];
+  float x1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x1[a] = m0 ? x[a] + act[a] * (1.f - act[3]) : x[a];
+  d0 = x1[0] - ps[4]; d1 = x1[1] - ps[5]; d2 = x1[2] - ps[6];
+  m1 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[7];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) x2[a] = m1 ? x1[a] + act[4 + a] * (1.f - act[7]) : x1[a];
+}
+
+// spring + gravity + ground friction + damping in the re-associated IEEE order "v2"
+// (oracle/csrc/cloth_oracle.hpp::cloth_substep_fwd_v2): only +,-,*,/,sqrt, no FMA contraction in this file.
+__device__ __forceinline__ void force_v2(const ClothConst& c, int i, const int* nb, const float4* X4, float k, float kLs,
+                                         float kLd, float mu, const float* x, const float* v, float* v3) {
+  float F0 = 0.f, F1 = 0.f, F2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const int j = nb[l];
+    const bool ok = j >= 0;
+    const float4 xj = X4[ok ? j : i];
+    const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
+    const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+    const float len = sqrtf(fmaxf(s2, 1e-12f));
+    const float inv = 1.0f / len;
+    const float coef = ((l < 4) ? kLs : kLd) - k * inv;
+    F0 += ok ? coef * r0 : 0.f; F1 += ok ? coef * r1 : 0.f; F2 += ok ? coef * r2 : 0.f;
+  }
+  F1 += -c.g;
+  const float v1y = v[1] - c.gdt;
+  const bool fm = x[1] <= c.eps;
+  const float cF = fminf(F1, 0.f);
+  const float muF = mu * cF * -1.0f;
+  const float xV = v[0], yV = v[2];
+  const float sV = sqrtf(xV * xV + yV * yV + c.eps);
+  const float tf = fm ? muF / sV : 0.f;
+  const float Ax = F0 - tf * xV, Az = F2 - tf * yV;
+  v3[0] = (xV + Ax * c.dt) * c.damp;
+  v3[1] = (v1y + F1 * c.dt) * c.damp;
+  v3[2] = (yV + Az * c.dt) * c.damp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) cloth_rollout_fwd_v2_kernel(ClothFwdArgs a) {
+  extern __shared__ float4 lds4[];  // [2][Pp]
+  const ClothConst c = a.c;
+  const int i = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const bool live = i < P;
+  int nb[8];
+#pragma unroll
+  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = a.x[((size_t)b * P + i) * 3 + d]; v[d] = a.v[((size_t)b * P + i) * 3 + d]; }
+  }
+  float ps[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  const float kLs = k / c.Ls, kLd = k / c.Ld;   // k / L0 with the rest lengths of cloth_simulator.py:61-63
+  const size_t rec = cloth_rec_floats(Pp);
+  float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
+  unsigned step = 0;
+  for (int t = 0; t < T; ++t) {
+    float act[8];
+    macro_action_f(a.actions + ((size_t)t * B + b) * 8, act);
+    for (int s = 0; s < S; ++s, ++step) {
+      float4* X4 = lds4 + (step & 1u) * Pp;
+      X4[i] = make_float4(x[0], x[1], x[2], 0.f);
+      if (ckb) {
+        float* r = ckb + (size_t)step * rec;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+        if (i == 0) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+        }
+      }
+      __syncthreads();
+      float vv[3], x2[3];
+      bool m0, m1;
+      force_v2(c, i, nb, X4, k, kLs, kLd, mu, x, v, vv);
+      grip_own(x, ps, act, m0, m1, x2);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        vv[d] = m0 ? act[3] * vv[d] : vv[d];
+        vv[d] = m1 ? act[7] * vv[d] : vv[d];
+      }
+      if (a.grasp && live) {
+        uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
+        g[i] = m0; g[P + i] = m1;
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ps[g * 4 + d] = clipf(ps[g * 4 + d] + (d < 3 ? act[g * 4 + d] : 0.f), 0.f, 1.f);  // :322-323
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {   // :326-329
+        const float vc = clipf(vv[d], -c.max_v, c.max_v);
+        x[d] = clipf(x2[d], 0.f, 1.f) + c.dt * vc;
+        v[d] = vc;
+      }
+    }
+    if (live) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.x_list) { a.x_list[o] = x[0]; a.x_list[o + 1] = x[1]; a.x_list[o + 2] = x[2]; }
+      if (a.v_list) { a.v_list[o] = v[0]; a.v_list[o + 1] = v[1]; a.v_list[o + 2] = v[2]; }
+    }
+    if (a.prim_list && i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) a.prim_list[((size_t)t * B + b) * 8 + d] = ps[d];
+    }
+  }
+  if (live) {
+    const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.x_out[o + d] = x[d]; a.v_out[o + d] = v[d]; }
+  }
+  if (i == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.prim_out[b * 8 + d] = ps[d];
+  }
+  if (ckb) {
+    float* r = ckb + (size_t)T * S * rec;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
+    if (i == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+    }
+  }
+}
+
+
+void cloth_launch_fwd_v2(const ClothFwdArgs& a, hipStream_t stream) {
+  const size_t shmem = (size_t)2 * a.c.Pp * sizeof(float4);
+  hipLaunchKernelGGL(cloth_rollout_fwd_v2_kernel, dim3(a.B), dim3(a.c.Pp), shmem, stream, a);
+}
+
+}  // namespace ud
