@@ -34,7 +34,7 @@ __device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  /
 
 struct FastInter {
   float F1, cF, muF, xV, yV, isV, tf;   // friction block
-  float v3[3], v4[3];
+  float r0[8], r1[8], r2[8], inv[8];    // link vectors and 1/|r| (reused by the spring adjoint)
 };
 
 // grippers, own-particle part only (:198-226): masks and displaced positions
@@ -66,6 +66,7 @@ __device__ __forceinline__ void force_fast(const ClothConst& c, int i, const int
     float coef = ((l < 4) ? kLs : kLd) - k * inv;
     coef = ok ? coef : 0.f;
     F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
+    if (KEEP) { in->r0[l] = r0; in->r1[l] = r1; in->r2[l] = r2; in->inv[l] = (s2 > 1e-12f) ? inv : -inv; }
   }
   F1 -= c.g;                                        // :278
   const float v1y = v[1] - c.gdt;                   // :259
@@ -298,9 +299,18 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       sm[6] = m1 ? sm[3] : 0.f; sm[7] = m1 ? sm[4] : 0.f; sm[8] = m1 ? sm[5] : 0.f;
       if (norm) {
 #pragma unroll
-        for (int q = 0; q < UD_NSUM; ++q) {
+        for (int q = 0; q < 6; ++q) {
           const float w = wave_sum_l63(sm[q]);
           if (lane == 63) rd[wv * UD_NSUM + q] = w;
+        }
+        if (__builtin_amdgcn_ballot_w64(m1) != 0) {   // wave-uniform: gripper 1 holds something in this wave
+#pragma unroll
+          for (int q = 6; q < UD_NSUM; ++q) {
+            const float w = wave_sum_l63(sm[q]);
+            if (lane == 63) rd[wv * UD_NSUM + q] = w;
+          }
+        } else if (lane == 63) {
+          rd[wv * UD_NSUM + 6] = 0.f; rd[wv * UD_NSUM + 7] = 0.f; rd[wv * UD_NSUM + 8] = 0.f;
         }
       }
       __syncthreads();   // barrier 1: X4 and the wave partials are visible
@@ -324,13 +334,15 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         const float n3v = sB * sB * (n2v - (1.f - s1 * s1) * nm);
         s3x = inv_norm(n3x, c.n_mask);                                    // :223 (gripper 0)
         s3v = inv_norm(fmaxf(n3v, 0.f), c.n_mask);                        // :224
-        // primitives (:333-334): 4-vector norms, uniform
+        // primitives (:333-334): 4-vector norms, uniform; only wave 0 carries the primitive cotangent
+        if (wv == 0) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const float n2 = gp[g * 4] * gp[g * 4] + gp[g * 4 + 1] * gp[g * 4 + 1] + gp[g * 4 + 2] * gp[g * 4 + 2] + gp[g * 4 + 3] * gp[g * 4 + 3];
-          const float sc = inv_norm(n2, c.n_mask);
+          for (int g = 0; g < 2; ++g) {
+            const float n2 = gp[g * 4] * gp[g * 4] + gp[g * 4 + 1] * gp[g * 4 + 1] + gp[g * 4 + 2] * gp[g * 4 + 2] + gp[g * 4 + 3] * gp[g * 4 + 3];
+            const float sc = inv_norm(n2, c.n_mask);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) gp[g * 4 + d] *= sc;
+            for (int d = 0; d < 4; ++d) gp[g * 4 + d] *= sc;
+          }
         }
       }
       // ---- neighbour-dependent forward recompute ----
@@ -346,7 +358,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         gx2n[d] = sA * (sx * av[d]);
         gv5n[d] = sB * (sv * bv[d] + (c.dt * sx) * bx[d]);
       }
-      {  // gripper 1
+      if (__builtin_amdgcn_ballot_w64(m1) != 0) {  // gripper 1 (wave-uniform skip when it holds nothing here)
         const float s1 = act[7];
         float dotv = v4[0] * gv5n[0] + v4[1] * gv5n[1] + v4[2] * gv5n[2];
         float dotx = gx2n[0] * act[4] + gx2n[1] * act[5] + gx2n[2] * act[6];
@@ -360,7 +372,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       float gxd[3], gv3[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) { gxd[d] = s3x * gx2n[d]; gv3[d] = s3v * gv5n[d]; }
-      {  // gripper 0
+      if (__builtin_amdgcn_ballot_w64(m0) != 0) {  // gripper 0
         const float s0 = act[3];
         float dotv = v3[0] * gv3[0] + v3[1] * gv3[1] + v3[2] * gv3[2];
         float dotx = gxd[0] * act[0] + gxd[1] * act[1] + gxd[2] * act[2];
@@ -372,15 +384,17 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         }
       }
       // primitives (:322-323), uniform; counted once (lane 0) in the action accumulators
+      if (wv == 0) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const float add = d < 3 ? act[g * 4 + d] : 0.f;
-          const float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
-          gp[g * 4 + d] = tt;
-          if (d < 3) ga[g * 4 + d] += (i == 0) ? tt : 0.f;
-        }
+          for (int d = 0; d < 4; ++d) {
+            const float add = d < 3 ? act[g * 4 + d] : 0.f;
+            const float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
+            gp[g * 4 + d] = tt;
+            if (d < 3) ga[g * 4 + d] += (i == 0) ? tt : 0.f;
+          }
+      }
       // ---- v3 = (v1 + F dt) damp ; ground friction (:281-290) ----
       float gF[3];
       {
@@ -409,13 +423,10 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       for (int l = 0; l < 8; ++l) {
         const int j = nb[l];
         const bool ok = j >= 0;
-        const int jj = ok ? j : i;
-        const float4 xj = X4[jj];
-        const float4 gj = G4[jj];
-        const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
-        const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
-        const bool big = s2 > 1e-12f;
-        const float inv = rsq(fmaxf(s2, 1e-12f));
+        const float4 gj = G4[ok ? j : i];
+        const float r0 = in.r0[l], r1 = in.r1[l], r2 = in.r2[l];
+        const bool big = in.inv[l] > 0.f;            // sign carries the clip(|r|^2, 1e-12) branch
+        const float inv = fabsf(in.inv[l]);
         const float d0 = gj.x - gF[0], d1 = gj.y - gF[1], d2 = gj.z - gF[2];
         const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
         const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
