@@ -255,3 +255,41 @@ def test_fast_mode_long_rollout_is_sane(fsim):
     h = _run_hip(fsim, x, v, prim, k, mu, actions)
     assert np.isfinite(h["x"]).all() and np.isfinite(h["v"]).all()
     assert h["x"].min() > -0.01 and h["x"].max() < 1.01 and np.abs(h["v"]).max() <= 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# generality: a non-rectangular mask whose particle count is not a multiple of the wave size
+# ---------------------------------------------------------------------------------------------------------
+def test_disk_mask_ragged_particle_count():
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    from conftest import cloth_reset_x
+    N = 80
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    mask = (((ii - 40) ** 2 + (jj - 37) ** 2) <= 9.3 ** 2).astype(np.float32)
+    P = int(mask.sum())
+    assert P % 64 != 0 and 200 < P < 512
+    sim = ClothSimulator(Conf(), 3, lambda x, v, i, j: v, mask)
+    orc = ClothOracle(mask, order=2)
+    assert sim.n_particles == orc.P == P
+    rng = np.random.default_rng(5)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, 3, 3, P_x=cloth_reset_x(N, mask), deform=0.0005, v_scale=0.01)
+    o = orc.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    g = _grads(rng, 3, 3, P)
+    ob = orc.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"], g["gprim_list"])
+    h = _run_hip(sim, x, v, prim, k, mu, actions, g=g)
+    assert o["grasp"].sum() > 0
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))   # 150 normalised reverse substeps, f32
+
+
+def test_mask_touching_border_is_refused():
+    from unidom_amd import _lib
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    mask = np.zeros((80, 80), np.float32)
+    mask[0:4, 10:20] = 1
+    with pytest.raises(_lib.UnidomError, match="border"):
+        ClothSimulator(Conf(), 1, lambda x, v, i, j: v, mask)

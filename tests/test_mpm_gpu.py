@@ -119,3 +119,46 @@ def test_bwd_matches_oracle(demo, clip, material, S, k):
         assert _rel(oh[key], ob[key]) < tol, (key, _rel(oh[key], ob[key]))
     for key in ("gfriction", "gmu", "glamda"):
         assert _rel(oh[key].reshape(-1), ob[key]) < 5 * tol, (key, oh[key], ob[key])
+
+
+def test_batched_envs_with_different_parameters(demo):
+    """B=5 envs with different states / actions / friction / Lame parameters in one launch == 5 oracle runs."""
+    from oracle.pyoracle import MpmOracle
+    S = 12
+    cases = [_adjoint_case(demo, S, k, 1, k, np.float32)[0] for k in (5, 20, 33, 47, 60)]
+    for n, st in enumerate(cases):
+        st["friction"] = np.float32([0.05 + 0.1 * n]); st["mu"] = np.float32([MU0 * (0.6 + 0.2 * n)])
+        st["lamda"] = np.float32([LA0 * (1.5 - 0.2 * n)]); st["action"] = np.float32([[0.2 * n - 0.4, 0.1, -0.3 + 0.1 * n, 0, 0, 0]])
+    stB = {k: np.concatenate([s[k] for s in cases]) for k in cases[0]}
+    oh = run_hip(make_sim(S, 5), stB)
+    orc = MpmOracle(67, steps=S)
+    for n, st in enumerate(cases):
+        of = orc.step_fwd(st)
+        assert _rel(oh["x"][n], of["x"][0]) < 1e-5 and _rel(oh["v"][n], of["v"][0]) < 1e-4   # north_star: 1e-4 relative
+        assert _rel(oh["C"][n], of["C"][0]) < 1e-3 and _rel(oh["F"][n], of["F"][0]) < 1e-5
+
+
+def test_liquid_material_forward(demo):
+    """material 0: mu = 0, la = 1 regardless of E (Q10)."""
+    from oracle.pyoracle import MpmOracle
+    S = 10
+    st, _ = _adjoint_case(demo, S, 30, 0, 2, np.float32)
+    of = MpmOracle(67, steps=S, material=np.zeros(67, np.int32)).step_fwd(st)
+    oh = run_hip(make_sim(S, 1, material=0), st)
+    assert _rel(oh["x"], of["x"]) < 1e-6 and _rel(oh["v"], of["v"]) < 1e-4 and _rel(oh["F"], of["F"]) < 1e-5
+
+
+def test_out_of_range_index_semantics(demo):
+    """Q5/Q9: particles whose 3x3x3 support leaves the `res` grid -- scatter drops, gather clamps, negative
+    indices wrap -- against the dense oracle."""
+    from oracle.pyoracle import MpmOracle
+    S = 3
+    st, _ = _adjoint_case(demo, S, 10, 1, 4, np.float32)
+    x = st["x"].copy()
+    x[0, :10, 2] += np.float32(0.27)      # z beyond res*dx = 0.5: upper out-of-range cells
+    x[0, 10:20, 0] -= np.float32(0.245)   # x*inv_dx - 0.5 < 0: base 0 with negative quadratic weights (Q13)
+    st["x"] = x
+    of = MpmOracle(67, steps=S).step_fwd(st)
+    oh = run_hip(make_sim(S, 1), st)
+    assert np.isfinite(of["x"]).all()
+    assert _rel(oh["x"], of["x"]) < 1e-6 and _rel(oh["v"], of["v"]) < 1e-4 and _rel(oh["C"], of["C"]) < 1e-3
