@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libunidom_hip.so")
+SO_PATH = os.environ.get("UNIDOM_HIP_SO", os.path.join(CSRC, "libunidom_hip.so"))   # override: diagnostic builds only
 
 # every symbol include/unidom_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

@@ -21,6 +21,10 @@
 // stencil cells (7/7/7/6); quad sums go through DPP quad_perm.  No MFMA: stencil / scatter work.
 #include "common.h"
 
+#ifndef UD_MPM_ABLATE
+#define UD_MPM_ABLATE 0   // timing-only diagnostic builds (never shipped): bit0 no SVD, bit1 no scatter, bit2 no grid op, bit3 no g2p, bit4 no clear, bit5 no insert
+#endif
+
 namespace ud {
 
 struct MpmConst {
@@ -78,10 +82,10 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
     float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
     float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
     float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
-    const bool rot = fabsf(ga) > 1.5e-8f * sqrtf(al * be);                                                   \
-    float zeta = (be - al) / (2.f * (rot ? ga : 1.f));                                                       \
-    float t = copysignf(1.f, zeta) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));                               \
-    float cs = 1.f / sqrtf(1.f + t * t), sn = cs * t;                                                        \
+    const bool rot = fabsf(ga) > 1.5e-8f * __builtin_amdgcn_sqrtf(al * be);                                  \
+    float zeta = (be - al) * __builtin_amdgcn_rcpf(2.f * (rot ? ga : 1.f));                                  \
+    float t = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta)); \
+    float cs = __builtin_amdgcn_rsqf(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */ \
     cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
       float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \
@@ -101,13 +105,14 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
   }
 
 // One-sided Jacobi (Hestenes) SVD of a 3x3: A = U diag(S) Vh, S descending >= 0.  The reference calls LAPACK
-// (third party); only U S Vh, U Vh and S -- gauge-invariant -- enter the dynamics.
+// (third party); only U S Vh, U Vh and S -- gauge-invariant -- enter the dynamics.  The rotation angle may be
+// approximate (v_rcp/v_rsq/v_sqrt, 1 ulp): each Givens pair (cs, sn) is orthonormal to round-off regardless.
 __device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* Vh) {
   float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = A[i];
 #pragma unroll 1
-  for (int sweep = 0; sweep < 6; ++sweep) {
+  for (int sweep = 0; sweep < 4; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
     UD_JROT(0, 1)
     UD_JROT(0, 2)
     UD_JROT(1, 2)
@@ -246,13 +251,25 @@ __device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int 
 }
 
 // ---- LDS cell table --------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned cell_hash(int cell, int logH) { return ((unsigned)cell * 2654435761u) >> (32 - logH); }
+__device__ __forceinline__ unsigned cell_hash(int cell, int logH) {
+  unsigned h = (unsigned)cell;
+  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
+  return h >> (32 - logH);
+}
 
-__device__ __forceinline__ int table_insert(int* key, int H, int logH, int cell) {
+// Keys persist for the whole launch (cells change slowly from substep to substep), so the common case is a plain
+// LDS read that finds the key; only a cell seen for the first time pays a ds_cmpst and is appended to the
+// occupied-slot list that the per-substep value clear and the grid op iterate over.
+__device__ __forceinline__ int table_insert(int* key, int* list, int* count, int H, int logH, int cell) {
   unsigned s = cell_hash(cell, logH);
   for (int probe = 0; probe < H; ++probe) {
-    int old = atomicCAS(&key[s], -1, cell);
-    if (old == -1 || old == cell) return (int)s;
+    int cur = key[s];
+    if (cur == cell) return (int)s;
+    if (cur == -1) {
+      const int old = atomicCAS(&key[s], -1, cell);
+      if (old == -1) { list[atomicAdd(count, 1)] = (int)s; return (int)s; }
+      if (old == cell) return (int)s;
+    }
     s = (s + 1) & (unsigned)(H - 1);
   }
   return -1;
@@ -263,15 +280,16 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 }
 
 // scatter index rule (Q5/Q9): negative wraps, out-of-range dropped (-1); gather rule: negative wraps, clamp
+// cell key = i | j << 10 | k << 20 (res <= 1024 per axis): decoding needs no integer division
 __device__ __forceinline__ int cell_scatter(const MpmConst& c, int i, int j, int k) {
   i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
   if (i < 0 || i >= c.res[0] || j < 0 || j >= c.res[1] || k < 0 || k >= c.res[2]) return -1;
-  return (i * c.res[1] + j) * c.res[2] + k;
+  return i | (j << 10) | (k << 20);
 }
 __device__ __forceinline__ int cell_gather(const MpmConst& c, int i, int j, int k) {
   i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
   i = min(max(i, 0), c.res[0] - 1); j = min(max(j, 0), c.res[1] - 1); k = min(max(k, 0), c.res[2] - 1);
-  return (i * c.res[1] + j) * c.res[2] + k;
+  return i | (j << 10) | (k << 20);
 }
 
 // quad (4-lane) all-reduce through DPP quad_perm
@@ -311,7 +329,12 @@ __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, 
   float mu = mu_s * h, la = la_s * h;
   if (material == 0) { mu = 0.f; la = 1.f; }                     // Q10
   float U[9], Vh[9], sr[3], sg[3];
-  svd3(Fu, U, sr, Vh);
+  if (UD_MPM_ABLATE & 1) {
+    for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.f : 0.f; Vh[i] = U[i]; }
+    sr[0] = Fu[0]; sr[1] = Fu[4]; sr[2] = Fu[8];
+  } else {
+    svd3(Fu, U, sr, Vh);
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) sg[i] = sr[i];
 #pragma unroll
@@ -365,6 +388,7 @@ struct Lds {
   float* ppos; float* prot;          // [S*3], [S*4]
   float* ppin; float* gppos; float* gpv;  // bwd only: [S*3] each
   float* scr;                        // [64] scratch
+  int* list; int* count;             // occupied slots [H], their number
 };
 
 __device__ __forceinline__ void prim_at(const Lds& L, int f, int S, const float* psize, const float* pv, float friction, PrimF& pf) {
@@ -417,9 +441,9 @@ __device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const 
     const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
     int ss = -1;
     if (sc >= 0) {
-      ss = table_insert(L.key, c.H, c.logH, sc);
+      ss = table_insert(L.key, L.list, L.count, c.H, c.logH, sc);
       ok = ok && (ss >= 0);
-      if (ss >= 0) {
+      if (ss >= 0 && !(UD_MPM_ABLATE & 2)) {
         const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
         lds_add(&L.m[ss], weight * c.p_mass);
 #pragma unroll
@@ -430,17 +454,14 @@ __device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const 
       }
     }
     int gs = ss;
-    if (gc != sc) { gs = table_insert(L.key, c.H, c.logH, gc); ok = ok && (gs >= 0); }
+    if (gc != sc) { gs = table_insert(L.key, L.list, L.count, c.H, c.logH, gc); ok = ok && (gs >= 0); }
     slots[t] = ((ss + 1) << 16) | (max(gs, 0) & 0xffff);
   }
   return ok;
 }
 
 __device__ __forceinline__ void decode_cell(const MpmConst& c, int cell, int& ci, int& cj, int& ck) {
-  ck = cell % c.res[2];
-  const int t = cell / c.res[2];
-  cj = t % c.res[1];
-  ci = t / c.res[1];
+  ci = cell & 1023; cj = (cell >> 10) & 1023; ck = (cell >> 20) & 1023;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,6 +475,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   Lds L;
   L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H;
   L.ppos = smem + 5 * H; L.prot = L.ppos + S * 3; L.scr = L.prot + S * 4;
+  L.list = (int*)(L.scr + 64); L.count = L.list + H;
   const int p = tid >> 2, qi = tid & 3;
   const bool live = p < N;
   const int pc = live ? p : 0;
@@ -467,6 +489,8 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   const float hard = a.hard[pc];
   for (int e = tid; e < S * 3; e += nt) L.ppos[e] = a.ppos[(size_t)b * S * 3 + e];
   for (int e = tid; e < S * 4; e += nt) L.prot[e] = a.prot[(size_t)b * S * 4 + e];
+  for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f; }
+  if (tid == 0) *L.count = 0;
   float pv[3], pw[3], psize[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {                                   // clip + set_action (:419-423, primitives.py:212-229)
@@ -481,7 +505,10 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   __syncthreads();
   for (int f = 0; f < S; ++f) {
     // ---- A: clear the cell table, read for FK, checkpoint ----
-    for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f; }
+    for (int e = tid, n = *L.count; e < n; e += nt) {   // clear the values of the slots seen so far
+      const int s = L.list[e];
+      L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f;
+    }
     float pending = 0.f;
     fk_read(L, f, S, pv, tid, pending);
     if (ck && live && qi == 0) {
@@ -501,27 +528,26 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
     Pre q;
     int slots[UD_NCELL];
     particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
-    if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
+    if (UD_MPM_ABLATE & 32) { for (int t = 0; t < UD_NCELL; ++t) slots[t] = (((tid * 7 + t) & (H - 1)) + 1) << 16 | ((tid * 7 + t) & (H - 1)); }
+    else if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
     __syncthreads();
     // ---- C: grid op on the occupied slots ----
-    {
+    if (!(UD_MPM_ABLATE & 4)) {
       PrimF pf;
       prim_at(L, f, S, psize, pv, friction, pf);
-      for (int s = tid; s < H; s += nt) {
-        const int cell = L.key[s];
-        if (cell >= 0) {
-          int ci, cj, ckk;
-          decode_cell(c, cell, ci, cj, ckk);
-          float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
-          grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
-          L.mv[s * 3] = vo[0]; L.mv[s * 3 + 1] = vo[1]; L.mv[s * 3 + 2] = vo[2];
-        }
+      for (int e = tid, n = *L.count; e < n; e += nt) {
+        const int s = L.list[e];
+        int ci, cj, ckk;
+        decode_cell(c, L.key[s], ci, cj, ckk);
+        float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
+        grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
+        L.mv[s * 3] = vo[0]; L.mv[s * 3 + 1] = vo[1]; L.mv[s * 3 + 2] = vo[2];
       }
     }
     __syncthreads();
     // ---- D: g2p (:196-221), advect ----
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (live) {
+    if (live && !(UD_MPM_ABLATE & 8)) {
 #pragma unroll
       for (int t = 0; t < UD_NCELL; ++t) {
         int i, j, k;
@@ -617,6 +643,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H; L.vel = smem + 5 * H; L.gacc = smem + 8 * H; L.gmm = smem + 11 * H;
   L.ppos = smem + 12 * H; L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3; L.gpv = L.gppos + S * 3;
   L.scr = L.gpv + S * 3;
+  L.list = (int*)(L.scr + 64); L.count = L.list + H;
   const int p = tid >> 2, qi = tid & 3;
   const bool live = p < N;
   const int pc = live ? p : 0;
@@ -628,6 +655,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     const float* tail = ck + (size_t)S * 24 * c.Np;
     for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.f; }
     for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
+    for (int s = tid; s < H; s += nt) {
+      L.key[s] = -1; L.m[s] = 0.f;
+      for (int d = 0; d < 3; ++d) { L.mv[s * 3 + d] = 0.f; L.gacc[s * 3 + d] = 0.f; }
+    }
+    if (tid == 0) *L.count = 0;
     // copy_frame adjoint: position[0] <- position[steps-1]
     for (int e = tid; e < S * 3; e += nt) {
       const int row = e / 3, d = e - row * 3;
@@ -665,8 +697,9 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       for (int d = 0; d < 9; ++d) { Cm[d] = r[(6 + d) * c.Np]; F[d] = r[(15 + d) * c.Np]; }
     }
     // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
-    for (int s = tid; s < H; s += nt) {
-      L.key[s] = -1; L.m[s] = 0.f;
+    for (int e = tid, n = *L.count; e < n; e += nt) {
+      const int s = L.list[e];
+      L.m[s] = 0.f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) { L.mv[s * 3 + d] = 0.f; L.gacc[s * 3 + d] = 0.f; }
     }
@@ -682,15 +715,13 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     // ---- C: grid op forward -> vel ----
     PrimF pf;
     prim_at(L, f, S, psize, pv, friction, pf);
-    for (int s = tid; s < H; s += nt) {
-      const int cell = L.key[s];
-      if (cell >= 0) {
-        int ci, cj, ckk;
-        decode_cell(c, cell, ci, cj, ckk);
-        float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
-        grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
-        L.vel[s * 3] = vo[0]; L.vel[s * 3 + 1] = vo[1]; L.vel[s * 3 + 2] = vo[2];
-      }
+    for (int e = tid, n = *L.count; e < n; e += nt) {
+      const int s = L.list[e];
+      int ci, cj, ckk;
+      decode_cell(c, L.key[s], ci, cj, ckk);
+      float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
+      grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
+      L.vel[s * 3] = vo[0]; L.vel[s * 3 + 1] = vo[1]; L.vel[s * 3 + 2] = vo[2];
     }
     __syncthreads();
     // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
@@ -729,11 +760,10 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     }
     __syncthreads();
     // ---- E: grid-op adjoint per occupied slot ----
-    for (int s = tid; s < H; s += nt) {
-      const int cell = L.key[s];
-      if (cell < 0) continue;
+    for (int e = tid, n = *L.count; e < n; e += nt) {
+      const int s = L.list[e];
       int ci, cj, ckk;
-      decode_cell(c, cell, ci, cj, ckk);
+      decode_cell(c, L.key[s], ci, cj, ckk);
       const float m = L.m[s];
       float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
       CellRec rec;
@@ -1008,6 +1038,7 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
     return UD_ERR_UNSUPPORTED;
   }
   if (S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
+  if (conf->res[0] > 1024 || conf->res[1] > 1024 || conf->res[2] > 1024) { ud::set_error("ud_mpm_create: res > 1024"); return UD_ERR_UNSUPPORTED; }
   auto* h = new ud_mpm;
   ud::MpmConst& c = h->c;
   c.N = N; c.Np = (N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.steps = S;
@@ -1022,8 +1053,8 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * N + 63) / 64 * 64);
-  h->lds_fwd = ((size_t)5 * Hh + (size_t)S * 7 + 64) * sizeof(float);
-  h->lds_bwd = ((size_t)12 * Hh + (size_t)S * 16 + 64) * sizeof(float);
+  h->lds_fwd = ((size_t)6 * Hh + (size_t)S * 7 + 64 + 4) * sizeof(float);    // key, m, mv[3], list + primitives + scratch + count
+  h->lds_bwd = ((size_t)13 * Hh + (size_t)S * 16 + 64 + 4) * sizeof(float);
   if (h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_material, N * sizeof(int));
