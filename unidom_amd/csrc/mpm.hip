@@ -428,34 +428,39 @@ __device__ __forceinline__ void fk_write(const Lds& L, int f, int S, const float
   }
 }
 
-// p2g of one quad lane: insert its cells, scatter mass / momentum.  slots[t] = (scatter_slot+1) << 16 | gather_slot
-__device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const Pre& q, const float* v, int qi, int* slots) {
+// p2g of one quad lane: find / insert its cells, scatter mass / momentum.
+// slots[t] = (scatter_slot+1) << 16 | gather_slot; pcell[t] = the cell key slots[t] was resolved for (a particle
+// crosses a cell boundary only every ~100 substeps, so the table probe is skipped almost always).
+__device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const Pre& q, const float* v, int qi, int* slots,
+                                         int* pcell) {
   bool ok = true;
 #pragma unroll
   for (int t = 0; t < UD_NCELL; ++t) {
     int i, j, k;
-    slots[t] = 0;
     if (!cell_of(qi, t, i, j, k)) continue;
     const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
     const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
     const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
-    int ss = -1;
-    if (sc >= 0) {
-      ss = table_insert(L.key, L.list, L.count, c.H, c.logH, sc);
-      ok = ok && (ss >= 0);
-      if (ss >= 0 && !(UD_MPM_ABLATE & 2)) {
-        const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-        lds_add(&L.m[ss], weight * c.p_mass);
+    int ss;
+    if (sc == gc && sc == pcell[t]) {
+      ss = (slots[t] >> 16) - 1;                       // cached
+    } else {
+      ss = -1;
+      if (sc >= 0 && !(UD_MPM_ABLATE & 32)) { ss = table_insert(L.key, L.list, L.count, c.H, c.logH, sc); ok = ok && (ss >= 0); }
+      int gs = ss;
+      if (gc != sc && !(UD_MPM_ABLATE & 32)) { gs = table_insert(L.key, L.list, L.count, c.H, c.logH, gc); ok = ok && (gs >= 0); }
+      slots[t] = ((ss + 1) << 16) | (max(gs, 0) & 0xffff);
+      pcell[t] = (sc == gc && ss >= 0) ? sc : -2;      // only in-range cells are cacheable
+    }
+    if (ss >= 0 && !(UD_MPM_ABLATE & 2)) {
+      const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+      lds_add(&L.m[ss], weight * c.p_mass);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          float ad = q.affine[a * 3] * dp0 + q.affine[a * 3 + 1] * dp1 + q.affine[a * 3 + 2] * dp2;
-          lds_add(&L.mv[ss * 3 + a], weight * (c.p_mass * v[a] + ad));
-        }
+      for (int a = 0; a < 3; ++a) {
+        float ad = q.affine[a * 3] * dp0 + q.affine[a * 3 + 1] * dp1 + q.affine[a * 3 + 2] * dp2;
+        lds_add(&L.mv[ss * 3 + a], weight * (c.p_mass * v[a] + ad));
       }
     }
-    int gs = ss;
-    if (gc != sc) { gs = table_insert(L.key, L.list, L.count, c.H, c.logH, gc); ok = ok && (gs >= 0); }
-    slots[t] = ((ss + 1) << 16) | (max(gs, 0) & 0xffff);
   }
   return ok;
 }
@@ -500,6 +505,9 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   }
   const float friction = a.friction[b], mu_s = a.mu[b], la_s = a.lamda[b];
   bool ok = true;
+  int slots[UD_NCELL], pcell[UD_NCELL];
+#pragma unroll
+  for (int t = 0; t < UD_NCELL; ++t) { slots[t] = 0; pcell[t] = -2; }
   const size_t ck_env = ((size_t)S * 24 * c.Np + (size_t)S * 10);
   float* ck = a.ckpt ? a.ckpt + (size_t)b * ck_env : nullptr;
   __syncthreads();
@@ -526,10 +534,8 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
     // ---- B: FK write, particle pre-pass, p2g ----
     fk_write(L, f, S, pw, tid, pending);
     Pre q;
-    int slots[UD_NCELL];
     particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
-    if (UD_MPM_ABLATE & 32) { for (int t = 0; t < UD_NCELL; ++t) slots[t] = (((tid * 7 + t) & (H - 1)) + 1) << 16 | ((tid * 7 + t) & (H - 1)); }
-    else if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
+    if (live) ok = p2g_lane(c, L, q, v, qi, slots, pcell) && ok;
     __syncthreads();
     // ---- C: grid op on the occupied slots ----
     if (!(UD_MPM_ABLATE & 4)) {
@@ -684,6 +690,9 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   const float friction = a.friction[b], mu_s = a.mu[b], la_s = a.lamda[b];
   float acc_fric = 0.f, acc_mu = 0.f, acc_la = 0.f;
   bool ok = true;
+  int slots[UD_NCELL], pcell[UD_NCELL];
+#pragma unroll
+  for (int t = 0; t < UD_NCELL; ++t) { slots[t] = 0; pcell[t] = -2; }
   float pend_val = 0.f, pend_pv = 0.f;   // FK-adjoint values computed in phase F, written at the top of the next iteration
   bool pend = false;
   __syncthreads();
@@ -708,9 +717,8 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     // ---- B: particle pre-pass, p2g ----
     Pre q;
     PreB kb;
-    int slots[UD_NCELL];
     particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
-    if (live) ok = p2g_lane(c, L, q, v, qi, slots) && ok;
+    if (live) ok = p2g_lane(c, L, q, v, qi, slots, pcell) && ok;
     __syncthreads();
     // ---- C: grid op forward -> vel ----
     PrimF pf;
