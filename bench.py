@@ -65,6 +65,40 @@ def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
             "fwd_only_value": n / t_f}
 
 
+def saturation_probe(env, device, num_envs=1024, reps=3):
+    """NOT the headline metric: the same two kernels with enough environments to fill the chip (the headline
+    workload has 4 envs = 4 workgroups on 256 CUs, so its HBM fraction is fixed by the workload, not the kernel).
+    One step_diff worth of substeps (40 x 50), forward with checkpoints + adjoint, kernel time from HIP events."""
+    from unidom_amd.engine.cloth_simulator import ClothSimulator, _Rollout
+    sim = ClothSimulator(env.conf, num_envs, env.get_collision_func(), env.cloth_mask, device=device, mode=env.simulator.mode)
+    st = sim.reset_jax()
+    g = torch.Generator(device=device).manual_seed(0)
+    x = (st.x + 1e-4 * torch.randn(st.x.shape, device=device, generator=g)).abs().requires_grad_(True)
+    v = (0.01 * torch.randn(st.v.shape, device=device, generator=g)).requires_grad_(True)
+    prim = torch.stack([st.primitive0, st.primitive1], 1).contiguous()
+    k = st.stiffness.to(torch.float32)
+    pick = x.detach()[:, 100, :]
+    acts = torch.zeros((MACRO, num_envs, 8), device=device)
+    acts[:3, :, :3] = (pick - prim[:, 0, :3])[None] / 3 * 50 / 50
+    acts[:3, :, 3] = 1
+    acts[3:13, :, 1] = 0.006
+    acts[13:33, :, 0] = 0.004
+    acts[33:, :, 3] = 1
+    sim.profile = {"fwd": [], "bwd": []}
+    for _ in range(reps + 1):
+        xo, vo, po = _Rollout.apply(sim, x, v, prim, k, st.mu, acts, False)
+        (xo.sum() + vo.sum()).backward()
+    torch.cuda.synchronize(device)
+    ms = {kk: float(np.mean([a.elapsed_time(b) for a, b in vv[1:]])) for kk, vv in sim.profile.items()}
+    n = num_envs * MACRO * SUBSTEPS
+    tot = (ms["fwd"] + ms["bwd"]) * 1e-3
+    return {"note": "same kernels, chip filled; not the headline workload", "num_envs": num_envs,
+            "kernel_ms": ms, "substeps_per_sec_fwd_bwd": n / tot,
+            "achieved_GBs": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9, "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9},
+            "hbm_frac": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
 def touched_cells(x, n_grid=64):
     """G_act of SURVEY.md 8(d): number of grid cells with >= 1 particle contribution, counted on the host."""
     base = (x * n_grid - 0.5).astype(np.int32)
@@ -139,6 +173,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
     ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "whip_rope"],
                     help="fold_cloth1 = the headline metric (default); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--kernel-mode", type=int, default=0,
@@ -221,6 +256,8 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
                          "note": "latency/occupancy bound: 4 envs = 4 workgroups on 256 CUs, 2000 sequential substeps"},
         }
+        if not args.no_saturation:
+            out["saturation"] = saturation_probe(env, device)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
