@@ -162,3 +162,70 @@ def test_out_of_range_index_semantics(demo):
     oh = run_hip(make_sim(S, 1), st)
     assert np.isfinite(of["x"]).all()
     assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4 and _rel(oh["C"], of["C"]) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# many-workgroup path (N > 128): the scaled whip_rope configuration n_grid=128 -> res 64^3, N=798
+# ---------------------------------------------------------------------------------------------------------
+class ScaledConf(LegacyConf):
+    n_grid = 128
+    res = (64, 64, 64)
+    dx, inv_dx = 1 / 128, 128.0
+    p_vol = (dx * 0.5) ** 2
+    p_mass = p_vol * 1
+    E, nu = 100, 0.1
+
+
+def _scaled_case(S, seed, B=1):
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    conf = ScaledConf()
+    conf.steps = S
+    sim = SimpleMPMSimulator(conf, B, use_position_control=True)
+    st0 = sim.add_box(conf, None, size=[0.38, 0.006, 0.006], init_pos=[0.25, 0.01, 0.25], z_rotation_angle=np.pi / 2,
+                      material=1, density=2.75, hardness=1.0)
+    x = st0.x.cpu().numpy()
+    N = x.shape[0]
+    sim.n_particles = N
+    sim._make_handle()
+    rng = np.random.default_rng(seed)
+    mu0, la0 = 100 / (2 * 1.1), 100 * 0.1 / (1.1 * 0.8)
+    ppos = np.zeros((S, 3), np.float32)
+    ppos[0] = x[N // 3] + np.float32([0.0, 0.0, 0.0])
+    prot = np.zeros((S, 4), np.float32); prot[:, 0] = 1
+    st = dict(x=np.repeat(x[None], B, 0), v=(rng.normal(size=(B, N, 3)) * 0.05).astype(np.float32),
+              C=(rng.normal(size=(B, N, 3, 3)) * 1.0).astype(np.float32),
+              F=(np.eye(3, dtype=np.float32)[None, None] + rng.normal(size=(B, N, 3, 3)).astype(np.float32) * 0.01),
+              J=np.ones((B, N), np.float32), ppos=np.repeat(ppos[None], B, 0), prot=np.repeat(prot[None], B, 0),
+              psize=np.repeat(np.float32([[0.02, 0.02, 0.02]]), B, 0), friction=np.full(B, 0.1, np.float32),
+              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32),
+              action=np.repeat(np.float32([[0.4, -0.1, 0.3, 0, 0, 0]]) / 50, B, 0))   # env scale: a/50 (whip_rope_env.py:112)
+    g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)), gC=rng.normal(size=(B, N, 3, 3)) * 0.01,
+             gF=rng.normal(size=(B, N, 3, 3)) * 0.1, gppos=rng.normal(size=(B, S, 3)))
+    return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
+
+
+def test_large_path_matches_oracle_n798():
+    from oracle.pyoracle import MpmOracle
+    S = 5   # dt=1e-4 at dx=1/128 is 4x the CFL number of the default config: keep the window short
+    sim, st, g, N = _scaled_case(S, 0, B=2)
+    assert N == 798
+    st["action"][1] = np.float32([-0.3, 0.2, 0.1, 0, 0, 0]) / 50
+    orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
+    of = orc.step_fwd(st, nthreads=2)
+    assert all(np.isfinite(of[k]).all() for k in ("x", "v", "C", "F"))
+    st64 = {k: v.astype(np.float64) for k, v in st.items()}
+    ob = orc.step_bwd(st64, {k: v.astype(np.float64) for k, v in g.items()}, clip=True, nthreads=2)
+    oh = run_hip(sim, st, g=g, clip=True)
+    assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4     # north_star: 1e-4 relative
+    assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
+    np.testing.assert_allclose(oh["J"], of["J"], rtol=1e-5)
+    for key in ("ppos", "prot", "pv", "pw"):
+        np.testing.assert_allclose(oh[key], of[key], rtol=0, atol=1e-7)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
+    for key in ("gfriction", "gmu", "glamda"):
+        assert _rel(oh[key].reshape(-1), ob[key]) < 2e-2, (key, oh[key], ob[key])
+    # a second call on the same handle (persistent grid arena must be back to all-zero)
+    oh2 = run_hip(sim, st)
+    assert _rel(oh2["x"], of["x"]) < 5e-6 and _rel(oh2["v"], of["v"]) < 1e-4

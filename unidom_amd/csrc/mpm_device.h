@@ -1,0 +1,425 @@
+// Device functions shared by the MPM kernels (mpm.hip: one workgroup per env, LDS cell table;
+// mpm_large.hip: many workgroups per env, dense grid in HBM).  Reference citations: see mpm.hip.
+#pragma once
+#include "common.h"
+
+#ifndef UD_MPM_ABLATE
+#define UD_MPM_ABLATE 0   // timing-only diagnostic builds (never shipped): bit0 no SVD, bit1 no scatter, bit2 no grid op, bit3 no g2p, bit4 no clear, bit5 no insert
+#endif
+
+namespace ud {
+
+struct MpmConst {
+  int N, Np, n_grid, res[3], steps;
+  float dt, dx, inv_dx, p_mass, p_vol, stress_c, dx2, dtg[3];
+  int H, logH, nthreads;
+};
+
+// ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------
+__device__ __forceinline__ void m_mul(const float* A, const float* B, float* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void m_mul_bt(const float* A, const float* B, float* R) {  // A * B^T
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+__device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* R) {  // A^T * B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+#define UD_JROT(p, q)                                                                                       \
+  {                                                                                                         \
+    float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
+    float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
+    float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
+    const bool rot = fabsf(ga) > 1.5e-8f * __builtin_amdgcn_sqrtf(al * be);                                  \
+    float zeta = (be - al) * __builtin_amdgcn_rcpf(2.f * (rot ? ga : 1.f));                                  \
+    float t = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta)); \
+    float cs = __builtin_amdgcn_rsqf(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */ \
+    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
+      float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \
+      a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                                    \
+      float vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                                          \
+      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                                  \
+    }                                                                                                        \
+  }
+
+#define UD_CSWAP(p, q)                                                                  \
+  if (sv[p] < sv[q]) {                                                                  \
+    float ts = sv[p]; sv[p] = sv[q]; sv[q] = ts;                                        \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                     \
+      float t1 = a[i * 3 + p]; a[i * 3 + p] = a[i * 3 + q]; a[i * 3 + q] = t1;          \
+      float t2 = vv[i * 3 + p]; vv[i * 3 + p] = vv[i * 3 + q]; vv[i * 3 + q] = t2;      \
+    }                                                                                   \
+  }
+
+// One-sided Jacobi (Hestenes) SVD of a 3x3: A = U diag(S) Vh, S descending >= 0.  The reference calls LAPACK
+// (third party); only U S Vh, U Vh and S -- gauge-invariant -- enter the dynamics.  The rotation angle may be
+// approximate (v_rcp/v_rsq/v_sqrt, 1 ulp): each Givens pair (cs, sn) is orthonormal to round-off regardless.
+__device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* Vh) {
+  float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = A[i];
+#pragma unroll 1
+  for (int sweep = 0; sweep < 4; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
+    UD_JROT(0, 1)
+    UD_JROT(0, 2)
+    UD_JROT(1, 2)
+  }
+  float sv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrtf(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+  UD_CSWAP(0, 1)
+  UD_CSWAP(1, 2)
+  UD_CSWAP(0, 1)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S[j] = sv[j];
+    float inv = sv[j] > FLT_MIN ? 1.f / sv[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
+  }
+}
+
+__device__ __forceinline__ float safe_inv(float x) { return x / (x * x + 1e-12f); }
+
+// svd_safe_batch.py:65-102 (real 3x3): cotangents (dU, dS, dVh) -> dA
+__device__ __forceinline__ void svd3_bwd(const float* U, const float* S, const float* Vh, const float* dU,
+                                         const float* dS, const float* dVh, float* dA) {
+  float UtdU[9], VtdV[9];
+  m_mul_at(U, dU, UtdU);     // Ut @ dU
+  m_mul_bt(Vh, dVh, VtdV);   // Vt @ Hc(dVh),  Vt = Cc(Vh) = Vh
+  float S2[3] = {S[0] * S[0], S[1] * S[1], S[2] * S[2]};
+  float Si[3] = {safe_inv(S[0]), safe_inv(S[1]), safe_inv(S[2])};
+  float JJ[9], KK[9];        // (J + J^H) * S  and  S * (K + K^H) handled below
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float Fij = (i == j) ? 0.f : safe_inv(S2[j] - S2[i]);
+      JJ[i * 3 + j] = Fij * UtdU[i * 3 + j];
+      KK[i * 3 + j] = Fij * VtdV[i * 3 + j];
+    }
+  // M = dS(diag) + (J+J^T) colscale S + rowscale S (K+K^T)   (the L - L^H term vanishes: L is a real diagonal)
+  float M[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float t = (JJ[i * 3 + j] + JJ[j * 3 + i]) * S[j] + S[i] * (KK[i * 3 + j] + KK[j * 3 + i]);
+      M[i * 3 + j] = t + ((i == j) ? dS[i] : 0.f);
+    }
+  float UM[9];
+  m_mul(U, M, UM);
+  m_mul(UM, Vh, dA);
+  // projector terms: Pc_U_perp @ (dU * S_inv) @ Vt + (Uc * S_inv) @ dVh @ Pc_V_perp
+  float Pu[9], Pv[9], T1[9], T2[9], T3[9];
+  m_mul_bt(U, U, Pu);
+  m_mul_at(Vh, Vh, Pv);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Pu[i] = ((i % 4 == 0) ? 1.f : 0.f) - Pu[i]; Pv[i] = ((i % 4 == 0) ? 1.f : 0.f) - Pv[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { T1[i * 3 + j] = dU[i * 3 + j] * Si[j]; T2[i * 3 + j] = U[i * 3 + j] * Si[j]; }
+  m_mul(Pu, T1, T3);
+  m_mul(T3, Vh, T1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dA[i] += T1[i];
+  m_mul(T2, dVh, T3);
+  m_mul(T3, Pv, T1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dA[i] += T1[i];
+}
+
+// ---- primitive helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void qrot(const float* q, const float* v, float* o) {  // :95-102
+  float uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
+  float w0 = q[2] * uv2 - q[3] * uv1, w1 = q[3] * uv0 - q[1] * uv2, w2 = q[1] * uv1 - q[2] * uv0;
+  o[0] = v[0] + 2.f * (q[0] * uv0 + w0);
+  o[1] = v[1] + 2.f * (q[0] * uv1 + w1);
+  o[2] = v[2] + 2.f * (q[0] * uv2 + w2);
+}
+
+struct PrimF {          // primitive 0 at substep f (uniform)
+  float pos[3], iq[4], size[3], pv[3];
+  float friction;       // state.friction (ground), not the primitive's own
+};
+
+__device__ __forceinline__ float box_sdf(const float* size, const float* gp) {  // box.py:6-18
+  float q0 = clipf(fabsf(gp[0]) - size[0], 0.f, INFINITY);
+  float q1 = clipf(fabsf(gp[1]) - size[1], 0.f, INFINITY);
+  float q2 = clipf(fabsf(gp[2]) - size[2], 0.f, INFINITY);
+  float out = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + 1e-12f);
+  float tmp = q1 > q2 ? q1 : q2;
+  tmp = q0 > tmp ? q0 : tmp;
+  tmp = clipf(tmp, -INFINITY, 0.f);
+  return out + tmp;
+}
+
+struct CellRec {
+  float v1[3];
+  bool ctrl, fric, bnd[3];
+};
+
+// grid op of one cell (:283-313): (m, mv) -> v.  REC: keep what the adjoint needs.
+template <bool REC>
+__device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int ci, int cj, int ck, float m,
+                                        const float* mv, float* vo, CellRec* rec) {
+  float v[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = ((m > 0.f) ? mv[a] / m : mv[a]) + c.dtg[a];
+  float gp[3] = {(float)ci * c.dx, (float)cj * c.dx, (float)ck * c.dx};
+  float d[3] = {gp[0] - pf.pos[0], gp[1] - pf.pos[1], gp[2] - pf.pos[2]}, loc[3];
+  qrot(pf.iq, d, loc);
+  const bool ctrl = box_sdf(pf.size, loc) < pf.size[0] * 1.5f;   // :232-239
+#pragma unroll
+  for (int a = 0; a < 3; ++a) v[a] = ctrl ? pf.pv[a] / c.dt : v[a];
+  if (REC) { rec->ctrl = ctrl; rec->v1[0] = v[0]; rec->v1[1] = v[1]; rec->v1[2] = v[2]; }
+  const bool fric = (cj < 3) && (v[1] <= 0.f);                    // :297-307
+  {
+    float g0 = (float)ci, g1 = (float)cj, g2 = (float)ck;
+    float lin = v[1] + 1e-30f;
+    float vit0 = v[0] - lin * 0.f - g0 * 1e-30f, vit1 = v[1] - lin * 1.f - g1 * 1e-30f, vit2 = v[2] - lin * 0.f - g2 * 1e-30f;
+    float e0 = vit0 + 1e-12f, e1 = vit1 + 1e-12f, e2 = vit2 + 1e-12f;
+    float lit = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    float s = clipf(1.f + pf.friction * lin / lit, 0.f, INFINITY);
+    float f0 = s * (vit0 + g0 * 1e-30f), f2 = s * (vit2 + g2 * 1e-30f);
+    v[0] = fric ? f0 : v[0];
+    v[1] = fric ? 0.f : v[1];
+    v[2] = fric ? f2 : v[2];
+  }
+  if (REC) rec->fric = fric;
+  const int id[3] = {ci, cj, ck};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {                                    // :310-313 (Q8: n_grid, not res)
+    const bool b = (id[a] < 3 && v[a] < 0.f) || (id[a] > c.n_grid - 3 && v[a] > 0.f);
+    if (REC) rec->bnd[a] = b;
+    vo[a] = b ? 0.f : v[a];
+  }
+}
+
+// scatter index rule (Q5/Q9): negative wraps, out-of-range dropped (-1); gather rule: negative wraps, clamp
+// cell key = i | j << 10 | k << 20 (res <= 1024 per axis): decoding needs no integer division
+__device__ __forceinline__ int cell_scatter(const MpmConst& c, int i, int j, int k) {
+  i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
+  if (i < 0 || i >= c.res[0] || j < 0 || j >= c.res[1] || k < 0 || k >= c.res[2]) return -1;
+  return i | (j << 10) | (k << 20);
+}
+__device__ __forceinline__ int cell_gather(const MpmConst& c, int i, int j, int k) {
+  i += (i < 0) ? c.res[0] : 0; j += (j < 0) ? c.res[1] : 0; k += (k < 0) ? c.res[2] : 0;
+  i = min(max(i, 0), c.res[0] - 1); j = min(max(j, 0), c.res[1] - 1); k = min(max(k, 0), c.res[2] - 1);
+  return i | (j << 10) | (k << 20);
+}
+
+__device__ __forceinline__ float sel3(const float* w, int d, int i) {  // w[i*3+d] without dynamic register indexing
+  return (i == 0) ? w[d] : ((i == 1) ? w[3 + d] : w[6 + d]);
+}
+__device__ __forceinline__ void decode_cell(const MpmConst& c, int cell, int& ci, int& cj, int& ck) {
+  ci = cell & 1023; cj = (cell >> 10) & 1023; ck = (cell >> 20) & 1023;
+}
+
+// ---- particle pre-pass (:233-268) ---------------------------------------------------------------------
+struct Pre {
+  int base[3];
+  float fx[3], w[9];           // w[k*3+d]
+  float Fn[9], affine[9];
+};
+struct PreB {                   // extras the adjoint needs
+  float U[9], Vh[9], sig_raw[3], sig[3], Jd, mu, la, A[9];
+};
+
+template <bool KEEP>
+__device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, const float* Cm, const float* F,
+                                             float mu_s, float la_s, int material, float hard, Pre& q, PreB* kb) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    q.base[d] = (int)(x[d] * c.inv_dx - 0.5f);   // truncation (:233)
+    float f = x[d] * c.inv_dx - (float)q.base[d];
+    q.fx[d] = f;
+    q.w[0 * 3 + d] = 0.5f * ((1.5f - f) * (1.5f - f));
+    q.w[1 * 3 + d] = 0.75f - (f - 1.f) * (f - 1.f);
+    q.w[2 * 3 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+  }
+  float IC[9], Fu[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[i];
+  m_mul(IC, F, Fu);                                              // :238
+  float h = clipf(hard, 0.1f, 5.f);
+  float mu = mu_s * h, la = la_s * h;
+  if (material == 0) { mu = 0.f; la = 1.f; }                     // Q10
+  float U[9], Vh[9], sr[3], sg[3];
+  if (UD_MPM_ABLATE & 1) {
+    for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.f : 0.f; Vh[i] = U[i]; }
+    sr[0] = Fu[0]; sr[1] = Fu[4]; sr[2] = Fu[8];
+  } else {
+    svd3(Fu, U, sr, Vh);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) sg[i] = sr[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q.Fn[i] = Fu[i];
+  if (material == 2) {                                           // :250-258
+    float US[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sg[i] = clipf(sr[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) US[i * 3 + j] = U[i * 3 + j] * sg[j];
+    m_mul(US, Vh, q.Fn);
+  }
+  float Jd = sg[0] * sg[1] * sg[2];
+  float R[9], A[9], St[9];
+  m_mul(U, Vh, R);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) A[i] = q.Fn[i] - R[i];
+  m_mul_bt(A, q.Fn, St);
+  float vol = la * Jd * (Jd - 1.f);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float s = 2.f * mu * St[i] + ((i % 4 == 0) ? vol : 0.f);
+    q.affine[i] = c.stress_c * s / c.dx2 + c.p_mass * Cm[i];
+  }
+  if (KEEP) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { kb->U[i] = U[i]; kb->Vh[i] = Vh[i]; kb->A[i] = A[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { kb->sig_raw[i] = sr[i]; kb->sig[i] = sg[i]; }
+    kb->Jd = Jd; kb->mu = mu; kb->la = la;
+  }
+}
+
+
+// Adjoint of grid_op for one cell: g (cotangent of the cell's output velocity, in) -> g (cotangent of mv, out),
+// gmm (cotangent of m), dfric (contribution to d state.friction), dpv (contribution to d primitive v[f], valid
+// when the function returns true = the cell is position-controlled).  Reverse of :283-313.
+__device__ __forceinline__ bool grid_op_adjoint(const MpmConst& c, const PrimF& pf, int ci, int cj, int ck, float m,
+                                                const float* mvv, float* g, float& gmm, float& dfric, float* dpv) {
+  float vo[3];
+  CellRec rec;
+  grid_op<true>(c, pf, ci, cj, ck, m, mvv, vo, &rec);
+  dfric = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g[d] = rec.bnd[d] ? 0.f : g[d];
+  if (rec.fric) {
+    const float g0 = (float)ci, g1 = (float)cj, g2 = (float)ck;
+    const float* vv = rec.v1;
+    float lin = vv[1] + 1e-30f;
+    float vit[3] = {vv[0] - g0 * 1e-30f, vv[1] - lin - g1 * 1e-30f, vv[2] - g2 * 1e-30f};
+    float e[3] = {vit[0] + 1e-12f, vit[1] + 1e-12f, vit[2] + 1e-12f};
+    float lit = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    float arg = 1.f + pf.friction * lin / lit;
+    float sc = clipf(arg, 0.f, INFINITY);
+    float qv0 = vit[0] + g0 * 1e-30f, qv2 = vit[2] + g2 * 1e-30f;
+    float gs_ = g[0] * qv0 + g[2] * qv2;
+    float gvit[3] = {sc * g[0], 0.f, sc * g[2]};
+    float garg = gs_ * clip_grad(arg, 0.f, INFINITY);
+    dfric = garg * lin / lit;
+    float glin = garg * pf.friction / lit;
+    float glit = -garg * pf.friction * lin / (lit * lit);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gvit[d] += glit * e[d] / lit;
+    glin -= gvit[1];
+    g[0] = gvit[0]; g[1] = gvit[1] + glin; g[2] = gvit[2];
+  }
+  if (rec.ctrl) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { dpv[d] = g[d] / c.dt; g[d] = 0.f; }
+  }
+  if (m > 0.f) {
+    gmm = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { float vn = mvv[d] / m; gmm -= g[d] * vn / m; g[d] = g[d] / m; }
+  } else if (m == 0.f) {   // Q7: the mv/m branch sees cotangent 0 and 0/0 -> NaN
+    g[0] = g[1] = g[2] = NAN; gmm = NAN;
+  } else {                 // m < 0 (negative quadratic weights below dx/2, Q13): pass-through branch
+    gmm = 0.f;
+  }
+  return rec.ctrl;
+}
+
+// Adjoint of the particle pre-pass (:233-268) given the gathered stencil cotangents:
+//   gw[k*3+d] (weights), gfx (fractional position), gaff (affine), gvp (momentum v) ; gx/gv/gC/gF in: cotangents of
+//   the substep outputs (gF = cotangent of F_out = Fn), out: cotangents of the substep inputs.
+__device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q, const PreB& kb, const float* Cm, const float* F,
+                                                 int material, const float* gw, float* gfx, const float* gaff, const float* gvp,
+                                                 float* gx, float* gv, float* gC, float* gF, float& gmu_p, float& gla_p) {
+  // weights -> fx
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float fxd = q.fx[d];
+    gfx[d] += gw[0 * 3 + d] * (-(1.5f - fxd)) + gw[1 * 3 + d] * (-2.f * (fxd - 1.f)) + gw[2 * 3 + d] * (fxd - 0.5f);
+  }
+  float gS[9], gCn[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gCn[d] = gaff[d] * c.p_mass; gS[d] = gaff[d] / c.dx2 * c.stress_c; }
+  // stress = 2 mu A Fn^T + la J (J-1) I
+  float AFt[9], T1[9], gA[9], gFn[9];
+  m_mul_bt(kb.A, q.Fn, AFt);
+  gmu_p = 0.f;
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gmu_p += gS[d] * 2.f * AFt[d];
+  m_mul(gS, q.Fn, gA);
+  m_mul_at(gS, kb.A, T1);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gA[d] *= 2.f * kb.mu; gFn[d] = gF[d] + 2.f * kb.mu * T1[d] + gA[d]; }
+  const float trg = gS[0] + gS[4] + gS[8];
+  const float gJ = kb.la * (2.f * kb.Jd - 1.f) * trg;
+  gla_p = kb.Jd * (kb.Jd - 1.f) * trg;
+  float gU[9], gVh[9], gR[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gR[d] = -gA[d];
+  m_mul_bt(gR, kb.Vh, gU);
+  m_mul_at(kb.U, gR, gVh);
+  float gsig[3] = {gJ * kb.sig[1] * kb.sig[2], gJ * kb.sig[0] * kb.sig[2], gJ * kb.sig[0] * kb.sig[1]};
+  float gFu[9];
+  if (material == 2) {
+    float US[9], SV[9], T2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { US[i * 3 + j] = kb.U[i * 3 + j] * kb.sig[j]; SV[i * 3 + j] = kb.Vh[i * 3 + j] * kb.sig[i]; }
+    m_mul_bt(gFn, SV, T1);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gU[d] += T1[d];
+    m_mul_at(US, gFn, T1);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gVh[d] += T1[d];
+    m_mul_at(kb.U, gFn, T1);
+    m_mul_bt(T1, kb.Vh, T2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      gsig[i] += T2[i * 4];
+      gsig[i] *= clip_grad(kb.sig_raw[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
+    }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gFu[d] = 0.f;
+  } else {
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gFu[d] = gFn[d];
+  }
+  float dA[9];
+  svd3_bwd(kb.U, kb.sig_raw, kb.Vh, gU, gsig, gVh, dA);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gFu[d] += dA[d];
+  // Fu = (I + dt C) F
+  float IC[9];
+  m_mul_bt(gFu, F, T1);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = gCn[d] + c.dt * T1[d]; IC[d] = ((d % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[d]; }
+  m_mul_at(IC, gFu, gF);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gx[d] = gx[d] + gfx[d] * c.inv_dx; gv[d] = gvp[d]; }
+}
+
+}  // namespace ud

@@ -1,0 +1,718 @@
+// MLS-MPM `step` for environments too large for one workgroup (N > 128 particles: the scaled whip_rope configs
+// n_grid 128 / 256 -> N = 798 / 6675): many workgroups per env, the `res` grid dense in HBM, a handful of small
+// kernels per substep.  Same arithmetic (shared device functions, mpm_device.h) and the same C ABI as mpm.hip.
+//
+// Per substep the forward runs  clear+FK -> p2g -> grid op -> g2p  and the backward
+// clear+FK-adjoint -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint:
+//   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells with an
+//     epoch stamp; the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
+//     the next substep visit only touched cells (never the 32^3..128^3 dense volume the reference sweeps ~10x);
+//   * particle state history (24 floats/particle/substep, SoA) doubles as the backward's checkpoint;
+//   * no host synchronisation: all launches go to the caller's stream in order.
+// First version: one lane per particle, plain global atomics (the Morton-sorted, LDS-tiled p2g of north_star is the
+// next optimisation step for this path).
+#include "mpm_device.h"
+#include "mpm_large.h"
+
+namespace ud {
+
+struct LargeBuf {
+  float4* val;      // [B][G]  (m, mvx, mvy, mvz); after the grid op (fwd): (m, vx, vy, vz)
+  float4* vel;      // [B][G]  bwd: grid velocity after the grid op
+  float4* gacc;     // [B][G]  bwd: cotangent of grid velocity -> (g_mv xyz, g_m)
+  int* stamp;       // [B][G]
+  int* list;        // [2][B][cap]
+  int* count;       // [2][B]
+  float* ppos;      // [B][S*3]  primitive position (evolving)
+  float* prot;      // [B][S*4]
+  float* ppin;      // [B][S*3]  input position array (bwd clip factors)
+  float* trq;       // [B][S]    Q6 scalar per substep
+  float* gppos;     // [B][S*3]  bwd
+  float* gpv;       // [B][S*3]  bwd
+  float* acc;       // [B][4]    bwd: friction, mu, lamda accumulators
+  float* pscr;      // [B][Np][12] bwd: per-particle gw[9], gfx[3] between kernels
+  float* hist;      // [B][2][24][Np] ping-pong state when the caller passes no checkpoint
+  float* gstate;    // [B][24][Np] bwd: cotangent state (gx,gv,gC,gF) SoA
+};
+
+struct LargeArgs {
+  MpmConst c;
+  LargeBuf w;
+  const int* material;
+  const float* hard;
+  int B, f, epoch, cap;
+  long G;
+  const float* hist_in;   // state at substep f      [B][*][24][Np] with stride
+  float* hist_out;        // state at substep f + 1
+  long hist_stride_b;     // floats between envs
+  const float *psize, *friction, *mu, *lamda, *action;
+};
+
+__device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
+  int ci, cj, ck;
+  decode_cell(c, key, ci, cj, ck);
+  return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
+}
+
+__device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long lin) {
+  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
+  if (old != a.epoch) {
+    const int cur = a.f & 1;
+    const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
+    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = key;
+  }
+}
+
+__device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, float* pv) {
+  const int S = a.c.steps, fc = min(max(a.f, 0), S - 1);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    pv[d] = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+    pf.pos[d] = a.w.ppos[(long)b * S * 3 + fc * 3 + d]; pf.size[d] = a.psize[b * 3 + d]; pf.pv[d] = pv[d];
+  }
+  const float* r = a.w.prot + (long)b * S * 4 + fc * 4;
+  float r0 = r[0], r1 = -r[1], r2 = -r[2], r3 = -r[3];
+  float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;
+  pf.iq[0] = r0 / n; pf.iq[1] = r1 / n; pf.iq[2] = r2 / n; pf.iq[3] = r3 / n;
+  pf.friction = a.friction[b];
+}
+
+__device__ __forceinline__ void load_state(const float* h, int Np, int p, float* x, float* v, float* Cm, float* F) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[d] = h[d * Np + p]; v[d] = h[(3 + d) * Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { Cm[d] = h[(6 + d) * Np + p]; F[d] = h[(15 + d) * Np + p]; }
+}
+
+// ---- forward kernels ---------------------------------------------------------------------------------
+// clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
+__global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int prev = (a.f + 1) & 1, cur = a.f & 1;   // works for f ascending (forward) and descending (backward)
+  const int n = min(a.w.count[prev * a.B + b], a.cap);
+  if (t < n) {
+    const long lin = cell_lin(a.c, a.w.list[((long)prev * a.B + b) * a.cap + t]);
+    a.w.val[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (clear_bwd) a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0) {
+    const int S = a.c.steps, f = a.f, tid = threadIdx.x;
+    if (tid == 0) a.w.count[cur * a.B + b] = 0;
+    if (do_fk) {
+      float* pp = a.w.ppos + (long)b * S * 3;
+      float* pr = a.w.prot + (long)b * S * 4;
+      for (int e0 = 0; e0 < S * 3; e0 += blockDim.x) {   // read all, then write all (one block per env)
+        const int e = e0 + tid;
+        float pending = 0.f;
+        if (e < S * 3) {
+          const int row = e / 3, d = e - row * 3;
+          const float pva = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+          pending = (row == f + 1) ? (pp[min(f, S - 1) * 3 + d] + pva) : pp[e];
+        }
+        __syncthreads();
+        if (e < S * 3) pp[e] = clipf(pending, -2.f, 2.f);
+        __syncthreads();
+      }
+      if (tid == 0 && f + 1 < S) {
+        float pw[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pw[d] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+        float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;
+        float sn = sinf(ang / 2.f);
+        float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
+        const float* r = pr + f * 4;
+        float o0 = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+        float o1 = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+        float o2 = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+        float o3 = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+        float nn = clipf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3), 1e-12f, INFINITY);
+        float* w = pr + (f + 1) * 4;
+        w[0] = o0 / nn; w[1] = o1 / nn; w[2] = o2 / nn; w[3] = o3 / nn;
+      }
+    }
+  }
+}
+
+// particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
+__global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const MpmConst& c = a.c;
+  if (p >= c.N) return;
+  float x[3], v[3], Cm[9], F[9];
+  load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+  Pre q;
+  particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[p], a.hard[p], q, nullptr);
+  if (store_F) {
+    float* ho = a.hist_out + (long)b * a.hist_stride_b;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
+  }
+  float4* val = a.w.val + (long)b * a.G;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+    const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    if (sc >= 0) {
+      const long lin = cell_lin(c, sc);
+      const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+      float* cell = (float*)(val + lin);
+      atomicAdd(cell, weight * c.p_mass);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
+        atomicAdd(cell + 1 + r, weight * (c.p_mass * v[r] + ad));
+      }
+      touch(a, b, sc, lin);
+    }
+    if (gc != sc) touch(a, b, gc, cell_lin(c, gc));   // Q5: a clamped gather cell takes part with m = 0
+  }
+}
+
+// grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
+__global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cur = a.f & 1;
+  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
+  int ci, cj, ck;
+  decode_cell(a.c, key, ci, cj, ck);
+  const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
+  PrimF pf;
+  float pv[3];
+  load_prim(a, b, pf, pv);
+  const float4 mv = a.w.val[(long)b * a.G + lin];
+  const float mvv[3] = {mv.y, mv.z, mv.w};
+  float vo[3];
+  grid_op<false>(a.c, pf, ci, cj, ck, mv.x, mvv, vo, nullptr);
+  if (to_vel) a.w.vel[(long)b * a.G + lin] = make_float4(vo[0], vo[1], vo[2], 0.f);
+  else a.w.val[(long)b * a.G + lin] = make_float4(mv.x, vo[0], vo[1], vo[2]);
+}
+
+// g2p + advect (:196-221, :318-328)
+__global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const MpmConst& c = a.c;
+  if (p >= c.N) return;
+  const float* hi = a.hist_in + (long)b * a.hist_stride_b;
+  float* ho = a.hist_out + (long)b * a.hist_stride_b;
+  float x[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) x[d] = hi[d * c.Np + p];
+  int base[3];
+  float fx[3], w[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    base[d] = (int)(x[d] * c.inv_dx - 0.5f);
+    const float f = x[d] * c.inv_dx - (float)base[d];
+    fx[d] = f;
+    w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+  }
+  const float4* val = a.w.val + (long)b * a.G;
+  float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const float weight = sel3(w, 0, i) * sel3(w, 1, j) * sel3(w, 2, k);
+    const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+    const float4 g4 = val[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
+    const float g[3] = {g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      nv[r] += weight * g[r];
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = x[d] + c.dt * nv[d]; ho[(3 + d) * c.Np + p] = nv[d]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+  if (p < 3) {   // Q6: row p of particle p; three adds per substep on a zero-initialised word
+    const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
+    atomicAdd(&a.w.trq[(long)b * c.steps + a.f], (p == 0) ? r0 : ((p == 1) ? r1 : r2));
+  }
+}
+
+// AoS boundary <-> SoA history; nan_to_num on the way in (norm_grad_state fwd, :377-381)
+__global__ void __launch_bounds__(256) lg_pack(MpmConst c, int B, const float* x, const float* v, const float* Cm, const float* F,
+                                               float* hist, long stride_b, int sanitize) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.N) return;
+  float* h = hist + (long)b * stride_b;
+  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    h[d * c.Np + p] = sanitize ? nan_to_num(x[o3 + d]) : x[o3 + d];
+    h[(3 + d) * c.Np + p] = sanitize ? nan_to_num(v[o3 + d]) : v[o3 + d];
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {
+    h[(6 + d) * c.Np + p] = sanitize ? nan_to_num(Cm[o9 + d]) : Cm[o9 + d];
+    h[(15 + d) * c.Np + p] = sanitize ? nan_to_num(F[o9 + d]) : F[o9 + d];
+  }
+}
+
+__global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int B, const float* hist, long stride_b, float* x, float* v, float* Cm,
+                                                 float* F) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.N) return;
+  const float* h = hist + (long)b * stride_b;
+  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[o3 + d] = h[d * c.Np + p]; v[o3 + d] = h[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { Cm[o9 + d] = h[(6 + d) * c.Np + p]; F[o9 + d] = h[(15 + d) * c.Np + p]; }
+}
+
+// forward prologue / epilogue for the primitive arrays, J and the outputs set_action writes
+__global__ void __launch_bounds__(256) lg_prim_in(LargeArgs a, const float* ppos, const float* prot) {
+  const int b = blockIdx.x, S = a.c.steps;
+  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) { a.w.ppos[(long)b * S * 3 + e] = ppos[(long)b * S * 3 + e]; a.w.ppin[(long)b * S * 3 + e] = ppos[(long)b * S * 3 + e]; }
+  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[(long)b * S * 4 + e] = prot[(long)b * S * 4 + e];
+  for (int e = threadIdx.x; e < S; e += blockDim.x) a.w.trq[(long)b * S + e] = 0.f;
+  if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
+}
+
+__global__ void __launch_bounds__(256) lg_fwd_out(LargeArgs a, const float* J, float* Jo, float* ppos_o, float* prot_o, float* pv_o,
+                                                  float* pw_o, float* ck_tail, long ck_stride_b) {
+  const int b = blockIdx.x, S = a.c.steps, N = a.c.N;
+  for (int p = threadIdx.x; p < N; p += blockDim.x) {
+    float Jp = nan_to_num(J[(long)b * N + p]);
+    for (int f = 0; f < S; ++f) Jp = Jp * (1.f + a.c.dt * a.w.trq[(long)b * S + f]);   // :327
+    Jo[(long)b * N + p] = Jp;
+  }
+  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
+    const int row = e / 3, d = e - row * 3;
+    const float* pp = a.w.ppos + (long)b * S * 3;
+    ppos_o[(long)b * S * 3 + e] = (row == 0) ? pp[(S - 1) * 3 + d] : pp[e];       // copy_frame(steps, 0), Q5
+    pv_o[(long)b * S * 3 + e] = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+    pw_o[(long)b * S * 3 + e] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+    if (ck_tail) { ck_tail[(long)b * ck_stride_b + e] = pp[e]; ck_tail[(long)b * ck_stride_b + S * 7 + e] = a.w.ppin[(long)b * S * 3 + e]; }
+  }
+  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) {
+    const int row = e / 4, d = e - row * 4;
+    const float* pr = a.w.prot + (long)b * S * 4;
+    prot_o[(long)b * S * 4 + e] = (row == 0) ? pr[(S - 1) * 4 + d] : pr[e];
+    if (ck_tail) ck_tail[(long)b * ck_stride_b + S * 3 + e] = pr[e];
+  }
+}
+
+// ---- backward kernels ---------------------------------------------------------------------------------
+__device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pin, int f, int j, int a, float pva) {
+  if (j == f + 1) return pp[f * 3 + a] + pva;
+  if (j <= f) return (f == 0) ? pin[j * 3 + a] : pp[j * 3 + a];
+  return (f == 0) ? pin[j * 3 + a] : clipf(pin[j * 3 + a], -2.f, 2.f);
+}
+
+// FK adjoint of substep f (one block per env)
+__global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
+  const int b = blockIdx.x, S = a.c.steps, f = a.f;
+  const float* pp = a.w.ppos + (long)b * S * 3;
+  const float* pin = a.w.ppin + (long)b * S * 3;
+  float* gp = a.w.gppos + (long)b * S * 3;
+  float* gpv = a.w.gpv + (long)b * S * 3;
+  for (int e0 = 0; e0 < S * 3; e0 += blockDim.x) {
+    const int e = e0 + threadIdx.x;
+    float val = 0.f, t = 0.f;
+    if (e < S * 3) {
+      const int row = e / 3, d = e - row * 3;
+      const float pva = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+      val = gp[e] * clip_grad(ppos_preclip_g(pp, pin, f, row, d, pva), -2.f, 2.f);
+      if (f + 1 < S) {
+        if (row == f + 1) val = 0.f;
+        if (row == f) { t = gp[e + 3] * clip_grad(ppos_preclip_g(pp, pin, f, f + 1, d, pva), -2.f, 2.f); val += t; }
+      }
+    }
+    __syncthreads();
+    if (e < S * 3) { gp[e] = val; gpv[e] += t; }
+    __syncthreads();
+  }
+}
+
+// g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
+__global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const MpmConst& c = a.c;
+  if (p >= c.N) return;
+  const float* hi = a.hist_in + (long)b * a.hist_stride_b;
+  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float x[3], gx[3], gv[3], gC[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[d] = hi[d * c.Np + p]; gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
+  int base[3];
+  float fx[3], w[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    base[d] = (int)(x[d] * c.inv_dx - 0.5f);
+    const float f = x[d] * c.inv_dx - (float)base[d];
+    fx[d] = f;
+    w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+  }
+  float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+  const float4* vel = a.w.vel + (long)b * a.G;
+  float4* gacc = a.w.gacc + (long)b * a.G;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
+    const float weight = wi * wj * wk;
+    const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+    const long lin = cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k));
+    const float4 v4 = vel[lin];
+    const float vv[3] = {v4.x, v4.y, v4.z};
+    float gwt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+      atomicAdd((float*)(gacc + lin) + r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
+      gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+      gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+      gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+    }
+  }
+  float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
+#pragma unroll
+  for (int d = 0; d < 9; ++d) ps[d] = gw[d];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) ps[9 + d] = gfx[d];
+}
+
+// grid-op adjoint over the active cells
+__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cur = a.f & 1;
+  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
+  int ci, cj, ck;
+  decode_cell(a.c, key, ci, cj, ck);
+  const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
+  PrimF pf;
+  float pv[3];
+  load_prim(a, b, pf, pv);
+  const float4 mv = a.w.val[(long)b * a.G + lin];
+  const float mvv[3] = {mv.y, mv.z, mv.w};
+  const float4 g4 = a.w.gacc[(long)b * a.G + lin];
+  float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric, dpv[3];
+  const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
+  if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+  if (ctrl) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
+  }
+  a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+}
+
+// p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
+__global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const MpmConst& c = a.c;
+  if (p >= c.N) return;
+  float x[3], v[3], Cm[9], F[9];
+  load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+  Pre q;
+  PreB kb;
+  const int material = a.material[p];
+  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[p], q, &kb);
+  float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gx[3], gv[3], gC[9], gF[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+  const float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
+  float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gw[d] = ps[d]; gaff[d] = 0.f; }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gfx[d] = ps[9 + d];
+  const float4* gacc = a.w.gacc + (long)b * a.G;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    if (sc < 0) continue;
+    const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+    const float weight = wi * wj * wk;
+    const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
+    const float4 g4 = gacc[cell_lin(c, sc)];
+    const float gcv[3] = {g4.x, g4.y, g4.z};
+    float gwt = c.p_mass * g4.w;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+      gwt += gcv[r] * (c.p_mass * v[r] + ad);
+      gvp[r] += weight * c.p_mass * gcv[r];
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) {
+        gaff[r * 3 + s2] += weight * gcv[r] * dpos[s2];
+        gfx[s2] -= c.dx * weight * gcv[r] * q.affine[r * 3 + s2];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+      gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+      gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+    }
+  }
+  float gmu_p, gla_p;
+  particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+  if (material != 0) {
+    const float h = clipf(a.hard[p], 0.1f, 5.f);
+    atomicAdd(&a.w.acc[b * 4 + 1], gmu_p * h);
+    atomicAdd(&a.w.acc[b * 4 + 2], gla_p * h);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
+}
+
+// backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
+__global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_tail, long ck_stride_b, const float* gppos) {
+  const int b = blockIdx.x, S = a.c.steps;
+  const float* tail = ck_tail + (long)b * ck_stride_b;
+  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
+    a.w.ppos[(long)b * S * 3 + e] = tail[e];
+    a.w.ppin[(long)b * S * 3 + e] = tail[S * 7 + e];
+    a.w.gpv[(long)b * S * 3 + e] = 0.f;
+    const int row = e / 3, d = e - row * 3;
+    float g = gppos[(long)b * S * 3 + e];
+    if (S > 1) {
+      if (row == 0) g = 0.f;
+      if (row == S - 1) g += gppos[(long)b * S * 3 + d];
+    }
+    a.w.gppos[(long)b * S * 3 + e] = g;
+  }
+  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[(long)b * S * 4 + e] = tail[S * 3 + e];
+  if (threadIdx.x < 4) a.w.acc[b * 4 + threadIdx.x] = 0.f;
+  if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
+}
+
+// backward epilogue: set_action adjoint, action clip, norm_grad / norm_grad_state, outputs (one block per env)
+__global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
+                                                  float* gfric, float* gmu, float* glam, float* gaction) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, S = a.c.steps, N = a.c.N, Np = a.c.Np, tid = threadIdx.x;
+  float* gs = a.w.gstate + (long)b * 24 * Np;
+  float* gp = a.w.gppos + (long)b * S * 3;
+  float ac[6], ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ac[d] = clipf(a.action[b * 6 + d], -1.f, 1.f);
+  for (int j = 0; j < S; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float t = a.w.gpv[(long)b * S * 3 + j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
+  float tf = a.w.acc[b * 4 + 0], tm = a.w.acc[b * 4 + 1], tl = a.w.acc[b * 4 + 2];
+  float sn = 0.f;
+  if (clip) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { ga[d] = nan_to_num(ga[d] + 0.f); n2 += ga[d] * ga[d]; }
+    const float nrm = sqrtf(n2);
+    if (!(nrm < 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) ga[d] = ga[d] / nrm;
+    }
+    float s2 = 0.f;
+    for (int e = tid; e < 24 * Np; e += blockDim.x) {
+      const int p = e % Np;
+      if (p < N) { const float t = nan_to_num(gs[e] + 0.f); gs[e] = t; s2 += t * t; }
+    }
+    for (int e = tid; e < S * 3; e += blockDim.x) { const float t = nan_to_num(gp[e] + 0.f); gp[e] = t; s2 += t * t; }
+    tf = nan_to_num(tf); tm = nan_to_num(tm); tl = nan_to_num(tl);
+    if (tid == 0) {
+      s2 += tf * tf + tm * tm + tl * tl;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+    }
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) red[tid >> 6] = s2;
+    __syncthreads();
+    float tot = 0.f;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) tot += red[q];
+    sn = sqrtf(tot);
+  }
+  const bool sc = clip && !(sn < 1.f);
+  for (int p = tid; p < N; p += blockDim.x) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      gx0[((long)b * N + p) * 3 + d] = sc ? gs[d * Np + p] / sn : gs[d * Np + p];
+      gv0[((long)b * N + p) * 3 + d] = sc ? gs[(3 + d) * Np + p] / sn : gs[(3 + d) * Np + p];
+    }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) {
+      gC0[((long)b * N + p) * 9 + d] = sc ? gs[(6 + d) * Np + p] / sn : gs[(6 + d) * Np + p];
+      gF0[((long)b * N + p) * 9 + d] = sc ? gs[(15 + d) * Np + p] / sn : gs[(15 + d) * Np + p];
+    }
+  }
+  for (int e = tid; e < S * 3; e += blockDim.x) gppos0[(long)b * S * 3 + e] = sc ? gp[e] / sn : gp[e];
+  if (tid == 0) {
+    gfric[b] = sc ? tf / sn : tf; gmu[b] = sc ? tm / sn : tm; glam[b] = sc ? tl / sn : tl;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) gaction[b * 6 + d] = ga[d];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------------
+struct MpmLarge {
+  MpmConst c;
+  const int* d_material;
+  const float* d_hard;
+  int B = 0, cap = 0, epoch = 1;
+  long G = 0;
+  LargeBuf w{};
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+};
+
+MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard) {
+  auto* L = new MpmLarge;
+  L->c = c; L->d_material = d_material; L->d_hard = d_hard;
+  L->G = (long)c.res[0] * c.res[1] * c.res[2];
+  L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
+  return L;
+}
+
+void mpm_large_destroy(MpmLarge* L) {
+  if (!L) return;
+  if (L->arena) (void)hipFree(L->arena);
+  delete L;
+}
+
+size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B) {
+  return (size_t)B * ((size_t)(L->c.steps + 1) * 24 * L->c.Np + (size_t)L->c.steps * 10) * sizeof(float);
+}
+
+static int reserve(MpmLarge* L, int B, hipStream_t stream) {
+  if (B <= L->B) return UD_OK;
+  if (L->arena) { (void)hipStreamSynchronize(stream); (void)hipFree(L->arena); L->arena = nullptr; }
+  const MpmConst& c = L->c;
+  const long G = L->G, S = c.steps;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_val = take((size_t)B * G * 16), o_vel = take((size_t)B * G * 16), o_gacc = take((size_t)B * G * 16);
+  const size_t o_stamp = take((size_t)B * G * 4), o_list = take((size_t)2 * B * L->cap * 4), o_count = take((size_t)2 * B * 4);
+  const size_t o_ppos = take((size_t)B * S * 3 * 4), o_prot = take((size_t)B * S * 4 * 4), o_ppin = take((size_t)B * S * 3 * 4);
+  const size_t o_trq = take((size_t)B * S * 4), o_gppos = take((size_t)B * S * 3 * 4), o_gpv = take((size_t)B * S * 3 * 4);
+  const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 12 * 4);
+  const size_t o_hist = take((size_t)B * 2 * 24 * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
+  hipError_t e = hipMalloc(&L->arena, off);
+  if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
+  e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, stamps and counters start at zero
+  if (e != hipSuccess) { set_error("ud_mpm (large path): memset failed"); return UD_ERR_HIP; }
+  char* base = (char*)L->arena;
+  L->w.val = (float4*)(base + o_val); L->w.vel = (float4*)(base + o_vel); L->w.gacc = (float4*)(base + o_gacc);
+  L->w.stamp = (int*)(base + o_stamp); L->w.list = (int*)(base + o_list); L->w.count = (int*)(base + o_count);
+  L->w.ppos = (float*)(base + o_ppos); L->w.prot = (float*)(base + o_prot); L->w.ppin = (float*)(base + o_ppin);
+  L->w.trq = (float*)(base + o_trq); L->w.gppos = (float*)(base + o_gppos); L->w.gpv = (float*)(base + o_gpv);
+  L->w.acc = (float*)(base + o_acc); L->w.pscr = (float*)(base + o_pscr); L->w.hist = (float*)(base + o_hist);
+  L->w.gstate = (float*)(base + o_gstate);
+  L->arena_bytes = off; L->B = B; L->epoch = 1;
+  return UD_OK;
+}
+
+static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* friction, const float* mu, const float* lamda,
+                           const float* action) {
+  LargeArgs a;
+  a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.epoch = 0; a.cap = L->cap; a.G = L->G;
+  a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0;
+  a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
+  (void)B;
+  return a;
+}
+
+int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
+                       const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
+                       const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,
+                       float* prot_o, float* pv_o, float* pw_o, float* ckpt, int* status, hipStream_t st) {
+  int rc = reserve(L, B, st);
+  if (rc) return rc;
+  const MpmConst& c = L->c;
+  const int S = c.steps, N = c.N, Np = c.Np;
+  const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
+  a.B = L->B;
+  // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
+  float* hist = ckpt ? ckpt : L->w.hist;
+  const long rec = (long)24 * Np;
+  const long stride_b = ckpt ? ((long)(S + 1) * rec + (long)S * 10) : 2 * rec;
+  a.hist_stride_b = stride_b;
+  hipLaunchKernelGGL(lg_prim_in, dim3(B), blk, 0, st, a, ppos, prot);
+  hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, x, v, C, F, hist, stride_b, 1);
+  for (int f = 0; f < S; ++f) {
+    a.f = f; a.epoch = L->epoch++;
+    a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
+    a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
+    hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 1, 0);
+    hipLaunchKernelGGL(lg_p2g, gp, blk, 0, st, a, 1);
+    hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 0);
+    hipLaunchKernelGGL(lg_g2p, gp, blk, 0, st, a);
+  }
+  // restore the all-zero grid invariant (cells of the last substep)
+  a.f = S; a.epoch = L->epoch++;
+  hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 0);
+  const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
+  hipLaunchKernelGGL(lg_unpack, gp, blk, 0, st, c, B, last, stride_b, xo, vo, Co, Fo);
+  float* tail = ckpt ? ckpt + (long)(S + 1) * rec : nullptr;
+  hipLaunchKernelGGL(lg_fwd_out, dim3(B), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("ud_mpm_step_fwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize, const float* friction, const float* mu,
+                       const float* lamda, const float* action, const float* gx, const float* gv, const float* gC, const float* gF,
+                       const float* gppos, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0, float* gfric,
+                       float* gmu, float* glam, float* gaction, int* status, hipStream_t st) {
+  int rc = reserve(L, B, st);
+  if (rc) return rc;
+  const MpmConst& c = L->c;
+  const int S = c.steps, N = c.N, Np = c.Np;
+  const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
+  const long rec = (long)24 * Np;
+  const long stride_b = (long)(S + 1) * rec + (long)S * 10;
+  a.hist_stride_b = stride_b;
+  hipLaunchKernelGGL(lg_bwd_in, dim3(B), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos);
+  hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
+  for (int f = S - 1; f >= 0; --f) {
+    // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
+    a.f = f; a.epoch = L->epoch++;
+    a.hist_in = ckpt + (long)f * rec;
+    hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
+    hipLaunchKernelGGL(lg_p2g, gp, blk, 0, st, a, 0);
+    hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 1);
+    hipLaunchKernelGGL(lg_g2p_adj, gp, blk, 0, st, a);
+    hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(lg_p2g_adj, gp, blk, 0, st, a);
+    hipLaunchKernelGGL(lg_fk_adj, dim3(B), blk, 0, st, a);
+  }
+  a.f = -1; a.epoch = L->epoch++;
+  hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
+  hipLaunchKernelGGL(lg_bwd_out, dim3(B), blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction);
+  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("ud_mpm_step_bwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+}  // namespace ud
