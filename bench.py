@@ -167,6 +167,83 @@ def bench_whip_rope(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_mpm_scaled(args, rank, world, device):
+    """Scaling stress test: whip_rope's rope seeded at n_grid 128 / 256 (N = 798 / 6675, res 64^3 /
+    128^3), one simulator.step (70 substeps) forward + adjoint per "step"; dt = 1e-4 is kept, so the CFL number is
+    2x / 4x the default config's -- a throughput measurement, not a physics claim."""
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator, _Step
+    from unidom_amd.envs.whip_rope_env import DefaultConf
+    conf = DefaultConf()
+    ng = args.n_grid
+    conf.n_grid, conf.res = ng, (ng // 2,) * 3
+    conf.dx, conf.inv_dx = 1 / ng, float(ng)
+    conf.p_vol = (conf.dx * 0.5) ** 2
+    conf.p_mass = conf.p_vol * conf.p_rho
+    B = args.envs
+    sim = SimpleMPMSimulator(conf, B, use_position_control=True, device=device)
+    st0 = sim.add_box(conf, None, size=conf.rope_width, init_pos=[0.25, 0.01, 0.25], z_rotation_angle=conf.rope_z_rotation_angle,
+                      material=1, density=2.75, hardness=1.0)
+    N = st0.x.shape[0]
+    sim.n_particles = N
+    sim._make_handle()
+    S = conf.steps
+    g = torch.Generator(device=device).manual_seed(rank)
+    x = st0.x[None].repeat(B, 1, 1).contiguous().requires_grad_(True)
+    v = torch.zeros((B, N, 3), device=device, requires_grad=True)
+    Cm = torch.zeros((B, N, 3, 3), device=device, requires_grad=True)
+    F = torch.eye(3, device=device)[None, None].repeat(B, N, 1, 1).contiguous().requires_grad_(True)
+    J = torch.ones((B, N), device=device)
+    ppos = torch.zeros((B, S, 3), device=device); ppos[:, 0] = torch.tensor([0.25, 0.01, 0.05], device=device)
+    prot = torch.zeros((B, S, 4), device=device); prot[..., 0] = 1
+    psize = torch.full((B, 3), 0.02, device=device)
+    fr = torch.full((B, 1), 0.1, device=device); mu = torch.full((B, 1), 45.45, device=device); la = torch.full((B, 1), 11.36, device=device)
+    act = (torch.tanh(torch.randn((B, 6), device=device, generator=g)) / 50).requires_grad_(True)
+
+    def one():
+        out = _Step.apply(sim, x, v, Cm, F, J, ppos, prot, psize, fr, mu, la, act)
+        (out[0].sum() + out[1].sum()).backward()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one()
+    sim.profile = {"fwd": [], "bwd": []}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, sim.profile = sim.profile, None
+    tm = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm[0])
+    if rank == 0:
+        units = world * B * S * args.steps
+        g_act = touched_cells(st0.x.detach().cpu().numpy(), ng)
+        k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
+        dom = max(k_ms, key=k_ms.get)
+        per_launch = B * S * ((192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act))
+        achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"whip_rope rope seeded at n_grid={ng} (N={N}, res {ng // 2}^3, {S} substeps/step), "
+                                   f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
+            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +253,9 @@ def main():
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
     ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "whip_rope"],
                     help="fold_cloth1 = the headline metric (default); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
+    ap.add_argument("--n-grid", type=int, default=64, help="whip_rope only: 64 (default env, N=67), 128 (N=798) or 256 (N=6675): "
+                    "the scaled configurations of SURVEY.md 8(d), simulator-level (the env's goal/obs sizes are tied to N=67)")
+    ap.add_argument("--envs", type=int, default=32, help="whip_rope only: envs per GPU")
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
     args = ap.parse_args()
@@ -186,6 +266,8 @@ def main():
 
     rank, world, device = init_distributed(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.workload == "whip_rope" and args.n_grid != 64:
+        return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
         return bench_whip_rope(args, rank, world, device)
 

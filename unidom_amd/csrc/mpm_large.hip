@@ -84,6 +84,50 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
   for (int d = 0; d < 9; ++d) { Cm[d] = h[(6 + d) * Np + p]; F[d] = h[(15 + d) * Np + p]; }
 }
 
+
+// ---- block-level LDS staging of scatter-adds (north_star: "p2g staged through LDS with per-cell atomics localised
+// by ... particle blocks"): consecutive particles are spatial neighbours (lattice seeding order), so the 256
+// particles of a block touch a few hundred distinct cells; they are summed in an LDS cell table first and each
+// distinct cell is then flushed with ONE global atomic per component.  That removes the ~50-way same-address
+// contention plain global atomics suffer on a compact body (measured: 17 us -> see DESIGN.md per env-substep).
+#define LG_H 2048
+#define LG_LOGH 11
+struct BlockTable { int* key; float* val; };   // key[LG_H], val[LG_H*4]
+
+__device__ __forceinline__ unsigned lg_hash(int cell) {
+  unsigned h = (unsigned)cell;
+  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
+  return h >> (32 - LG_LOGH);
+}
+
+__device__ __forceinline__ void bt_clear(const BlockTable& t) {
+  for (int s = threadIdx.x; s < LG_H; s += blockDim.x) {
+    t.key[s] = -1;
+    t.val[s * 4] = 0.f; t.val[s * 4 + 1] = 0.f; t.val[s * 4 + 2] = 0.f; t.val[s * 4 + 3] = 0.f;
+  }
+}
+
+// returns the slot of `cell`, or -1 when the table is full (the caller then falls back to a global atomic)
+__device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
+  unsigned s = lg_hash(cell);
+  for (int probe = 0; probe < 64; ++probe) {
+    const int cur = t.key[s];
+    if (cur == cell) return (int)s;
+    if (cur == -1) {
+      const int old = atomicCAS(&t.key[s], -1, cell);
+      if (old == -1 || old == cell) return (int)s;
+    }
+    s = (s + 1) & (LG_H - 1);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, int cell, int comp, float v) {
+  const int s = bt_slot(t, cell);
+  if (s >= 0) __hip_atomic_fetch_add(&t.val[s * 4 + comp], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else atomicAdd(global_cell + comp, v);
+}
+
 // ---- forward kernels ---------------------------------------------------------------------------------
 // clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
 __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
@@ -135,38 +179,62 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 
 // particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
 __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
+  __shared__ int s_key[LG_H];
+  __shared__ float s_val[LG_H * 4];
+  const BlockTable bt{s_key, s_val};
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
-  if (p >= c.N) return;
-  float x[3], v[3], Cm[9], F[9];
-  load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
-  Pre q;
-  particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[p], a.hard[p], q, nullptr);
-  if (store_F) {
-    float* ho = a.hist_out + (long)b * a.hist_stride_b;
-#pragma unroll
-    for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
-  }
+  bt_clear(bt);
+  __syncthreads();
   float4* val = a.w.val + (long)b * a.G;
-#pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
-    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
-    const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
-    const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
-    const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
-    if (sc >= 0) {
-      const long lin = cell_lin(c, sc);
-      const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-      float* cell = (float*)(val + lin);
-      atomicAdd(cell, weight * c.p_mass);
+  if (p < c.N) {
+    float x[3], v[3], Cm[9], F[9];
+    load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+    Pre q;
+    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[p], a.hard[p], q, nullptr);
+    if (store_F) {
+      float* ho = a.hist_out + (long)b * a.hist_stride_b;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
-        atomicAdd(cell + 1 + r, weight * (c.p_mass * v[r] + ad));
-      }
-      touch(a, b, sc, lin);
+      for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
     }
-    if (gc != sc) touch(a, b, gc, cell_lin(c, gc));   // Q5: a clamped gather cell takes part with m = 0
+#pragma unroll 1
+    for (int cidx = 0; cidx < 27; ++cidx) {
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+      const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+      const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+      if (sc >= 0) {
+        const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+        const int sl = bt_slot(bt, sc);
+        float* cell = (sl >= 0) ? &bt.val[sl * 4] : (float*)(val + cell_lin(c, sc));
+        float contrib[4];
+        contrib[0] = weight * c.p_mass;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
+          contrib[1 + r] = weight * (c.p_mass * v[r] + ad);
+        }
+        if (sl >= 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(cell + r, contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {   // block table full: straight to HBM
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(cell + r, contrib[r]);
+          touch(a, b, sc, cell_lin(c, sc));
+        }
+      }
+      if (gc != sc) touch(a, b, gc, cell_lin(c, gc));   // Q5: a clamped gather cell takes part with m = 0
+    }
+  }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < LG_H; sl += blockDim.x) {   // flush: one global atomic per distinct cell and component
+    const int key = bt.key[sl];
+    if (key < 0) continue;
+    const long lin = cell_lin(c, key);
+    float* cell = (float*)(val + lin);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, bt.val[sl * 4 + r]);
+    touch(a, b, key, lin);
   }
 }
 
@@ -333,9 +401,15 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
 __global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
+  __shared__ int s_key[LG_H];
+  __shared__ float s_val[LG_H * 4];
+  const BlockTable bt{s_key, s_val};
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
-  if (p >= c.N) return;
+  bt_clear(bt);
+  __syncthreads();
+  float4* gacc = a.w.gacc + (long)b * a.G;
+  if (p < c.N) {
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
   const float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float x[3], gx[3], gv[3], gC[9];
@@ -358,21 +432,21 @@ __global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
 #pragma unroll
   for (int d = 0; d < 9; ++d) gw[d] = 0.f;
   const float4* vel = a.w.vel + (long)b * a.G;
-  float4* gacc = a.w.gacc + (long)b * a.G;
 #pragma unroll 1
   for (int cidx = 0; cidx < 27; ++cidx) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
     const float weight = wi * wj * wk;
     const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
-    const long lin = cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k));
+    const int gkey = cell_gather(c, base[0] + i, base[1] + j, base[2] + k);
+    const long lin = cell_lin(c, gkey);
     const float4 v4 = vel[lin];
     const float vv[3] = {v4.x, v4.y, v4.z};
     float gwt = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-      atomicAdd((float*)(gacc + lin) + r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
+      bt_add(bt, (float*)(gacc + lin), gkey, r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
       gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
@@ -389,6 +463,15 @@ __global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
   for (int d = 0; d < 9; ++d) ps[d] = gw[d];
 #pragma unroll
   for (int d = 0; d < 3; ++d) ps[9 + d] = gfx[d];
+  }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < LG_H; sl += blockDim.x) {
+    const int key = bt.key[sl];
+    if (key < 0) continue;
+    float* cell = (float*)(gacc + cell_lin(c, key));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, bt.val[sl * 4 + r]);
+  }
 }
 
 // grid-op adjoint over the active cells
