@@ -148,6 +148,38 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
                     float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_friction, float* g_mu,
                     float* g_lamda, float* g_action, int* status, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PlasticineLab-style MLS-MPM, float64, von-Mises plasticity, sticky Sphere primitives (GenORM Torus task,
+ * BASELINE config 5) -- replaces TaichiEnv.step -> MPMSimulator.step(is_copy=True) = `substeps` x substep
+ *   GenORM/policy/pbm/plb/engine/mpm_simulator.py:438-449 (step), :256-268 (substep: clear_grid, compute_F_tmp,
+ *   svd, p2g :166-195 with compute_von_mises :133-150, forward_kinematics, grid_op :200-232, g2p :234-253),
+ *   engine/primitive/primitives.py:17-53 (Sphere), engine/primitive/primive_base.py:118-121,185-192.
+ * Forward only this round (the Torus rollout of optimizer/solver.py:290-350 never differentiates).
+ * Parity for this entry point is UNPINNED: taichi is absent and the reference ships no recording of this path.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct ud_plb ud_plb;
+
+typedef struct {
+  int n_particles;
+  int n_grid;            /* int(128 * quality * 0.5)                  mpm_simulator.py:14-18 */
+  int substeps;          /* int(2e-3 // dt)                           :32 */
+  double dt;             /* 0.5e-4 / (quality * 0.5)                  :21 */
+  double gravity[3];     /* SIMULATOR.gravity (the kernel applies x30, :205) */
+  double ground_friction;
+  int n_primitives;      /* 1 or 2 Spheres; only primitive 0 is actuated (3 action dims) */
+  double radius[2];
+  double lower_bound[3], upper_bound[3];   /* primitive xyz_limit */
+} ud_plb_conf;
+
+int ud_plb_create(const ud_plb_conf* conf, ud_plb** out);
+void ud_plb_destroy(ud_plb* h);
+/* One env.step for B independent envs (float64 device arrays): x, v [B,N,3]; C, F [B,N,3,3]; prim_pos
+ * [B,n_primitives,3]; softness [B,n_primitives]; action [B,3]; E, nu, yield_stress [B]. */
+int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
+                    const double* prim_pos, const double* softness, const double* action, const double* E,
+                    const double* nu, const double* yield_stress, double* x_out, double* v_out, double* C_out,
+                    double* F_out, double* prim_pos_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

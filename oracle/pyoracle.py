@@ -186,3 +186,31 @@ def svd3(A):
     U, S, Vh = np.empty_like(A), np.empty(3, A.dtype), np.empty_like(A)
     getattr(lib(), "oc_svd3_" + _suf(A.dtype))(_p(A), _p(U), _p(S), _p(Vh))
     return U, S, Vh
+
+
+class PlbOracle:
+    """CPU restatement (f64, dense grid) of the Taichi PlasticineLab forward step (GenORM Torus, BASELINE config 5).
+    PARITY UNPINNED (see oracle/csrc/plb_oracle.hpp)."""
+
+    def __init__(self, N=1000, n_grid=64, substeps=19, dt=1e-4, gravity=(0, -0.4, 0), ground_friction=0.5, radius=(0.025, 0.025)):
+        self.N, self.n_prim = N, len(radius)
+        lib().oc_plb_create.restype = C.c_void_p
+        g = np.ascontiguousarray(gravity, np.float64)
+        r = np.ascontiguousarray(radius, np.float64)
+        self.h = C.c_void_p(lib().oc_plb_create(C.c_int(N), C.c_int(n_grid), C.c_int(substeps), C.c_double(dt), _p(g),
+                                               C.c_double(ground_friction), C.c_int(self.n_prim), _p(r)))
+
+    def __del__(self):
+        try:
+            lib().oc_plb_destroy(self.h)
+        except Exception:
+            pass
+
+    def step(self, x, v, Cm, F, prim_pos, softness, action, E, nu, ys, nthreads=1):
+        c = lambda a: np.ascontiguousarray(a, np.float64)
+        x, v, Cm, F, prim_pos, softness, action, E, nu, ys = map(c, (x, v, Cm, F, prim_pos, softness, action, E, nu, ys))
+        B = x.shape[0]
+        xo, vo, Co, Fo, po = np.empty_like(x), np.empty_like(v), np.empty_like(Cm), np.empty_like(F), np.empty_like(prim_pos)
+        lib().oc_plb_step(self.h, C.c_int(B), _p(x), _p(v), _p(Cm), _p(F), _p(prim_pos), _p(softness), _p(action), _p(E), _p(nu),
+                          _p(ys), _p(xo), _p(vo), _p(Co), _p(Fo), _p(po), C.c_int(nthreads))
+        return dict(x=xo, v=vo, C=Co, F=Fo, prim_pos=po)

@@ -19,6 +19,7 @@ SYMBOLS = [
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
     "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
+    "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd",
 ]
 
 
@@ -35,6 +36,12 @@ class ud_mpm_conf(C.Structure):
     _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("res", C.c_int * 3), ("steps", C.c_int),
                 ("dt", C.c_float), ("p_mass", C.c_float), ("p_vol", C.c_float), ("gravity", C.c_float * 3),
                 ("use_position_control", C.c_int)]
+
+
+class ud_plb_conf(C.Structure):
+    _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("substeps", C.c_int), ("dt", C.c_double),
+                ("gravity", C.c_double * 3), ("ground_friction", C.c_double), ("n_primitives", C.c_int),
+                ("radius", C.c_double * 2), ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3)]
 
 
 def build(force: bool = False) -> str:

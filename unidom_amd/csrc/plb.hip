@@ -1,0 +1,474 @@
+// PlasticineLab-style MLS-MPM forward step for gfx950, float64 (GenORM Torus task, BASELINE config 5).
+//
+// What it replaces (reference, /root/reference/GenORM/policy/pbm/plb/engine/):
+//   mpm_simulator.py  step :438-449, substep :256-268 = clear_grid :69-79, compute_F_tmp :91-94, svd :96-99,
+//                     p2g :166-195 (compute_von_mises :133-150), grid_op :200-232, g2p :234-253
+//   primitive/primitives.py Sphere.sdf/collider_v/collide :17-53 ; primitive/primive_base.py forward_kinematics :118-121,
+//                     set_velocity :185-192
+// The reference drives 7 Taichi kernels per substep from Python over a dense n_grid^3 grid, one env per process.
+// Here B envs run batched: per substep  clear (touched cells only) -> p2g -> grid op (touched cells only) -> g2p,
+// the p2g scatter is summed per workgroup in an LDS cell table (ds_add_f64) and flushed with one
+// global_atomic_add_f64 per distinct cell and component; the grid lives dense in HBM (n_grid^3 x 4 doubles per env)
+// but only cells on the per-env active list are ever read, written or cleared.  No MFMA (scatter / stencil work).
+// ti.svd (third party) is replaced by a one-sided Jacobi SVD in registers.  Parity: UNPINNED (see the header).
+#include "common.h"
+
+#include <vector>
+
+namespace ud {
+
+struct PlbConst {
+  int N, Np, n_grid, S, np;
+  double dt, dx, inv_dx, p_mass, p_vol, g30dt[3], fric, radius[2], lo[3], hi[3];
+};
+
+struct PlbBuf {
+  double* val;    // [B][G][4] (m, mv) -> after the grid op (m, v)
+  int* stamp;     // [B][G]
+  int* list;      // [2][B][cap]
+  int* count;     // [2][B]
+  double* pos;    // [B][S+1][np][3] primitive positions of this step
+  double* hist;   // [B][2][24][Np]
+};
+
+struct PlbArgs {
+  PlbConst c;
+  PlbBuf w;
+  int B, f, epoch, cap;
+  long G;
+  const double *softness, *E, *nu, *ys;
+};
+
+// ---- double 3x3 helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void dm_mul(const double* A, const double* B, double* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, double* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+
+#define UD_DJROT(p, q)                                                                       \
+  {                                                                                          \
+    double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                      \
+    double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                      \
+    double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                      \
+    const bool rot = fabs(ga) > 1e-17 * sqrt(al * be);                                        \
+    double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
+    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
+    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
+    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
+      double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
+      a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
+      double vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                          \
+      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                   \
+    }                                                                                         \
+  }
+#define UD_DCSWAP(p, q)                                                              \
+  if (sv[p] < sv[q]) {                                                               \
+    double ts = sv[p]; sv[p] = sv[q]; sv[q] = ts;                                    \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                  \
+      double t1 = a[i * 3 + p]; a[i * 3 + p] = a[i * 3 + q]; a[i * 3 + q] = t1;      \
+      double t2 = vv[i * 3 + p]; vv[i * 3 + p] = vv[i * 3 + q]; vv[i * 3 + q] = t2;  \
+    }                                                                                \
+  }
+
+// A = U diag(S) Vh, S descending >= 0 (one-sided Jacobi, 6 sweeps reach f64 round-off for |F - I| = O(1))
+__device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, double* Vh) {
+  double a[9], vv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = A[i];
+#pragma unroll 1
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    UD_DJROT(0, 1)
+    UD_DJROT(0, 2)
+    UD_DJROT(1, 2)
+  }
+  double sv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+  UD_DCSWAP(0, 1)
+  UD_DCSWAP(1, 2)
+  UD_DCSWAP(0, 1)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S[j] = sv[j];
+    const double inv = sv[j] > 1e-300 ? 1.0 / sv[j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
+  }
+}
+
+__device__ __forceinline__ double dsel3(const double* w, int d, int i) { return (i == 0) ? w[d] : ((i == 1) ? w[3 + d] : w[6 + d]); }
+
+__device__ __forceinline__ long plb_lin(const PlbConst& c, int i, int j, int k) { return ((long)i * c.n_grid + j) * c.n_grid + k; }
+
+__device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin) {
+  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
+  if (old != a.epoch) {
+    const int cur = a.f & 1;
+    const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
+    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = (int)lin;
+  }
+}
+
+// ---- kernels -------------------------------------------------------------------------------------------
+// primitive positions for the whole step: pos[s+1] = clamp(pos[s] + v), v = clip(action)*scale/substeps for primitive 0
+__global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* action) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const PlbConst& c = a.c;
+  double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
+  for (int i = 0; i < c.np * 3; ++i) P[i] = prim_pos[(long)b * c.np * 3 + i];
+  for (int s = 0; s < c.S; ++s)
+    for (int pi = 0; pi < c.np; ++pi)
+      for (int d = 0; d < 3; ++d) {
+        const double pv = (pi == 0) ? fmin(fmax(action[b * 3 + d], -1.0), 1.0) * 1.0 / (double)c.S : 0.0;
+        P[((s + 1) * c.np + pi) * 3 + d] = fmax(fmin(P[(s * c.np + pi) * 3 + d] + pv, c.hi[d]), c.lo[d]);
+      }
+  a.w.count[0 * a.B + b] = 0;
+  a.w.count[1 * a.B + b] = 0;
+}
+
+__global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int prev = (a.f + 1) & 1, cur = a.f & 1;
+  if (t < min(a.w.count[prev * a.B + b], a.cap)) {
+    double* cell = a.w.val + ((long)b * a.G + a.w.list[((long)prev * a.B + b) * a.cap + t]) * 4;
+    cell[0] = 0.0; cell[1] = 0.0; cell[2] = 0.0; cell[3] = 0.0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = 0;
+}
+
+#define PLB_H 1024
+#define PLB_LOGH 10
+__device__ __forceinline__ unsigned plb_hash(int cell) {
+  unsigned h = (unsigned)cell;
+  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
+  return h >> (32 - PLB_LOGH);
+}
+
+// compute_F_tmp + svd + von Mises + p2g (:91-99, :133-195)
+__global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
+  __shared__ int s_key[PLB_H];
+  __shared__ double s_val[PLB_H * 4];
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s * 4] = 0; s_val[s * 4 + 1] = 0; s_val[s * 4 + 2] = 0; s_val[s * 4 + 3] = 0; }
+  __syncthreads();
+  double* val = a.w.val + (long)b * a.G * 4;
+  if (p < c.N) {
+    const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
+    double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
+    double x[3], v[3], Cm[9], F[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; v[d] = hi_[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = hi_[(6 + d) * c.Np + p]; F[d] = hi_[(15 + d) * c.Np + p]; }
+    const double E = a.E[b], nu = a.nu[b];
+    const double mu = E / (2 * (1 + nu)), lam = E * nu / ((1 + nu) * (1 - 2 * nu));
+    int base[3];
+    double fx[3], w[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      base[d] = (int)(x[d] * c.inv_dx - 0.5);
+      const double f = x[d] * c.inv_dx - (double)base[d];
+      fx[d] = f;
+      w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
+    }
+    double IC[9], Ft[9], U[9], Vh[9], sig[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
+    dm_mul(IC, F, Ft);
+    dsvd3(Ft, U, sig, Vh);
+    double eps[3], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
+    double eh[3], nn = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { eh[i] = eps[i] - sum / 3; nn += eh[i] * eh[i]; }
+    const double ehn = sqrt(nn + 1e-8);
+    const double dg = ehn - a.ys[b] / (2 * mu);
+    double nF[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nF[i] = Ft[i];
+    if (dg > 0) {
+      double US[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double s = exp(eps[i] - (dg / ehn) * eh[i]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) US[r * 3 + i] = U[r * 3 + i] * s;
+      }
+      dm_mul(US, Vh, nF);
+    }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = nF[d];
+    const double J = nF[0] * (nF[4] * nF[8] - nF[5] * nF[7]) - nF[1] * (nF[3] * nF[8] - nF[5] * nF[6]) + nF[2] * (nF[3] * nF[7] - nF[4] * nF[6]);
+    double R[9], A[9], St[9], aff[9];
+    dm_mul(U, Vh, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = nF[i] - R[i];
+    dm_mul_bt(A, nF, St);
+    const double sc = -c.dt * c.p_vol * 4 * c.inv_dx * c.inv_dx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
+#pragma unroll 1
+    for (int cidx = 0; cidx < 27; ++cidx) {
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
+      const double dp0 = ((double)i - fx[0]) * c.dx, dp1 = ((double)j - fx[1]) * c.dx, dp2 = ((double)k - fx[2]) * c.dx;
+      const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+      const long lin = plb_lin(c, ci, cj, ck);
+      double contrib[4];
+      contrib[0] = weight * c.p_mass;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) contrib[1 + r] = weight * (c.p_mass * v[r] + aff[r * 3] * dp0 + aff[r * 3 + 1] * dp1 + aff[r * 3 + 2] * dp2);
+      // block-level staging
+      unsigned s = plb_hash((int)lin);
+      int slot = -1;
+      for (int probe = 0; probe < 64; ++probe) {
+        const int cur = s_key[s];
+        if (cur == (int)lin) { slot = (int)s; break; }
+        if (cur == -1) {
+          const int old = atomicCAS(&s_key[s], -1, (int)lin);
+          if (old == -1 || old == (int)lin) { slot = (int)s; break; }
+        }
+        s = (s + 1) & (PLB_H - 1);
+      }
+      if (slot >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&s_val[slot * 4 + r], contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(val + lin * 4 + r, contrib[r]);
+        plb_touch(a, b, lin);
+      }
+    }
+  }
+  __syncthreads();
+  for (int sl = threadIdx.x; sl < PLB_H; sl += blockDim.x) {
+    const int key = s_key[sl];
+    if (key < 0) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[sl * 4 + r]);
+    plb_touch(a, b, key);
+  }
+}
+
+// grid_op (:200-232) over the touched cells
+__global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  const int cur = a.f & 1;
+  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
+  double* cell = a.w.val + ((long)b * a.G + lin) * 4;
+  const double m = cell[0];
+  double vv[3] = {0.0, 0.0, 0.0};
+  if (m > 1e-12) {
+    const int n = c.n_grid;
+    const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vv[k] = (1.0 / m) * cell[1 + k] + c.g30dt[k];
+    const double gp[3] = {I[0] * c.dx, I[1] * c.dx, I[2] * c.dx};
+    const double* P0 = a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
+    const double* P1 = P0 + c.np * 3;
+    for (int pi = 0; pi < c.np; ++pi) {                                    // Sphere.collide (sticky), primitives.py:46-53
+      const double d0 = gp[0] - P0[pi * 3], d1 = gp[1] - P0[pi * 3 + 1], d2 = gp[2] - P0[pi * 3 + 2];
+      const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi];
+      const double soft = a.softness[b * c.np + pi];
+      const double infl = fmin(exp(-dist * soft), 1.0);
+      if (((soft > 0 && infl > 0.1) || dist <= 0.001) && soft > 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vv[k] = (P1[pi * 3 + k] - P0[pi * 3 + k]) / c.dt;   // collider_v, identity rotations
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (I[d] < 3 && vv[d] < 0) {
+        if (d != 1 || c.fric == 0) vv[d] = 0;
+        else if (c.fric < 10) {
+          const double lin_ = vv[1] + 1e-30;
+          const double vit[3] = {vv[0] - I[0] * 1e-30, vv[1] - lin_ - I[1] * 1e-30, vv[2] - I[2] * 1e-30};
+          const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
+          const double s = fmax(1.0 + c.fric * lin_ / lit, 0.0);
+          vv[0] = s * (vit[0] + I[0] * 1e-30); vv[2] = s * (vit[2] + I[2] * 1e-30); vv[1] = 0;
+        } else { vv[0] = 0; vv[1] = 0; vv[2] = 0; }
+      }
+      if (I[d] > n - 3 && vv[d] > 0) vv[d] = 0;
+    }
+  }
+  cell[1] = vv[0]; cell[2] = vv[1]; cell[3] = vv[2];
+}
+
+// g2p (:234-253)
+__global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (p >= c.N) return;
+  const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
+  double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
+  double x[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) x[d] = hi_[d * c.Np + p];
+  int base[3];
+  double fx[3], w[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    base[d] = (int)(x[d] * c.inv_dx - 0.5);
+    const double f = x[d] * c.inv_dx - (double)base[d];
+    fx[d] = f;
+    w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
+  }
+  const double* val = a.w.val + (long)b * a.G * 4;
+  double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
+    const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
+    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+    const double* cell = val + plb_lin(c, ci, cj, ck) * 4;
+    const double g[3] = {cell[1], cell[2], cell[3]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      nv[r] += weight * g[r];
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4 * c.inv_dx * weight * g[r] * dp[s2];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    ho[(3 + d) * c.Np + p] = nv[d];
+    ho[d * c.Np + p] = fmax(fmin(x[d] + c.dt * nv[d], 1.0 - 3 * c.dx), 0.0);
+  }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+}
+
+__global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, const double* v, const double* Cm, const double* F) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (p >= c.N) return;
+  double* h = a.w.hist + (long)b * 2 * 24 * c.Np;
+  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { h[d * c.Np + p] = x[o3 + d]; h[(3 + d) * c.Np + p] = v[o3 + d]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { h[(6 + d) * c.Np + p] = Cm[o9 + d]; h[(15 + d) * c.Np + p] = F[o9 + d]; }
+}
+
+__global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x, double* v, double* Cm, double* F, double* prim_o) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (blockIdx.x == 0 && threadIdx.x < c.np * 3)
+    prim_o[(long)b * c.np * 3 + threadIdx.x] = a.w.pos[((long)b * (c.S + 1) + c.S) * c.np * 3 + threadIdx.x];   // copyframe(cur, 0)
+  if (p >= c.N) return;
+  const double* h = a.w.hist + ((long)b * 2 + slot) * 24 * c.Np;
+  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[o3 + d] = h[d * c.Np + p]; v[o3 + d] = h[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { Cm[o9 + d] = h[(6 + d) * c.Np + p]; F[o9 + d] = h[(15 + d) * c.Np + p]; }
+}
+
+}  // namespace ud
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct ud_plb {
+  ud::PlbConst c;
+  int B = 0, cap = 0, epoch = 1;
+  long G = 0;
+  ud::PlbBuf w{};
+  void* arena = nullptr;
+};
+
+static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
+  if (B <= h->B) return UD_OK;
+  if (h->arena) { (void)hipStreamSynchronize(st); (void)hipFree(h->arena); h->arena = nullptr; }
+  const ud::PlbConst& c = h->c;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_val = take((size_t)B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
+  const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
+  hipError_t e = hipMalloc(&h->arena, off);
+  if (e != hipSuccess) { ud::set_error("ud_plb: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); h->B = 0; return UD_ERR_HIP; }
+  e = hipMemsetAsync(h->arena, 0, off, st);
+  if (e != hipSuccess) { ud::set_error("ud_plb: memset failed"); return UD_ERR_HIP; }
+  char* base = (char*)h->arena;
+  h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
+  h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
+  h->B = B; h->epoch = 1;
+  return UD_OK;
+}
+
+extern "C" {
+
+int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
+  if (!conf || !out) { ud::set_error("ud_plb_create: null argument"); return UD_ERR_INVALID; }
+  if (conf->n_particles < 1 || conf->n_grid < 8 || conf->n_grid > 512 || conf->substeps < 1 || conf->n_primitives < 0 || conf->n_primitives > 2) {
+    ud::set_error("ud_plb_create: bad sizes"); return UD_ERR_INVALID;
+  }
+  auto* h = new ud_plb;
+  ud::PlbConst& c = h->c;
+  c.N = conf->n_particles; c.Np = (c.N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.S = conf->substeps; c.np = conf->n_primitives;
+  c.dt = conf->dt; c.dx = 1.0 / conf->n_grid; c.inv_dx = (double)conf->n_grid;
+  c.p_vol = (c.dx * 0.5) * (c.dx * 0.5); c.p_mass = c.p_vol * 1;
+  for (int d = 0; d < 3; ++d) { c.g30dt[d] = conf->dt * conf->gravity[d] * 30; c.lo[d] = conf->lower_bound[d]; c.hi[d] = conf->upper_bound[d]; }
+  c.fric = conf->ground_friction;
+  c.radius[0] = conf->radius[0]; c.radius[1] = conf->radius[1];
+  h->G = (long)c.n_grid * c.n_grid * c.n_grid;
+  h->cap = (int)std::min<long>(h->G, (long)27 * c.N);
+  *out = h;
+  return UD_OK;
+}
+
+void ud_plb_destroy(ud_plb* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+}
+
+int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
+                    const double* prim_pos, const double* softness, const double* action, const double* E,
+                    const double* nu, const double* yield_stress, double* x_out, double* v_out, double* C_out,
+                    double* F_out, double* prim_pos_out, void* stream) {
+  if (!h || !x || !v || !C || !F || !prim_pos || !softness || !action || !E || !nu || !yield_stress || !x_out || !v_out || !C_out ||
+      !F_out || !prim_pos_out) {
+    ud::set_error("ud_plb_step_fwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1) { ud::set_error("ud_plb_step_fwd: B=%d", B); return UD_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = plb_reserve(h, B, st);
+  if (rc) return rc;
+  ud::PlbArgs a;
+  a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
+  a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
+  const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
+  hipLaunchKernelGGL(ud::plb_prologue, dim3((B + 63) / 64), dim3(64), 0, st, a, prim_pos, action);
+  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F);
+  for (int f = 0; f < h->c.S; ++f) {
+    a.f = f; a.epoch = h->epoch++;
+    hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_p2g, gp, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_g2p, gp, blk, 0, st, a);
+  }
+  a.f = h->c.S; a.epoch = h->epoch++;
+  hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);   // back to the all-zero grid invariant
+  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S & 1, x_out, v_out, C_out, F_out, prim_pos_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { ud::set_error("ud_plb_step_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+}  // extern "C"
