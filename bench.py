@@ -167,6 +167,61 @@ def bench_whip_rope(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_torus(args, rank, world, device):
+    """BASELINE config 5: PlasticineLab Torus (f64 elasto-plastic MPM, N=1000), 8 envs per GPU (64 on 8 GPUs), forward
+    only like the reference's scripted rollout (solver.py:290-350).  --n-grid 64 = quality 1 (19 substeps/step),
+    --n-grid 128 = quality 2 (the "128^3 grid" of BASELINE.json, dt 5e-5, 39 substeps/step).  One "step" = 10 env.steps."""
+    from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
+    cfg = PlbConf()
+    cfg.quality = 2.0 if args.n_grid == 128 else 1.0
+    B = 8 if args.envs == 32 else args.envs
+    sim = PlbSimulator(cfg, B, device=device)
+    st = sim.reset()
+    start = np.array([0.2, 0.3, 0.5])
+    p0 = np.array(cfg.prim_init_pos[0])
+    act = np.diff(np.linspace(p0, start, 200), axis=0)[0]          # solver.py:299-302: constant displacement per env.step
+    action = torch.tensor(np.repeat(act[None], B, 0), dtype=torch.float64, device=device)
+    inner = 10
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        st = sim.step(st, action)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * inner):
+        st = sim.step(st, action)
+    sync()
+    dt = time.perf_counter() - t0
+    tm = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm[0])
+    if rank == 0:
+        assert torch.isfinite(st.x).all()
+        units = world * B * sim.substeps * inner * args.steps
+        g_act = touched_cells(st.x[0].cpu().numpy().astype(np.float64), sim.n_grid)
+        per_sub = 2 * (192 * sim.n_particles + 56 * g_act)          # f64: double the f32 figure (SURVEY.md 8d)
+        achieved = units / world * per_sub / dt / 1e9
+        print(json.dumps({
+            "metric": "plb_substeps_per_sec_fwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"PlasticineLab Torus (f64 von-Mises MPM, N={sim.n_particles}, n_grid={sim.n_grid}, "
+                                   f"{sim.substeps} substeps/env.step), forward rollout, {B} envs per GPU, step = {inner} env.steps",
+                       "touched_cells": g_act, "parity": "unpinned (taichi absent)"},
+            "roofline": {"bound": "hbm", "kernel": "plb path (4 kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "launch/latency bound: 8 envs x 1000 particles per substep"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_mpm_scaled(args, rank, world, device):
     """Scaling stress test: whip_rope's rope seeded at n_grid 128 / 256 (N = 798 / 6675, res 64^3 /
     128^3), one simulator.step (70 substeps) forward + adjoint per "step"; dt = 1e-4 is kept, so the CFL number is
@@ -251,7 +306,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "whip_rope"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "whip_rope", "torus"],
                     help="fold_cloth1 = the headline metric (default); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--n-grid", type=int, default=64, help="whip_rope only: 64 (default env, N=67), 128 (N=798) or 256 (N=6675): "
                     "the scaled configurations of SURVEY.md 8(d), simulator-level (the env's goal/obs sizes are tied to N=67)")
@@ -266,6 +321,8 @@ def main():
 
     rank, world, device = init_distributed(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.workload == "torus":
+        return bench_torus(args, rank, world, device)
     if args.workload == "whip_rope" and args.n_grid != 64:
         return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
