@@ -11,7 +11,8 @@
  *   - every data pointer is a DEVICE pointer (HBM) unless marked "host"; float32, C-contiguous, AoS at the
  *     boundary ([B,P,3] etc., the reference's own layouts); the library transposes to SoA internally.
  *   - purely functional like the reference (NamedTuple._replace): inputs are never written, the caller owns
- *     every state / gradient / checkpoint buffer; a handle owns only constant tables.
+ *     every state / gradient / checkpoint buffer; a handle owns constant tables and, for the many-workgroup MPM and
+ *     PLB paths, a scratch arena (HBM grid + active-cell lists) that is (re)allocated when a larger batch arrives.
  *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside.
  *   - return value: 0 = ok, negative = ud_status; ud_last_error() gives the text (thread-local).
  *   - a handle is bound to the device current at create time; not thread-safe per handle.
@@ -103,9 +104,10 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
  *   core/engine/primitives/box.py:6-18 (box SDF)
  * driven by lax.scan over the macro actions of one step_diff (core/envs/basic/mpm_env.py:141).
  * One call = one `simulator.step` = conf.steps substeps for B independent envs, ONE kernel launch.
- * Scope this round: one box primitive in position-control mode (whip_rope); N <= 128 particles per env
- * (one workgroup per env, the touched part of the `res` grid lives in an LDS cell table); materials 1
- * (elastic), 2 (plastic clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.
+ * Scope this round: one box primitive in position-control mode (whip_rope); materials 1 (elastic), 2 (plastic
+ * clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.  N <= 128 particles per env: one workgroup per env, the
+ * touched part of the `res` grid in an LDS cell table, ONE launch per step.  N > 128: many workgroups per env, dense
+ * grid in HBM, a few launches per substep (all on `stream`).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct ud_mpm ud_mpm;
 

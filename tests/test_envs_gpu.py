@@ -89,3 +89,20 @@ def test_apg_update_runs(name, num_envs, ep_len):
     assert torch.isfinite(m["grad_norm"]) and float(m["grad_norm"]) > 0
     assert not torch.equal(w0, learner.policy.layers[0].weight)
     assert m["reward"].shape == (ep_len, num_envs)
+
+
+def test_apg_entry_point_cli(tmp_path):
+    """`python -m unidom_amd.algorithms.apg.apg_no_para` with the reference's flags (train_no_para.sh), 2 iterations."""
+    import json
+    from unidom_amd.algorithms.apg import apg_no_para
+    logdir = str(tmp_path / "log")
+    apg_no_para.main(["--env", "fold_cloth1", "--ep_len", "1", "--num_envs", "2", "--lr", "1e-4", "--gpus", "1",
+                      "--max_grad_norm", "0.3", "--seed", "0", "--eval_freq", "100", "--max_it", "1",
+                      "--train_min_stiff", "1000", "--train_max_stiff", "1600", "--eval_min_stiff", "10",
+                      "--eval_max_stiff", "1800", "--logdir", logdir])
+    recs = [json.loads(l) for l in open(os.path.join(logdir, "log.jsonl"))]
+    assert [r["iter"] for r in recs] == [0, 1]
+    np.random.seed(0)
+    assert abs(recs[0]["core_env_stiffness"] - np.random.uniform(1000, 1600)) < 1e-9    # apg_para.py:326-329
+    assert all(np.isfinite(r["train_reward"]) and np.isfinite(r["grad_norm"]) for r in recs)
+    assert os.path.exists(os.path.join(logdir, "apg_fold_cloth1_0.pt"))
