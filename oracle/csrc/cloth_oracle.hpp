@@ -166,7 +166,7 @@ void cloth_substep_fwd(const ClothTables<T>& tb, const ClothParams<T>& pr, T k, 
 
 // Forward substep, operation order "v2": the same formulas re-associated into far fewer IEEE operations
 //   spring      f = r * (k/L0 - k * (1/|r|))     instead of  k*r/|r|*(|r|-L0)/L0   (6 divisions + sqrt -> 1 + sqrt)
-//   friction    t = dm*muF / sV ; A = F - t*V     instead of  F - dm*muF*V/sV
+//   friction    t = dm*muF * (1/sV) ; A = F - t*V  instead of  F - dm*muF*V/sV   (1/sV does not wait for F)
 //   the static-friction block (:293-306) is dropped: sV = sqrt(.+small_num) > small_num always (small_num < 1)
 // Only +,-,*,/,sqrt, no FMA: a CPU and a GPU build of this order agree bit for bit (the default HIP forward,
 // csrc/cloth.hip::substep_fwd_v2).  Against the reference order it differs by f32 round-off per substep
@@ -195,8 +195,8 @@ void cloth_substep_fwd_v2(const ClothTables<T>& tb, const ClothParams<T>& pr, T 
     T cF = std::min(F[1], T(0));
     T muF = mu * cF * T(-1);
     T xV = v1[0], yV = v1[2];
-    T sV = std::sqrt(xV * xV + yV * yV + eps);
-    T tf = fm ? muF / sV : T(0);
+    T isV = T(1) / std::sqrt(xV * xV + yV * yV + eps);
+    T tf = fm ? muF * isV : T(0);
     T Ff[3] = {F[0] - tf * xV, F[1], F[2] - tf * yV};
     T vv[3], xx[3] = {xi[0], xi[1], xi[2]};
     for (int a = 0; a < 3; ++a) vv[a] = (v1[a] + Ff[a] * pr.dt) * pr.damp;

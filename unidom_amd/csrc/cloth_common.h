@@ -47,6 +47,34 @@ struct ClothBwdArgs {
 __host__ __device__ inline size_t cloth_rec_floats(int Pp) { return (size_t)6 * Pp + 8; }
 __host__ __device__ inline size_t cloth_env_records(int T, int S) { return (size_t)T * S + 1; }
 
+// The grasp test |x - pos| <= radius (cloth_simulator.py:201,213) without a per-particle square root.  IEEE sqrtf
+// is monotone, so  sqrtf(s) <= r  <=>  s <= T(r)  where T(r) is the largest float whose correctly rounded root is
+// <= r: the booleans are identical to the sqrt form's (this is what keeps cloth_v2.hip bit-exact to the oracle).
+// T(r) lies within [-1, +3] ulp of RN(r*r) (|(r + ulp/2)^2 - r^2| < 2.5 ulp(r^2)), so a short walk finds it; the
+// result is verified and a miss traps instead of returning a wrong set.
+__device__ inline float grasp_thr(float r) {
+  if (!(r >= 0.f)) return -1.f;                         // negative / NaN radius never grasps (s >= 0)
+  if (r == INFINITY) return r;
+  unsigned t = __builtin_bit_cast(unsigned, r * r);
+  for (int it = 0; it < 4; ++it) if (sqrtf(__builtin_bit_cast(float, t)) > r) --t;
+  for (int it = 0; it < 4; ++it) if (sqrtf(__builtin_bit_cast(float, t + 1u)) <= r) ++t;
+  if (!(sqrtf(__builtin_bit_cast(float, t)) <= r && !(sqrtf(__builtin_bit_cast(float, t + 1u)) <= r))) __builtin_trap();
+  return __builtin_bit_cast(float, t);
+}
+
+// The radius is component 3 of a primitive; the substep maps it to clip(radius + 0, 0, 1) (:322-323), which is
+// idempotent: only the very first substep of a rollout can see an unclipped radius.  Two thresholds per gripper
+// (first substep / every later one), computed once per launch, uniform.
+struct GraspThr {
+  float first, rest;
+  __device__ __forceinline__ void init(float radius0) {
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, radius0)));
+    first = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grasp_thr(r0))));
+    rest = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, grasp_thr(clipf(r0 + 0.f, 0.f, 1.f)))));
+  }
+  __device__ __forceinline__ float at(bool first_substep) const { return first_substep ? first : rest; }
+};
+
 void cloth_launch_fwd_v2(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_fwd_fast(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_bwd_fast(const ClothBwdArgs& a, hipStream_t stream);

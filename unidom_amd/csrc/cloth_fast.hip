@@ -34,39 +34,48 @@ __device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  /
 
 struct FastInter {
   float F1, cF, muF, xV, yV, isV, tf;   // friction block
-  float r0[8], r1[8], r2[8], inv[8];    // link vectors and 1/|r| (reused by the spring adjoint)
+  float r0[8], r1[8], r2[8];            // link vectors (reused by the spring adjoint)
+  float w[8];                           // 1/L0 - 1/|r|            (spring coefficient / k)
+  float c2k[8];                         // k / |r|^3, or 0 where clip(|r|^2, 1e-12) is active
 };
 
-// grippers, own-particle part only (:198-226): masks and displaced positions
-__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, bool& m0, bool& m1, float* x2) {
+// grippers, own-particle part only (:198-226): masks and displaced positions.  No FMA contraction in here: the
+// squared distances must carry the same bits as the forward that wrote the checkpoints (cloth_v2.hip) so that the
+// discrete grasp sets of the adjoint are the forward's.  thr0/thr1 = grasp_thr(radius), see cloth_common.h.
+__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, float thr0, float thr1, bool& m0,
+                                         bool& m1, float* x2) {
+#pragma clang fp contract(off)
   float d0 = x[0] - ps[0], d1 = x[1] - ps[1], d2 = x[2] - ps[2];
-  m0 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[3];
+  m0 = (d0 * d0 + d1 * d1 + d2 * d2) <= thr0;
   float x1[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) x1[a] = m0 ? x[a] + act[a] * (1.f - act[3]) : x[a];
   d0 = x1[0] - ps[4]; d1 = x1[1] - ps[5]; d2 = x1[2] - ps[6];
-  m1 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[7];
+  m1 = (d0 * d0 + d1 * d1 + d2 * d2) <= thr1;
 #pragma unroll
   for (int a = 0; a < 3; ++a) x2[a] = m1 ? x1[a] + act[4 + a] * (1.f - act[7]) : x1[a];
 }
 
 // spring + gravity + ground friction + damping: (x, v, neighbours in X4) -> v3 ; keeps the adjoint's inputs
 template <bool KEEP>
-__device__ __forceinline__ void force_fast(const ClothConst& c, int i, const int* nb, const float4* X4, float k, float kLs,
-                                           float kLd, float mu, const float* x, const float* v, float* v3, FastInter* in) {
+// nbs[l] = neighbour index, or the particle itself where the lattice has no neighbour: then r == 0 exactly and the
+// (finite) coefficient multiplies zeros, so neither the force nor its adjoint needs a select.
+__device__ __forceinline__ void force_fast(const ClothConst& c, const int* nbs, const float4* X4, float k, float iLs,
+                                           float iLd, float mu, const float* x, const float* v, float* v3, FastInter* in) {
   float F0 = 0.f, F1 = 0.f, F2 = 0.f;
 #pragma unroll
   for (int l = 0; l < 8; ++l) {
-    const int j = nb[l];
-    const bool ok = j >= 0;
-    const float4 xj = X4[ok ? j : i];
+    const float4 xj = X4[nbs[l]];
     const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
     const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
     const float inv = rsq(fmaxf(s2, 1e-12f));
-    float coef = ((l < 4) ? kLs : kLd) - k * inv;
-    coef = ok ? coef : 0.f;
+    const float w = ((l < 4) ? iLs : iLd) - inv;
+    const float coef = k * w;
     F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
-    if (KEEP) { in->r0[l] = r0; in->r1[l] = r1; in->r2[l] = r2; in->inv[l] = (s2 > 1e-12f) ? inv : -inv; }
+    if (KEEP) {
+      in->r0[l] = r0; in->r1[l] = r1; in->r2[l] = r2; in->w[l] = w;
+      in->c2k[l] = (s2 > 1e-12f) ? k * inv * inv * inv : 0.f;
+    }
   }
   F1 -= c.g;                                        // :278
   const float v1y = v[1] - c.gdt;                   // :259
@@ -92,9 +101,9 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
   const int i = threadIdx.x, b = blockIdx.x;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
   const bool live = i < P;
-  int nb[8];
+  int nbs[8];
 #pragma unroll
-  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  for (int l = 0; l < 8; ++l) { const int j = a.nbr[l * Pp + i]; nbs[l] = j >= 0 ? j : i; }
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   if (live) {
 #pragma unroll
@@ -104,7 +113,9 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
 #pragma unroll
   for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
   const float k = a.k[b], mu = a.mu[b];
-  const float kLs = k / c.Ls, kLd = k / c.Ld;
+  const float iLs = 1.f / c.Ls, iLd = 1.f / c.Ld;
+  GraspThr th0, th1;
+  th0.init(ps[3]); th1.init(ps[7]);
   const size_t rec = cloth_rec_floats(Pp);
   float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
   unsigned step = 0;
@@ -127,8 +138,8 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
       float vv[3], x2[3];
       bool m0, m1;
       FastInter dummy;
-      force_fast<false>(c, i, nb, X4, k, kLs, kLd, mu, x, v, vv, &dummy);
-      grip_own(x, ps, act, m0, m1, x2);
+      force_fast<false>(c, nbs, X4, k, iLs, iLd, mu, x, v, vv, &dummy);
+      grip_own(x, ps, act, th0.at(step == 0), th1.at(step == 0), m0, m1, x2);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         vv[d] = m0 ? act[3] * vv[d] : vv[d];
@@ -194,9 +205,9 @@ __device__ __forceinline__ float wave_sum_l63(float v) {
 }
 
 // 1 / (n_mask * sqrt(n2)) with norm_grad's nan_to_num semantics: a zero (or non-finite) norm zeroes the cotangent
-__device__ __forceinline__ float inv_norm(float n2, float n_mask) {
+__device__ __forceinline__ float inv_norm(float n2, float inv_n_mask) {
   const bool okv = (n2 > 0.f) && (n2 < INFINITY);
-  return okv ? rsq(n2) / n_mask : 0.f;
+  return okv ? rsq(n2) * inv_n_mask : 0.f;
 }
 
 #define UD_NSUM 9
@@ -213,25 +224,28 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
   float4* Gb = lds4 + 2 * Pp;
   float* red = (float*)(lds4 + 4 * Pp);
   float* mac = red + 2 * 16 * UD_NSUM;
-  int nb[8];
+  int nbs[8];
 #pragma unroll
-  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  for (int l = 0; l < 8; ++l) { const int j = a.nbr[l * Pp + i]; nbs[l] = j >= 0 ? j : i; }
   float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
   if (live) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) { gx[d] = a.g_x[((size_t)b * P + i) * 3 + d]; gv[d] = a.g_v[((size_t)b * P + i) * 3 + d]; }
   }
-  float gp[8];
-#pragma unroll
-  for (int d = 0; d < 8; ++d) gp[d] = a.g_prim[b * 8 + d];
+  // primitive cotangent: component d lives in lane d of wave 0 (lanes 0-3 gripper 0, 4-7 gripper 1)
+  float gpl = (i < 8) ? a.g_prim[b * 8 + i] : 0.f;
+  const bool pm3 = (i < 8) && ((i & 3) < 3);
+  const float inm = 1.f / c.n_mask;
   const float k = a.k[b], mu = a.mu[b];
   const float Ls = c.Ls, Ld = c.Ld;
-  const float kLs = k / Ls, kLd = k / Ld, iLs = 1.f / Ls, iLd = 1.f / Ld;
+  const float iLs = 1.f / Ls, iLd = 1.f / Ld;
   float gk = 0.f, gmu = 0.f;
   const size_t rec = cloth_rec_floats(Pp);
   const float* ck = a.ckpt + (size_t)b * cloth_env_records(T, S) * rec;
+  GraspThr th0, th1;   // from record 0 = the rollout's input primitives, exactly what the forward derived them from
+  th0.init(ck[6 * Pp + 3]); th1.init(ck[6 * Pp + 7]);
   // records: `cur` = input of the substep being reversed, `vnext` = v of the record after it (= clip(v5))
-  float vnext[3], nx[3], nv[3], nps[8];
+  float vnext[3], nx[3], nv[3], nps[8], npsl;
   {
     const float* r = ck + (size_t)T * S * rec;
 #pragma unroll
@@ -241,6 +255,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
     for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
 #pragma unroll
     for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+    npsl = r[6 * Pp + (i & 7)];
   }
   unsigned step = 0;
   for (int t = T - 1; t >= 0; --t) {
@@ -249,21 +264,21 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       if (a.g_x_list) { gx[0] += a.g_x_list[o]; gx[1] += a.g_x_list[o + 1]; gx[2] += a.g_x_list[o + 2]; }
       if (a.g_v_list) { gv[0] += a.g_v_list[o]; gv[1] += a.g_v_list[o + 1]; gv[2] += a.g_v_list[o + 2]; }
     }
-    if (a.g_prim_list) {
-#pragma unroll
-      for (int d = 0; d < 8; ++d) gp[d] += a.g_prim_list[((size_t)t * B + b) * 8 + d];
-    }
+    if (a.g_prim_list && i < 8) gpl += a.g_prim_list[((size_t)t * B + b) * 8 + i];
     const float* a8 = a.actions + ((size_t)t * B + b) * 8;
     float act[8], ga[8];
     macro_action_f(a8, act);
 #pragma unroll
     for (int d = 0; d < 8; ++d) ga[d] = 0.f;
+    const float addl = pm3 ? clipf(a8[i & 7], -2.0f, 2.0f) / 50.0f : 0.f;   // this lane's component of the primitive move
+    float gaP = 0.f;
     for (int s = S - 1; s >= 0; --s, ++step) {
       float x[3], v[3], ps[8];
 #pragma unroll
       for (int d = 0; d < 3; ++d) { x[d] = nx[d]; v[d] = nv[d]; }
 #pragma unroll
       for (int d = 0; d < 8; ++d) ps[d] = nps[d];
+      const float psl = npsl;
       {  // prefetch the record this loop consumes next
         const long q = (long)t * S + s - 1;
         const float* r = ck + (size_t)(q < 0 ? 0 : q) * rec;
@@ -271,6 +286,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
 #pragma unroll
         for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
+        npsl = r[6 * Pp + (i & 7)];
       }
       const unsigned par = step & 1u;
       float4* X4 = Xb + par * Pp;
@@ -280,12 +296,12 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       // ---- own-particle forward pieces and the nine sums (no neighbour data needed) ----
       bool m0, m1;
       float x2[3];
-      grip_own(x, ps, act, m0, m1, x2);
+      grip_own(x, ps, act, th0.at(t == 0 && s == 0), th1.at(t == 0 && s == 0), m0, m1, x2);
       m0 = m0 && live; m1 = m1 && live;
       float av[3], bv[3], bx[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        const float Dx = clip_grad(x2[d], 0.f, 1.f);
+        const float Dx = clip_grad_lt(x2[d], 0.f, 1.f);
         const float Dv = (fabsf(vnext[d]) < c.max_v) ? 1.f : 0.f;
         av[d] = Dx * gx[d]; bv[d] = Dv * gv[d]; bx[d] = Dv * gx[d];
       }
@@ -298,19 +314,14 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       sm[5] = bx[0] * bx[0] + bx[1] * bx[1] + bx[2] * bx[2];
       sm[6] = m1 ? sm[3] : 0.f; sm[7] = m1 ? sm[4] : 0.f; sm[8] = m1 ? sm[5] : 0.f;
       if (norm) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const float w = wave_sum_l63(sm[q]);
-          if (lane == 63) rd[wv * UD_NSUM + q] = w;
-        }
+        const float sm8[8] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[6], sm[7]};
+        const float w8 = wave_sum8_t(sm8, lane);
+        if ((lane & 0x2C) == 0) rd[wv * UD_NSUM + (((lane >> 2) & 4) | (lane & 3))] = w8;
         if (__builtin_amdgcn_ballot_w64(m1) != 0) {   // wave-uniform: gripper 1 holds something in this wave
-#pragma unroll
-          for (int q = 6; q < UD_NSUM; ++q) {
-            const float w = wave_sum_l63(sm[q]);
-            if (lane == 63) rd[wv * UD_NSUM + q] = w;
-          }
+          const float w = wave_sum_l63(sm[8]);
+          if (lane == 63) rd[wv * UD_NSUM + 8] = w;
         } else if (lane == 63) {
-          rd[wv * UD_NSUM + 6] = 0.f; rd[wv * UD_NSUM + 7] = 0.f; rd[wv * UD_NSUM + 8] = 0.f;
+          rd[wv * UD_NSUM + 8] = 0.f;
         }
       }
       __syncthreads();   // barrier 1: X4 and the wave partials are visible
@@ -321,34 +332,31 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         float T_[UD_NSUM];
 #pragma unroll
         for (int q = 0; q < UD_NSUM; ++q) T_[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), q));
-        sx = inv_norm(T_[0], c.n_mask);                                   // :331
-        sv = inv_norm(T_[1], c.n_mask);                                   // :332
+        sx = inv_norm(T_[0], inm);                                   // :331
+        sv = inv_norm(T_[1], inm);                                   // :332
         const float cx = c.dt * sx;
         const float n2x = sx * sx * T_[2];                                // |g_x2|^2
         const float n2v = sv * sv * T_[3] + 2.f * sv * cx * T_[4] + cx * cx * T_[5];
-        sA = inv_norm(n2x, c.n_mask);                                     // :223 (gripper 1)
-        sB = inv_norm(n2v, c.n_mask);                                     // :224
+        sA = inv_norm(n2x, inm);                                     // :223 (gripper 1)
+        sB = inv_norm(n2v, inm);                                     // :224
         const float n3x = sA * sA * n2x;
         const float s1 = act[7];
         const float nm = sv * sv * T_[6] + 2.f * sv * cx * T_[7] + cx * cx * T_[8];
         const float n3v = sB * sB * (n2v - (1.f - s1 * s1) * nm);
-        s3x = inv_norm(n3x, c.n_mask);                                    // :223 (gripper 0)
-        s3v = inv_norm(fmaxf(n3v, 0.f), c.n_mask);                        // :224
+        s3x = inv_norm(n3x, inm);                                    // :223 (gripper 0)
+        s3v = inv_norm(fmaxf(n3v, 0.f), inm);                        // :224
         // primitives (:333-334): 4-vector norms, uniform; only wave 0 carries the primitive cotangent
         if (wv == 0) {
-#pragma unroll
-          for (int g = 0; g < 2; ++g) {
-            const float n2 = gp[g * 4] * gp[g * 4] + gp[g * 4 + 1] * gp[g * 4 + 1] + gp[g * 4 + 2] * gp[g * 4 + 2] + gp[g * 4 + 3] * gp[g * 4 + 3];
-            const float sc = inv_norm(n2, c.n_mask);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) gp[g * 4 + d] *= sc;
-          }
+          float n2 = gpl * gpl;
+          n2 += dpp_f<0xB1>(n2);
+          n2 += dpp_f<0x4E>(n2);   // quad total = this gripper's 4-vector norm^2
+          gpl *= inv_norm(n2, inm);
         }
       }
       // ---- neighbour-dependent forward recompute ----
       float v3[3], v4[3];
       FastInter in;
-      force_fast<true>(c, i, nb, X4, k, kLs, kLd, mu, x, v, v3, &in);
+      force_fast<true>(c, nbs, X4, k, iLs, iLd, mu, x, v, v3, &in);
 #pragma unroll
       for (int d = 0; d < 3; ++d) v4[d] = m0 ? act[3] * v3[d] : v3[d];
       // ---- reverse: clip (:326-329) and the two grippers (:313-314) with their normalisations folded in ----
@@ -385,15 +393,8 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       }
       // primitives (:322-323), uniform; counted once (lane 0) in the action accumulators
       if (wv == 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const float add = d < 3 ? act[g * 4 + d] : 0.f;
-            const float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
-            gp[g * 4 + d] = tt;
-            if (d < 3) ga[g * 4 + d] += (i == 0) ? tt : 0.f;
-          }
+        gpl *= clip_grad_lt(psl + addl, 0.f, 1.f);
+        gaP += pm3 ? gpl : 0.f;
       }
       // ---- v3 = (v1 + F dt) damp ; ground friction (:281-290) ----
       float gF[3];
@@ -421,19 +422,14 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       float ax0 = gxd[0], ax1 = gxd[1], ax2 = gxd[2];
 #pragma unroll
       for (int l = 0; l < 8; ++l) {
-        const int j = nb[l];
-        const bool ok = j >= 0;
-        const float4 gj = G4[ok ? j : i];
+        const float4 gj = G4[nbs[l]];               // a missing neighbour reads gF itself: d = 0 and r = 0
         const float r0 = in.r0[l], r1 = in.r1[l], r2 = in.r2[l];
-        const bool big = in.inv[l] > 0.f;            // sign carries the clip(|r|^2, 1e-12) branch
-        const float inv = fabsf(in.inv[l]);
         const float d0 = gj.x - gF[0], d1 = gj.y - gF[1], d2 = gj.z - gF[2];
         const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
         const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
-        float c1 = ((l < 4) ? kLs : kLd) - k * inv;
-        float c2 = big ? k * inv * inv * inv * rd_ : 0.f;
-        c1 = ok ? c1 : 0.f; c2 = ok ? c2 : 0.f;
-        gk += ok ? rg * (((l < 4) ? iLs : iLd) - inv) : 0.f;
+        const float c1 = k * in.w[l];
+        const float c2 = in.c2k[l] * rd_;
+        gk += rg * in.w[l];
         ax0 += c1 * d0 + c2 * r0; ax1 += c1 * d1 + c2 * r1; ax2 += c1 * d2 + c2 * r2;
       }
       gx[0] = ax0; gx[1] = ax1; gx[2] = ax2;
@@ -443,15 +439,15 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
     // macro-step boundary: robot_step's action transform (:168-169)
     {
       __syncthreads();
-#pragma unroll
-      for (int d = 0; d < 8; ++d) {
-        const float w = wave_sum_l63(ga[d]);
-        if (lane == 63) mac[wv * 8 + d] = w;
+      {
+        const float w8 = wave_sum8_t(ga, lane);
+        if ((lane & 0x2C) == 0) mac[wv * 8 + (((lane >> 2) & 4) | (lane & 3))] = w8;
       }
       __syncthreads();
       if (i < 8) {
         float tot = 0.f;
         for (int q = 0; q < nw; ++q) tot += mac[q * 8 + i];
+        tot += gaP;
         const int d = i & 3;
         a.g_actions[((size_t)t * B + b) * 8 + i] = (d < 3) ? tot / 50.0f * clip_grad(a8[i], -2.0f, 2.0f) : tot;
       }
@@ -468,11 +464,10 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
     if (lane == 63) { mac[wv * 2] = w0; mac[wv * 2 + 1] = w1; }
   }
   __syncthreads();
+  if (i < 8) a.g_prim0[b * 8 + i] = gpl;
   if (i == 0) {
     float t0 = 0.f, t1 = 0.f;
     for (int q = 0; q < nw; ++q) { t0 += mac[q * 2]; t1 += mac[q * 2 + 1]; }
-#pragma unroll
-    for (int d = 0; d < 8; ++d) a.g_prim0[b * 8 + d] = gp[d];
     a.g_k[b] = t0;
     a.g_mu[b] = t1;
   }

@@ -6,6 +6,7 @@
 // Same mapping as the other cloth kernels: one workgroup per env, one particle per lane, float4 positions
 // double-buffered in LDS, one barrier per substep, per-substep checkpoints to HBM.
 #include "cloth_common.h"
+#include "exact_math.h"
 
 namespace ud {
 
@@ -19,34 +20,39 @@ __device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  /
 }
 
 // grippers, own-particle part only (:198-226): masks and displaced positions
-__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, bool& m0, bool& m1, float* x2) {
+// thr0/thr1 = grasp_thr(radius): s <= thr is the same boolean as sqrtf(s) <= radius (cloth_common.h)
+__device__ __forceinline__ void grip_own(const float* x, const float* ps, const float* act, float thr0, float thr1, bool& m0,
+                                         bool& m1, float* x2) {
   float d0 = x[0] - ps[0], d1 = x[1] - ps[1], d2 = x[2] - ps[2];
-  m0 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[3];
+  m0 = (d0 * d0 + d1 * d1 + d2 * d2) <= thr0;
   float x1[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) x1[a] = m0 ? x[a] + act[a] * (1.f - act[3]) : x[a];
   d0 = x1[0] - ps[4]; d1 = x1[1] - ps[5]; d2 = x1[2] - ps[6];
-  m1 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2) <= ps[7];
+  m1 = (d0 * d0 + d1 * d1 + d2 * d2) <= thr1;
 #pragma unroll
   for (int a = 0; a < 3; ++a) x2[a] = m1 ? x1[a] + act[4 + a] * (1.f - act[7]) : x1[a];
 }
 
 // spring + gravity + ground friction + damping in the re-associated IEEE order "v2"
 // (oracle/csrc/cloth_oracle.hpp::cloth_substep_fwd_v2): only +,-,*,/,sqrt, no FMA contraction in this file.
-__device__ __forceinline__ void force_v2(const ClothConst& c, int i, const int* nb, const float4* X4, float k, float kLs,
+// nbs[l] = neighbour index, or the particle itself where the lattice has no neighbour.  Then r == 0 exactly and
+// coef is finite, so coef * r == +-0, and F (which starts at +0 and therefore is never -0) takes it without
+// changing a bit: the same result as the oracle's "skip the link" without three selects per link.
+__device__ __forceinline__ void force_v2(const ClothConst& c, const int* nbs, const float4* X4, float k, float kLs,
                                          float kLd, float mu, const float* x, const float* v, float* v3) {
   float F0 = 0.f, F1 = 0.f, F2 = 0.f;
 #pragma unroll
   for (int l = 0; l < 8; ++l) {
-    const int j = nb[l];
-    const bool ok = j >= 0;
-    const float4 xj = X4[ok ? j : i];
+    const float4 xj = X4[nbs[l]];
     const float r0 = xj.x - x[0], r1 = xj.y - x[1], r2 = xj.z - x[2];
     const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
-    const float len = sqrtf(fmaxf(s2, 1e-12f));
-    const float inv = 1.0f / len;
+    // sqrtf / division in their exact_math.h forms: the clip keeps the argument in [1e-12, FLT_MAX] (an overflowed
+    // |r|^2 gives 1/len = 5e-20 instead of 0, which k/L0 - k/len rounds to the same float) and len in [1e-6, 2^64]
+    const float len = sqrt_rn_inrange(fminf(fmaxf(s2, 1e-12f), FLT_MAX));
+    const float inv = rcp_rn_inrange(len);
     const float coef = ((l < 4) ? kLs : kLd) - k * inv;
-    F0 += ok ? coef * r0 : 0.f; F1 += ok ? coef * r1 : 0.f; F2 += ok ? coef * r2 : 0.f;
+    F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
   }
   F1 += -c.g;
   const float v1y = v[1] - c.gdt;
@@ -54,8 +60,8 @@ __device__ __forceinline__ void force_v2(const ClothConst& c, int i, const int* 
   const float cF = fminf(F1, 0.f);
   const float muF = mu * cF * -1.0f;
   const float xV = v[0], yV = v[2];
-  const float sV = sqrtf(xV * xV + yV * yV + c.eps);
-  const float tf = fm ? muF / sV : 0.f;
+  const float isV = 1.0f / sqrtf(xV * xV + yV * yV + c.eps);   // independent of the spring sum: off the F -> v3 chain
+  const float tf = fm ? muF * isV : 0.f;
   const float Ax = F0 - tf * xV, Az = F2 - tf * yV;
   v3[0] = (xV + Ax * c.dt) * c.damp;
   v3[1] = (v1y + F1 * c.dt) * c.damp;
@@ -71,9 +77,9 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_v2_kernel(ClothFwdArgs 
   const int i = threadIdx.x, b = blockIdx.x;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
   const bool live = i < P;
-  int nb[8];
+  int nbs[8];
 #pragma unroll
-  for (int l = 0; l < 8; ++l) nb[l] = a.nbr[l * Pp + i];
+  for (int l = 0; l < 8; ++l) { const int j = a.nbr[l * Pp + i]; nbs[l] = j >= 0 ? j : i; }
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
   if (live) {
 #pragma unroll
@@ -84,6 +90,8 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_v2_kernel(ClothFwdArgs 
   for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
   const float k = a.k[b], mu = a.mu[b];
   const float kLs = k / c.Ls, kLd = k / c.Ld;   // k / L0 with the rest lengths of cloth_simulator.py:61-63
+  GraspThr th0, th1;
+  th0.init(ps[3]); th1.init(ps[7]);
   const size_t rec = cloth_rec_floats(Pp);
   float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
   unsigned step = 0;
@@ -105,8 +113,8 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_v2_kernel(ClothFwdArgs 
       __syncthreads();
       float vv[3], x2[3];
       bool m0, m1;
-      force_v2(c, i, nb, X4, k, kLs, kLd, mu, x, v, vv);
-      grip_own(x, ps, act, m0, m1, x2);
+      force_v2(c, nbs, X4, k, kLs, kLd, mu, x, v, vv);
+      grip_own(x, ps, act, th0.at(step == 0), th1.at(step == 0), m0, m1, x2);
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         vv[d] = m0 ? act[3] * vv[d] : vv[d];
