@@ -193,6 +193,54 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
+// The adjoint works on link PAIRS: pair p = (straight link p, diagonal link p+4), one float2 per quantity, so that
+// the per-link arithmetic is v_pk_{add,mul,fma}_f32 (two links per instruction).  Positions and force cotangents
+// are staged in LDS as SoA planes with a compile-time stride, so a pair is two ds_read_b32 with immediate plane
+// offsets landing in adjacent registers -- no register shuffling to build the operands.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int UD_CLOTH_MAXP = 1024;   // LDS plane stride (floats); the kernels refuse Pp > 1024
+
+struct PairInter {
+  float F1, cF, muF, xV, yV, isV, tf;   // friction block
+  f2 r0[4], r1[4], r2[4];               // link vectors
+  f2 w[4];                              // 1/L0 - 1/|r|
+  f2 c2k[4];                            // k / |r|^3, or 0 where clip(|r|^2, 1e-12) is active
+};
+
+__device__ __forceinline__ void force_pairs(const ClothConst& c, const int* nbs, const float* Xs, float k, f2 iL2, float mu,
+                                            const float* x, const float* v, float* v3, PairInter* in) {
+  f2 F0 = {0.f, 0.f}, F1 = {0.f, 0.f}, F2 = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ja = nbs[p], jb = nbs[p + 4];
+    const f2 r0 = f2{Xs[ja], Xs[jb]} - x[0];
+    const f2 r1 = f2{Xs[UD_CLOTH_MAXP + ja], Xs[UD_CLOTH_MAXP + jb]} - x[1];
+    const f2 r2 = f2{Xs[2 * UD_CLOTH_MAXP + ja], Xs[2 * UD_CLOTH_MAXP + jb]} - x[2];
+    const f2 s2 = r0 * r0 + r1 * r1 + r2 * r2;
+    const f2 inv = {rsq(fmaxf(s2.x, 1e-12f)), rsq(fmaxf(s2.y, 1e-12f))};
+    const f2 w = iL2 - inv;
+    const f2 coef = k * w;
+    F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
+    const f2 c3 = (k * inv) * (inv * inv);
+    in->r0[p] = r0; in->r1[p] = r1; in->r2[p] = r2; in->w[p] = w;
+    in->c2k[p] = f2{s2.x > 1e-12f ? c3.x : 0.f, s2.y > 1e-12f ? c3.y : 0.f};
+  }
+  const float Fx = F0.x + F0.y, Fz = F2.x + F2.y;
+  const float Fy = F1.x + F1.y - c.g;               // :278
+  const float v1y = v[1] - c.gdt;                   // :259
+  const bool fm = x[1] <= c.eps;                    // :281
+  const float cF = fminf(Fy, 0.f);
+  const float muF = -(mu * cF);                     // :282
+  const float xV = v[0], yV = v[2];
+  const float isV = rsq(xV * xV + yV * yV + c.eps); // :285
+  const float tf = fm ? muF * isV : 0.f;            // :288-290 (sV > small_num always holds)
+  const float Ax = Fx - tf * xV, Az = Fz - tf * yV;
+  v3[0] = (xV + Ax * c.dt) * c.damp;                // :308-309
+  v3[1] = (v1y + Fy * c.dt) * c.damp;
+  v3[2] = (yV + Az * c.dt) * c.damp;
+  in->F1 = Fy; in->cF = cF; in->muF = muF; in->xV = xV; in->yV = yV; in->isV = isV; in->tf = tf;
+}
+
 // wave-wide sum that leaves the total in lane 63 (row butterflies + row_bcast15 / row_bcast31)
 __device__ __forceinline__ float wave_sum_l63(float v) {
   v += dpp_f<0xB1>(v);
@@ -211,19 +259,31 @@ __device__ __forceinline__ float inv_norm(float n2, float inv_n_mask) {
 }
 
 #define UD_NSUM 9
+#define UD_RSTR 16   // floats per wave in the partial-sum buffer (9 used)
+
+// sum over the four 16-lane rows of a wave, position by position; every row returns the total (gfx950 lane swaps)
+__device__ __forceinline__ float rows_sum4(float v) {
+  float a0 = v, a1 = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a0), "+v"(a1));
+  float s0 = a0 + a1, s1 = s0;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s0), "+v"(s1));
+  return s0 + s1;
+}
 
 __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArgs a) {
-  extern __shared__ float4 lds4[];  // X4[2][Pp] | G4[2][Pp] | red[2][16*UD_NSUM] | mac[16*8]
+  extern __shared__ float ldsf[];  // Xs[3][MAXP] | Gs[3][MAXP] | red[2][16][UD_RSTR] | mac[16*8]
   const ClothConst c = a.c;
   const int i = threadIdx.x, b = blockIdx.x;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
   const int nw = Pp >> 6, lane = i & 63, wv = i >> 6;
   const bool live = i < P;
   const bool norm = a.normalize != 0;
-  float4* Xb = lds4;
-  float4* Gb = lds4 + 2 * Pp;
-  float* red = (float*)(lds4 + 4 * Pp);
-  float* mac = red + 2 * 16 * UD_NSUM;
+  // single-buffered: every X read sits between barrier 1 and barrier 2 and the next X write comes after barrier 2;
+  // every G read sits between barrier 2 and the next barrier 1 and the next G write comes after that barrier
+  float* Xs = ldsf;
+  float* Gs = ldsf + 3 * UD_CLOTH_MAXP;
+  float* red = ldsf + 6 * UD_CLOTH_MAXP;
+  float* mac = red + 2 * 16 * UD_RSTR;
   int nbs[8];
 #pragma unroll
   for (int l = 0; l < 8; ++l) { const int j = a.nbr[l * Pp + i]; nbs[l] = j >= 0 ? j : i; }
@@ -238,14 +298,18 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
   const float inm = 1.f / c.n_mask;
   const float k = a.k[b], mu = a.mu[b];
   const float Ls = c.Ls, Ld = c.Ld;
-  const float iLs = 1.f / Ls, iLd = 1.f / Ld;
-  float gk = 0.f, gmu = 0.f;
+  const f2 iL2 = {1.f / Ls, 1.f / Ld};
+  f2 gk2 = {0.f, 0.f};
+  float gmu = 0.f;
   const size_t rec = cloth_rec_floats(Pp);
   const float* ck = a.ckpt + (size_t)b * cloth_env_records(T, S) * rec;
   GraspThr th0, th1;   // from record 0 = the rollout's input primitives, exactly what the forward derived them from
   th0.init(ck[6 * Pp + 3]); th1.init(ck[6 * Pp + 7]);
   // records: `cur` = input of the substep being reversed, `vnext` = v of the record after it (= clip(v5))
-  float vnext[3], nx[3], nv[3], nps[8], npsl;
+  // The primitive rows of the records are read through the constant address space (scalar loads into SGPRs: the
+  // checkpoints are read-only for this kernel), straight into `ps` once the previous substep is done with it.
+  typedef const __attribute__((address_space(4))) float* cfptr;
+  float vnext[3], nx[3], nv[3], ps[8], psl;
   {
     const float* r = ck + (size_t)T * S * rec;
 #pragma unroll
@@ -254,10 +318,13 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
 #pragma unroll
     for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
 #pragma unroll
-    for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
-    npsl = r[6 * Pp + (i & 7)];
+    for (int d = 0; d < 8; ++d) ps[d] = ((cfptr)r)[6 * Pp + d];
+    psl = r[6 * Pp + (i & 7)];
   }
+  for (int q = i; q < 2 * 16 * UD_RSTR; q += Pp) red[q] = 0.f;   // slots of waves this launch does not have are read as zeros
+  __syncthreads();
   unsigned step = 0;
+  const float* rp = ck + ((size_t)T * S - 1) * rec;   // record held in nx/nv/nps
   for (int t = T - 1; t >= 0; --t) {
     if (live) {
       const size_t o = (((size_t)t * B + b) * P + i) * 3;
@@ -273,26 +340,18 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
     const float addl = pm3 ? clipf(a8[i & 7], -2.0f, 2.0f) / 50.0f : 0.f;   // this lane's component of the primitive move
     float gaP = 0.f;
     for (int s = S - 1; s >= 0; --s, ++step) {
-      float x[3], v[3], ps[8];
+      float x[3], v[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) { x[d] = nx[d]; v[d] = nv[d]; }
-#pragma unroll
-      for (int d = 0; d < 8; ++d) ps[d] = nps[d];
-      const float psl = npsl;
       {  // prefetch the record this loop consumes next
-        const long q = (long)t * S + s - 1;
-        const float* r = ck + (size_t)(q < 0 ? 0 : q) * rec;
+        rp = (rp != ck) ? rp - rec : rp;            // uniform; the last iteration re-reads record 0 and ignores it
+        const float* r = rp;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { nx[d] = r[d * Pp + i]; nv[d] = r[(3 + d) * Pp + i]; }
-#pragma unroll
-        for (int d = 0; d < 8; ++d) nps[d] = r[6 * Pp + d];
-        npsl = r[6 * Pp + (i & 7)];
+        for (int d = 0; d < 3; ++d) { nx[d] = r[(unsigned)(d * Pp + i)]; nv[d] = r[(unsigned)((3 + d) * Pp + i)]; }
       }
       const unsigned par = step & 1u;
-      float4* X4 = Xb + par * Pp;
-      float4* G4 = Gb + par * Pp;
-      float* rd = red + par * 16 * UD_NSUM;
-      X4[i] = make_float4(x[0], x[1], x[2], 0.f);
+      float* rd = red + par * 16 * UD_RSTR;
+      Xs[i] = x[0]; Xs[UD_CLOTH_MAXP + i] = x[1]; Xs[2 * UD_CLOTH_MAXP + i] = x[2];
       // ---- own-particle forward pieces and the nine sums (no neighbour data needed) ----
       bool m0, m1;
       float x2[3];
@@ -316,19 +375,23 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       if (norm) {
         const float sm8[8] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[6], sm[7]};
         const float w8 = wave_sum8_t(sm8, lane);
-        if ((lane & 0x2C) == 0) rd[wv * UD_NSUM + (((lane >> 2) & 4) | (lane & 3))] = w8;
+        if ((lane & 0x2C) == 0) rd[wv * UD_RSTR + (((lane >> 2) & 4) | (lane & 3))] = w8;
         if (__builtin_amdgcn_ballot_w64(m1) != 0) {   // wave-uniform: gripper 1 holds something in this wave
           const float w = wave_sum_l63(sm[8]);
-          if (lane == 63) rd[wv * UD_NSUM + 8] = w;
+          if (lane == 63) rd[wv * UD_RSTR + 8] = w;
         } else if (lane == 63) {
-          rd[wv * UD_NSUM + 8] = 0.f;
+          rd[wv * UD_RSTR + 8] = 0.f;
         }
       }
       __syncthreads();   // barrier 1: X4 and the wave partials are visible
       float sx = 1.f, sv = 1.f, sA = 1.f, sB = 1.f, s3x = 1.f, s3v = 1.f;   // cumulative scale factors
       if (norm) {
+        // row g of the wave adds the partials of waves g, g+4, g+8, g+12 (slots of absent waves stay zero), then the
+        // four rows are added position by position: one LDS round trip instead of a dependent read per wave
         float tot = 0.f;
-        if (lane < UD_NSUM) for (int q = 0; q < nw; ++q) tot += rd[q * UD_NSUM + lane];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) tot += rd[((lane >> 4) + 4 * m) * UD_RSTR + (lane & 15)];
+        tot = rows_sum4(tot);
         float T_[UD_NSUM];
 #pragma unroll
         for (int q = 0; q < UD_NSUM; ++q) T_[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), q));
@@ -355,8 +418,8 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       }
       // ---- neighbour-dependent forward recompute ----
       float v3[3], v4[3];
-      FastInter in;
-      force_fast<true>(c, nbs, X4, k, iLs, iLd, mu, x, v, v3, &in);
+      PairInter in;
+      force_pairs(c, nbs, Xs, k, iL2, mu, x, v, v3, &in);
 #pragma unroll
       for (int d = 0; d < 3; ++d) v4[d] = m0 ? act[3] * v3[d] : v3[d];
       // ---- reverse: clip (:326-329) and the two grippers (:313-314) with their normalisations folded in ----
@@ -366,30 +429,24 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         gx2n[d] = sA * (sx * av[d]);
         gv5n[d] = sB * (sv * bv[d] + (c.dt * sx) * bx[d]);
       }
-      if (__builtin_amdgcn_ballot_w64(m1) != 0) {  // gripper 1 (wave-uniform skip when it holds nothing here)
-        const float s1 = act[7];
-        float dotv = v4[0] * gv5n[0] + v4[1] * gv5n[1] + v4[2] * gv5n[2];
-        float dotx = gx2n[0] * act[4] + gx2n[1] * act[5] + gx2n[2] * act[6];
-        ga[7] += m1 ? (dotv - dotx) : 0.f;
+      {  // gripper 1, branch-free: masks as 0/1 factors
+        const float s1 = act[7], m1f = m1 ? 1.f : 0.f, sc1 = m1 ? s1 : 1.f, h1 = (1.f - s1) * m1f;
+        const float dotv = v4[0] * gv5n[0] + v4[1] * gv5n[1] + v4[2] * gv5n[2];
+        const float dotx = gx2n[0] * act[4] + gx2n[1] * act[5] + gx2n[2] * act[6];
+        ga[7] += (dotv - dotx) * m1f;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ga[4 + d] += m1 ? gx2n[d] * (1.f - s1) : 0.f;
-          gv5n[d] = m1 ? s1 * gv5n[d] : gv5n[d];
-        }
+        for (int d = 0; d < 3; ++d) { ga[4 + d] += gx2n[d] * h1; gv5n[d] *= sc1; }
       }
       float gxd[3], gv3[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) { gxd[d] = s3x * gx2n[d]; gv3[d] = s3v * gv5n[d]; }
-      if (__builtin_amdgcn_ballot_w64(m0) != 0) {  // gripper 0
-        const float s0 = act[3];
-        float dotv = v3[0] * gv3[0] + v3[1] * gv3[1] + v3[2] * gv3[2];
-        float dotx = gxd[0] * act[0] + gxd[1] * act[1] + gxd[2] * act[2];
-        ga[3] += m0 ? (dotv - dotx) : 0.f;
+      {  // gripper 0
+        const float s0 = act[3], m0f = m0 ? 1.f : 0.f, sc0 = m0 ? s0 : 1.f, h0 = (1.f - s0) * m0f;
+        const float dotv = v3[0] * gv3[0] + v3[1] * gv3[1] + v3[2] * gv3[2];
+        const float dotx = gxd[0] * act[0] + gxd[1] * act[1] + gxd[2] * act[2];
+        ga[3] += (dotv - dotx) * m0f;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          ga[d] += m0 ? gxd[d] * (1.f - s0) : 0.f;
-          gv3[d] = m0 ? s0 * gv3[d] : gv3[d];
-        }
+        for (int d = 0; d < 3; ++d) { ga[d] += gxd[d] * h0; gv3[d] *= sc0; }
       }
       // primitives (:322-323), uniform; counted once (lane 0) in the action accumulators
       if (wv == 0) {
@@ -416,22 +473,28 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         gF[2] = live ? gAz : 0.f;
         gv[0] = g2x + gxV; gv[1] = g2y; gv[2] = g2z + gyV;   // v1 = v - (0, g dt, 0)
       }
-      G4[i] = make_float4(gF[0], gF[1], gF[2], 0.f);
-      __syncthreads();   // barrier 2: G4 visible
-      // ---- spring adjoint, gather form: g_x_i = gxd + sum_l J_il (gF_j - gF_i) ----
-      float ax0 = gxd[0], ax1 = gxd[1], ax2 = gxd[2];
+      Gs[i] = gF[0]; Gs[UD_CLOTH_MAXP + i] = gF[1]; Gs[2 * UD_CLOTH_MAXP + i] = gF[2];
+      __syncthreads();   // barrier 2: Gs visible
 #pragma unroll
-      for (int l = 0; l < 8; ++l) {
-        const float4 gj = G4[nbs[l]];               // a missing neighbour reads gF itself: d = 0 and r = 0
-        const float r0 = in.r0[l], r1 = in.r1[l], r2 = in.r2[l];
-        const float d0 = gj.x - gF[0], d1 = gj.y - gF[1], d2 = gj.z - gF[2];
-        const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
-        const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
-        const float c1 = k * in.w[l];
-        const float c2 = in.c2k[l] * rd_;
-        gk += rg * in.w[l];
-        ax0 += c1 * d0 + c2 * r0; ax1 += c1 * d1 + c2 * r1; ax2 += c1 * d2 + c2 * r2;
+      for (int d = 0; d < 8; ++d) ps[d] = ((cfptr)rp)[6 * Pp + d];   // next substep's primitives (rp already moved)
+      psl = rp[(unsigned)(6 * Pp + (i & 7))];
+      // ---- spring adjoint, gather form: g_x_i = gxd + sum_l J_il (gF_j - gF_i) ----
+      f2 A0 = {gxd[0], 0.f}, A1 = {gxd[1], 0.f}, A2 = {gxd[2], 0.f};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int ja = nbs[p], jb = nbs[p + 4];       // a missing neighbour reads gF itself: d = 0 and r = 0
+        const f2 d0 = f2{Gs[ja], Gs[jb]} - gF[0];
+        const f2 d1 = f2{Gs[UD_CLOTH_MAXP + ja], Gs[UD_CLOTH_MAXP + jb]} - gF[1];
+        const f2 d2 = f2{Gs[2 * UD_CLOTH_MAXP + ja], Gs[2 * UD_CLOTH_MAXP + jb]} - gF[2];
+        const f2 r0 = in.r0[p], r1 = in.r1[p], r2 = in.r2[p];
+        const f2 rd_ = r0 * d0 + r1 * d1 + r2 * d2;
+        const f2 rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
+        const f2 c1 = k * in.w[p];
+        const f2 c2 = in.c2k[p] * rd_;
+        gk2 += rg * in.w[p];
+        A0 += c1 * d0 + c2 * r0; A1 += c1 * d1 + c2 * r1; A2 += c1 * d2 + c2 * r2;
       }
+      const float ax0 = A0.x + A0.y, ax1 = A1.x + A1.y, ax2 = A2.x + A2.y;
       gx[0] = ax0; gx[1] = ax1; gx[2] = ax2;
 #pragma unroll
       for (int d = 0; d < 3; ++d) vnext[d] = v[d];   // this substep's input v is the previous substep's clip(v5)
@@ -460,7 +523,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
   }
   __syncthreads();
   {
-    const float w0 = wave_sum_l63(gk), w1 = wave_sum_l63(gmu);
+    const float w0 = wave_sum_l63(gk2.x + gk2.y), w1 = wave_sum_l63(gmu);
     if (lane == 63) { mac[wv * 2] = w0; mac[wv * 2 + 1] = w1; }
   }
   __syncthreads();
@@ -479,7 +542,7 @@ void cloth_launch_fwd_fast(const ClothFwdArgs& a, hipStream_t stream) {
 }
 
 void cloth_launch_bwd_fast(const ClothBwdArgs& a, hipStream_t stream) {
-  const size_t shmem = (size_t)4 * a.c.Pp * sizeof(float4) + (2 * 16 * UD_NSUM + 16 * 8) * sizeof(float);
+  const size_t shmem = (size_t)(6 * UD_CLOTH_MAXP + 2 * 16 * UD_RSTR + 16 * 8) * sizeof(float);
   hipLaunchKernelGGL(cloth_rollout_bwd_fast_kernel, dim3(a.B), dim3(a.c.Pp), shmem, stream, a);
 }
 
