@@ -165,7 +165,9 @@ void cloth_substep_fwd(const ClothTables<T>& tb, const ClothParams<T>& pr, T k, 
 }
 
 // Forward substep, operation order "v2": the same formulas re-associated into far fewer IEEE operations
-//   spring      f = r * (k/L0 - k * (1/|r|))     instead of  k*r/|r|*(|r|-L0)/L0   (6 divisions + sqrt -> 1 + sqrt)
+//   spring      f = r * (k/L0 - k * (1/|r|))     instead of  k*r/|r|*(|r|-L0)/L0   (6 divisions + sqrt -> 1 + sqrt);
+//               F = (sum over the straight links 0-3) + (sum over the diagonal links 4-7): the HIP kernel carries a
+//               straight and a diagonal link in the two halves of a packed-f32 register
 //   friction    t = dm*muF * (1/sV) ; A = F - t*V  instead of  F - dm*muF*V/sV   (1/sV does not wait for F)
 //   the static-friction block (:293-306) is dropped: sV = sqrt(.+small_num) > small_num always (small_num < 1)
 // Only +,-,*,/,sqrt, no FMA: a CPU and a GPU build of this order agree bit for bit (the default HIP forward,
@@ -179,7 +181,7 @@ void cloth_substep_fwd_v2(const ClothTables<T>& tb, const ClothParams<T>& pr, T 
   for (int i = 0; i < P; ++i) {
     const T xi[3] = {x[i * 3], x[i * 3 + 1], x[i * 3 + 2]};
     T v1[3] = {v[i * 3], v[i * 3 + 1] - pr.gravity_dt, v[i * 3 + 2]};
-    T F[3] = {0, 0, 0};
+    T Fs[3] = {0, 0, 0}, Fd[3] = {0, 0, 0};   // straight links 0-3 and diagonal links 4-7, each summed in link order
     for (int l = 0; l < 8; ++l) {
       int j = tb.nbr[i * 8 + l];
       if (j < 0) continue;
@@ -188,8 +190,10 @@ void cloth_substep_fwd_v2(const ClothTables<T>& tb, const ClothParams<T>& pr, T 
       T len = std::sqrt(std::max(s, T(1e-12)));
       T inv = T(1) / len;
       T coef = k / tb.L0[i * 8 + l] - k * inv;
-      for (int a = 0; a < 3; ++a) F[a] += coef * r[a];
+      T* Fa = (l < 4) ? Fs : Fd;
+      for (int a = 0; a < 3; ++a) Fa[a] += coef * r[a];
     }
+    T F[3] = {Fs[0] + Fd[0], Fs[1] + Fd[1], Fs[2] + Fd[2]};
     F[1] += -pr.gravity;
     bool fm = xi[1] <= eps;
     T cF = std::min(F[1], T(0));

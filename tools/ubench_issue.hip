@@ -13,6 +13,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define SALU8 "s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
 #define CND8 "v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
 #define RSQ8 "v_rsq_f32 %0, %0\n v_rsq_f32 %1, %1\n v_rsq_f32 %2, %2\n v_rsq_f32 %3, %3\n v_rsq_f32 %4, %4\n v_rsq_f32 %5, %5\n v_rsq_f32 %6, %6\n v_rsq_f32 %7, %7\n"
+#define CNDS8 "v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+#define CMPS8 "v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cmp_lt_f32_e64 s[22:23], %1, %8\n v_cmp_lt_f32_e64 s[24:25], %2, %8\n v_cmp_lt_f32_e64 s[26:27], %3, %8\n v_cmp_lt_f32_e64 s[20:21], %4, %8\n v_cmp_lt_f32_e64 s[22:23], %5, %8\n v_cmp_lt_f32_e64 s[24:25], %6, %8\n v_cmp_lt_f32_e64 s[26:27], %7, %8\n"
+#define CMPCND8 "v_cmp_lt_f32_e64 s[20:21], %0, %8\n v_cmp_lt_f32_e64 s[22:23], %1, %8\n v_cmp_lt_f32_e64 s[24:25], %2, %8\n v_cmp_lt_f32_e64 s[26:27], %3, %8\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[22:23]\n v_cndmask_b32_e64 %6, %6, %8, s[24:25]\n v_cndmask_b32_e64 %7, %7, %8, s[26:27]\n"
+#define CMPVCC8 "v_cmp_lt_f32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cmp_lt_f32_e32 vcc, %2, %8\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cmp_lt_f32_e32 vcc, %4, %8\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cmp_lt_f32_e32 vcc, %6, %8\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+#define DPP8 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %4, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xf\n"
+#define MOV8 "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+#define MULS8 "v_mul_f32 %0, %0, %9\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %9\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %9\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %9\n v_mul_f32 %7, %7, %9\n"
 #define DEPMUL8 "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n"
 
 template <int KIND>
@@ -20,6 +27,8 @@ __global__ void __launch_bounds__(1024) k(float* out, int iters, float s, float 
   float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
   f2 sv = {s, s}, sw = {s2, s2};
+  const unsigned long long m64 = 0x5555aaaa5555aaaaull + (unsigned)iters;
+  const float sf = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
   int s0 = iters, s1 = iters + 1, s2i = iters + 2, s3 = iters + 3;
   long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -32,6 +41,13 @@ __global__ void __launch_bounds__(1024) k(float* out, int iters, float s, float 
     if (KIND == 6) asm volatile(R8(SALU8) : "+s"(s0), "+s"(s1), "+s"(s2i), "+s"(s3) :: "scc");
     if (KIND == 7) asm volatile(R8(CND8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s));
     if (KIND == 8) asm volatile(R8(RSQ8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    if (KIND == 10) asm volatile(R8(CNDS8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "s"(m64));
+    if (KIND == 11) asm volatile(R8(CMPS8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "s20","s21","s22","s23","s24","s25","s26","s27");
+    if (KIND == 12) asm volatile(R8(CMPCND8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "s20","s21","s22","s23","s24","s25","s26","s27");
+    if (KIND == 13) asm volatile(R8(CMPVCC8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s) : "vcc");
+    if (KIND == 14) asm volatile(R8(DPP8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    if (KIND == 15) asm volatile(R8(MOV8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    if (KIND == 16) asm volatile(R8(MULS8) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(s), "s"(sf));
     if (KIND == 9) asm volatile(R8(DEPMUL8) : "+v"(a0) : "v"(s));
   }
   long t1 = __builtin_readcyclecounter();
@@ -70,6 +86,13 @@ int main() {
     run<7>("v_cndmask x64", th, 64);
     run<8>("v_rsq_f32 x64", th, 64);
     run<9>("dependent v_mul x64", th, 64);
+    run<10>("v_cndmask_e64 (sgpr cond)", th, 64);
+    run<11>("v_cmp_e64 -> sgpr pair", th, 64);
+    run<12>("4 v_cmp_e64 + 4 cndmask_e64", th, 64);
+    run<13>("(v_cmp vcc; v_cndmask vcc)", th, 64);
+    run<14>("v_add_f32_dpp x64", th, 64);
+    run<15>("v_mov_b32 x64", th, 64);
+    run<16>("v_mul_f32 v, v, sgpr", th, 64);
   }
   return 0;
 }

@@ -31,4 +31,67 @@ __device__ __forceinline__ float rcp_rn_inrange(float d) {
   return __builtin_fmaf(e3, r, q);
 }
 
+// The same two functions on a pair of values (v_pk_fma_f32 for the residual corrections; IEEE per component).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 sqrt_rn_inrange2(f2 x) {
+  const f2 s = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+  const i2 sb = __builtin_bit_cast(i2, s);
+  const f2 sd = __builtin_bit_cast(f2, sb - 1), su = __builtin_bit_cast(f2, sb + 1);
+  const f2 rd = __builtin_elementwise_fma(-sd, s, x), ru = __builtin_elementwise_fma(-su, s, x);
+  f2 r;
+  r.x = (rd.x <= 0.0f) ? sd.x : s.x; r.x = (ru.x > 0.0f) ? su.x : r.x;
+  r.y = (rd.y <= 0.0f) ? sd.y : s.y; r.y = (ru.y > 0.0f) ? su.y : r.y;
+  return r;
+}
+
+__device__ __forceinline__ f2 rcp_rn_inrange2(f2 d) {
+  const f2 one = {1.0f, 1.0f};
+  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 e = __builtin_elementwise_fma(-d, r, one);
+  r = __builtin_elementwise_fma(e, r, r);
+  const f2 e2 = __builtin_elementwise_fma(-d, r, one);
+  const f2 q = __builtin_elementwise_fma(e2, r, r);
+  const f2 e3 = __builtin_elementwise_fma(-d, q, one);
+  return __builtin_elementwise_fma(e3, r, q);
+}
+
+// Four pairs at once, written stage by stage: a dependent v_pk_fma_f32 -> v_pk_fma_f32 costs a wait state, and the
+// four chains are independent, so breadth-first order lets each stage's instructions fill the others' latency.
+__device__ __forceinline__ void rcp_sqrt_rn_inrange2x4(const f2 (&x)[4], f2 (&out)[4]) {
+  const f2 one = {1.0f, 1.0f};
+  f2 s[4], sd[4], su[4], rd[4], ru[4], d[4], r[4], e[4], q[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) s[p] = f2{__builtin_amdgcn_sqrtf(x[p].x), __builtin_amdgcn_sqrtf(x[p].y)};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const i2 sb = __builtin_bit_cast(i2, s[p]);
+    sd[p] = __builtin_bit_cast(f2, sb - 1); su[p] = __builtin_bit_cast(f2, sb + 1);
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) rd[p] = __builtin_elementwise_fma(-sd[p], s[p], x[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) ru[p] = __builtin_elementwise_fma(-su[p], s[p], x[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    d[p].x = (rd[p].x <= 0.0f) ? sd[p].x : s[p].x; d[p].x = (ru[p].x > 0.0f) ? su[p].x : d[p].x;
+    d[p].y = (rd[p].y <= 0.0f) ? sd[p].y : s[p].y; d[p].y = (ru[p].y > 0.0f) ? su[p].y : d[p].y;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) r[p] = f2{__builtin_amdgcn_rcpf(d[p].x), __builtin_amdgcn_rcpf(d[p].y)};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) e[p] = __builtin_elementwise_fma(-d[p], r[p], one);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) r[p] = __builtin_elementwise_fma(e[p], r[p], r[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) e[p] = __builtin_elementwise_fma(-d[p], r[p], one);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) q[p] = __builtin_elementwise_fma(e[p], r[p], r[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) e[p] = __builtin_elementwise_fma(-d[p], q[p], one);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) out[p] = __builtin_elementwise_fma(e[p], r[p], q[p]);
+}
+
 }  // namespace ud
