@@ -182,6 +182,26 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
                     const double* nu, const double* yield_stress, double* x_out, double* v_out, double* C_out,
                     double* F_out, double* prim_pos_out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Cloth-env arithmetic either side of the rollout (the reference jit-fuses it into step_diff; here one forward and
+ * one backward kernel per piece, one workgroup per env, instead of ~180 elementwise launches per step_diff).
+ *   ud_chamfer_*    core/utils/util.py:138-153  calc_chamfer(x [B,P,3], y [Q,3]) -> [B]:
+ *                   d(p,q) = sqrt(mean_xyz((x_p - y_q)^2)); out = mean_q min_p d + mean_p min_q d.
+ *                   idx_xy [B,P] / idx_yx [B,Q] (int32) are the argmins the backward routes the cotangent through.
+ *   ud_cloth_pnp_*  core/envs/basic/cloth_env.py:134-173 get_pnp_actions (actions [B,6], primitive0 [B,4]) ->
+ *                   macro_actions [40,B,8], and :206-209 contact_distance [B] = min_p |actions[:, :3] - x_p|.
+ * P, Q <= 4096.  The backward entry points return what jax.grad returns for the same expressions.
+ * ------------------------------------------------------------------------------------------------ */
+int ud_chamfer_fwd(int B, int P, int Q, const float* x, const float* y, float* out, int* idx_xy, int* idx_yx, void* stream);
+int ud_chamfer_bwd(int B, int P, int Q, const float* x, const float* y, const int* idx_xy, const int* idx_yx,
+                   const float* g_out, float* g_x, void* stream);
+int ud_cloth_pnp_fwd(int B, int P, const float* actions, const float* primitive0, const float* x, float* macro_actions,
+                     float* contact_distance, int* contact_idx, void* stream);
+/* g_contact_distance may be NULL (no auxiliary reward); g_x [B,P,3] is written in full (zero except the contact row) */
+int ud_cloth_pnp_bwd(int B, int P, const float* actions, const float* x, const float* contact_distance,
+                     const int* contact_idx, const float* g_macro_actions, const float* g_contact_distance,
+                     float* g_actions, float* g_primitive0, float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,5 @@
 """GPU: the reference-shaped env / APG surface over the kernels (ClothEnv, MPMEnv, env_functions, APG update)."""
+import math
 import os
 
 import numpy as np
@@ -106,3 +107,69 @@ def test_apg_entry_point_cli(tmp_path):
     assert abs(recs[0]["core_env_stiffness"] - np.random.uniform(1000, 1600)) < 1e-9    # apg_para.py:326-329
     assert all(np.isfinite(r["train_reward"]) and np.isfinite(r["grad_norm"]) for r in recs)
     assert os.path.exists(os.path.join(logdir, "apg_fold_cloth1_0.pt"))
+
+
+# ---- fused env arithmetic (csrc/env_glue.hip) against the op-by-op torch restatement ---------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,Q,B", [(512, 512, 4), (333, 700, 3), (64, 17, 1)])
+def test_fused_chamfer_matches_op_by_op(P, Q, B):
+    from unidom_amd.envs.basic import _fused
+    from unidom_amd.utils.util import calc_chamfer
+    g = torch.Generator(device="cuda").manual_seed(P + Q)
+    x = torch.rand((B, P, 3), device="cuda", generator=g).requires_grad_(True)
+    y = torch.rand((Q, 3), device="cuda", generator=g)
+    w = torch.rand((B,), device="cuda", generator=g) + 0.5
+    ref = calc_chamfer(x, y)
+    (gref,) = torch.autograd.grad((ref * w).sum(), x)
+    out = _fused.chamfer(x, y)
+    (gout,) = torch.autograd.grad((out * w).sum(), x)
+    # f32 on both sides; differences = summation order of the two means and of the argmin scatter
+    torch.testing.assert_close(out, ref, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(gout, gref, rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aux", [True, False])
+def test_fused_pnp_and_contact_match_op_by_op(aux):
+    from unidom_amd.envs.basic import _fused
+    from unidom_amd.envs.basic.cloth_env import ClothEnv
+    from unidom_amd.engine.cloth_simulator import ClothState
+    B, P = 4, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    actions = torch.rand((B, 6), device="cuda", generator=g).requires_grad_(True)
+    prim0 = torch.rand((B, 4), device="cuda", generator=g).requires_grad_(True)
+    x = torch.rand((B, P, 3), device="cuda", generator=g).requires_grad_(True)
+    st = ClothState(x=x, v=None, primitive0=prim0, primitive1=None, action0=None, action1=None, key=None, cur_step=None,
+                    stiffness=None, mu=None)
+    macro_ref = ClothEnv.get_pnp_actions(actions, st)
+    contact_ref = torch.sqrt(((actions[..., :3][:, None, :] - x) ** 2).sum(-1)).min(-1).values
+    macro, contact = _fused.pnp_and_contact(actions, prim0, x)
+    # the kernel divides (as jnp does); torch's tensor / scalar multiplies by the rounded reciprocal: 1 ulp apart
+    torch.testing.assert_close(macro, macro_ref, rtol=3e-7, atol=0)
+    torch.testing.assert_close(contact, contact_ref, rtol=1e-6, atol=0)
+    wm = torch.rand(macro.shape, device="cuda", generator=g)
+    wc = torch.rand((B,), device="cuda", generator=g) if aux else torch.zeros((B,), device="cuda")
+    loss = lambda m, c: (m * wm).sum() + ((c * wc).sum() if aux else 0.0)
+    gref = torch.autograd.grad(loss(macro_ref, contact_ref), (actions, prim0, x), allow_unused=True)
+    gout = torch.autograd.grad(loss(macro, contact), (actions, prim0, x), allow_unused=True)
+    for a, r in zip(gout, gref):
+        r = torch.zeros_like(a) if r is None else r
+        torch.testing.assert_close(a, r, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_step_diff_real_reward_is_lazy_and_right():
+    from unidom_amd.envs.registration import env_functions
+    from unidom_amd.utils.util import calc_chamfer
+    from unidom_amd.utils import prng
+    env = env_functions["fold_cloth1"](batch_size=2, seed=0, aux_reward=True)
+    _, state = env.reset(prng.PRNGKey(0))
+    actions = torch.tensor([[0.4, 0.0, 0.45, 0.6, 0.0, 0.5], [0.5, 0.0, 0.5, 0.45, 0.0, 0.6]], device="cuda")
+    _, reward, _, info = env.step_diff(actions, state)
+    assert "real_reward" in info and "real_reward" not in dict.keys(info)   # not computed yet
+    old = calc_chamfer(state.x, env.goal)
+    new = calc_chamfer(info["state"].x, env.goal)
+    contact = torch.sqrt(((actions[:, None, :3] - state.x) ** 2).sum(-1)).min(-1).values
+    torch.testing.assert_close(info["real_reward"], old - new + 0.1 * contact, rtol=1e-5, atol=1e-6)   # cloth_env.py:226
+    expect = (math.e ** (-new * 10) + math.e ** (-contact)) * 0.99 ** info["state"].cur_step
+    torch.testing.assert_close(reward, expect, rtol=1e-5, atol=1e-6)

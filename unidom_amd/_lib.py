@@ -20,6 +20,7 @@ SYMBOLS = [
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
     "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
     "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd",
+    "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
 ]
 
 
