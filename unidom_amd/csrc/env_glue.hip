@@ -31,40 +31,47 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 }
 
 // ---- chamfer -------------------------------------------------------------------------------------
+// grid (B, tiles, 2): z = 0 scans, for 64 particles per workgroup, all goal points; z = 1 the other way round.
+// Four lanes share a row (each takes every fourth column), the quad then reduces (value, first index) with DPP.
+// The two means are accumulated into out[b] (zeroed by the caller) with one atomic per workgroup.
+constexpr int CH_ROWS = GLUE_T / 4;
+
 __global__ void __launch_bounds__(GLUE_T) chamfer_fwd_kernel(int P, int Q, const float* __restrict__ x, const float* __restrict__ y,
                                                              float* __restrict__ out, int* __restrict__ ixy, int* __restrict__ iyx) {
-  extern __shared__ float lds[];   // xs[3][P] | ys[3][Q] | scratch[8]
-  float* xs = lds;
-  float* ys = lds + 3 * P;
-  float* scratch = ys + 3 * Q;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ float lds[];   // cols[3][nc] | scratch[8]
+  const int b = blockIdx.x, tid = threadIdx.x, dir = blockIdx.z;
   const float* xb = x + (size_t)b * P * 3;
-  for (int i = tid; i < P; i += GLUE_T) { xs[i] = xb[i * 3]; xs[P + i] = xb[i * 3 + 1]; xs[2 * P + i] = xb[i * 3 + 2]; }
-  for (int i = tid; i < Q; i += GLUE_T) { ys[i] = y[i * 3]; ys[Q + i] = y[i * 3 + 1]; ys[2 * Q + i] = y[i * 3 + 2]; }
+  const float* rows = dir == 0 ? xb : y;
+  const float* cols = dir == 0 ? y : xb;
+  const int nr = dir == 0 ? P : Q, nc = dir == 0 ? Q : P;
+  const int r0 = blockIdx.y * CH_ROWS;
+  if (r0 >= nr) return;   // uniform: the grid is sized for the larger cloud
+  float* cs = lds;
+  float* scratch = lds + 3 * nc;
+  for (int i = tid; i < nc; i += GLUE_T) { cs[i] = cols[i * 3]; cs[nc + i] = cols[i * 3 + 1]; cs[2 * nc + i] = cols[i * 3 + 2]; }
   __syncthreads();
-  float s_xy = 0.f, s_yx = 0.f;
-  for (int p = tid; p < P; p += GLUE_T) {   // for every particle the closest goal point
-    const float ax = xs[p], ay = xs[P + p], az = xs[2 * P + p];
-    float best = INFINITY; int bi = 0;
-    for (int q = 0; q < Q; ++q) {
-      const float m = mean_sq3(ax, ay, az, ys[q], ys[Q + q], ys[2 * Q + q]);
-      if (m < best) { best = m; bi = q; }
-    }
-    ixy[(size_t)b * P + p] = bi;
-    s_xy += sqrtf(best);   // min of sqrt == sqrt of min (sqrtf is monotone)
+  const int r = r0 + (tid >> 2), c0 = tid & 3;
+  const bool live = r < nr;
+  const int rr = live ? r : nr - 1;
+  const float ax = rows[rr * 3], ay = rows[rr * 3 + 1], az = rows[rr * 3 + 2];
+  float best = INFINITY; int bi = 0x7fffffff;
+  for (int c = c0; c < nc; c += 4) {
+    const float m = dir == 0 ? mean_sq3(ax, ay, az, cs[c], cs[nc + c], cs[2 * nc + c])
+                             : mean_sq3(cs[c], cs[nc + c], cs[2 * nc + c], ax, ay, az);   // (x - y) in both directions
+    if (m < best) { best = m; bi = c; }
   }
-  for (int q = tid; q < Q; q += GLUE_T) {   // for every goal point the closest particle
-    const float bx = ys[q], by = ys[Q + q], bz = ys[2 * Q + q];
-    float best = INFINITY; int bi = 0;
-    for (int p = 0; p < P; ++p) {
-      const float m = mean_sq3(xs[p], xs[P + p], xs[2 * P + p], bx, by, bz);
-      if (m < best) { best = m; bi = p; }
-    }
-    iyx[(size_t)b * Q + q] = bi;
-    s_yx += sqrtf(best);
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {   // the four lanes of a row: smallest value, then smallest index
+    const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  const float t_xy = block_sum(s_xy, scratch), t_yx = block_sum(s_yx, scratch);
-  if (tid == 0) out[b] = t_yx / (float)Q + t_xy / (float)P;   // y2x_min + x2y_min
+  float s = 0.f;
+  if (live && c0 == 0) {
+    (dir == 0 ? ixy + (size_t)b * P : iyx + (size_t)b * Q)[r] = bi;
+    s = sqrtf(best);   // min of sqrt == sqrt of min (sqrtf is monotone)
+  }
+  const float t = block_sum(s, scratch);
+  if (tid == 0) atomicAdd(&out[b], t / (float)nr);
 }
 
 __global__ void __launch_bounds__(GLUE_T) chamfer_bwd_kernel(int P, int Q, const float* __restrict__ x, const float* __restrict__ y,
@@ -184,9 +191,11 @@ extern "C" {
 int ud_chamfer_fwd(int B, int P, int Q, const float* x, const float* y, float* out, int* idx_xy, int* idx_yx, void* stream) {
   if (B <= 0 || P <= 0 || Q <= 0 || !x || !y || !out || !idx_xy || !idx_yx) { set_error("ud_chamfer_fwd: bad argument"); return UD_ERR_INVALID; }
   if (P > GLUE_MAXPTS || Q > GLUE_MAXPTS) { set_error("ud_chamfer_fwd: P=%d / Q=%d above the %d points staged in LDS", P, Q, GLUE_MAXPTS); return UD_ERR_UNSUPPORTED; }
-  const size_t shmem = (size_t)(3 * P + 3 * Q + 8) * sizeof(float);
-  UD_HIP_CHECK(hipFuncSetAttribute((const void*)chamfer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  hipLaunchKernelGGL(chamfer_fwd_kernel, dim3(B), dim3(GLUE_T), shmem, (hipStream_t)stream, P, Q, x, y, out, idx_xy, idx_yx);
+  const int big = P > Q ? P : Q;
+  const size_t shmem = (size_t)(3 * big + 8) * sizeof(float);
+  UD_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)B * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(chamfer_fwd_kernel, dim3(B, (big + CH_ROWS - 1) / CH_ROWS, 2), dim3(GLUE_T), shmem, (hipStream_t)stream, P, Q, x, y,
+                     out, idx_xy, idx_yx);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;
 }

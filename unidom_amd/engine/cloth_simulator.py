@@ -130,6 +130,7 @@ class ClothSimulator:
         # (default), 1 reference-order forward and adjoint, 2 fast-math forward + restructured adjoint
         self.mode = int(getattr(conf, "kernel_mode", 0) if mode is None else mode)
         self.profile = None                  # bench.py: {"fwd": [...], "bwd": [...]} lists of (start, end) events
+        self._suction_col = torch.tensor([[False, False, False, True] * 2], device=self.device)   # columns robot_step leaves unscaled
 
         self.num_triangles = (self.N - 1) * (self.N - 1) * 2
         idx_i, idx_j = np.nonzero(self.cloth_mask)            # :52 (row-major)
@@ -214,9 +215,9 @@ class ClothSimulator:
         k = state.stiffness.to(torch.float32)
         out = _Rollout.apply(self, state.x, state.v, prim, k, state.mu, actions, want_lists)
         xo, vo, po = out[:3]
-        a_last = actions[-1]
-        act0 = torch.cat([a_last[:, :3].clamp(-2, 2) / 50.0, a_last[:, 3:4]], -1)   # :168
-        act1 = torch.cat([a_last[:, 4:7].clamp(-2, 2) / 50.0, a_last[:, 7:8]], -1)  # :169
+        a_last = actions[-1].detach()                                                # bookkeeping fields, never differentiated
+        both = torch.where(self._suction_col, a_last, a_last.clamp(-2, 2) / 50.0)    # :168-169 for both grippers at once
+        act0, act1 = both[:, :4], both[:, 4:]
         key = prng.split_first(state.key, T)                                         # :172, once per robot_step
         new = state._replace(x=xo, v=vo, primitive0=po[:, 0], primitive1=po[:, 1], action0=act0, action1=act1, key=key)
         if not want_lists:

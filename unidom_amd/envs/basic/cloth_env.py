@@ -152,16 +152,16 @@ class ClothEnv:
             obs_list = self.get_obs(state_list) if want_lists else obs                               # :216-219
             done = state.cur_step >= self.max_steps
             chamfer_distance = _fused.chamfer(state.x, self.goal)                                    # :222
-            reward = math.e ** (-chamfer_distance * 10)
+            reward = torch.exp(chamfer_distance * -10.0)                                             # :223  e ** (-10 d)
             if self.aux_reward:
-                reward = reward + math.e ** (-contact_distance)                                      # :225
+                reward = reward + torch.exp(-contact_distance)                                       # :225
 
             def real_reward():   # :205, :226 -- nothing on the gradient path reads it (XLA drops it from the jitted
                 with torch.no_grad():   # loss), so the second chamfer pass runs only when somebody asks
                     return _fused.chamfer(x_before, self.goal) - chamfer_distance + 0.1 * contact_distance
 
             info = _StepInfo({"state": state, "obs_list": obs_list, "state_list": state_list}, real_reward=real_reward)
-            reward = reward * 0.99 ** state.cur_step                                                 # :228
+            reward = reward * torch.pow(0.99, state.cur_step.to(torch.float32))                      # :228
             return obs, reward, done, info
 
         return step_diff
