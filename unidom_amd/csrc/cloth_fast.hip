@@ -198,10 +198,13 @@ __global__ void __launch_bounds__(512) cloth_rollout_fwd_fast_kernel(ClothFwdArg
 // are staged in LDS as SoA planes with a compile-time stride, so a pair is two ds_read_b32 with immediate plane
 // offsets landing in adjacent registers -- no register shuffling to build the operands.
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr int UD_CLOTH_MAXP = 1024;   // LDS plane stride (floats); the kernels refuse Pp > 1024
+constexpr int UD_CLOTH_MAXP = 1024 + 1;   // LDS plane stride (floats; the kernels refuse Pp > 1024).  Odd on purpose: a stride that is a
+                                          // multiple of 64 lets the compiler fuse the x and y reads of one neighbour into ds_read2st64,
+                                          // which then needs register moves to regroup them by link pair
 
 struct PairInter {
   float F1, cF, muF, xV, yV, isV, tf;   // friction block
+  float S0, S1, S2;                     // sum_l w_l r_l = spring force / k (the stiffness gradient is gF . S)
   f2 r0[4], r1[4], r2[4];               // link vectors
   f2 w[4];                              // 1/L0 - 1/|r|
   f2 c2k[4];                            // k / |r|^3, or 0 where clip(|r|^2, 1e-12) is active
@@ -210,23 +213,28 @@ struct PairInter {
 __device__ __forceinline__ void force_pairs(const ClothConst& c, const int* nbs, const float* Xs, float k, f2 iL2, float mu,
                                             const float* x, const float* v, float* v3, PairInter* in) {
   f2 F0 = {0.f, 0.f}, F1 = {0.f, 0.f}, F2 = {0.f, 0.f};
+  f2 q0[4], q1[4], q2[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {   // all 24 LDS reads in flight before the first use
+    const int ja = nbs[p], jb = nbs[p + 4];
+    q0[p] = f2{Xs[ja], Xs[jb]};
+    q1[p] = f2{Xs[UD_CLOTH_MAXP + ja], Xs[UD_CLOTH_MAXP + jb]};
+    q2[p] = f2{Xs[2 * UD_CLOTH_MAXP + ja], Xs[2 * UD_CLOTH_MAXP + jb]};
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int ja = nbs[p], jb = nbs[p + 4];
-    const f2 r0 = f2{Xs[ja], Xs[jb]} - x[0];
-    const f2 r1 = f2{Xs[UD_CLOTH_MAXP + ja], Xs[UD_CLOTH_MAXP + jb]} - x[1];
-    const f2 r2 = f2{Xs[2 * UD_CLOTH_MAXP + ja], Xs[2 * UD_CLOTH_MAXP + jb]} - x[2];
+    const f2 r0 = q0[p] - x[0], r1 = q1[p] - x[1], r2 = q2[p] - x[2];
     const f2 s2 = r0 * r0 + r1 * r1 + r2 * r2;
     const f2 inv = {rsq(fmaxf(s2.x, 1e-12f)), rsq(fmaxf(s2.y, 1e-12f))};
     const f2 w = iL2 - inv;
-    const f2 coef = k * w;
-    F0 += coef * r0; F1 += coef * r1; F2 += coef * r2;
+    F0 += w * r0; F1 += w * r1; F2 += w * r2;
     const f2 c3 = (k * inv) * (inv * inv);
     in->r0[p] = r0; in->r1[p] = r1; in->r2[p] = r2; in->w[p] = w;
     in->c2k[p] = f2{s2.x > 1e-12f ? c3.x : 0.f, s2.y > 1e-12f ? c3.y : 0.f};
   }
-  const float Fx = F0.x + F0.y, Fz = F2.x + F2.y;
-  const float Fy = F1.x + F1.y - c.g;               // :278
+  const float S0 = F0.x + F0.y, S1 = F1.x + F1.y, S2 = F2.x + F2.y;
+  const float Fx = k * S0, Fz = k * S2;
+  const float Fy = k * S1 - c.g;                    // :278
   const float v1y = v[1] - c.gdt;                   // :259
   const bool fm = x[1] <= c.eps;                    // :281
   const float cF = fminf(Fy, 0.f);
@@ -238,6 +246,7 @@ __device__ __forceinline__ void force_pairs(const ClothConst& c, const int* nbs,
   v3[0] = (xV + Ax * c.dt) * c.damp;                // :308-309
   v3[1] = (v1y + Fy * c.dt) * c.damp;
   v3[2] = (yV + Az * c.dt) * c.damp;
+  in->S0 = S0; in->S1 = S1; in->S2 = S2;
   in->F1 = Fy; in->cF = cF; in->muF = muF; in->xV = xV; in->yV = yV; in->isV = isV; in->tf = tf;
 }
 
@@ -299,8 +308,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
   const float k = a.k[b], mu = a.mu[b];
   const float Ls = c.Ls, Ld = c.Ld;
   const f2 iL2 = {1.f / Ls, 1.f / Ld};
-  f2 gk2 = {0.f, 0.f};
-  float gmu = 0.f;
+  float gk = 0.f, gmu = 0.f;
   const size_t rec = cloth_rec_floats(Pp);
   const float* ck = a.ckpt + (size_t)b * cloth_env_records(T, S) * rec;
   GraspThr th0, th1;   // from record 0 = the rollout's input primitives, exactly what the forward derived them from
@@ -480,21 +488,25 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
       psl = rp[(unsigned)(6 * Pp + (i & 7))];
       // ---- spring adjoint, gather form: g_x_i = gxd + sum_l J_il (gF_j - gF_i) ----
       f2 A0 = {gxd[0], 0.f}, A1 = {gxd[1], 0.f}, A2 = {gxd[2], 0.f};
+      f2 h0[4], h1[4], h2[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {   // all 24 LDS reads in flight before the first use
+        const int ja = nbs[p], jb = nbs[p + 4];       // a missing neighbour reads gF itself: d = 0 and r = 0
+        h0[p] = f2{Gs[ja], Gs[jb]};
+        h1[p] = f2{Gs[UD_CLOTH_MAXP + ja], Gs[UD_CLOTH_MAXP + jb]};
+        h2[p] = f2{Gs[2 * UD_CLOTH_MAXP + ja], Gs[2 * UD_CLOTH_MAXP + jb]};
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int ja = nbs[p], jb = nbs[p + 4];       // a missing neighbour reads gF itself: d = 0 and r = 0
-        const f2 d0 = f2{Gs[ja], Gs[jb]} - gF[0];
-        const f2 d1 = f2{Gs[UD_CLOTH_MAXP + ja], Gs[UD_CLOTH_MAXP + jb]} - gF[1];
-        const f2 d2 = f2{Gs[2 * UD_CLOTH_MAXP + ja], Gs[2 * UD_CLOTH_MAXP + jb]} - gF[2];
+        const f2 d0 = h0[p] - gF[0], d1 = h1[p] - gF[1], d2 = h2[p] - gF[2];
         const f2 r0 = in.r0[p], r1 = in.r1[p], r2 = in.r2[p];
         const f2 rd_ = r0 * d0 + r1 * d1 + r2 * d2;
-        const f2 rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
         const f2 c1 = k * in.w[p];
         const f2 c2 = in.c2k[p] * rd_;
-        gk2 += rg * in.w[p];
         A0 += c1 * d0 + c2 * r0; A1 += c1 * d1 + c2 * r1; A2 += c1 * d2 + c2 * r2;
       }
       const float ax0 = A0.x + A0.y, ax1 = A1.x + A1.y, ax2 = A2.x + A2.y;
+      gk += gF[0] * in.S0 + gF[1] * in.S1 + gF[2] * in.S2;   // sum_l w_l (r_l . gF) = gF . S
       gx[0] = ax0; gx[1] = ax1; gx[2] = ax2;
 #pragma unroll
       for (int d = 0; d < 3; ++d) vnext[d] = v[d];   // this substep's input v is the previous substep's clip(v5)
@@ -523,7 +535,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
   }
   __syncthreads();
   {
-    const float w0 = wave_sum_l63(gk2.x + gk2.y), w1 = wave_sum_l63(gmu);
+    const float w0 = wave_sum_l63(gk), w1 = wave_sum_l63(gmu);
     if (lane == 63) { mac[wv * 2] = w0; mac[wv * 2 + 1] = w1; }
   }
   __syncthreads();
