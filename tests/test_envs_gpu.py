@@ -173,3 +173,39 @@ def test_step_diff_real_reward_is_lazy_and_right():
     torch.testing.assert_close(info["real_reward"], old - new + 0.1 * contact, rtol=1e-5, atol=1e-6)   # cloth_env.py:226
     expect = (math.e ** (-new * 10) + math.e ** (-contact)) * 0.99 ** info["state"].cur_step
     torch.testing.assert_close(reward, expect, rtol=1e-5, atol=1e-6)
+
+
+# ---- the sibling cloth envs: same mask, same kernels, other confs ---------------------------
+def test_sibling_cloth_envs_confs():
+    from unidom_amd.envs.registration import env_functions
+    e3 = env_functions["fold_cloth3"](batch_size=2)
+    assert (e3.max_steps, e3.conf.stiffness, e3.conf.mu, e3.conf.use_substep_obs) == (4, 900, 0.5, True)   # fold_cloth3_env.py:23-47
+    u1, u3 = env_functions["unfold_cloth1"](batch_size=2), env_functions["unfold_cloth3"](batch_size=2)
+    for u, n in ((u1, 1), (u3, 3)):
+        assert (u.max_steps, u.conf.mu, u.conf.use_substep_obs, u.random_fold_steps) == (15, 3, False, n)   # unfold_cloth1_env.py:25-44,75
+    assert u3.conf.task == "unfold_cloth3" and u3.goal.shape == (512, 3) and e3.goal.shape == (512, 3)
+
+
+def test_unfold_cloth1_reset_folds_and_step_matches_oracle():
+    """reset = particle jitter + one random pick-and-place through step_diff (unfold_cloth1_env.py:68-79); then one
+    step_diff of the mu = 3 cloth against the CPU restatement (order v2: bit-exact positions)."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.envs.registration import env_functions
+    np.random.seed(3)
+    env = env_functions["unfold_cloth1"](batch_size=2, aux_reward=True)
+    flat = env.simulator.reset_jax()
+    obs, st = env.reset(np.array([0, 11], np.uint32))
+    assert obs.shape == (2, 1544) and int(st.cur_step[0]) == 1
+    assert float((st.x - flat.x).abs().max()) > 1e-3                    # the fold moved the cloth
+    assert float(st.mu[0]) == 3.0
+    actions = torch.tensor([[0.45, 0.0, 0.5, 0.6, 0.0, 0.55], [0.5, 0.0, 0.45, 0.4, 0.0, 0.6]], device=env.device)
+    _, reward, _, info = env.step_diff(actions, st)
+    from unidom_amd.envs.basic import _fused
+    macro = _fused.pnp_and_contact(actions, st.primitive0, st.x)[0].cpu().numpy()   # the macro actions step_diff fed the kernel
+    orc = ClothOracle(np.asarray(env.cloth_mask), order=2)
+    prim = torch.stack([st.primitive0, st.primitive1], 1).cpu().numpy()
+    ref = orc.rollout_fwd(st.x.cpu().numpy(), st.v.cpu().numpy(), prim, st.stiffness.float().cpu().numpy(),
+                          st.mu.cpu().numpy(), macro, nthreads=2)
+    np.testing.assert_array_equal(info["state"].x.cpu().numpy(), ref["x"])      # friction-heavy conf, still bit-exact
+    np.testing.assert_array_equal(info["state"].v.cpu().numpy(), ref["v"])
+    assert torch.isfinite(reward).all()

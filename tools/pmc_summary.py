@@ -1,0 +1,31 @@
+"""Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json (HBM bytes per launch of the ud:: kernels).
+
+usage: python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json]
+FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) gfx950 tallies 128-B read
+requests at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is.  Each counter comes from its own pass.
+"""
+import csv, json, sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    per = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or not r["Kernel_Name"].startswith("ud::"):
+            continue
+        per[r["Kernel_Name"].split("(")[0].replace("ud::", "")].append(float(r["Counter_Value"]))
+    return per
+
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+out = {}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
+    out[k] = {"FETCH_SIZE": {"n": len(f), "mean_kb": sum(f) / len(f), "min_kb": min(f), "max_kb": max(f)},
+              "WRITE_SIZE": {"n": len(w), "mean_kb": sum(w) / len(w), "min_kb": min(w), "max_kb": max(w)},
+              "hbm_bytes_per_launch": (2 * max(f) + max(w)) * 1024,
+              "note": "2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KB x 1024, separate --pmc passes; "
+                      "max over launches (forward launches under no_grad write no checkpoints)"}
+json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json", "w"), indent=1)
+for k, v in out.items():
+    print(k, "%.1f MB/launch" % (v["hbm_bytes_per_launch"] / 1e6), "fetch n=%d" % v["FETCH_SIZE"]["n"])

@@ -1,12 +1,19 @@
 """Name -> env class, same keys as the reference's registry for the envs on the hot path
-(/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  The other reference envs
-(fold_cloth3, fold_tshirt, shape_rope, pour_water, ...) are "next" rows and raise."""
+(/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  fold_cloth3 / unfold_cloth1 / unfold_cloth3 are
+the same 512-particle cloth and the same kernels under other confs; the remaining reference envs (fold_tshirt --
+3573 particles, needs a multi-workgroup cloth kernel --, shape_rope, pour_water, pour_soup) are "next" rows
+ and are absent from the registry."""
 from .fold_cloth1_env import FoldCloth1Env
 from .fold_cloth1_para_env import FoldCloth1ParaEnv
+from .fold_cloth3_env import FoldCloth3Env
+from .unfold_cloth1_env import UnfoldCloth1Env, UnfoldCloth3Env
 
 env_functions = {
     "fold_cloth1": FoldCloth1Env,
     "fold_cloth1_para": FoldCloth1ParaEnv,
+    "fold_cloth3": FoldCloth3Env,
+    "unfold_cloth1": UnfoldCloth1Env,
+    "unfold_cloth3": UnfoldCloth3Env,
 }
 
 try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
