@@ -73,8 +73,10 @@ __device__ __forceinline__ int table_insert(int* key, int* list, int* count, int
   return -1;
 }
 
-__device__ __forceinline__ void lds_add(float* p, float v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// LDS accumulation is in float64: on gfx950 ds_add_f32 retires one wave-instruction per ~190 cycles per CU even
+// without conflicts, ds_add_f64 one per ~9 (tools/ubench_lds_atomic.hip) -- the f32 scatter was >50 % of a substep.
+__device__ __forceinline__ void lds_add(double* p, float v) {
+  __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // quad (4-lane) all-reduce through DPP quad_perm
@@ -93,11 +95,14 @@ __device__ __forceinline__ bool cell_of(int q, int t, int& i, int& j, int& k) {
 }
 
 // LDS layout helpers
+// Cell slot s owns 32 bytes at acc[4s]: while p2g scatters they are four doubles (m, mv[3]); the grid op reads them and
+// rewrites the same bytes as floats {m, mv[3], vel[3], -} (accf = float view, 8 per slot).  In the adjoint gacc[3s..3s+2]
+// are doubles while the g2p adjoint scatters; the grid-op adjoint rewrites them as floats {g_mv[3], g_m, -, -} (6 per slot).
 struct Lds {
-  int* key; float* m; float* mv;    // [H], [H], [3H]  (fwd: mv becomes the grid velocity after the grid op)
-  float* vel; float* gacc; float* gmm;  // bwd only: [3H], [3H], [H]
+  int* key; double* acc;             // [H], [4H]
+  double* gacc;                      // bwd only: [3H]
   float* ppos; float* prot;          // [S*3], [S*4]
-  float* ppin; float* gppos; float* gpv;  // bwd only: [S*3] each
+  float* ppin; float* gppos; double* gpv;  // bwd only: [S*3] each (gpv accumulates atomically -> double)
   float* scr;                        // [64] scratch
   int* list; int* count;             // occupied slots [H], their number
 };
@@ -165,11 +170,11 @@ __device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const 
     }
     if (ss >= 0 && !(UD_MPM_ABLATE & 2)) {
       const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-      lds_add(&L.m[ss], weight * c.p_mass);
+      lds_add(&L.acc[ss * 4], weight * c.p_mass);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         float ad = q.affine[a * 3] * dp0 + q.affine[a * 3 + 1] * dp1 + q.affine[a * 3 + 2] * dp2;
-        lds_add(&L.mv[ss * 3 + a], weight * (c.p_mass * v[a] + ad));
+        lds_add(&L.acc[ss * 4 + 1 + a], weight * (c.p_mass * v[a] + ad));
       }
     }
   }
@@ -185,9 +190,10 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   const int tid = threadIdx.x, b = blockIdx.x, nt = blockDim.x;
   const int N = c.N, S = c.steps, H = c.H;
   Lds L;
-  L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H;
-  L.ppos = smem + 5 * H; L.prot = L.ppos + S * 3; L.scr = L.prot + S * 4;
+  L.key = (int*)smem; L.acc = (double*)(smem + H);
+  L.ppos = smem + 9 * H; L.prot = L.ppos + S * 3; L.scr = L.prot + S * 4;
   L.list = (int*)(L.scr + 64); L.count = L.list + H;
+  float* accf = (float*)L.acc;
   const int p = tid >> 2, qi = tid & 3;
   const bool live = p < N;
   const int pc = live ? p : 0;
@@ -201,7 +207,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   const float hard = a.hard[pc];
   for (int e = tid; e < S * 3; e += nt) L.ppos[e] = a.ppos[(size_t)b * S * 3 + e];
   for (int e = tid; e < S * 4; e += nt) L.prot[e] = a.prot[(size_t)b * S * 4 + e];
-  for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f; }
+  for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0; }
   if (tid == 0) *L.count = 0;
   float pv[3], pw[3], psize[3];
 #pragma unroll
@@ -222,7 +228,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
     // ---- A: clear the cell table, read for FK, checkpoint ----
     for (int e = tid, n = *L.count; e < n; e += nt) {   // clear the values of the slots seen so far
       const int s = L.list[e];
-      L.m[s] = 0.f; L.mv[s * 3] = 0.f; L.mv[s * 3 + 1] = 0.f; L.mv[s * 3 + 2] = 0.f;
+      L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0;
     }
     float pending = 0.f;
     fk_read(L, f, S, pv, tid, pending);
@@ -252,9 +258,10 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
         const int s = L.list[e];
         int ci, cj, ckk;
         decode_cell(c, L.key[s], ci, cj, ckk);
-        float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
-        grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
-        L.mv[s * 3] = vo[0]; L.mv[s * 3 + 1] = vo[1]; L.mv[s * 3 + 2] = vo[2];
+        const float mm = (float)L.acc[s * 4];
+        float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+        grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
+        accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];   // same thread read the doubles above
       }
     }
     __syncthreads();
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
         const int gs = slots[t] & 0xffff;
         const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
         const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
-        const float g[3] = {L.mv[gs * 3], L.mv[gs * 3 + 1], L.mv[gs * 3 + 2]};
+        const float g[3] = {accf[gs * 8 + 4], accf[gs * 8 + 5], accf[gs * 8 + 6]};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           nv[r] += weight * g[r];
@@ -353,10 +360,13 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   const int N = c.N, S = c.steps, H = c.H;
   const int nw = nt >> 6;
   Lds L;
-  L.key = (int*)smem; L.m = smem + H; L.mv = smem + 2 * H; L.vel = smem + 5 * H; L.gacc = smem + 8 * H; L.gmm = smem + 11 * H;
-  L.ppos = smem + 12 * H; L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3; L.gpv = L.gppos + S * 3;
-  L.scr = L.gpv + S * 3;
+  L.key = (int*)smem; L.acc = (double*)(smem + H); L.gacc = (double*)(smem + 9 * H);
+  L.gpv = (double*)(smem + 15 * H);
+  L.ppos = smem + 15 * H + 6 * S; L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3;
+  L.scr = L.gppos + S * 3;
   L.list = (int*)(L.scr + 64); L.count = L.list + H;
+  float* accf = (float*)L.acc;
+  float* gaccf = (float*)L.gacc;
   const int p = tid >> 2, qi = tid & 3;
   const bool live = p < N;
   const int pc = live ? p : 0;
@@ -366,11 +376,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   const float* ck = a.ckpt + (size_t)b * ck_env;
   {
     const float* tail = ck + (size_t)S * 24 * c.Np;
-    for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.f; }
+    for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.0; }
     for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
     for (int s = tid; s < H; s += nt) {
-      L.key[s] = -1; L.m[s] = 0.f;
-      for (int d = 0; d < 3; ++d) { L.mv[s * 3 + d] = 0.f; L.gacc[s * 3 + d] = 0.f; }
+      L.key[s] = -1; L.acc[s * 4] = 0.0;
+      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
     }
     if (tid == 0) *L.count = 0;
     // copy_frame adjoint: position[0] <- position[steps-1]
@@ -415,11 +425,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
     for (int e = tid, n = *L.count; e < n; e += nt) {
       const int s = L.list[e];
-      L.m[s] = 0.f;
+      L.acc[s * 4] = 0.0;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { L.mv[s * 3 + d] = 0.f; L.gacc[s * 3 + d] = 0.f; }
+      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
     }
-    if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += pend_pv; }
+    if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += (double)pend_pv; }
     __syncthreads();
     // ---- B: particle pre-pass, p2g ----
     Pre q;
@@ -434,9 +444,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       const int s = L.list[e];
       int ci, cj, ckk;
       decode_cell(c, L.key[s], ci, cj, ckk);
-      float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]}, vo[3];
-      grid_op<false>(c, pf, ci, cj, ckk, L.m[s], mvv, vo, nullptr);
-      L.vel[s * 3] = vo[0]; L.vel[s * 3 + 1] = vo[1]; L.vel[s * 3 + 2] = vo[2];
+      const float mm = (float)L.acc[s * 4];
+      float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+      grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
+      accf[s * 8] = mm; accf[s * 8 + 1] = mvv[0]; accf[s * 8 + 2] = mvv[1]; accf[s * 8 + 3] = mvv[2];   // raw values for the adjoint
+      accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];
     }
     __syncthreads();
     // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
@@ -458,7 +470,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-          const float vel = L.vel[gs * 3 + r];
+          const float vel = accf[gs * 8 + 4 + r];
           lds_add(&L.gacc[gs * 3 + r], weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
           gwt += vel * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
@@ -479,17 +491,16 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       const int s = L.list[e];
       int ci, cj, ckk;
       decode_cell(c, L.key[s], ci, cj, ckk);
-      const float m = L.m[s];
-      float mvv[3] = {L.mv[s * 3], L.mv[s * 3 + 1], L.mv[s * 3 + 2]};
-      float g[3] = {L.gacc[s * 3], L.gacc[s * 3 + 1], L.gacc[s * 3 + 2]}, gmm, dfric, dpv[3];
+      const float m = accf[s * 8];
+      float mvv[3] = {accf[s * 8 + 1], accf[s * 8 + 2], accf[s * 8 + 3]};
+      float g[3] = {(float)L.gacc[s * 3], (float)L.gacc[s * 3 + 1], (float)L.gacc[s * 3 + 2]}, gmm, dfric, dpv[3];
       const bool ctrl = grid_op_adjoint(c, pf, ci, cj, ckk, m, mvv, g, gmm, dfric, dpv);
       acc_fric += dfric;
       if (ctrl) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) lds_add(&L.gpv[f * 3 + d], dpv[d]);
       }
-      L.gacc[s * 3] = g[0]; L.gacc[s * 3 + 1] = g[1]; L.gacc[s * 3 + 2] = g[2];
-      L.gmm[s] = gmm;
+      gaccf[s * 6] = g[0]; gaccf[s * 6 + 1] = g[1]; gaccf[s * 6 + 2] = g[2]; gaccf[s * 6 + 3] = gmm;   // same thread read the doubles
     }
     __syncthreads();
     // ---- F: p2g adjoint (gather) + particle pre-pass adjoint + FK adjoint ----
@@ -506,10 +517,10 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
         const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
         const float weight = wi * wj * wk;
         const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
-        float gwt = c.p_mass * L.gmm[ss];
+        float gwt = c.p_mass * gaccf[ss * 6 + 3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          const float gc = L.gacc[ss * 3 + r];
+          const float gc = gaccf[ss * 6 + r];
           const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
           gwt += gc * (c.p_mass * v[r] + ad);
           gvp[r] += weight * c.p_mass * gc;
@@ -557,7 +568,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     }
     __syncthreads();
   }
-  if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += pend_pv; }
+  if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += (double)pend_pv; }
   __syncthreads();
   // ---- step boundary: set_action adjoint, action clip, norm_grad(_state) (:375-411, :419-423) ----
   float* red = L.scr;
@@ -567,7 +578,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[3] = {0.f, 0.f, 0.f};
   for (int j = 0; j < S; ++j)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { const float t = L.gpv[j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
+    for (int d = 0; d < 3; ++d) { const float t = (float)L.gpv[j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
   // rotation path (action[3:6]): the reference's d|w|/dw at w = 0 is NaN and nan_to_num zeroes it here -> 0
 #pragma unroll
   for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
@@ -669,8 +680,8 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * std::min(N, 128) + 63) / 64 * 64);
   const bool large = N > 128;
-  h->lds_fwd = ((size_t)6 * Hh + (size_t)S * 7 + 64 + 4) * sizeof(float);    // key, m, mv[3], list + primitives + scratch + count
-  h->lds_bwd = ((size_t)13 * Hh + (size_t)S * 16 + 64 + 4) * sizeof(float);
+  h->lds_fwd = ((size_t)10 * Hh + (size_t)S * 7 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list + primitives + scratch + count
+  h->lds_bwd = ((size_t)16 * Hh + (size_t)S * 19 + 64 + 4) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), adjoint primitive arrays
   if (!large && h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_material, N * sizeof(int));
