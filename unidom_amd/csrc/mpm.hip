@@ -184,27 +184,91 @@ __device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// Two lane mappings share the workgroup:
+//   compact  lane = particle (tid < N, the first ceil(N/64) waves): owns the particle state x, v, C, F, J and runs the
+//            particle pre-pass (F update, Jacobi SVD, stress) ONCE per particle; the other waves skip it (wave-uniform
+//            branch), so its ~800 instructions are no longer issued four times per particle on every SIMD;
+//   quad     lane = 4*particle + q: the 27-cell stencil work (p2g scatter, g2p gather), 7/7/7/6 cells per lane.
+// The pre-pass hands (base, fx, w, affine, v) to the quads through LDS (7 float4 per particle, SoA) under the barrier that
+// already separates the table clear from p2g; g2p returns (v_new, C_new) the same way under the end-of-substep barrier.
+constexpr int UD_STG = 7, UD_RET = 3;   // float4 per particle: pre-pass -> quads, quads -> state
+
+// forward kinematics of the whole step, once per launch (the per-substep form of :185-194 is a recurrence on rows that
+// nothing else reads): P[0] = clip(in[0]); P[f+1] = clip(P'[f] + v) with P'[0] = in[0] (read before the first clip) and
+// P'[f] = P[f] after that; rotation[f+1] = normalise(qmul(w2quat(w), rotation[f])); iq[f] = inverse rotation for the SDF.
+__device__ __forceinline__ void fk_prologue(const Lds& L, float* iq, int S, const float* pv, const float* pw, int tid) {
+  if (tid < 3) {
+    const float pva = (tid == 0) ? pv[0] : ((tid == 1) ? pv[1] : pv[2]);
+    float prev = L.ppos[tid];
+    L.ppos[tid] = clipf(prev, -2.f, 2.f);
+    for (int f = 0; f + 1 < S; ++f) {
+      const float nxt = clipf(prev + pva, -2.f, 2.f);
+      L.ppos[(f + 1) * 3 + tid] = nxt;
+      prev = nxt;
+    }
+  }
+  if (tid == 64 || (blockDim.x <= 64 && tid == 3)) {   // another wave when there is one
+    const float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;   // w2quat :84-92
+    const float sn = sinf(ang / 2.f);
+    const float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
+    float r[4] = {L.prot[0], L.prot[1], L.prot[2], L.prot[3]};
+    for (int f = 0; f + 1 < S; ++f) {                   // qmul :73-81, normalize :66-70
+      const float o0 = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+      const float o1 = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+      const float o2 = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+      const float o3 = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+      const float nn = clipf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3), 1e-12f, INFINITY);
+      r[0] = o0 / nn; r[1] = o1 / nn; r[2] = o2 / nn; r[3] = o3 / nn;
+      float* w = L.prot + (f + 1) * 4;
+      w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; w[3] = r[3];
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f < S; f += blockDim.x) {           // inv_trans :105-109
+    const float r0 = L.prot[f * 4], r1 = -L.prot[f * 4 + 1], r2 = -L.prot[f * 4 + 2], r3 = -L.prot[f * 4 + 3];
+    const float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;
+    iq[f * 4] = r0 / n; iq[f * 4 + 1] = r1 / n; iq[f * 4 + 2] = r2 / n; iq[f * 4 + 3] = r3 / n;
+  }
+}
+
+__device__ __forceinline__ void prim_from_lds(const Lds& L, const float* iq, int f, const float* psize, const float* pv,
+                                              float friction, PrimF& pf) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { pf.pos[a] = L.ppos[f * 3 + a]; pf.size[a] = psize[a]; pf.pv[a] = pv[a]; }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) pf.iq[a] = iq[f * 4 + a];
+  pf.friction = friction;
+}
+
 __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   extern __shared__ float smem[];
   const MpmConst c = a.c;
   const int tid = threadIdx.x, b = blockIdx.x, nt = blockDim.x;
-  const int N = c.N, S = c.steps, H = c.H;
+  const int N = c.N, S = c.steps, H = c.H, Np = c.Np;
   Lds L;
   L.key = (int*)smem; L.acc = (double*)(smem + H);
-  L.ppos = smem + 9 * H; L.prot = L.ppos + S * 3; L.scr = L.prot + S * 4;
+  float4* stage = (float4*)(smem + 9 * H);              // [UD_STG][Np]
+  float4* ret = stage + UD_STG * Np;                    // [UD_RET][Np]
+  L.ppos = (float*)(ret + UD_RET * Np); L.prot = L.ppos + S * 3;
+  float* iq = L.prot + S * 4;
+  L.scr = iq + S * 4;
   L.list = (int*)(L.scr + 64); L.count = L.list + H;
   float* accf = (float*)L.acc;
+  // quad mapping
   const int p = tid >> 2, qi = tid & 3;
   const bool live = p < N;
-  const int pc = live ? p : 0;
-  float x[3], v[3], Cm[9], F[9], Jp;
+  // compact mapping
+  const bool clive = tid < N;
+  const bool cwave = (tid & ~63) < N;                   // wave-uniform: this wave holds compact lanes
+  const int cp = clive ? tid : 0;
+  float x[3], v[3], Cm[9], F[9], Fn[9], Jp;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) { x[d] = nan_to_num(a.x[((size_t)b * N + pc) * 3 + d]); v[d] = nan_to_num(a.v[((size_t)b * N + pc) * 3 + d]); }
+  for (int d = 0; d < 3; ++d) { x[d] = nan_to_num(a.x[((size_t)b * N + cp) * 3 + d]); v[d] = nan_to_num(a.v[((size_t)b * N + cp) * 3 + d]); }
 #pragma unroll
-  for (int d = 0; d < 9; ++d) { Cm[d] = nan_to_num(a.C[((size_t)b * N + pc) * 9 + d]); F[d] = nan_to_num(a.F[((size_t)b * N + pc) * 9 + d]); }
-  Jp = nan_to_num(a.J[(size_t)b * N + pc]);                      // norm_grad_state fwd (:377-381)
-  const int material = a.material[pc];
-  const float hard = a.hard[pc];
+  for (int d = 0; d < 9; ++d) { Cm[d] = nan_to_num(a.C[((size_t)b * N + cp) * 9 + d]); F[d] = nan_to_num(a.F[((size_t)b * N + cp) * 9 + d]); Fn[d] = F[d]; }
+  Jp = nan_to_num(a.J[(size_t)b * N + cp]);                      // norm_grad_state fwd (:377-381)
+  const int material = a.material[cp];
+  const float hard = a.hard[cp];
   for (int e = tid; e < S * 3; e += nt) L.ppos[e] = a.ppos[(size_t)b * S * 3 + e];
   for (int e = tid; e < S * 4; e += nt) L.prot[e] = a.prot[(size_t)b * S * 4 + e];
   for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0; }
@@ -224,36 +288,67 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   const size_t ck_env = ((size_t)S * 24 * c.Np + (size_t)S * 10);
   float* ck = a.ckpt ? a.ckpt + (size_t)b * ck_env : nullptr;
   __syncthreads();
+  fk_prologue(L, iq, S, pv, pw, tid);
+  __syncthreads();
   for (int f = 0; f < S; ++f) {
-    // ---- A: clear the cell table, read for FK, checkpoint ----
+    // ---- A: clear the cell table; compact lanes: land the previous g2p, checkpoint, particle pre-pass -> stage ----
     for (int e = tid, n = *L.count; e < n; e += nt) {   // clear the values of the slots seen so far
       const int s = L.list[e];
       L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0;
     }
-    float pending = 0.f;
-    fk_read(L, f, S, pv, tid, pending);
-    if (ck && live && qi == 0) {
-      float* r = ck + (size_t)f * 24 * c.Np + p;
+    if (cwave) {
+      if (f > 0) {
+        const float4 r0 = ret[cp], r1 = ret[Np + cp], r2 = ret[2 * Np + cp];
+        const float nv[3] = {r0.x, r0.y, r0.z};
+        const float nC[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { r[d * c.Np] = x[d]; r[(3 + d) * c.Np] = v[d]; }
+        for (int d = 0; d < 3; ++d) { v[d] = nv[d]; x[d] = x[d] + c.dt * nv[d]; }
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { r[(6 + d) * c.Np] = Cm[d]; r[(15 + d) * c.Np] = F[d]; }
-    }
-    if (f > 0) {  // J of the previous substep (:327, Q6): one scalar shared by all particles
-      float trq = L.scr[0] + L.scr[1] + L.scr[2];
-      Jp = Jp * (1.f + c.dt * trq);
+        for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = Fn[d]; }
+        const float trq = L.scr[0] + L.scr[1] + L.scr[2];   // J of the previous substep (:327, Q6): one scalar for all particles
+        Jp = Jp * (1.f + c.dt * trq);
+      }
+      if (ck && clive) {
+        float* r = ck + (size_t)f * 24 * c.Np + cp;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { r[d * c.Np] = x[d]; r[(3 + d) * c.Np] = v[d]; }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { r[(6 + d) * c.Np] = Cm[d]; r[(15 + d) * c.Np] = F[d]; }
+      }
+      Pre q;
+      particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) Fn[d] = q.Fn[d];
+      if (clive) {
+        stage[cp] = make_float4(__int_as_float(q.base[0]), __int_as_float(q.base[1]), __int_as_float(q.base[2]), q.fx[0]);
+        stage[Np + cp] = make_float4(q.fx[1], q.fx[2], q.w[0], q.w[1]);
+        stage[2 * Np + cp] = make_float4(q.w[2], q.w[3], q.w[4], q.w[5]);
+        stage[3 * Np + cp] = make_float4(q.w[6], q.w[7], q.w[8], q.affine[0]);
+        stage[4 * Np + cp] = make_float4(q.affine[1], q.affine[2], q.affine[3], q.affine[4]);
+        stage[5 * Np + cp] = make_float4(q.affine[5], q.affine[6], q.affine[7], q.affine[8]);
+        stage[6 * Np + cp] = make_float4(v[0], v[1], v[2], 0.f);
+      }
     }
     __syncthreads();
-    // ---- B: FK write, particle pre-pass, p2g ----
-    fk_write(L, f, S, pw, tid, pending);
+    // ---- B: quads read their particle's pre-pass, p2g ----
     Pre q;
-    particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
-    if (live) ok = p2g_lane(c, L, q, v, qi, slots, pcell) && ok;
+    float vq[3] = {0.f, 0.f, 0.f};
+    if (live) {
+      const float4 s0 = stage[p], s1 = stage[Np + p], s2 = stage[2 * Np + p], s3 = stage[3 * Np + p], s4 = stage[4 * Np + p],
+                   s5 = stage[5 * Np + p], s6 = stage[6 * Np + p];
+      q.base[0] = __float_as_int(s0.x); q.base[1] = __float_as_int(s0.y); q.base[2] = __float_as_int(s0.z);
+      q.fx[0] = s0.w; q.fx[1] = s1.x; q.fx[2] = s1.y;
+      q.w[0] = s1.z; q.w[1] = s1.w; q.w[2] = s2.x; q.w[3] = s2.y; q.w[4] = s2.z; q.w[5] = s2.w; q.w[6] = s3.x; q.w[7] = s3.y; q.w[8] = s3.z;
+      q.affine[0] = s3.w; q.affine[1] = s4.x; q.affine[2] = s4.y; q.affine[3] = s4.z; q.affine[4] = s4.w;
+      q.affine[5] = s5.x; q.affine[6] = s5.y; q.affine[7] = s5.z; q.affine[8] = s5.w;
+      vq[0] = s6.x; vq[1] = s6.y; vq[2] = s6.z;
+      ok = p2g_lane(c, L, q, vq, qi, slots, pcell) && ok;
+    }
     __syncthreads();
     // ---- C: grid op on the occupied slots ----
     if (!(UD_MPM_ABLATE & 4)) {
       PrimF pf;
-      prim_at(L, f, S, psize, pv, friction, pf);
+      prim_from_lds(L, iq, f, psize, pv, friction, pf);
       for (int e = tid, n = *L.count; e < n; e += nt) {
         const int s = L.list[e];
         int ci, cj, ckk;
@@ -265,7 +360,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
       }
     }
     __syncthreads();
-    // ---- D: g2p (:196-221), advect ----
+    // ---- D: g2p (:196-221): quads gather, lane 0 of the quad returns (v_new, C_new) to the particle's compact lane ----
     float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live && !(UD_MPM_ABLATE & 8)) {
 #pragma unroll
@@ -288,27 +383,35 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
     for (int d = 0; d < 3; ++d) nv[d] = quad_sum(nv[d]);
 #pragma unroll
     for (int d = 0; d < 9; ++d) nC[d] = quad_sum(nC[d]);
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { v[d] = nv[d]; x[d] = x[d] + c.dt * nv[d]; }
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = q.Fn[d]; }
-    if (live && qi == 0 && p < 3) {   // row p of particle p (Q6)
-      const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
-      L.scr[p] = (p == 0) ? r0 : ((p == 1) ? r1 : r2);
+    if (live && qi == 0) {
+      ret[p] = make_float4(nv[0], nv[1], nv[2], nC[0]);
+      ret[Np + p] = make_float4(nC[1], nC[2], nC[3], nC[4]);
+      ret[2 * Np + p] = make_float4(nC[5], nC[6], nC[7], nC[8]);
+      if (p < 3) {   // row p of particle p (Q6)
+        const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
+        L.scr[p] = (p == 0) ? r0 : ((p == 1) ? r1 : r2);
+      }
     }
     if (tid == 0 && N < 3) { for (int e = N; e < 3; ++e) L.scr[e] = 0.f; }
     __syncthreads();
   }
-  {
-    float trq = L.scr[0] + L.scr[1] + L.scr[2];
+  if (cwave) {   // land the last g2p
+    const float4 r0 = ret[cp], r1 = ret[Np + cp], r2 = ret[2 * Np + cp];
+    const float nv[3] = {r0.x, r0.y, r0.z};
+    const float nC[9] = {r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { v[d] = nv[d]; x[d] = x[d] + c.dt * nv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = Fn[d]; }
+    const float trq = L.scr[0] + L.scr[1] + L.scr[2];
     Jp = Jp * (1.f + c.dt * trq);
   }
-  if (live && qi == 0) {
+  if (clive) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { a.xo[((size_t)b * N + p) * 3 + d] = x[d]; a.vo[((size_t)b * N + p) * 3 + d] = v[d]; }
+    for (int d = 0; d < 3; ++d) { a.xo[((size_t)b * N + cp) * 3 + d] = x[d]; a.vo[((size_t)b * N + cp) * 3 + d] = v[d]; }
 #pragma unroll
-    for (int d = 0; d < 9; ++d) { a.Co[((size_t)b * N + p) * 9 + d] = Cm[d]; a.Fo[((size_t)b * N + p) * 9 + d] = F[d]; }
-    a.Jo[(size_t)b * N + p] = Jp;
+    for (int d = 0; d < 9; ++d) { a.Co[((size_t)b * N + cp) * 9 + d] = Cm[d]; a.Fo[((size_t)b * N + cp) * 9 + d] = F[d]; }
+    a.Jo[(size_t)b * N + cp] = Jp;
   }
   // checkpoint tail: primitive arrays before copy_frame (position | rotation)
   if (ck) {
@@ -680,7 +783,7 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * std::min(N, 128) + 63) / 64 * 64);
   const bool large = N > 128;
-  h->lds_fwd = ((size_t)10 * Hh + (size_t)S * 7 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list + primitives + scratch + count
+  h->lds_fwd = ((size_t)10 * Hh + (size_t)4 * 10 * h->c.Np + (size_t)S * 11 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list, stage/ret (10 float4 per particle), primitives + inverse rotations, scratch, count
   h->lds_bwd = ((size_t)16 * Hh + (size_t)S * 19 + 64 + 4) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), adjoint primitive arrays
   if (!large && h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
   hipError_t e = hipGetDevice(&h->device);
