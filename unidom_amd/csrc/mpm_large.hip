@@ -92,7 +92,13 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
 // contention plain global atomics suffer on a compact body (measured: 17 us -> see DESIGN.md per env-substep).
 #define LG_H 2048
 #define LG_LOGH 11
-struct BlockTable { int* key; float* val; };   // key[LG_H], val[LG_H*4]
+// staged values are float64: ds_add_f32 retires ~20x slower than ds_add_f64 on gfx950 (tools/ubench_lds_atomic.hip)
+struct BlockTable { int* key; double* val; };   // key[LG_H], val[LG_H*4]
+constexpr size_t LG_TABLE_BYTES = (size_t)LG_H * (sizeof(int) + 4 * sizeof(double));   // dynamic LDS of the staging kernels
+__device__ __forceinline__ BlockTable bt_make() {
+  extern __shared__ double lg_smem[];
+  return BlockTable{(int*)(lg_smem + LG_H * 4), lg_smem};
+}
 
 __device__ __forceinline__ unsigned lg_hash(int cell) {
   unsigned h = (unsigned)cell;
@@ -103,7 +109,7 @@ __device__ __forceinline__ unsigned lg_hash(int cell) {
 __device__ __forceinline__ void bt_clear(const BlockTable& t) {
   for (int s = threadIdx.x; s < LG_H; s += blockDim.x) {
     t.key[s] = -1;
-    t.val[s * 4] = 0.f; t.val[s * 4 + 1] = 0.f; t.val[s * 4 + 2] = 0.f; t.val[s * 4 + 3] = 0.f;
+    t.val[s * 4] = 0.0; t.val[s * 4 + 1] = 0.0; t.val[s * 4 + 2] = 0.0; t.val[s * 4 + 3] = 0.0;
   }
 }
 
@@ -124,7 +130,7 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
 
 __device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, int cell, int comp, float v) {
   const int s = bt_slot(t, cell);
-  if (s >= 0) __hip_atomic_fetch_add(&t.val[s * 4 + comp], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (s >= 0) __hip_atomic_fetch_add(&t.val[s * 4 + comp], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else atomicAdd(global_cell + comp, v);
 }
 
@@ -179,9 +185,7 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 
 // particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
 __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
-  __shared__ int s_key[LG_H];
-  __shared__ float s_val[LG_H * 4];
-  const BlockTable bt{s_key, s_val};
+  const BlockTable bt = bt_make();
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
   bt_clear(bt);
@@ -206,7 +210,6 @@ __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
       if (sc >= 0) {
         const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
         const int sl = bt_slot(bt, sc);
-        float* cell = (sl >= 0) ? &bt.val[sl * 4] : (float*)(val + cell_lin(c, sc));
         float contrib[4];
         contrib[0] = weight * c.p_mass;
 #pragma unroll
@@ -216,8 +219,9 @@ __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
         }
         if (sl >= 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(cell + r, contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&bt.val[sl * 4 + r], (double)contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {   // block table full: straight to HBM
+          float* cell = (float*)(val + cell_lin(c, sc));
 #pragma unroll
           for (int r = 0; r < 4; ++r) atomicAdd(cell + r, contrib[r]);
           touch(a, b, sc, cell_lin(c, sc));
@@ -233,7 +237,7 @@ __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
     const long lin = cell_lin(c, key);
     float* cell = (float*)(val + lin);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, bt.val[sl * 4 + r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[sl * 4 + r]);
     touch(a, b, key, lin);
   }
 }
@@ -401,9 +405,7 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
 __global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
-  __shared__ int s_key[LG_H];
-  __shared__ float s_val[LG_H * 4];
-  const BlockTable bt{s_key, s_val};
+  const BlockTable bt = bt_make();
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
   bt_clear(bt);
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
     if (key < 0) continue;
     float* cell = (float*)(gacc + cell_lin(c, key));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, bt.val[sl * 4 + r]);
+    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, (float)bt.val[sl * 4 + r]);
   }
 }
 
@@ -671,6 +673,9 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   L->c = c; L->d_material = d_material; L->d_hard = d_hard;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
+  // the staging kernels use 72 KB of dynamic LDS (above the 64 KB default)
+  (void)hipFuncSetAttribute((const void*)lg_p2g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
+  (void)hipFuncSetAttribute((const void*)lg_g2p_adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
   return L;
 }
 
@@ -745,7 +750,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 1, 0);
-    hipLaunchKernelGGL(lg_p2g, gp, blk, 0, st, a, 1);
+    hipLaunchKernelGGL(lg_p2g, gp, blk, LG_TABLE_BYTES, st, a, 1);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 0);
     hipLaunchKernelGGL(lg_g2p, gp, blk, 0, st, a);
   }
@@ -782,9 +787,9 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     a.f = f; a.epoch = L->epoch++;
     a.hist_in = ckpt + (long)f * rec;
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-    hipLaunchKernelGGL(lg_p2g, gp, blk, 0, st, a, 0);
+    hipLaunchKernelGGL(lg_p2g, gp, blk, LG_TABLE_BYTES, st, a, 0);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 1);
-    hipLaunchKernelGGL(lg_g2p_adj, gp, blk, 0, st, a);
+    hipLaunchKernelGGL(lg_g2p_adj, gp, blk, LG_TABLE_BYTES, st, a);
     hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
     hipLaunchKernelGGL(lg_p2g_adj, gp, blk, 0, st, a);
     hipLaunchKernelGGL(lg_fk_adj, dim3(B), blk, 0, st, a);
