@@ -456,6 +456,8 @@ __device__ __forceinline__ float ppos_preclip(const Lds& L, int f, int S, int j,
   return (f == 0) ? L.ppin[j * 3 + a] : clipf(L.ppin[j * 3 + a], -2.f, 2.f);
 }
 
+constexpr int UD_PARK = 16;   // float4 per particle parked across the stencil phases of the adjoint
+
 __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   extern __shared__ float smem[];
   const MpmConst c = a.c;
@@ -465,7 +467,10 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   Lds L;
   L.key = (int*)smem; L.acc = (double*)(smem + H); L.gacc = (double*)(smem + 9 * H);
   L.gpv = (double*)(smem + 15 * H);
-  L.ppos = smem + 15 * H + 6 * S; L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3;
+  // `park`: what only the particle adjoint at the end of the iteration needs from the pre-pass (Fn, U, Vh, sigma, A, C, F:
+  // 63 floats per particle) waits in LDS while the stencil phases run, instead of holding ~60 VGPRs live in every lane
+  float4* park = (float4*)(smem + 15 * H + 6 * S + (S & 1) * 2);
+  L.ppos = (float*)(park + UD_PARK * c.Np); L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3;
   L.scr = L.gppos + S * 3;
   L.list = (int*)(L.scr + 64); L.count = L.list + H;
   float* accf = (float*)L.acc;
@@ -538,6 +543,17 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     Pre q;
     PreB kb;
     particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
+    if (live && qi == 0) {
+      float pk[UD_PARK * 4];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { pk[d] = kb.sig_raw[d]; pk[3 + d] = kb.sig[d]; }
+      pk[6] = kb.Jd; pk[7] = kb.mu; pk[8] = kb.la;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { pk[9 + d] = q.Fn[d]; pk[18 + d] = kb.U[d]; pk[27 + d] = kb.Vh[d]; pk[36 + d] = kb.A[d]; pk[45 + d] = Cm[d]; pk[54 + d] = F[d]; }
+      pk[63] = 0.f;
+#pragma unroll
+      for (int k = 0; k < UD_PARK; ++k) park[k * c.Np + p] = make_float4(pk[k * 4], pk[k * 4 + 1], pk[k * 4 + 2], pk[k * 4 + 3]);
+    }
     if (live) ok = p2g_lane(c, L, q, v, qi, slots, pcell) && ok;
     __syncthreads();
     // ---- C: grid op forward -> vel ----
@@ -646,8 +662,17 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) { gfx[d] = quad_sum(gfx[d]); gvp[d] = quad_sum(gvp[d]); }
     {
+      Pre qa; PreB ka;
+      float Ca[9], Fa[9], pk[UD_PARK * 4];
+#pragma unroll
+      for (int k = 0; k < UD_PARK; ++k) { const float4 t = park[k * c.Np + pc]; pk[k * 4] = t.x; pk[k * 4 + 1] = t.y; pk[k * 4 + 2] = t.z; pk[k * 4 + 3] = t.w; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { qa.fx[d] = q.fx[d]; ka.sig_raw[d] = pk[d]; ka.sig[d] = pk[3 + d]; }
+      ka.Jd = pk[6]; ka.mu = pk[7]; ka.la = pk[8];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { qa.Fn[d] = pk[9 + d]; ka.U[d] = pk[18 + d]; ka.Vh[d] = pk[27 + d]; ka.A[d] = pk[36 + d]; Ca[d] = pk[45 + d]; Fa[d] = pk[54 + d]; }
       float gmu_p, gla_p;
-      particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+      particle_adjoint(c, qa, ka, Ca, Fa, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
       const float h = clipf(hard, 0.1f, 5.f);
       if (live && qi == 0 && material != 0) { acc_mu += gmu_p * h; acc_la += gla_p * h; }
     }
@@ -780,11 +805,12 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
+  while (Hh > 1024 && ((size_t)16 * Hh + (size_t)64 * c.Np + (size_t)S * 19 + 72) * sizeof(float) > 160 * 1024) { Hh /= 2; --lg; }   // LDS budget of the adjoint
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * std::min(N, 128) + 63) / 64 * 64);
   const bool large = N > 128;
   h->lds_fwd = ((size_t)10 * Hh + (size_t)4 * 10 * h->c.Np + (size_t)S * 11 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list, stage/ret (10 float4 per particle), primitives + inverse rotations, scratch, count
-  h->lds_bwd = ((size_t)16 * Hh + (size_t)S * 19 + 64 + 4) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), adjoint primitive arrays
+  h->lds_bwd = ((size_t)16 * Hh + (size_t)4 * 16 * h->c.Np + (size_t)S * 19 + 64 + 8) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), park (16 float4 per particle), adjoint primitive arrays
   if (!large && h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_material, N * sizeof(int));
