@@ -67,6 +67,7 @@ class MPMEnv:
         self.spec = None
         self.state = None
         self.init_state = None
+        self._target_center = None
         self.step_diff = self.build_step_diff()
         if not os.path.exists(conf.goal_path):
             print("**************** Warning: goal file does not exist!")
@@ -104,8 +105,9 @@ class MPMEnv:
     def build_step_diff(self):
         def pre_step(actions, state: MPMState):   # :99-114
             state_center = state.x.mean(1)
-            target_center = torch.tensor(self.conf.res, dtype=torch.float32, device=self.device) * 0.5 / self.conf.n_grid
-            shift = target_center - state_center
+            if self._target_center is None:   # constant of the conf: built once, not an H2D copy per step
+                self._target_center = torch.tensor(self.conf.res, dtype=torch.float32, device=self.device) * 0.5 / self.conf.n_grid
+            shift = self._target_center - state_center
             shift = torch.cat([shift[:, 0:1], torch.zeros_like(shift[:, 0:1]), shift[:, 2:3]], -1)
             actions = self.process_pre_step_actions(actions, shift)
             shift = shift[:, None, :]
@@ -133,8 +135,10 @@ class MPMEnv:
             return type(first)(**fields)
 
         def step_diff(actions, state: MPMState):   # :130-167
-            pickup_place = actions[..., :3]
-            contact_distance = torch.sqrt(((pickup_place[:, None, :] - state.x) ** 2).sum(-1)).min(-1).values
+            contact_distance = None
+            if self.aux_reward:   # :131-132 (only the auxiliary reward reads it)
+                pickup_place = actions[..., :3]
+                contact_distance = torch.sqrt(((pickup_place[:, None, :] - state.x) ** 2).sum(-1)).min(-1).values
             shift = None
             if self.focus_computation:
                 actions, state, shift = pre_step(actions, state)

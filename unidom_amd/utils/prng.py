@@ -63,12 +63,13 @@ def split_first(key: np.ndarray, times: int = 1) -> np.ndarray:
 
 
 def random_bits(key: np.ndarray, n: int) -> np.ndarray:
-    """threefry_random_bits for 32-bit words: hash iota(n) (padded to even), halves as x0/x1 lanes."""
+    """threefry_random_bits for 32-bit words: hash iota(n) (padded to even), halves as x0/x1 lanes.
+    key [..., 2] -> [..., n] (leading dims = vmap over keys, evaluated in one vectorised pass)."""
     key = np.asarray(key, dtype=np.uint32)
     m = n + (n % 2)
     cnt = np.arange(m, dtype=np.uint32)
-    y0, y1 = threefry2x32(key, cnt[: m // 2], cnt[m // 2:])
-    return np.concatenate([y0, y1])[:n]
+    y0, y1 = threefry2x32(key[..., None, :], cnt[: m // 2], cnt[m // 2:])
+    return np.concatenate([y0, y1], axis=-1)[..., :n]
 
 
 def uniform(key: np.ndarray, n: int, minval=0.0, maxval=1.0) -> np.ndarray:
@@ -90,4 +91,4 @@ def normal(key: np.ndarray, n: int) -> np.ndarray:
 
 def normal_batch(keys: np.ndarray, n: int) -> np.ndarray:
     """vmap(lambda k: normal(k, (n,)))(keys): keys [B,2] -> [B,n]."""
-    return np.stack([normal(k, n) for k in np.asarray(keys, dtype=np.uint32)])
+    return normal(np.asarray(keys, dtype=np.uint32), n)
