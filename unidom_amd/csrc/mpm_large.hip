@@ -92,6 +92,7 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
 // contention plain global atomics suffer on a compact body (measured: 17 us -> see DESIGN.md per env-substep).
 #define LG_H 2048
 #define LG_LOGH 11
+#define LG_SCATTER_T 128   // particles per workgroup in the two scatter kernels: ~500 distinct cells per block, 36 KB of LDS
 // staged values are float64: ds_add_f32 retires ~20x slower than ds_add_f64 on gfx950 (tools/ubench_lds_atomic.hip)
 struct BlockTable { int* key; double* val; };   // key[LG_H], val[LG_H*4]
 constexpr size_t LG_TABLE_BYTES = (size_t)LG_H * (sizeof(int) + 4 * sizeof(double));   // dynamic LDS of the staging kernels
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 }
 
 // particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
-__global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
+__global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) {
   const BlockTable bt = bt_make();
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
@@ -230,15 +231,37 @@ __global__ void __launch_bounds__(256) lg_p2g(LargeArgs a, int store_F) {
       if (gc != sc) touch(a, b, gc, cell_lin(c, gc));   // Q5: a clamped gather cell takes part with m = 0
     }
   }
+  // flush: one global atomic per distinct cell and component.  Cells this substep sees for the first time (epoch stamp)
+  // join the env's active list; the appends of a block are aggregated -- one atomicAdd on the env's counter per block
+  // instead of one per cell (20 k same-address atomics per env-substep at n_grid 256 were 80 % of the whole step).
+  __shared__ int s_new, s_base;
+  if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
-  for (int sl = threadIdx.x; sl < LG_H; sl += blockDim.x) {   // flush: one global atomic per distinct cell and component
+  constexpr int PER = LG_H / LG_SCATTER_T;
+  unsigned newmask = 0;
+  int nnew = 0;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int sl = threadIdx.x + u * LG_SCATTER_T;
     const int key = bt.key[sl];
     if (key < 0) continue;
     const long lin = cell_lin(c, key);
     float* cell = (float*)(val + lin);
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[sl * 4 + r]);
-    touch(a, b, key, lin);
+    if (atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
+  }
+  const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
+  __syncthreads();
+  const int cur = a.f & 1;
+  if (threadIdx.x == 0) s_base = s_new ? atomicAdd(&a.w.count[cur * a.B + b], s_new) : 0;
+  __syncthreads();
+  int e = s_base + mine;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    if (!(newmask & (1u << u))) continue;
+    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = bt.key[threadIdx.x + u * LG_SCATTER_T];
+    ++e;
   }
 }
 
@@ -404,7 +427,7 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
 }
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
-__global__ void __launch_bounds__(256) lg_g2p_adj(LargeArgs a) {
+__global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   const BlockTable bt = bt_make();
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const MpmConst& c = a.c;
@@ -673,7 +696,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   L->c = c; L->d_material = d_material; L->d_hard = d_hard;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
-  // the staging kernels use 72 KB of dynamic LDS (above the 64 KB default)
+  // dynamic LDS of the staging kernels (36 KB; set explicitly so that a larger LG_H keeps working)
   (void)hipFuncSetAttribute((const void*)lg_p2g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
   return L;
@@ -736,6 +759,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  const dim3 gs((N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
@@ -750,7 +774,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 1, 0);
-    hipLaunchKernelGGL(lg_p2g, gp, blk, LG_TABLE_BYTES, st, a, 1);
+    hipLaunchKernelGGL(lg_p2g, gs, blks, LG_TABLE_BYTES, st, a, 1);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 0);
     hipLaunchKernelGGL(lg_g2p, gp, blk, 0, st, a);
   }
@@ -776,6 +800,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  const dim3 gs((N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   const long rec = (long)24 * Np;
   const long stride_b = (long)(S + 1) * rec + (long)S * 10;
@@ -787,9 +812,9 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     a.f = f; a.epoch = L->epoch++;
     a.hist_in = ckpt + (long)f * rec;
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-    hipLaunchKernelGGL(lg_p2g, gp, blk, LG_TABLE_BYTES, st, a, 0);
+    hipLaunchKernelGGL(lg_p2g, gs, blks, LG_TABLE_BYTES, st, a, 0);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 1);
-    hipLaunchKernelGGL(lg_g2p_adj, gp, blk, LG_TABLE_BYTES, st, a);
+    hipLaunchKernelGGL(lg_g2p_adj, gs, blks, LG_TABLE_BYTES, st, a);
     hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
     hipLaunchKernelGGL(lg_p2g_adj, gp, blk, 0, st, a);
     hipLaunchKernelGGL(lg_fk_adj, dim3(B), blk, 0, st, a);
