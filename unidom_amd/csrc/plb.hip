@@ -252,13 +252,33 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
       }
     }
   }
+  // flush; first-seen cells are appended to the env's active list with ONE counter atomic per block (same-address
+  // global atomics on the counter, one per cell, dominated the substep in the f32 large path: mpm_large.hip)
+  __shared__ int s_new, s_base;
+  if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
-  for (int sl = threadIdx.x; sl < PLB_H; sl += blockDim.x) {
-    const int key = s_key[sl];
+  constexpr int PER = PLB_H / 256;
+  unsigned newmask = 0;
+  int nnew = 0;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int key = s_key[threadIdx.x + u * 256];
     if (key < 0) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[sl * 4 + r]);
-    plb_touch(a, b, key);
+    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[(threadIdx.x + u * 256) * 4 + r]);
+    if (atomicExch(&a.w.stamp[(long)b * a.G + key], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
+  }
+  const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
+  __syncthreads();
+  const int cur = a.f & 1;
+  if (threadIdx.x == 0) s_base = s_new ? atomicAdd(&a.w.count[cur * a.B + b], s_new) : 0;
+  __syncthreads();
+  int e = s_base + mine;
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    if (!(newmask & (1u << u))) continue;
+    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = s_key[threadIdx.x + u * 256];
+    ++e;
   }
 }
 
