@@ -30,14 +30,14 @@ class LegacyConf:   # whip_rope_env.py:27-73 with the legacy overrides of SURVEY
     n_primitive = 1
 
 
-def make_sim(steps, B, material=1):
+def make_sim(steps, B, material=1, N=67):
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
     conf = LegacyConf()
     conf.steps = steps
     sim = SimpleMPMSimulator(conf, B, use_position_control=True)
-    sim.n_particles = 67
-    sim.material = np.full(67, material, np.int32)
-    sim.h = np.ones(67, np.float32)
+    sim.n_particles = N
+    sim.material = np.full(N, material, np.int32)
+    sim.h = np.ones(N, np.float32)
     sim._make_handle()
     return sim
 
@@ -119,6 +119,36 @@ def test_bwd_matches_oracle(demo, clip, material, S, k):
         assert _rel(oh[key], ob[key]) < tol, (key, _rel(oh[key], ob[key]))
     for key in ("gfriction", "gmu", "glamda"):
         assert _rel(oh[key].reshape(-1), ob[key]) < 5 * tol, (key, oh[key], ob[key])
+
+
+@pytest.mark.parametrize("N", [30, 64, 96, 97, 128])
+def test_particle_counts_cover_both_adjoint_kernels(demo, N):
+    """N <= 96 runs the wave-specialised adjoint (particle waves + stencil waves), 97..128 the single-mapping one;
+    64 / 96 / 128 are the exact-wave edges, 30 / 97 the ragged ones.  Bodies: the first N rope particles, or the rope
+    plus a second strand shifted by 3 cells."""
+    from oracle.pyoracle import MpmOracle
+    S = 4
+    st, g = _adjoint_case(demo, S, 40, 1, 3, np.float32)
+    def body(a):   # [1,67,...] -> [1,N,...]
+        if N <= 67:
+            return a[:, :N].copy()
+        extra = a[:, :N - 67].copy()
+        return np.concatenate([a, extra], 1)
+    st = dict(st); g = dict(g)
+    for k in ("x", "v", "C", "F"):
+        st[k] = body(st[k]); g["g" + k] = body(g["g" + k])
+    if N > 67:
+        st["x"][:, 67:, 2] += np.float32(3 / 64)
+    st["J"] = st["J"][:, :1].repeat(N, 1) if st["J"].ndim == 2 else st["J"]
+    st64 = {kk: v.astype(np.float64) for kk, v in st.items()}
+    g64 = {kk: v.astype(np.float64) for kk, v in g.items()}
+    orc = MpmOracle(N, steps=S)
+    of, ob = orc.step_fwd(st), orc.step_bwd(st64, g64, clip=True)
+    oh = run_hip(make_sim(S, 1, N=N), st, g=g, clip=True)
+    assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4 and _rel(oh["F"], of["F"]) < 5e-5
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < 2e-3, (key, _rel(oh[key], ob[key]))
 
 
 def test_batched_envs_with_different_parameters(demo):

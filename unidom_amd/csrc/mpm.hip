@@ -486,7 +486,7 @@ __device__ __forceinline__ float ppos_preclip(const Lds& L, int f, int S, int j,
   return (f == 0) ? L.ppin[j * 3 + a] : clipf(L.ppin[j * 3 + a], -2.f, 2.f);
 }
 
-constexpr int UD_PARK = 16;   // float4 per particle parked across the stencil phases of the adjoint
+constexpr int UD_PARK = 12;   // float4 per particle parked across the stencil phases of the adjoint
 
 __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   extern __shared__ float smem[];
@@ -497,8 +497,8 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   Lds L;
   L.key = (int*)smem; L.acc = (double*)(smem + H); L.gacc = (double*)(smem + 9 * H);
   L.gpv = (double*)(smem + 15 * H);
-  // `park`: what only the particle adjoint at the end of the iteration needs from the pre-pass (Fn, U, Vh, sigma, A, C, F:
-  // 63 floats per particle) waits in LDS while the stencil phases run, instead of holding ~60 VGPRs live in every lane
+  // `park`: what only the particle adjoint at the end of the iteration needs from the pre-pass (Fn, U, Vh, sigma, A:
+  // 45 floats per particle) waits in LDS while the stencil phases run, instead of holding them live in every lane
   float4* park = (float4*)(smem + 15 * H + 6 * S + (S & 1) * 2);
   L.ppos = (float*)(park + UD_PARK * c.Np); L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3;
   L.scr = L.gppos + S * 3;
@@ -579,8 +579,8 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       for (int d = 0; d < 3; ++d) { pk[d] = kb.sig_raw[d]; pk[3 + d] = kb.sig[d]; }
       pk[6] = kb.Jd; pk[7] = kb.mu; pk[8] = kb.la;
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { pk[9 + d] = q.Fn[d]; pk[18 + d] = kb.U[d]; pk[27 + d] = kb.Vh[d]; pk[36 + d] = kb.A[d]; pk[45 + d] = Cm[d]; pk[54 + d] = F[d]; }
-      pk[63] = 0.f;
+      for (int d = 0; d < 9; ++d) { pk[9 + d] = q.Fn[d]; pk[18 + d] = kb.U[d]; pk[27 + d] = kb.Vh[d]; pk[36 + d] = kb.A[d]; }
+      pk[45] = 0.f; pk[46] = 0.f; pk[47] = 0.f;
 #pragma unroll
       for (int k = 0; k < UD_PARK; ++k) park[k * c.Np + p] = make_float4(pk[k * 4], pk[k * 4 + 1], pk[k * 4 + 2], pk[k * 4 + 3]);
     }
@@ -704,7 +704,12 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       for (int d = 0; d < 3; ++d) { qa.fx[d] = q.fx[d]; ka.sig_raw[d] = pk[d]; ka.sig[d] = pk[3 + d]; }
       ka.Jd = pk[6]; ka.mu = pk[7]; ka.la = pk[8];
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { qa.Fn[d] = pk[9 + d]; ka.U[d] = pk[18 + d]; ka.Vh[d] = pk[27 + d]; ka.A[d] = pk[36 + d]; Ca[d] = pk[45 + d]; Fa[d] = pk[54 + d]; }
+      for (int d = 0; d < 9; ++d) { qa.Fn[d] = pk[9 + d]; ka.U[d] = pk[18 + d]; ka.Vh[d] = pk[27 + d]; ka.A[d] = pk[36 + d]; }
+      {  // C and F of this substep come back from the checkpoint (L2-resident) rather than from LDS
+        const float* r = ck + (size_t)f * 24 * c.Np + pc;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { Ca[d] = r[(6 + d) * c.Np]; Fa[d] = r[(15 + d) * c.Np]; }
+      }
       float gmu_p, gla_p;
       particle_adjoint(c, qa, ka, Ca, Fa, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
       const float h = clipf(hard, 0.1f, 5.f);
@@ -797,6 +802,410 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
   if (tid == 0 && a.status) a.status[b] = bad ? 1 : 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward, wave-specialised (N <= 96)
+// ------------------------------------------------------------------------------------------------
+// The one-mapping adjoint above keeps the particle pre-pass / SVD-VJP state and the stencil state live in the same
+// lanes (256 VGPRs + scratch traffic inside the per-cell loops).  Here the first ceil(N/64) waves are PARTICLE waves
+// (lane = particle: checkpoint load, pre-pass with adjoint extras, particle adjoint) and the remaining waves are STENCIL
+// waves (lane = 4*particle + q: p2g recompute, grid op, g2p adjoint scatter, grid-op adjoint, p2g adjoint gather).  The
+// two roles are separate loop nests behind one wave-uniform branch, so each gets its own register allocation, and
+// they overlap in time: while the stencil waves run substep f, the particle waves finish the particle adjoint of
+// substep f+1 (ready before the g2p adjoint needs its result) and then pre-compute the pre-pass of substep f-1 (it
+// only needs the checkpoint).  Hand-offs go through LDS (stage: particle -> stencil, ret: stencil -> particle); both
+// roles execute the same six workgroup barriers per substep.
+constexpr int UD_WS_STG = 10, UD_WS_RET = 6;   // float4 per particle
+
+struct PartSet { float fx[3], Fn[9], U[9], Vh[9], A[9], sig_raw[3], sig[3], Jd, mu, la, Cm[9], F[9]; };
+
+__global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
+  extern __shared__ float smem[];
+  const MpmConst c = a.c;
+  const int tid = threadIdx.x, b = blockIdx.x, nt = blockDim.x;
+  const int N = c.N, S = c.steps, H = c.H, Np = c.Np;
+  const int nw = nt >> 6;
+  const int nP = (N + 63) / 64 * 64;                  // particle threads first
+  const int nS = nt - nP;                             // stencil threads
+  const bool prole = tid < nP;
+  Lds L;
+  L.key = (int*)smem; L.acc = (double*)(smem + H); L.gacc = (double*)(smem + 9 * H);
+  L.gpv = (double*)(smem + 15 * H);
+  float4* stage = (float4*)(smem + 15 * H + 6 * S + (S & 1) * 2);
+  float4* ret = stage + UD_WS_STG * Np;
+  L.ppos = (float*)(ret + UD_WS_RET * Np); L.prot = L.ppos + S * 3; L.ppin = L.prot + S * 4; L.gppos = L.ppin + S * 3;
+  L.scr = L.gppos + S * 3;
+  L.list = (int*)(L.scr + 64); L.count = L.list + H;
+  float* accf = (float*)L.acc;
+  float* gaccf = (float*)L.gacc;
+  // particle role
+  const bool clive = prole && tid < N;
+  const int cp = clive ? tid : 0;
+  // stencil role
+  const int ft = tid - nP;                            // stencil thread id (>= 0 in the stencil role)
+  const int p = ft >> 2, qi = ft & 3;
+  const bool live = !prole && p < N;
+  const bool fkl = !prole && ft < S * 3;              // lanes that own the primitive-position cotangent entries
+  const size_t ck_env = ((size_t)S * 24 * c.Np + (size_t)S * 10);
+  const float* ck = a.ckpt + (size_t)b * ck_env;
+  {
+    const float* tail = ck + (size_t)S * 24 * c.Np;
+    for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.0; }
+    for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
+    for (int s = tid; s < H; s += nt) {
+      L.key[s] = -1; L.acc[s * 4] = 0.0;
+      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+    }
+    if (tid == 0) *L.count = 0;
+    for (int e = tid; e < S * 3; e += nt) {           // copy_frame adjoint: position[0] <- position[steps-1]
+      const int row = e / 3, d = e - row * 3;
+      float g = a.gppos[(size_t)b * S * 3 + e];
+      if (S > 1) {
+        if (row == 0) g = 0.f;
+        if (row == S - 1) g += a.gppos[(size_t)b * S * 3 + d];
+      }
+      L.gppos[e] = g;
+    }
+  }
+  float ac[6], pv[3], pw[3], psize[3];
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ac[d] = clipf(a.action[b * 6 + d], -1.f, 1.f);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { pv[d] = ac[d] * 1.f / (float)S; pw[d] = ac[3 + d] * 1.f / (float)S; psize[d] = a.psize[b * 3 + d]; }
+  const float friction = a.friction[b], mu_s = a.mu[b], la_s = a.lamda[b];
+  float acc_fric = 0.f, acc_mu = 0.f, acc_la = 0.f;
+  bool ok = true;
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9], gF[9];   // particle role: cotangents of the particle state
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = 0.f; }
+  __syncthreads();
+
+  if (prole) {
+    // ================================ particle waves ================================
+    const int material = a.material[cp];
+    const float hard = a.hard[cp];
+    const float hcl = clipf(hard, 0.1f, 5.f);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = a.gx[((size_t)b * N + cp) * 3 + d]; gv[d] = a.gv[((size_t)b * N + cp) * 3 + d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = a.gC[((size_t)b * N + cp) * 9 + d]; gF[d] = a.gF[((size_t)b * N + cp) * 9 + d]; }
+    // pre-pass of substep f: keeps what the particle adjoint needs in `out`, hands the stencil part to the quads
+    auto prepass = [&](int f, PartSet& out) {
+      float x[3], v[3];
+      const float* r = ck + (size_t)f * 24 * c.Np + cp;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = r[d * c.Np]; v[d] = r[(3 + d) * c.Np]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { out.Cm[d] = r[(6 + d) * c.Np]; out.F[d] = r[(15 + d) * c.Np]; }
+      Pre q; PreB kb;
+      particle_pre<true>(c, x, out.Cm, out.F, mu_s, la_s, material, hard, q, &kb);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { out.fx[d] = q.fx[d]; out.sig_raw[d] = kb.sig_raw[d]; out.sig[d] = kb.sig[d]; }
+      out.Jd = kb.Jd; out.mu = kb.mu; out.la = kb.la;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { out.Fn[d] = q.Fn[d]; out.U[d] = kb.U[d]; out.Vh[d] = kb.Vh[d]; out.A[d] = kb.A[d]; }
+      if (clive) {
+        stage[cp] = make_float4(__int_as_float(q.base[0]), __int_as_float(q.base[1]), __int_as_float(q.base[2]), q.fx[0]);
+        stage[Np + cp] = make_float4(q.fx[1], q.fx[2], q.w[0], q.w[1]);
+        stage[2 * Np + cp] = make_float4(q.w[2], q.w[3], q.w[4], q.w[5]);
+        stage[3 * Np + cp] = make_float4(q.w[6], q.w[7], q.w[8], q.affine[0]);
+        stage[4 * Np + cp] = make_float4(q.affine[1], q.affine[2], q.affine[3], q.affine[4]);
+        stage[5 * Np + cp] = make_float4(q.affine[5], q.affine[6], q.affine[7], q.affine[8]);
+        stage[6 * Np + cp] = make_float4(v[0], v[1], v[2], 0.f);
+      }
+    };
+    PartSet cur, prevset;
+    prepass(S - 1, cur);
+    prevset = cur;
+    for (int f = S - 1; f >= 0; --f) {
+      __syncthreads();   // b1: table cleared, stage[0..6] of substep f visible
+      if (f != S - 1) {  // finish the particle adjoint of substep f+1 (its stencil cotangents arrived under b6)
+        Pre q; PreB kb;
+        float gw[9], gfx[3], gaff[9], gvp[3], rt[UD_WS_RET * 4];
+#pragma unroll
+        for (int k = 0; k < UD_WS_RET; ++k) { const float4 t = ret[k * Np + cp]; rt[k * 4] = t.x; rt[k * 4 + 1] = t.y; rt[k * 4 + 2] = t.z; rt[k * 4 + 3] = t.w; }
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { gw[d] = rt[d]; gaff[d] = rt[12 + d]; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { gfx[d] = rt[9 + d]; gvp[d] = rt[21 + d]; }
+        // NOTE: `prev` (substep f+1) was saved before `cur` was overwritten with substep f -- see the end of the loop body
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { q.fx[d] = prevset.fx[d]; kb.sig_raw[d] = prevset.sig_raw[d]; kb.sig[d] = prevset.sig[d]; }
+        kb.Jd = prevset.Jd; kb.mu = prevset.mu; kb.la = prevset.la;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) { q.Fn[d] = prevset.Fn[d]; kb.U[d] = prevset.U[d]; kb.Vh[d] = prevset.Vh[d]; kb.A[d] = prevset.A[d]; }
+        float gmu_p, gla_p;
+        particle_adjoint(c, q, kb, prevset.Cm, prevset.F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+        if (clive && material != 0) { acc_mu += gmu_p * hcl; acc_la += gla_p * hcl; }
+      }
+      if (clive) {       // cotangents entering substep f's g2p adjoint
+        stage[7 * Np + cp] = make_float4(gv[0] + c.dt * gx[0], gv[1] + c.dt * gx[1], gv[2] + c.dt * gx[2], gC[0]);   // x_out = x + dt*v_new
+        stage[8 * Np + cp] = make_float4(gC[1], gC[2], gC[3], gC[4]);
+        stage[9 * Np + cp] = make_float4(gC[5], gC[6], gC[7], gC[8]);
+      }
+      __syncthreads();   // b2
+      __syncthreads();   // b3: stage[7..9] visible to the g2p adjoint
+      __syncthreads();   // b4: the quads are done reading stage
+      prevset = cur;     // substep f's set waits for its stencil cotangents
+      if (f > 0) prepass(f - 1, cur);   // overlaps the stencil waves' grid-op adjoint and gather
+      __syncthreads();   // b5
+      __syncthreads();   // b6: ret of substep f visible
+    }
+    {  // particle adjoint of substep 0
+      Pre q; PreB kb;
+      float gw[9], gfx[3], gaff[9], gvp[3], rt[UD_WS_RET * 4];
+#pragma unroll
+      for (int k = 0; k < UD_WS_RET; ++k) { const float4 t = ret[k * Np + cp]; rt[k * 4] = t.x; rt[k * 4 + 1] = t.y; rt[k * 4 + 2] = t.z; rt[k * 4 + 3] = t.w; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gw[d] = rt[d]; gaff[d] = rt[12 + d]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gfx[d] = rt[9 + d]; gvp[d] = rt[21 + d]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { q.fx[d] = prevset.fx[d]; kb.sig_raw[d] = prevset.sig_raw[d]; kb.sig[d] = prevset.sig[d]; }
+      kb.Jd = prevset.Jd; kb.mu = prevset.mu; kb.la = prevset.la;
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { q.Fn[d] = prevset.Fn[d]; kb.U[d] = prevset.U[d]; kb.Vh[d] = prevset.Vh[d]; kb.A[d] = prevset.A[d]; }
+      float gmu_p, gla_p;
+      particle_adjoint(c, q, kb, prevset.Cm, prevset.F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+      if (clive && material != 0) { acc_mu += gmu_p * hcl; acc_la += gla_p * hcl; }
+    }
+  } else {
+    // ================================ stencil waves ================================
+    int slots[UD_NCELL], pcell[UD_NCELL];
+#pragma unroll
+    for (int t = 0; t < UD_NCELL; ++t) { slots[t] = 0; pcell[t] = -2; }
+    float pend_val = 0.f, pend_pv = 0.f;   // FK-adjoint values computed in phase F, written at the top of the next iteration
+    bool pend = false;
+    for (int f = S - 1; f >= 0; --f) {
+      // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
+      for (int e = ft, n = *L.count; e < n; e += nS) {
+        const int s = L.list[e];
+        L.acc[s * 4] = 0.0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+      }
+      if (pend && fkl) { L.gppos[ft] = pend_val; L.gpv[ft] += (double)pend_pv; }
+      __syncthreads();   // b1
+      // ---- B: read the particle's pre-pass, p2g ----
+      Pre q;
+      float vq[3] = {0.f, 0.f, 0.f};
+      if (live) {
+        const float4 s0 = stage[p], s1 = stage[Np + p], s2 = stage[2 * Np + p], s3 = stage[3 * Np + p], s4 = stage[4 * Np + p],
+                     s5 = stage[5 * Np + p], s6 = stage[6 * Np + p];
+        q.base[0] = __float_as_int(s0.x); q.base[1] = __float_as_int(s0.y); q.base[2] = __float_as_int(s0.z);
+        q.fx[0] = s0.w; q.fx[1] = s1.x; q.fx[2] = s1.y;
+        q.w[0] = s1.z; q.w[1] = s1.w; q.w[2] = s2.x; q.w[3] = s2.y; q.w[4] = s2.z; q.w[5] = s2.w; q.w[6] = s3.x; q.w[7] = s3.y; q.w[8] = s3.z;
+        q.affine[0] = s3.w; q.affine[1] = s4.x; q.affine[2] = s4.y; q.affine[3] = s4.z; q.affine[4] = s4.w;
+        q.affine[5] = s5.x; q.affine[6] = s5.y; q.affine[7] = s5.z; q.affine[8] = s5.w;
+        vq[0] = s6.x; vq[1] = s6.y; vq[2] = s6.z;
+        ok = p2g_lane(c, L, q, vq, qi, slots, pcell) && ok;
+      }
+      __syncthreads();   // b2
+      // ---- C: grid op forward -> vel ----
+      PrimF pf;
+      prim_at(L, f, S, psize, pv, friction, pf);
+      for (int e = ft, n = *L.count; e < n; e += nS) {
+        const int s = L.list[e];
+        int ci, cj, ckk;
+        decode_cell(c, L.key[s], ci, cj, ckk);
+        const float mm = (float)L.acc[s * 4];
+        float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+        grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
+        accf[s * 8] = mm; accf[s * 8 + 1] = mvv[0]; accf[s * 8 + 2] = mvv[1]; accf[s * 8 + 3] = mvv[2];   // raw values for the adjoint
+        accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];
+      }
+      __syncthreads();   // b3
+      // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
+      float gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+      if (live) {
+        const float4 s7 = stage[7 * Np + p], s8 = stage[8 * Np + p], s9 = stage[9 * Np + p];
+        const float gnv[3] = {s7.x, s7.y, s7.z};
+        const float gCq[9] = {s7.w, s8.x, s8.y, s8.z, s8.w, s9.x, s9.y, s9.z, s9.w};
+#pragma unroll
+        for (int t = 0; t < UD_NCELL; ++t) {
+          int i, j, k;
+          if (!cell_of(qi, t, i, j, k)) continue;
+          const int gs = slots[t] & 0xffff;
+          const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+          const float weight = wi * wj * wk;
+          const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
+          float gwt = 0.f, gsc[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const float gCd = gCq[r * 3] * dp[0] + gCq[r * 3 + 1] * dp[1] + gCq[r * 3 + 2] * dp[2];
+            const float vel = accf[gs * 8 + 4 + r];
+            gsc[r] = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+            gwt += vel * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gCq[r * 3 + s2] * vel;
+          }
+          if (quadrun_reduce<3>(gs, gsc)) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lds_add(&L.gacc[gs * 3 + r], gsc[r]);
+          }
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+            gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+            gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+          }
+        }
+      }
+      __syncthreads();   // b4
+      // ---- E: grid-op adjoint per occupied slot ----
+      for (int e = ft, n = *L.count; e < n; e += nS) {
+        const int s = L.list[e];
+        int ci, cj, ckk;
+        decode_cell(c, L.key[s], ci, cj, ckk);
+        const float m = accf[s * 8];
+        float mvv[3] = {accf[s * 8 + 1], accf[s * 8 + 2], accf[s * 8 + 3]};
+        float g[3] = {(float)L.gacc[s * 3], (float)L.gacc[s * 3 + 1], (float)L.gacc[s * 3 + 2]}, gmm, dfric, dpv[3];
+        const bool ctrl = grid_op_adjoint(c, pf, ci, cj, ckk, m, mvv, g, gmm, dfric, dpv);
+        acc_fric += dfric;
+        if (ctrl) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) lds_add(&L.gpv[f * 3 + d], dpv[d]);
+        }
+        gaccf[s * 6] = g[0]; gaccf[s * 6 + 1] = g[1]; gaccf[s * 6 + 2] = g[2]; gaccf[s * 6 + 3] = gmm;   // same thread read the doubles
+      }
+      __syncthreads();   // b5
+      // ---- F: p2g adjoint (gather) -> ret; FK adjoint ----
+      float gaff[9], gvp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gaff[d] = 0.f;
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < UD_NCELL; ++t) {
+          int i, j, k;
+          if (!cell_of(qi, t, i, j, k)) continue;
+          const int ss = (slots[t] >> 16) - 1;
+          if (ss < 0) continue;
+          const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+          const float weight = wi * wj * wk;
+          const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
+          float gwt = c.p_mass * gaccf[ss * 6 + 3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const float gc = gaccf[ss * 6 + r];
+            const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+            gwt += gc * (c.p_mass * vq[r] + ad);
+            gvp[r] += weight * c.p_mass * gc;
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+              gaff[r * 3 + s2] += weight * gc * dpos[s2];
+              gfx[s2] -= c.dx * weight * gc * q.affine[r * 3 + s2];
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+            gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+            gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gw[d] = quad_sum(gw[d]); gaff[d] = quad_sum(gaff[d]); }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gfx[d] = quad_sum(gfx[d]); gvp[d] = quad_sum(gvp[d]); }
+      if (live && qi == 0) {
+        ret[p] = make_float4(gw[0], gw[1], gw[2], gw[3]);
+        ret[Np + p] = make_float4(gw[4], gw[5], gw[6], gw[7]);
+        ret[2 * Np + p] = make_float4(gw[8], gfx[0], gfx[1], gfx[2]);
+        ret[3 * Np + p] = make_float4(gaff[0], gaff[1], gaff[2], gaff[3]);
+        ret[4 * Np + p] = make_float4(gaff[4], gaff[5], gaff[6], gaff[7]);
+        ret[5 * Np + p] = make_float4(gaff[8], gvp[0], gvp[1], gvp[2]);
+      }
+      // FK adjoint (:185-187): position' = clip(set(position, f+1, position[f] + v[f])); reads now, writes in A
+      pend = true;
+      pend_val = 0.f; pend_pv = 0.f;
+      if (fkl) {
+        const int row = ft / 3, d = ft - row * 3;
+        const float pva = (d == 0) ? pv[0] : ((d == 1) ? pv[1] : pv[2]);
+        const float mine = L.gppos[ft] * clip_grad(ppos_preclip(L, f, S, row, d, pva), -2.f, 2.f);
+        float val = mine;
+        if (f + 1 < S) {
+          if (row == f + 1) val = 0.f;
+          if (row == f) {
+            const float t = L.gppos[ft + 3] * clip_grad(ppos_preclip(L, f, S, f + 1, d, pva), -2.f, 2.f);
+            val += t;
+            pend_pv = t;
+          }
+        }
+        pend_val = val;
+      }
+      __syncthreads();   // b6
+    }
+    if (pend && fkl) { L.gppos[ft] = pend_val; L.gpv[ft] += (double)pend_pv; }
+  }
+  __syncthreads();
+  // ---- step boundary: set_action adjoint, action clip, norm_grad(_state) (:375-411, :419-423) ----
+  float* red = L.scr;
+  float tot_fric = block_sum1(acc_fric, red, nw);
+  float tot_mu = block_sum1(acc_mu, red, nw);
+  float tot_la = block_sum1(acc_la, red, nw);
+  float ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < S; ++j)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float t = (float)L.gpv[j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
+  // rotation path (action[3:6]): the reference's d|w|/dw at w = 0 is NaN and nan_to_num zeroes it here -> 0
+#pragma unroll
+  for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
+  if (a.clip) {
+    float n2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) { ga[d] = nan_to_num(ga[d] + 0.f); n2 += ga[d] * ga[d]; }
+    const float nrm = sqrtf(n2);
+    if (!(nrm < 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 6; ++d) ga[d] = ga[d] / nrm;
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = nan_to_num(gx[d] + 0.f); gv[d] = nan_to_num(gv[d] + 0.f); }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = nan_to_num(gC[d] + 0.f); gF[d] = nan_to_num(gF[d] + 0.f); }
+    if (prole && clive) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) s2 += gx[d] * gx[d] + gv[d] * gv[d];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) s2 += gC[d] * gC[d] + gF[d] * gF[d];
+    }
+    if (fkl) { const float t = nan_to_num(L.gppos[ft] + 0.f); L.gppos[ft] = t; s2 += t * t; }
+    tot_fric = nan_to_num(tot_fric); tot_mu = nan_to_num(tot_mu); tot_la = nan_to_num(tot_la);
+    if (tid == 0) {
+      s2 += tot_fric * tot_fric + tot_mu * tot_mu + tot_la * tot_la;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+    }
+    const float sn = sqrtf(block_sum1(s2, red, nw));
+    if (!(sn < 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gx[d] = gx[d] / sn; gv[d] = gv[d] / sn; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gC[d] = gC[d] / sn; gF[d] = gF[d] / sn; }
+      if (fkl) L.gppos[ft] = L.gppos[ft] / sn;
+      tot_fric = tot_fric / sn; tot_mu = tot_mu / sn; tot_la = tot_la / sn;
+    }
+  }
+  if (prole && clive) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a.gx0[((size_t)b * N + cp) * 3 + d] = gx[d]; a.gv0[((size_t)b * N + cp) * 3 + d] = gv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { a.gC0[((size_t)b * N + cp) * 9 + d] = gC[d]; a.gF0[((size_t)b * N + cp) * 9 + d] = gF[d]; }
+  }
+  if (fkl) a.gppos0[(size_t)b * S * 3 + ft] = L.gppos[ft];
+  if (tid == 0) {
+    a.gfric[b] = tot_fric; a.gmu[b] = tot_mu; a.glam[b] = tot_la;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) a.gaction[b * 6 + d] = ga[d];
+  }
+  const int bad = __syncthreads_or(ok ? 0 : 1);
+  if (tid == 0 && a.status) a.status[b] = bad ? 1 : 0;
+}
+
 }  // namespace ud
 
 // ------------------------------------------------------------------------------------------------
@@ -810,6 +1219,7 @@ struct ud_mpm {
   int* d_material = nullptr;
   float* d_hard = nullptr;
   size_t lds_fwd = 0, lds_bwd = 0;
+  int nthreads_bwd_ws = 0;         // > 0: the wave-specialised adjoint kernel (N <= 96) with this many threads
   ud::MpmLarge* large = nullptr;   // N > 128: many-workgroup path (mpm_large.hip)
 };
 
@@ -839,12 +1249,13 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
-  while (Hh > 1024 && ((size_t)16 * Hh + (size_t)64 * c.Np + (size_t)S * 19 + 72) * sizeof(float) > 160 * 1024) { Hh /= 2; --lg; }   // LDS budget of the adjoint
+  const size_t per_particle = (N <= 96) ? 64 : 48;   // floats of LDS hand-off per particle in the adjoint (stage+ret / park)
+  while (Hh > 1024 && ((size_t)16 * Hh + per_particle * c.Np + (size_t)S * 19 + 72) * sizeof(float) > 160 * 1024) { Hh /= 2; --lg; }   // LDS budget of the adjoint
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * std::min(N, 128) + 63) / 64 * 64);
   const bool large = N > 128;
   h->lds_fwd = ((size_t)10 * Hh + (size_t)4 * 10 * h->c.Np + (size_t)S * 11 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list, stage/ret (10 float4 per particle), primitives + inverse rotations, scratch, count
-  h->lds_bwd = ((size_t)16 * Hh + (size_t)4 * 16 * h->c.Np + (size_t)S * 19 + 64 + 8) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), park (16 float4 per particle), adjoint primitive arrays
+  h->lds_bwd = ((size_t)16 * Hh + per_particle * h->c.Np + (size_t)S * 19 + 64 + 8) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), stage+ret (16 float4 per particle, N <= 96) or park (12), adjoint primitive arrays
   if (!large && h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_material, N * sizeof(int));
@@ -853,6 +1264,8 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   if (e == hipSuccess) e = hipMemcpy(h->d_hard, hardness, N * sizeof(float), hipMemcpyHostToDevice);
   if (!large && e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::mpm_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fwd);
   if (!large && e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::mpm_step_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bwd);
+  if (!large && e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::mpm_step_bwd_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bwd);
+  if (!large && N <= 96) h->nthreads_bwd_ws = (N + 63) / 64 * 64 + (4 * N + 63) / 64 * 64;   // particle waves + stencil waves <= 512
   if (e != hipSuccess) {
     ud::set_error("ud_mpm_create: %s", hipGetErrorString(e));
     if (h->d_material) (void)hipFree(h->d_material);
@@ -927,7 +1340,10 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
   a.gx = g_x; a.gv = g_v; a.gC = g_C; a.gF = g_F; a.gppos = g_prim_position; a.clip = clip;
   a.gx0 = g_x0; a.gv0 = g_v0; a.gC0 = g_C0; a.gF0 = g_F0; a.gppos0 = g_prim_position0; a.gfric = g_friction;
   a.gmu = g_mu; a.glam = g_lamda; a.gaction = g_action; a.status = status;
-  hipLaunchKernelGGL(ud::mpm_step_bwd_kernel, dim3(B), dim3(h->c.nthreads), h->lds_bwd, (hipStream_t)stream, a);
+  if (h->nthreads_bwd_ws > 0)
+    hipLaunchKernelGGL(ud::mpm_step_bwd_ws_kernel, dim3(B), dim3(h->nthreads_bwd_ws), h->lds_bwd, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(ud::mpm_step_bwd_kernel, dim3(B), dim3(h->c.nthreads), h->lds_bwd, (hipStream_t)stream, a);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;
 }
