@@ -66,7 +66,8 @@ class WhipRopeEnv(MPMEnv):
 
     def auto_reset(self, state, state_new, key):   # :94-106 (vmapped over envs in the reference)
         key = prng.split(np.asarray(key, dtype=np.uint32))[..., 0, :]
-        shift = torch.tensor(prng.normal_batch(key, 2) * np.float32(0.02), device=state.x.device)   # [B,2]
+        # pinned staging + non_blocking copy: torch.tensor(ndarray, device=...) would wait for every kernel queued so far
+        shift = torch.from_numpy(prng.normal_batch(key, 2) * np.float32(0.02)).pin_memory().to(state.x.device, non_blocking=True)   # [B,2]
         p = state.primitives[0]
         position = p.position.clone()
         position[:, 0, 0] = position[:, 0, 0] + shift[:, 0]
