@@ -158,7 +158,8 @@ def bench_whip_rope(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"whip_rope (MLS-MPM, N={N}, res 32^3, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": f"mpm_step_{dom}_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
                          "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers"}}), flush=True)
@@ -373,7 +374,7 @@ def main():
         units = world * NUM_ENVS_PER_GPU * EP_LEN * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
-        kname = {"fwd": "cloth_rollout_fwd_fast_kernel" if args.kernel_mode == 2 else "cloth_rollout_fwd_kernel",
+        kname = {"fwd": {0: "cloth_rollout_fwd_v2_kernel", 1: "cloth_rollout_fwd_kernel", 2: "cloth_rollout_fwd_fast_kernel"}[args.kernel_mode],
                  "bwd": "cloth_rollout_bwd_kernel" if args.kernel_mode == 1 else "cloth_rollout_bwd_fast_kernel"}[dom]
         per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
