@@ -307,8 +307,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "whip_rope", "torus"],
-                    help="fold_cloth1 = the headline metric (default); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus"],
+                    help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
+                         "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
+    ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
     ap.add_argument("--n-grid", type=int, default=64, help="whip_rope only: 64 (default env, N=67), 128 (N=798) or 256 (N=6675): "
                     "the scaled configurations of SURVEY.md 8(d), simulator-level (the env's goal/obs sizes are tied to N=67)")
     ap.add_argument("--envs", type=int, default=32, help="whip_rope only: envs per GPU")
@@ -329,10 +331,17 @@ def main():
     if args.workload == "whip_rope":
         return bench_whip_rope(args, rank, world, device)
 
+    global NUM_ENVS_PER_GPU
+    para = args.workload == "fold_cloth1_para"
+    NUM_ENVS_PER_GPU = args.cloth_envs if args.cloth_envs else (32 if para else 4)
     from unidom_amd.envs.fold_cloth1_env import DefaultConf
     conf = DefaultConf()
     conf.kernel_mode = args.kernel_mode
-    env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, conf=conf, seed=0, aux_reward=True, device=device)
+    if para:   # apg_para.py: stiffness drawn from [train_min_stiff, train_max_stiff] = [1000, 1600], obs normalised with [10, 1800]
+        env = env_functions["fold_cloth1_para"](batch_size=NUM_ENVS_PER_GPU, conf=conf, aux_reward=True, stiffness=1300,
+                                                eval_min_max_stiff=[10, 1800], device=device)
+    else:
+        env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, conf=conf, seed=0, aux_reward=True, device=device)
     learner = APG(env, EP_LEN, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
     key_env = prng.split(prng.PRNGKey(0), world)[rank]
     _, state = env.reset(key_env)
@@ -380,13 +389,13 @@ def main():
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and NUM_ENVS_PER_GPU == 4:   # the PMC passes were taken on the headline shape (4 envs per launch)
             traffic = json.load(open(tj)).get(kname, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "fold_cloth1 (mass-spring cloth, P=512) APG loss+grad+update: num_envs=4 per GPU, "
+            "config": {"workload": f"{args.workload} (mass-spring cloth, P=512) APG loss+grad+update: num_envs={NUM_ENVS_PER_GPU} per GPU, "
                                    "ep_len=3, 40 macro x 50 substeps per step_diff",
                        "kernel_mode": args.kernel_mode, "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
                        "parallelism": f"env-sharded dp{world}, 1 RCCL all-reduce of {learner.n_params} f32 per update"},
