@@ -216,6 +216,54 @@ def test_default_bwd_matches_oracle_full_step_diff(dsim, oracle2):
         assert _rel(h[key], o[key]) < 5e-3, (key, _rel(h[key], o[key]))
 
 
+@pytest.mark.parametrize("r0,r1", [(1.7, -0.1), (0.0, 3.0e19), (0.2, float("inf")), (float("nan"), 0.05)])
+def test_default_mode_grasp_radius_edge_cases(dsim, oracle2, r0, r1):
+    """The kernels replace sqrt(s) <= radius by s <= T(radius) with T found once per launch for the first substep's radius and
+    for every later one (clip(radius, 0, 1), cloth_simulator.py:322-323).  Radii outside [0,1], zero, huge, inf and NaN must
+    give the oracle's grasp sets and states bit for bit, and the adjoint (which re-derives the sets) must follow."""
+    rng = np.random.default_rng(21)
+    B, T = 2, 2
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    prim[:, 0, 3] = r0
+    prim[:, 1, 3] = r1
+    o = oracle2.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    h = _run_hip(dsim, x, v, prim, k, mu, actions)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "x_list", "v_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    np.testing.assert_array_equal(h["prim"][..., :3], o["prim"][..., :3])
+    g = _grads(rng, B, T, x.shape[1])
+    g["gprim"][..., 3] = 0; g["gprim_list"][..., 3] = 0       # the radius itself carries no gradient of interest here
+    ob = oracle2.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"], g["gprim_list"])
+    hb = _run_hip(dsim, x, v, prim, k, mu, actions, g=g)
+    for key in ("gx", "gv", "gactions", "gk", "gmu"):
+        assert np.isfinite(hb[key]).all(), key
+        assert _rel(hb[key], ob[key]) < 1e-3, (key, _rel(hb[key], ob[key]))
+
+
+@pytest.mark.parametrize("S", [1, 3, 7])
+def test_default_mode_odd_substep_counts(oracle2, S):
+    """substeps is a handle constant (ud_cloth_conf.substeps); odd counts exercise the LDS double-buffer parity across macro steps."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    conf = Conf()
+    conf.substeps = S
+    sim = ClothSimulator(conf, 2, lambda x, v, i, j: v, fold_cloth1_mask())
+    orc = ClothOracle(fold_cloth1_mask(), substeps=S, order=2)
+    rng = np.random.default_rng(S)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, 2, 5)
+    o = orc.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    h = _run_hip(sim, x, v, prim, k, mu, actions)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    g = _grads(rng, 2, 5, x.shape[1])
+    ob = orc.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"], g["gprim_list"])
+    hb = _run_hip(sim, x, v, prim, k, mu, actions, g=g)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert _rel(hb[key], ob[key]) < 1e-3, (key, _rel(hb[key], ob[key]))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # mode 2: fast-math forward.  f32 round-off differences are amplified by this stiff system (k/L0 = 72000,
 # omega*dt ~ 1.4, chattering ground friction: v noise ~ mu*g*dt = 5e-4 on every grounded particle), so the
