@@ -90,33 +90,56 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
 // particles of a block touch a few hundred distinct cells; they are summed in an LDS cell table first and each
 // distinct cell is then flushed with ONE global atomic per component.  That removes the ~50-way same-address
 // contention plain global atomics suffer on a compact body (measured: 17 us -> see DESIGN.md per env-substep).
-#define LG_H 2048
-#define LG_LOGH 11
-#define LG_SCATTER_T 128   // particles per workgroup in the two scatter kernels: ~500 distinct cells per block, 36 KB of LDS
+#define LG_SCATTER_T 128   // threads per workgroup in the two scatter kernels
+#ifndef LG_LOGH1
+#define LG_LOGH1 9
+#endif
+// staging-table slots per block.  32 particles (4 lanes each) touch ~150-250 distinct cells; 128 particles (1 lane each)
+// touch 500-900, but a table that holds them all costs more to clear and flush than the spill to global atomics
+// it avoids (measured, n_grid 256: 2048 slots 47.8 k substeps/s, 512 slots 69 k).
+template <int LANES> struct LgTable { static constexpr int LOGH = LANES == 4 ? 9 : LG_LOGH1, H = 1 << LOGH; };
 // staged values are float64: ds_add_f32 retires ~20x slower than ds_add_f64 on gfx950 (tools/ubench_lds_atomic.hip)
-struct BlockTable { int* key; double* val; };   // key[LG_H], val[LG_H*4]
-constexpr size_t LG_TABLE_BYTES = (size_t)LG_H * (sizeof(int) + 4 * sizeof(double));   // dynamic LDS of the staging kernels
+struct BlockTable { int* key; double* val; };   // key[H], val[H*4]
+
+// The particle kernels use the small path's lane mapping: lane = 4*particle + q, the quad splits the 27 stencil cells
+// 7/7/7/6 and reduces with DPP.  One lane per particle left the chip mostly idle (N = 798, 32 envs: 400 waves on
+// 1024 SIMDs, each walking 27 cells serially).
+// LANES = 4 when the launch is small enough to need the parallelism (B*N below ~100 k particles: 1.2x at n_grid 128),
+// LANES = 1 (one lane per particle, serial 27-cell walk, no redundant pre-pass) once the chip is full (n_grid 256).
+template <int LANES>
+__device__ __forceinline__ float lg_quad_sum(float v) {
+  if (LANES == 4) {
+    v += dpp_f<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);  // quad_perm [2,3,0,1]
+  }
+  return v;
+}
+template <int LANES> constexpr size_t lg_table_bytes() { return (size_t)LgTable<LANES>::H * (sizeof(int) + 4 * sizeof(double)); }   // dynamic LDS
+template <int H>
 __device__ __forceinline__ BlockTable bt_make() {
   extern __shared__ double lg_smem[];
-  return BlockTable{(int*)(lg_smem + LG_H * 4), lg_smem};
+  return BlockTable{(int*)(lg_smem + H * 4), lg_smem};
 }
 
+template <int LOGH>
 __device__ __forceinline__ unsigned lg_hash(int cell) {
   unsigned h = (unsigned)cell;
   h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
-  return h >> (32 - LG_LOGH);
+  return h >> (32 - LOGH);
 }
 
+template <int H>
 __device__ __forceinline__ void bt_clear(const BlockTable& t) {
-  for (int s = threadIdx.x; s < LG_H; s += blockDim.x) {
+  for (int s = threadIdx.x; s < H; s += blockDim.x) {
     t.key[s] = -1;
     t.val[s * 4] = 0.0; t.val[s * 4 + 1] = 0.0; t.val[s * 4 + 2] = 0.0; t.val[s * 4 + 3] = 0.0;
   }
 }
 
 // returns the slot of `cell`, or -1 when the table is full (the caller then falls back to a global atomic)
+template <int H, int LOGH>
 __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
-  unsigned s = lg_hash(cell);
+  unsigned s = lg_hash<LOGH>(cell);
   for (int probe = 0; probe < 64; ++probe) {
     const int cur = t.key[s];
     if (cur == cell) return (int)s;
@@ -124,13 +147,14 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
       const int old = atomicCAS(&t.key[s], -1, cell);
       if (old == -1 || old == cell) return (int)s;
     }
-    s = (s + 1) & (LG_H - 1);
+    s = (s + 1) & (H - 1);
   }
   return -1;
 }
 
+template <int H, int LOGH>
 __device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, int cell, int comp, float v) {
-  const int s = bt_slot(t, cell);
+  const int s = bt_slot<H, LOGH>(t, cell);
   if (s >= 0) __hip_atomic_fetch_add(&t.val[s * 4 + comp], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else atomicAdd(global_cell + comp, v);
 }
@@ -185,11 +209,13 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 }
 
 // particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
+template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) {
-  const BlockTable bt = bt_make();
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
+  const BlockTable bt = bt_make<TH>();
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
-  bt_clear(bt);
+  bt_clear<TH>(bt);
   __syncthreads();
   float4* val = a.w.val + (long)b * a.G;
   if (p < c.N) {
@@ -197,20 +223,20 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
     Pre q;
     particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[p], a.hard[p], q, nullptr);
-    if (store_F) {
+    if (store_F && qi == 0) {
       float* ho = a.hist_out + (long)b * a.hist_stride_b;
 #pragma unroll
       for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
     }
 #pragma unroll 1
-    for (int cidx = 0; cidx < 27; ++cidx) {
+    for (int cidx = qi; cidx < 27; cidx += LANES) {
       const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
       const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
       const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
       const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
       if (sc >= 0) {
         const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-        const int sl = bt_slot(bt, sc);
+        const int sl = bt_slot<TH, TLOG>(bt, sc);
         float contrib[4];
         contrib[0] = weight * c.p_mass;
 #pragma unroll
@@ -237,7 +263,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   __shared__ int s_new, s_base;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
-  constexpr int PER = LG_H / LG_SCATTER_T;
+  constexpr int PER = TH / LG_SCATTER_T;
   unsigned newmask = 0;
   int nnew = 0;
 #pragma unroll
@@ -286,10 +312,11 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
 }
 
 // g2p + advect (:196-221, :318-328)
+template <int LANES>
 __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
-  if (p >= c.N) return;
+  if (p >= c.N) return;   // whole quads leave together
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
   float* ho = a.hist_out + (long)b * a.hist_stride_b;
   float x[3];
@@ -307,7 +334,7 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
   const float4* val = a.w.val + (long)b * a.G;
   float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
+  for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const float weight = sel3(w, 0, i) * sel3(w, 1, j) * sel3(w, 2, k);
     const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
@@ -320,6 +347,11 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
       for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
     }
   }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) nv[d] = lg_quad_sum<LANES>(nv[d]);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) nC[d] = lg_quad_sum<LANES>(nC[d]);
+  if (qi != 0) return;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = x[d] + c.dt * nv[d]; ho[(3 + d) * c.Np + p] = nv[d]; }
 #pragma unroll
@@ -427,11 +459,13 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
 }
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
+template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
-  const BlockTable bt = bt_make();
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
+  const BlockTable bt = bt_make<TH>();
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
-  bt_clear(bt);
+  bt_clear<TH>(bt);
   __syncthreads();
   float4* gacc = a.w.gacc + (long)b * a.G;
   if (p < c.N) {
@@ -458,7 +492,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   for (int d = 0; d < 9; ++d) gw[d] = 0.f;
   const float4* vel = a.w.vel + (long)b * a.G;
 #pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
+  for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
     const float weight = wi * wj * wk;
@@ -471,7 +505,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-      bt_add(bt, (float*)(gacc + lin), gkey, r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
+      bt_add<TH, TLOG>(bt, (float*)(gacc + lin), gkey, r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
       gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
@@ -483,14 +517,20 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
       gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
     }
   }
-  float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
 #pragma unroll
-  for (int d = 0; d < 9; ++d) ps[d] = gw[d];
+  for (int d = 0; d < 9; ++d) gw[d] = lg_quad_sum<LANES>(gw[d]);
 #pragma unroll
-  for (int d = 0; d < 3; ++d) ps[9 + d] = gfx[d];
+  for (int d = 0; d < 3; ++d) gfx[d] = lg_quad_sum<LANES>(gfx[d]);
+  if (qi == 0) {
+    float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
+#pragma unroll
+    for (int d = 0; d < 9; ++d) ps[d] = gw[d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ps[9 + d] = gfx[d];
+  }
   }
   __syncthreads();
-  for (int sl = threadIdx.x; sl < LG_H; sl += blockDim.x) {
+  for (int sl = threadIdx.x; sl < TH; sl += blockDim.x) {
     const int key = bt.key[sl];
     if (key < 0) continue;
     float* cell = (float*)(gacc + cell_lin(c, key));
@@ -525,10 +565,11 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
 }
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
+template <int LANES>
 __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
-  if (p >= c.N) return;
+  if (p >= c.N) return;   // whole quads leave together
   float x[3], v[3], Cm[9], F[9];
   load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
   Pre q;
@@ -544,12 +585,12 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
   const float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
   float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int d = 0; d < 9; ++d) { gw[d] = ps[d]; gaff[d] = 0.f; }
+  for (int d = 0; d < 9; ++d) { gw[d] = (qi == 0) ? ps[d] : 0.f; gaff[d] = 0.f; }   // the g2p-adjoint partials enter the quad sum once
 #pragma unroll
-  for (int d = 0; d < 3; ++d) gfx[d] = ps[9 + d];
+  for (int d = 0; d < 3; ++d) gfx[d] = (qi == 0) ? ps[9 + d] : 0.f;
   const float4* gacc = a.w.gacc + (long)b * a.G;
 #pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
+  for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
     if (sc < 0) continue;
@@ -577,6 +618,11 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
       gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
     }
   }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<LANES>(gw[d]); gaff[d] = lg_quad_sum<LANES>(gaff[d]); }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<LANES>(gfx[d]); gvp[d] = lg_quad_sum<LANES>(gvp[d]); }
+  if (qi != 0) return;
   float gmu_p, gla_p;
   particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
@@ -696,9 +742,11 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   L->c = c; L->d_material = d_material; L->d_hard = d_hard;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
-  // dynamic LDS of the staging kernels (36 KB; set explicitly so that a larger LG_H keeps working)
-  (void)hipFuncSetAttribute((const void*)lg_p2g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
-  (void)hipFuncSetAttribute((const void*)lg_g2p_adj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LG_TABLE_BYTES);
+  // dynamic LDS of the staging kernels (set explicitly so that a table above the 64 KB default keeps working)
+  (void)hipFuncSetAttribute((const void*)lg_p2g<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
+  (void)hipFuncSetAttribute((const void*)lg_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
+  (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   return L;
 }
 
@@ -759,7 +807,9 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
-  const dim3 gs((N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);
+  const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
+  const dim3 gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);   // scatter kernels
+  const dim3 gq((lanes * N + 255) / 256, B);                                               // gather kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
@@ -774,9 +824,9 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 1, 0);
-    hipLaunchKernelGGL(lg_p2g, gs, blks, LG_TABLE_BYTES, st, a, 1);
+    if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), st, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), st, a, 1);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 0);
-    hipLaunchKernelGGL(lg_g2p, gp, blk, 0, st, a);
+    if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, st, a);
   }
   // restore the all-zero grid invariant (cells of the last substep)
   a.f = S; a.epoch = L->epoch++;
@@ -800,7 +850,9 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
-  const dim3 gs((N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);
+  const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
+  const dim3 gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);   // scatter kernels
+  const dim3 gq((lanes * N + 255) / 256, B);                                               // gather kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   const long rec = (long)24 * Np;
   const long stride_b = (long)(S + 1) * rec + (long)S * 10;
@@ -812,11 +864,11 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     a.f = f; a.epoch = L->epoch++;
     a.hist_in = ckpt + (long)f * rec;
     hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-    hipLaunchKernelGGL(lg_p2g, gs, blks, LG_TABLE_BYTES, st, a, 0);
+    if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), st, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), st, a, 0);
     hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 1);
-    hipLaunchKernelGGL(lg_g2p_adj, gs, blks, LG_TABLE_BYTES, st, a);
+    if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), st, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), st, a);
     hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(lg_p2g_adj, gp, blk, 0, st, a);
+    if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, st, a);
     hipLaunchKernelGGL(lg_fk_adj, dim3(B), blk, 0, st, a);
   }
   a.f = -1; a.epoch = L->epoch++;
