@@ -104,10 +104,13 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
  *   core/engine/primitives/box.py:6-18 (box SDF)
  * driven by lax.scan over the macro actions of one step_diff (core/envs/basic/mpm_env.py:141).
  * One call = one `simulator.step` = conf.steps substeps for B independent envs, ONE kernel launch.
- * Scope this round: one box primitive in position-control mode (whip_rope); materials 1 (elastic), 2 (plastic
- * clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.  N <= 128 particles per env: one workgroup per env, the
- * touched part of the `res` grid in an LDS cell table, ONE launch per step.  N > 128: many workgroups per env, dense
- * grid in HBM, a few launches per substep (all on `stream`).
+ *   core/engine/primitives/primitives.py:105-182 (inv_trans, sdf, finite-difference normal, collider velocity,
+ *   collide_batch)
+ * Scope this round: one box primitive, in position-control mode (whip_rope) or soft-contact mode (collide_batch:
+ * shape_rope); materials 1 (elastic), 2 (plastic clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.
+ * Position control with N <= 128 particles per env: one workgroup per env, the touched part of the `res` grid in an
+ * LDS cell table, ONE launch per step.  N > 128, or soft contact: many workgroups per env, dense grid in HBM, a few
+ * launches per substep (all on `stream`).
  * ------------------------------------------------------------------------------------------------ */
 typedef struct ud_mpm ud_mpm;
 
@@ -119,7 +122,9 @@ typedef struct {
   float dt;                  /* :48 */
   float p_mass, p_vol;       /* :62-63 */
   float gravity[3];          /* :64 */
-  int use_position_control;  /* 1: position_control_batch (only mode supported) */
+  int use_position_control;  /* 1: position_control_batch (primitives.py:232-239), 0: collide_batch soft contact (:154-182) */
+  float prim_friction;       /* PrimitiveState.friction  (create_primitive, mpm_env.py:201-207): collide_batch only */
+  float prim_softness;       /* PrimitiveState.softness  (666 in every reference env): collide_batch only */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */
@@ -139,16 +144,21 @@ int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const floa
                     float* prim_rotation_out, float* prim_v_out, float* prim_w_out, void* ckpt, int* status,
                     void* stream);
 
-/* Backward `step`: cotangents of (x,v,C,F, primitive position) at the step output -> cotangents at the step
- * input plus friction/mu/lamda [B] and action [B,6].  J receives no gradient (excluded from the reference's
- * substep loss, mpm_simulator.py:343-350); action[3:6] (rotation) is 0: the reference yields NaN there for
- * w = 0 and launders it with nan_to_num at this boundary.  clip != 0 applies norm_grad_state / norm_grad
- * (nan_to_num + global-norm clip to 1, :389-408). */
+/* Backward `step`: cotangents of (x,v,C,F, primitive position, primitive rotation) at the step output ->
+ * cotangents at the step input plus friction/mu/lamda [B] and action [B,6].  J receives no gradient (excluded
+ * from the reference's substep loss, mpm_simulator.py:343-350).  g_prim_rotation (in) and g_prim_rotation0 (out)
+ * [B,steps,4] may be NULL (= zero cotangent / not wanted).
+ * Position control: nothing reaches the rotation array (g_prim_rotation0 = 0) and action[3:6] is reported as 0 --
+ * the reference yields NaN there for w = 0 and launders it with nan_to_num at this boundary.
+ * Soft contact: rotation and action[3:6] carry the chain rule as the reference writes it, NaN at w = 0 included
+ * (d|w|/dw, primitives.py:86); clip != 0 launders it exactly like the reference.
+ * clip != 0 applies norm_grad_state / norm_grad (nan_to_num + global-norm clip to 1, :389-408); in soft-contact
+ * mode the norm also covers the cotangents of the primitive's rotation, size, friction and action_scale leaves. */
 int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, const float* friction,
                     const float* mu, const float* lamda, const float* action, const float* g_x, const float* g_v,
-                    const float* g_C, const float* g_F, const float* g_prim_position, int clip, float* g_x0,
-                    float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_friction, float* g_mu,
-                    float* g_lamda, float* g_action, int* status, void* stream);
+                    const float* g_C, const float* g_F, const float* g_prim_position, const float* g_prim_rotation, int clip,
+                    float* g_x0, float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_prim_rotation0,
+                    float* g_friction, float* g_mu, float* g_lamda, float* g_action, int* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PlasticineLab-style MLS-MPM, float64, von-Mises plasticity, sticky Sphere primitives (GenORM Torus task,

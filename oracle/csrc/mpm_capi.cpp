@@ -17,7 +17,8 @@ template <> const MpmParams<double>& P<double>(const OcMpm* h) { return h->pd; }
 
 template <class T>
 static void fill_params(MpmParams<T>& p, int N, int n_grid, const int* res, int steps, double dt, double p_mass,
-                        double p_vol, const double* gravity, int position_control, const int* material, const double* hard) {
+                        double p_vol, const double* gravity, int position_control, const int* material, const double* hard,
+                        double prim_friction, double prim_softness) {
   p.N = N; p.n_grid = n_grid; p.steps = steps;
   for (int d = 0; d < 3; ++d) p.res[d] = res[d];
   const double dx = 1.0 / n_grid;
@@ -26,6 +27,7 @@ static void fill_params(MpmParams<T>& p, int N, int n_grid, const int* res, int 
   p.dx2 = (T)(dx * dx);
   for (int d = 0; d < 3; ++d) p.dtg[d] = (T)dt * (T)gravity[d];
   p.position_control = position_control;
+  p.prim_friction = (T)prim_friction; p.prim_softness = (T)prim_softness;
   p.material.assign(material, material + N);
   p.h.resize(N);
   for (int i = 0; i < N; ++i) p.h[i] = (T)hard[i];
@@ -86,8 +88,8 @@ static void step_fwd(const OcMpm* h, int B, StepIO<T> io, T* xo, T* vo, T* Co, T
 
 template <class T>
 static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* gv, const T* gC, const T* gF,
-                     const T* gppos, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0, T* gfric, T* gmu, T* glam,
-                     T* gaction, int nthreads) {
+                     const T* gppos, const T* gprot, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0, T* gprot0, T* gfric,
+                     T* gmu, T* glam, T* gaction, int nthreads) {
   const auto& pr = P<T>(h);
   const int N = pr.N, S = pr.steps;
 #pragma omp parallel for num_threads(nthreads) schedule(static)
@@ -102,14 +104,20 @@ static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* 
     for (int i = 0; i < N * 3; ++i) { g.x[i] = gx[(size_t)b * N * 3 + i]; g.v[i] = gv[(size_t)b * N * 3 + i]; }
     for (int i = 0; i < N * 9; ++i) { g.C[i] = gC[(size_t)b * N * 9 + i]; g.F[i] = gF[(size_t)b * N * 9 + i]; }
     for (int i = 0; i < S * 3; ++i) g.ppos[i] = gppos[(size_t)b * S * 3 + i];
-    // copy_frame adjoint: position[0] <- position[steps-1]
+    if (gprot) for (int i = 0; i < S * 4; ++i) g.prot[i] = gprot[(size_t)b * S * 4 + i];
+    // copy_frame adjoint: position[0] <- position[steps-1], rotation likewise
     if (S - 1 != 0) for (int a = 0; a < 3; ++a) { g.ppos[(S - 1) * 3 + a] += g.ppos[a]; g.ppos[a] = 0; }
+    if (S - 1 != 0) for (int a = 0; a < 4; ++a) { g.prot[(S - 1) * 4 + a] += g.prot[a]; g.prot[a] = 0; }
     for (int f = S - 1; f >= 0; --f) mpm_substep_bwd(pr, f, states[f], g);
     // set_action adjoint (primitives.py:212-229); action_scale = 1 is a state leaf (its cotangent only enters the norm)
     T ga[6] = {0, 0, 0, 0, 0, 0}, gscale[6] = {0, 0, 0, 0, 0, 0};
     for (int j = 0; j < S; ++j)
       for (int c = 0; c < 3; ++c) { ga[c] += g.pv[j * 3 + c] * T(1) / (T)S; gscale[c] += g.pv[j * 3 + c] * ac[c] / (T)S; }
-    // rotation path: d|w|/dw at w = 0 is NaN in the reference and is zeroed by nan_to_num at this boundary -> 0
+    // rotation path.  Position control: no cotangent reaches rotation; d|w|/dw at w = 0 is NaN in the reference and
+    // is zeroed by nan_to_num at this boundary -> reported as 0.  Soft contact: the chain rule as written (NaN at w = 0).
+    if (!pr.position_control)
+      for (int j = 0; j < S; ++j)
+        for (int c = 0; c < 3; ++c) { ga[3 + c] += g.pw[j * 3 + c] * T(1) / (T)S; gscale[3 + c] += g.pw[j * 3 + c] * ac[3 + c] / (T)S; }
     for (int c = 0; c < 6; ++c) ga[c] *= clip_grad(io.action[b * 6 + c], T(-1), T(1));
     if (clip) {  // norm_grad_bwd / norm_grad_state_bwd (:389-394, :403-408)
       T n2 = 0;
@@ -118,14 +126,16 @@ static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* 
       if (!(nrm < T(1))) for (int c = 0; c < 6; ++c) ga[c] = ga[c] / nrm;
       T s2 = 0;
       auto acc = [&](std::vector<T>& a) { for (auto& q : a) { q = nan_to_num(q + T(0)); s2 += q * q; } };
-      acc(g.x); acc(g.v); acc(g.C); acc(g.F); acc(g.ppos);
+      acc(g.x); acc(g.v); acc(g.C); acc(g.F); acc(g.ppos); acc(g.prot);
+      for (int c = 0; c < 3; ++c) { g.psize[c] = nan_to_num(g.psize[c]); s2 += g.psize[c] * g.psize[c]; }
+      g.pfriction = nan_to_num(g.pfriction); s2 += g.pfriction * g.pfriction;
       g.friction = nan_to_num(g.friction); g.mu = nan_to_num(g.mu); g.lamda = nan_to_num(g.lamda);
       s2 += g.friction * g.friction + g.mu * g.mu + g.lamda * g.lamda;
-      for (int c = 0; c < 3; ++c) { gscale[c] = nan_to_num(gscale[c]); s2 += gscale[c] * gscale[c]; }
+      for (int c = 0; c < 6; ++c) { gscale[c] = nan_to_num(gscale[c]); s2 += gscale[c] * gscale[c]; }
       T sn = std::sqrt(s2);
       if (!(sn < T(1))) {
         auto sc = [&](std::vector<T>& a) { for (auto& q : a) q = q / sn; };
-        sc(g.x); sc(g.v); sc(g.C); sc(g.F); sc(g.ppos);
+        sc(g.x); sc(g.v); sc(g.C); sc(g.F); sc(g.ppos); sc(g.prot);
         g.friction /= sn; g.mu /= sn; g.lamda /= sn;
       }
     }
@@ -134,6 +144,7 @@ static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* 
     std::memcpy(gC0 + (size_t)b * N * 9, g.C.data(), sizeof(T) * N * 9);
     std::memcpy(gF0 + (size_t)b * N * 9, g.F.data(), sizeof(T) * N * 9);
     std::memcpy(gppos0 + (size_t)b * S * 3, g.ppos.data(), sizeof(T) * S * 3);
+    if (gprot0) std::memcpy(gprot0 + (size_t)b * S * 4, g.prot.data(), sizeof(T) * S * 4);
     gfric[b] = g.friction; gmu[b] = g.mu; glam[b] = g.lamda;
     for (int c = 0; c < 6; ++c) gaction[b * 6 + c] = ga[c];
   }
@@ -142,10 +153,11 @@ static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* 
 extern "C" {
 
 void* oc_mpm_create(int N, int n_grid, const int* res, int steps, double dt, double p_mass, double p_vol,
-                    const double* gravity, int position_control, const int* material, const double* hardness) {
+                    const double* gravity, int position_control, const int* material, const double* hardness,
+                    double prim_friction, double prim_softness) {
   auto* h = new OcMpm;
-  fill_params(h->pf, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness);
-  fill_params(h->pd, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness);
+  fill_params(h->pf, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness, prim_friction, prim_softness);
+  fill_params(h->pd, N, n_grid, res, steps, dt, p_mass, p_vol, gravity, position_control, material, hardness, prim_friction, prim_softness);
   return h;
 }
 void oc_mpm_destroy(void* h) { delete (OcMpm*)h; }
@@ -172,11 +184,11 @@ void oc_svd3_f64(const double* A, double* U, double* S, double* Vh) {
   void oc_mpm_step_bwd_##SUF(void* h, int B, const T* x, const T* v, const T* C, const T* F, const T* J,             \
                              const T* ppos, const T* prot, const T* psize, const T* friction, const T* mu,           \
                              const T* lamda, const T* action, const T* gx, const T* gv, const T* gC, const T* gF,   \
-                             const T* gppos, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0, T* gfric, T* gmu, \
-                             T* glam, T* gaction, int nthreads) {                                                    \
+                             const T* gppos, const T* gprot, int clip, T* gx0, T* gv0, T* gC0, T* gF0, T* gppos0,   \
+                             T* gprot0, T* gfric, T* gmu, T* glam, T* gaction, int nthreads) {                        \
     StepIO<T> io{x, v, C, F, J, ppos, prot, psize, friction, mu, lamda, action};                                     \
-    step_bwd<T>((OcMpm*)h, B, io, gx, gv, gC, gF, gppos, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam,         \
-                gaction, nthreads);                                                                                  \
+    step_bwd<T>((OcMpm*)h, B, io, gx, gv, gC, gF, gppos, gprot, clip, gx0, gv0, gC0, gF0, gppos0, gprot0, gfric, gmu, \
+                glam, gaction, nthreads);                                                                                \
   }
 DEFINE(f32, float)
 DEFINE(f64, double)

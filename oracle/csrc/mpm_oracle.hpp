@@ -14,7 +14,10 @@
 // the adjoint is validated against torch.autograd on the line-by-line twin and f64 finite differences.
 // The SVD itself is LAPACK in the reference (third-party); here a one-sided Jacobi (Hestenes) -- only the
 // gauge-invariant products U S Vh, U Vh and S enter the dynamics.
-// Scope: position-control primitives (whip_rope). collide_batch is forward-only in the twin ("next" row).
+//     normal_batch / _normal_batch (finite-difference normal) :117-141   collider_v_batch :144-151
+//     collide_batch :154-182
+// Scope: ONE box primitive, in position-control mode (whip_rope) or soft-contact mode (collide_batch: shape_rope).
+// The soft-contact adjoint is validated against torch.autograd on the twin in f64 (tests/test_oracle_mpm.py).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -119,6 +122,7 @@ struct MpmParams {
   T dx2;           // T(dx**2)
   T dtg[3];        // T(dt)*T(gravity) (:285)
   int position_control;
+  T prim_friction = T(0.1), prim_softness = T(666);   // PrimitiveState.friction / .softness (primitives.py:31-60)
   std::vector<int> material;  // [N]
   std::vector<T> h;           // [N] hardness, clipped to [0.1,5] at use (:241)
 };
@@ -161,6 +165,166 @@ template <class T> inline T sdf_at(const T size[3], const T pos[3], const T rot[
   T d[3] = {gp[0] - pos[0], gp[1] - pos[1], gp[2] - pos[2]}, loc[3];
   qrot(iq, d, loc);
   return box_sdf(size, loc);
+}
+
+// ---- adjoint helpers -------------------------------------------------------------------------------------
+// qrot adjoint: accumulates into gq[4], gv[3]
+template <class T> inline void qrot_bwd(const T q[4], const T v[3], const T go[3], T gq[4], T gv[3]) {
+  const T qv[3] = {q[1], q[2], q[3]};
+  auto cross = [](const T a[3], const T b[3], T o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+  T uv[3];
+  cross(qv, v, uv);
+  gq[0] += T(2) * (go[0] * uv[0] + go[1] * uv[1] + go[2] * uv[2]);
+  T guv[3] = {T(2) * q[0] * go[0], T(2) * q[0] * go[1], T(2) * q[0] * go[2]};
+  const T guuv[3] = {T(2) * go[0], T(2) * go[1], T(2) * go[2]};
+  T t[3];
+  cross(uv, guuv, t);                       // uuv = qv x uv: g_qv += uv x g_uuv ; g_uv += g_uuv x qv
+  for (int a = 0; a < 3; ++a) gq[1 + a] += t[a];
+  cross(guuv, qv, t);
+  for (int a = 0; a < 3; ++a) guv[a] += t[a];
+  cross(v, guv, t);                         // uv = qv x v: g_qv += v x g_uv ; g_v += g_uv x qv
+  for (int a = 0; a < 3; ++a) gq[1 + a] += t[a];
+  cross(guv, qv, t);
+  for (int a = 0; a < 3; ++a) gv[a] += go[a] + t[a];
+}
+
+// box_sdf adjoint (box.py:6-18): accumulates into gp[3], gsize[3]
+template <class T> inline void box_sdf_bwd(const T size[3], const T p[3], T gout, T gp[3], T gsize[3]) {
+  const T inf = std::numeric_limits<T>::infinity();
+  T xr[3], q[3];
+  for (int a = 0; a < 3; ++a) { xr[a] = std::abs(p[a]) - size[a]; q[a] = clipf(xr[a], T(0), inf); }
+  const T len = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + T(1e-12));
+  const int s1 = q[1] > q[2] ? 1 : 2;
+  const int sel = q[0] > q[s1] ? 0 : s1;
+  const T gt = gout * clip_grad(q[sel], -inf, T(0));
+  for (int a = 0; a < 3; ++a) {
+    const T gq = gout * q[a] / len + (a == sel ? gt : T(0));
+    const T gx = gq * clip_grad(xr[a], T(0), inf);
+    const T sg = p[a] > 0 ? T(1) : (p[a] < 0 ? T(-1) : T(0));
+    gp[a] += gx * sg;
+    gsize[a] -= gx;
+  }
+}
+
+// one box primitive as the grid op of substep f sees it (rows f and f+1 of position / rotation, clamped: Q5)
+template <class T> struct PrimCtx { T p0[3], r0[4], p1[3], r1[4], size[3], softness, friction; };
+template <class T> struct PrimGrad {
+  T p0[3], r0[4], p1[3], r1[4], size[3], friction;
+  PrimGrad() { std::memset(this, 0, sizeof(*this)); }
+};
+
+template <class T> struct CollideRec {
+  T iq[4], nq, rel[3], loc[3], e, infl, n[3], len, nl[3], D[3], cv[3], iv[3], nc, m, vt[3], vtn, arg, c, vtp[3];
+  bool flag;
+};
+
+// collide_batch (:154-182) for one grid cell at world position gp: v -> v_out
+template <class T>
+inline void collide_cell(const PrimCtx<T>& pc, T dt, const T gp[3], const T v[3], T vout[3], CollideRec<T>& r) {
+  const T inf = std::numeric_limits<T>::infinity();
+  // inv_trans_batch (:105-109)
+  const T cq[4] = {pc.r0[0], -pc.r0[1], -pc.r0[2], -pc.r0[3]};
+  r.nq = std::sqrt(cq[0] * cq[0] + cq[1] * cq[1] + cq[2] * cq[2] + cq[3] * cq[3]) + T(1e-12);
+  for (int a = 0; a < 4; ++a) r.iq[a] = cq[a] / r.nq;
+  for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
+  qrot(r.iq, r.rel, r.loc);
+  const T dist = box_sdf(pc.size, r.loc);
+  r.e = std::exp(-dist * pc.softness);
+  r.infl = clipf(r.e, -inf, T(1));
+  // _normal_batch (:117-134): central differences, d = 1e-6, in the primitive's frame
+  const T d = T(1.e-6), k = T(0.5 / 1.e-6);
+  for (int a = 0; a < 3; ++a) {
+    T inc[3] = {r.loc[0], r.loc[1], r.loc[2]}, dec[3] = {r.loc[0], r.loc[1], r.loc[2]};
+    inc[a] = inc[a] + d; dec[a] = dec[a] + (-d);
+    r.n[a] = k * (box_sdf(pc.size, inc) - box_sdf(pc.size, dec));
+  }
+  r.len = std::sqrt(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + T(1e-12));
+  for (int a = 0; a < 3; ++a) r.nl[a] = r.n[a] / r.len;
+  qrot(pc.r0, r.nl, r.D);                                           // normal_batch :137-141
+  // collider_v_batch (:144-151): relative_pos is the same expression as loc
+  T np_[3];
+  qrot(pc.r1, r.loc, np_);
+  for (int a = 0; a < 3; ++a) r.cv[a] = ((np_[a] + pc.p1[a]) - gp[a]) / dt;
+  for (int a = 0; a < 3; ++a) r.iv[a] = v[a] - r.cv[a];
+  r.nc = r.iv[0] * r.D[0] + r.iv[1] * r.D[1] + r.iv[2] * r.D[2];
+  r.m = clipf(r.nc, -inf, T(0));
+  for (int a = 0; a < 3; ++a) r.vt[a] = r.iv[a] - r.m * r.D[a];
+  const T vt_dot = r.vt[0] * r.vt[0] + r.vt[1] * r.vt[1] + r.vt[2] * r.vt[2];
+  r.vtn = std::sqrt(vt_dot + T(1e-12));
+  r.arg = r.vtn + r.nc * pc.friction;
+  r.c = clipf(r.arg, T(1e-12), inf);
+  r.flag = (r.nc < 0) && (std::sqrt(vt_dot) > T(1e-12));
+  const T fl = r.flag ? T(1) : T(0);
+  for (int a = 0; a < 3; ++a) {
+    const T vtf = r.vt[a] / r.vtn * r.c;
+    r.vtp[a] = vtf * fl + r.vt[a] * (T(1) - fl);
+    vout[a] = r.cv[a] + r.iv[a] * (T(1) - r.infl) + r.vtp[a] * r.infl;
+  }
+}
+
+// adjoint of collide_cell: gout (cotangent of v_out) -> gv (cotangent of v), accumulates the primitive's cotangents
+template <class T>
+inline void collide_cell_bwd(const PrimCtx<T>& pc, T dt, const T gp[3], const T v[3], const T gout[3], T gv[3], PrimGrad<T>& pg) {
+  const T inf = std::numeric_limits<T>::infinity();
+  CollideRec<T> r;
+  T vo[3];
+  collide_cell(pc, dt, gp, v, vo, r);
+  T gcv[3], giv[3], gvtp[3], ginfl = 0;
+  for (int a = 0; a < 3; ++a) {
+    gcv[a] = gout[a]; giv[a] = gout[a] * (T(1) - r.infl); gvtp[a] = gout[a] * r.infl;
+    ginfl += gout[a] * (r.vtp[a] - r.iv[a]);
+  }
+  T gvt[3] = {0, 0, 0}, gnc = 0;
+  {
+    const T fl = r.flag ? T(1) : T(0);
+    T gvtf[3], u[3], gc = 0, gu_vt = 0;
+    for (int a = 0; a < 3; ++a) { gvtf[a] = gvtp[a] * fl; gvt[a] = gvtp[a] * (T(1) - fl); u[a] = r.vt[a] / r.vtn; gc += gvtf[a] * u[a]; }
+    T gvtn = 0;
+    for (int a = 0; a < 3; ++a) { const T gu = gvtf[a] * r.c; gvt[a] += gu / r.vtn; gu_vt += gu * r.vt[a]; }
+    gvtn -= gu_vt / (r.vtn * r.vtn);
+    const T garg = gc * clip_grad(r.arg, T(1e-12), inf);
+    gvtn += garg; gnc += garg * pc.friction; pg.friction += garg * r.nc;
+    for (int a = 0; a < 3; ++a) gvt[a] += gvtn * r.vt[a] / r.vtn;
+  }
+  T gD[3], gm = 0;
+  for (int a = 0; a < 3; ++a) { giv[a] += gvt[a]; gm -= gvt[a] * r.D[a]; gD[a] = -r.m * gvt[a]; }
+  gnc += gm * clip_grad(r.nc, -inf, T(0));
+  for (int a = 0; a < 3; ++a) { giv[a] += gnc * r.D[a]; gD[a] += gnc * r.iv[a]; }
+  for (int a = 0; a < 3; ++a) { gv[a] = giv[a]; gcv[a] -= giv[a]; }
+  // collider velocity
+  T gloc[3] = {0, 0, 0}, gnp[3];
+  for (int a = 0; a < 3; ++a) { gnp[a] = gcv[a] / dt; pg.p1[a] += gnp[a]; }
+  qrot_bwd(pc.r1, r.loc, gnp, pg.r1, gloc);
+  // normal: D = qrot(r0, nl), nl = n / len, n by central differences of the sdf
+  T gnl[3] = {0, 0, 0};
+  qrot_bwd(pc.r0, r.nl, gD, pg.r0, gnl);
+  T dotn = gnl[0] * r.n[0] + gnl[1] * r.n[1] + gnl[2] * r.n[2];
+  const T glen = -dotn / (r.len * r.len);
+  const T d = T(1.e-6), k = T(0.5 / 1.e-6);
+  for (int a = 0; a < 3; ++a) {
+    const T gn = gnl[a] / r.len + glen * r.n[a] / r.len;
+    T inc[3] = {r.loc[0], r.loc[1], r.loc[2]}, dec[3] = {r.loc[0], r.loc[1], r.loc[2]};
+    inc[a] = inc[a] + d; dec[a] = dec[a] + (-d);
+    box_sdf_bwd(pc.size, inc, k * gn, gloc, pg.size);
+    box_sdf_bwd(pc.size, dec, -(k * gn), gloc, pg.size);
+  }
+  // influence
+  const T ge = ginfl * clip_grad(r.e, -inf, T(1));
+  const T gdist = -(ge * r.e) * pc.softness;
+  box_sdf_bwd(pc.size, r.loc, gdist, gloc, pg.size);
+  // loc = qrot(iq, gp - p0), iq = conj(r0) / (|conj(r0)| + 1e-12)
+  T giq[4] = {0, 0, 0, 0}, grel[3] = {0, 0, 0};
+  qrot_bwd(r.iq, r.rel, gloc, giq, grel);
+  for (int a = 0; a < 3; ++a) pg.p0[a] -= grel[a];
+  const T cq[4] = {pc.r0[0], -pc.r0[1], -pc.r0[2], -pc.r0[3]};
+  const T nrm = r.nq - T(1e-12);
+  T dq = 0;
+  for (int a = 0; a < 4; ++a) dq += giq[a] * cq[a];
+  const T gnq = -dq / (r.nq * r.nq);
+  for (int a = 0; a < 4; ++a) {
+    const T gcq = giq[a] / r.nq + gnq * cq[a] / nrm;
+    pg.r0[a] += (a == 0) ? gcq : -gcq;
+  }
 }
 
 // forward_kinematics (:185-194) in place on (ppos, prot)
@@ -241,6 +405,16 @@ template <class T> inline long cell_gather(const MpmParams<T>& pr, int i, int j,
   return ((long)id[0] * pr.res[1] + id[1]) * pr.res[2] + id[2];
 }
 
+template <class T, class ST>
+inline PrimCtx<T> prim_ctx(const MpmParams<T>& pr, const ST& st, int f) {
+  const int f0 = clampi<T>(f, pr.steps), f1 = clampi<T>(f + 1, pr.steps);
+  PrimCtx<T> pc;
+  for (int a = 0; a < 3; ++a) { pc.p0[a] = st.ppos[f0 * 3 + a]; pc.p1[a] = st.ppos[f1 * 3 + a]; pc.size[a] = st.psize[a]; }
+  for (int a = 0; a < 4; ++a) { pc.r0[a] = st.prot[f0 * 4 + a]; pc.r1[a] = st.prot[f1 * 4 + a]; }
+  pc.softness = pr.prim_softness; pc.friction = pr.prim_friction;
+  return pc;
+}
+
 // per-cell record of the grid op (enough to run its adjoint)
 template <class T>
 struct CellOp {
@@ -264,6 +438,13 @@ inline void grid_cell_op(const MpmParams<T>& pr, const MpmState<T>& st, int f, i
     T dist = sdf_at(st.psize, &st.ppos[fc * 3], &st.prot[fc * 4], gp);
     ctrl = dist < st.psize[0] * T(1.5);
     if (ctrl) for (int a = 0; a < 3; ++a) v[a] = st.pv[fc * 3 + a] / pr.dt;
+  } else {                                                          // collide_batch (:154-182)
+    T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx};
+    PrimCtx<T> pc = prim_ctx(pr, st, f);
+    CollideRec<T> cr;
+    T vo[3];
+    collide_cell(pc, pr.dt, gp, v, vo, cr);
+    for (int a = 0; a < 3; ++a) v[a] = vo[a];
   }
   if (rec) { rec->ctrl = ctrl; for (int a = 0; a < 3; ++a) rec->v1[a] = v[a]; }
   // friction (:297-307)
@@ -352,9 +533,13 @@ void mpm_substep_fwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmSt
 // cotangents of one MPM state (same leaves the reference differentiates, :343-354; J excluded)
 template <class T>
 struct MpmGrad {
-  std::vector<T> x, v, C, F, ppos, pv;
+  std::vector<T> x, v, C, F, ppos, pv, prot, pw;
   T friction = 0, mu = 0, lamda = 0;
-  void alloc(int N, int steps) { x.assign(N * 3, 0); v.assign(N * 3, 0); C.assign(N * 9, 0); F.assign(N * 9, 0); ppos.assign(steps * 3, 0); pv.assign(steps * 3, 0); }
+  T psize[3] = {0, 0, 0}, pfriction = 0;   // primitive size / friction leaves: only their norm enters (norm_grad_state)
+  void alloc(int N, int steps) {
+    x.assign(N * 3, 0); v.assign(N * 3, 0); C.assign(N * 9, 0); F.assign(N * 9, 0); ppos.assign(steps * 3, 0); pv.assign(steps * 3, 0);
+    prot.assign(steps * 4, 0); pw.assign(steps * 3, 0);
+  }
 };
 
 // ---- adjoint of one substep: g (cotangent of the outputs) -> g (cotangent of the inputs), in place -----
@@ -419,6 +604,8 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
   // grid-op adjoint per cell
   const int fc = clampi<T>(f, pr.steps);
   T gpv_f[3] = {0, 0, 0};
+  const PrimCtx<T> pctx = prim_ctx(pr, mid, f);
+  PrimGrad<T> pgrad;
   for (int ci = 0; ci < pr.res[0]; ++ci) for (int cj = 0; cj < pr.res[1]; ++cj) for (int ck = 0; ck < pr.res[2]; ++ck) {
     size_t c = ((size_t)ci * pr.res[1] + cj) * pr.res[2] + ck;
     const CellOp<T>& r = rec[c];
@@ -449,6 +636,11 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
     if (r.ctrl) {                                                   // position control
       for (int a = 0; a < 3; ++a) { gpv_f[a] += gvv[a] / pr.dt; gvv[a] = 0; }
     }
+    if (!pr.position_control) {                                     // collide_batch
+      T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx}, gin[3];
+      collide_cell_bwd(pctx, pr.dt, gp, r.v0, gvv, gin, pgrad);
+      for (int a = 0; a < 3; ++a) gvv[a] = gin[a];
+    }
     // gravity: pass. normalise (:283-284, Q7)
     T m = gm[c];
     if (m > 0) {
@@ -463,6 +655,51 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
       // m < 0 (negative quadratic weights when x*inv_dx < 0.5, truncating base :233): pass-through branch
       for (int a = 0; a < 3; ++a) ggv[c * 3 + a] = gvv[a];
       ggm[c] = 0;
+    }
+  }
+  if (!pr.position_control) {   // rows f and f+1 (clamped) of position / rotation as the grid op read them
+    const int f1 = clampi<T>(f + 1, pr.steps);
+    for (int a = 0; a < 3; ++a) { g.ppos[fc * 3 + a] += pgrad.p0[a]; g.ppos[f1 * 3 + a] += pgrad.p1[a]; g.psize[a] += pgrad.size[a]; }
+    for (int a = 0; a < 4; ++a) { g.prot[fc * 4 + a] += pgrad.r0[a]; g.prot[f1 * 4 + a] += pgrad.r1[a]; }
+    g.pfriction += pgrad.friction;
+    // rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))   (:190, qmul :73-81, w2quat :84-92)
+    if (f + 1 < pr.steps) {
+      const T inf = std::numeric_limits<T>::infinity();
+      T go_[4];
+      for (int a = 0; a < 4; ++a) { go_[a] = g.prot[(f + 1) * 4 + a]; g.prot[(f + 1) * 4 + a] = 0; }
+      const T* w = &in.pw[fc * 3];
+      const T* rr = &in.prot[fc * 4];
+      const T s = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+      const T nrm = std::sqrt(s), ang = nrm + T(1e-12), hh = ang / 2, sn = std::sin(hh), cs = std::cos(hh);
+      const T u[3] = {w[0] / ang, w[1] / ang, w[2] / ang};
+      const T q[4] = {cs, u[0] * sn, u[1] * sn, u[2] * sn};
+      const T o[4] = {rr[0] * q[0] - rr[1] * q[1] - rr[2] * q[2] - rr[3] * q[3],
+                      rr[0] * q[1] + rr[1] * q[0] - rr[2] * q[3] + rr[3] * q[2],
+                      rr[0] * q[2] + rr[1] * q[3] + rr[2] * q[0] - rr[3] * q[1],
+                      rr[0] * q[3] - rr[1] * q[2] + rr[2] * q[1] + rr[3] * q[0]};
+      const T oo = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+      const T nn = clipf(oo, T(1e-12), inf);
+      T dot = 0;
+      for (int a = 0; a < 4; ++a) dot += go_[a] * o[a];
+      const T goo = -dot / (nn * nn) * clip_grad(oo, T(1e-12), inf);
+      T gO[4];
+      for (int a = 0; a < 4; ++a) gO[a] = go_[a] / nn + goo * o[a] / oo;
+      const T gr[4] = {gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3],
+                       -gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2],
+                       -gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1],
+                       -gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0]};
+      const T gq[4] = {gO[0] * rr[0] + gO[1] * rr[1] + gO[2] * rr[2] + gO[3] * rr[3],
+                       -gO[0] * rr[1] + gO[1] * rr[0] - gO[2] * rr[3] + gO[3] * rr[2],
+                       -gO[0] * rr[2] + gO[1] * rr[3] + gO[2] * rr[0] - gO[3] * rr[1],
+                       -gO[0] * rr[3] - gO[1] * rr[2] + gO[2] * rr[1] + gO[3] * rr[0]};
+      for (int a = 0; a < 4; ++a) g.prot[fc * 4 + a] += gr[a];
+      T gh = -sn * gq[0], gsn = 0, gang = 0, gw[3];
+      for (int a = 0; a < 3; ++a) { gsn += gq[1 + a] * u[a]; const T gu = gq[1 + a] * sn; gw[a] = gu / ang; gang -= gu * w[a] / (ang * ang); }
+      gh += cs * gsn;
+      gang += gh / 2;
+      // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule gives 0.5/0 * 0 = NaN (laundered by nan_to_num at `step`)
+      const T gs = gang * (T(0.5) / nrm);
+      for (int a = 0; a < 3; ++a) g.pw[fc * 3 + a] += gw[a] + gs * (T(2) * w[a]);
     }
   }
   // primitives: FK adjoint (:185-194). position' = clip(set(position, f+1, position[f]+v[f]))

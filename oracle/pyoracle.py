@@ -128,7 +128,7 @@ class MpmOracle:
     """CPU restatement of SimpleMPMSimulator.step (mpm_simulator.py:413-429) + adjoint, dense grid."""
 
     def __init__(self, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0),
-                 position_control=True, material=None, hardness=None):
+                 position_control=True, material=None, hardness=None, prim_friction=0.1, prim_softness=666.0):
         self.N, self.steps, self.res, self.n_grid = N, steps, tuple(res), n_grid
         dx = 1 / n_grid
         p_vol = (dx * 0.5) ** 2
@@ -139,7 +139,7 @@ class MpmOracle:
         g = np.ascontiguousarray(gravity, dtype=np.float64)
         self.h = C.c_void_p(lib().oc_mpm_create(
             C.c_int(N), C.c_int(n_grid), _p(r), C.c_int(steps), C.c_double(dt), C.c_double(p_mass), C.c_double(p_vol),
-            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd)))
+            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd), C.c_double(prim_friction), C.c_double(prim_softness)))
 
     def __del__(self):
         try:
@@ -165,18 +165,18 @@ class MpmOracle:
         return o
 
     def step_bwd(self, st, g, clip=True, nthreads=1):
-        """g: dict gx gv gC gF gppos (cotangents of the step outputs)."""
+        """g: dict gx gv gC gF gppos [gprot] (cotangents of the step outputs)."""
         dt = st["x"].dtype
         a = self._prep(st, dt)
         B, N, S = a[0].shape[0], self.N, self.steps
         c = lambda q: np.ascontiguousarray(q, dtype=dt)
-        gin = [c(g[k]) for k in ("gx", "gv", "gC", "gF", "gppos")]
+        gin = [c(g[k]) for k in ("gx", "gv", "gC", "gF", "gppos")] + [c(g["gprot"]) if "gprot" in g else np.zeros((B, S, 4), dt)]
         o = dict(gx=np.empty((B, N, 3), dt), gv=np.empty((B, N, 3), dt), gC=np.empty((B, N, 3, 3), dt),
-                 gF=np.empty((B, N, 3, 3), dt), gppos=np.empty((B, S, 3), dt), gfriction=np.empty((B,), dt),
+                 gF=np.empty((B, N, 3, 3), dt), gppos=np.empty((B, S, 3), dt), gprot=np.empty((B, S, 4), dt), gfriction=np.empty((B,), dt),
                  gmu=np.empty((B,), dt), glamda=np.empty((B,), dt), gaction=np.empty((B, 6), dt))
         getattr(lib(), "oc_mpm_step_bwd_" + _suf(dt))(
             self.h, C.c_int(B), *[_p(q) for q in a], *[_p(q) for q in gin], C.c_int(int(clip)),
-            *[_p(o[k]) for k in ("gx", "gv", "gC", "gF", "gppos", "gfriction", "gmu", "glamda", "gaction")],
+            *[_p(o[k]) for k in ("gx", "gv", "gC", "gF", "gppos", "gprot", "gfriction", "gmu", "glamda", "gaction")],
             C.c_int(nthreads))
         return o
 

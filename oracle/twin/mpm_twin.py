@@ -402,11 +402,11 @@ class MPMTwin:
                              F=torch.nan_to_num(st.F), J=torch.nan_to_num(st.J))
             p = st.primitives[0]
             leaves = [st.x, st.v, st.C, st.F, st.J, st.friction, st.mu, st.lamda, p.position, p.rotation, p.v, p.w,
-                      p.size, p.action_buffer, p.action_scale]
+                      p.size, p.action_buffer, p.action_scale, p.friction]
             o = _NormGradTree.apply(*leaves)
             st = st._replace(x=o[0], v=o[1], C=o[2], F=o[3], J=o[4], friction=o[5], mu=o[6], lamda=o[7],
                              primitives=[p._replace(position=o[8], rotation=o[9], v=o[10], w=o[11], size=o[12],
-                                                    action_buffer=o[13], action_scale=o[14])] + st.primitives[1:])
+                                                    action_buffer=o[13], action_scale=o[14], friction=o[15])] + st.primitives[1:])
             action = _NormGradTree.apply(action)[0]
         action = _clip(action, -1, 1)
         prims = [set_action(c.steps, action[i * 6:(i + 1) * 6], p) for i, p in enumerate(st.primitives)]

@@ -259,3 +259,69 @@ def test_large_path_matches_oracle_n798():
     # a second call on the same handle (persistent grid arena must be back to all-zero)
     oh2 = run_hip(sim, st)
     assert _rel(oh2["x"], of["x"]) < 5e-6 and _rel(oh2["v"], of["v"]) < 1e-4
+
+
+# ---- soft contact (collide_batch, primitives.py:154-182) -- the mode shape_rope / pour_* use --------------------------
+def make_collide_sim(steps, B, material=1, N=67):
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    conf = LegacyConf()
+    conf.steps = steps
+    sim = SimpleMPMSimulator(conf, B, use_position_control=False)
+    sim.n_particles = N
+    sim.material = np.full(N, material, np.int32)
+    sim.h = np.ones(N, np.float32)
+    sim._make_handle()
+    return sim
+
+
+def run_hip_collide(sim, st, g, clip):
+    from unidom_amd.engine.mpm_simulator import _Step
+    dev = sim.device
+    t = lambda a, r=False: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=r)
+    X, V, Cm, F, PP, PR, FR, MU, LA, AC = (t(st[k], True) for k in ("x", "v", "C", "F", "ppos", "prot", "friction", "mu", "lamda", "action"))
+    sim.clip_grad = clip
+    out = _Step.apply(sim, X, V, Cm, F, t(st["J"]), PP, PR, t(st["psize"]), FR, MU, LA, AC)
+    res = {k: o.detach().cpu().numpy() for k, o in zip(("x", "v", "C", "F", "J", "ppos", "prot", "pv", "pw"), out)}
+    loss = (out[0] * t(g["gx"])).sum() + (out[1] * t(g["gv"])).sum() + (out[2] * t(g["gC"])).sum() + \
+        (out[3] * t(g["gF"])).sum() + (out[5] * t(g["gppos"])).sum() + (out[6] * t(g["gprot"])).sum()
+    loss.backward()
+    res.update(gx=X.grad.cpu().numpy(), gv=V.grad.cpu().numpy(), gC=Cm.grad.cpu().numpy(), gF=F.grad.cpu().numpy(),
+               gppos=PP.grad.cpu().numpy(), gprot=PR.grad.cpu().numpy(), gfriction=FR.grad.cpu().numpy(),
+               gmu=MU.grad.cpu().numpy(), glamda=LA.grad.cpu().numpy(), gaction=AC.grad.cpu().numpy())
+    sim.check_status()
+    return res
+
+
+@pytest.mark.parametrize("clip,material,S,k", [(False, 1, 3, 40), (True, 1, 3, 40), (False, 2, 3, 20), (True, 1, 20, 40)])
+def test_collide_matches_oracle(demo, clip, material, S, k):
+    """Soft contact with a rotated, turning box: forward vs the f32 oracle, adjoint vs the f64 oracle."""
+    from oracle.pyoracle import MpmOracle
+    from test_oracle_mpm import _collide_case
+    st, g = _collide_case(demo, S, k, material, 0, np.float32)
+    st64 = {kk: v.astype(np.float64) for kk, v in st.items()}
+    g64 = {kk: v.astype(np.float64) for kk, v in g.items()}
+    orc = MpmOracle(67, steps=S, material=np.full(67, material), position_control=False)
+    of, ob = orc.step_fwd(st), orc.step_bwd(st64, g64, clip=clip)
+    oh = run_hip_collide(make_collide_sim(S, 1, material), st, g, clip)
+    assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4, (_rel(oh["x"], of["x"]), _rel(oh["v"], of["v"]))
+    assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
+    for key in ("ppos", "prot", "pv", "pw"):
+        np.testing.assert_allclose(oh[key], of[key], rtol=0, atol=2e-7)
+    tol = 2e-3 if S <= 3 else 1e-2
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gprot", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < tol, (key, _rel(oh[key], ob[key]))
+    for key in ("gfriction", "gmu", "glamda"):
+        assert _rel(oh[key].reshape(-1), ob[key]) < 5 * tol, (key, oh[key], ob[key])
+    assert np.abs(oh["gaction"][0, 3:]).min() > 0 and np.abs(oh["gprot"]).max() > 0
+
+
+def test_collide_zero_rotation_action_laundered(demo):
+    """w = 0 (every shape_rope action): NaN from d|w|/dw, zeroed by the step-boundary nan_to_num like the reference."""
+    from test_oracle_mpm import _collide_case
+    st, g = _collide_case(demo, 2, 40, 1, 1, np.float32, w=(0, 0, 0))
+    raw = run_hip_collide(make_collide_sim(2, 1), st, g, clip=False)
+    assert np.isnan(raw["gaction"][0, 3:]).all() and np.isfinite(raw["gaction"][0, :3]).all()
+    assert np.isfinite(raw["gx"]).all() and np.isfinite(raw["gprot"]).all()
+    lau = run_hip_collide(make_collide_sim(2, 1), st, g, clip=True)
+    assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()

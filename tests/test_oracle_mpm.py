@@ -185,3 +185,59 @@ def test_adjoint_vs_finite_differences_f64(demo):
             fd = (Lf(sp) - Lf(sm)) / (2 * h)
             an = b[gname][idx]
             assert abs(fd - an) <= 2e-5 * max(1.0, abs(fd), abs(an)), (name, idx, fd, an)
+
+
+def _collide_case(d, S, k, material, seed, dtn=np.float64, w=(0.4, -0.3, 0.2)):
+    """Soft-contact (collide_batch) case: the gripper sits in the rope, rotated, and turns during the step."""
+    st, g = _adjoint_case(d, S, k, material, seed, dtn)
+    rng = np.random.default_rng(seed + 100)
+    q = np.array([0.9, 0.2, -0.3, 0.1], dtn)
+    st["prot"][0, :] = q / np.linalg.norm(q)
+    st["ppos"][0, 0] = st["x"][0, 5] + np.array([0.004, 0.002, -0.003], dtn)
+    st["action"] = np.array([[0.3, -0.2, 0.5, *w]], dtn)
+    g["gprot"] = rng.normal(size=(1, S, 4)).astype(dtn)
+    return st, g
+
+
+@pytest.mark.parametrize("clip,material,S,k", [(False, 1, 3, 40), (True, 1, 3, 40), (False, 2, 2, 20)])
+def test_collide_adjoint_matches_autograd_through_twin_f64(demo, clip, material, S, k):
+    """collide_batch (primitives.py:154-182: sdf, finite-difference normal, collider velocity, friction flag) and the
+    rotation chain (qmul / w2quat / forward_kinematics) -- hand-derived adjoint == torch.autograd through the twin, f64."""
+    st, g = _collide_case(demo, S, k, material, 0)
+    orc = MpmOracle(67, steps=S, material=np.full(67, material), position_control=False)
+    of, ob = orc.step_fwd(st), orc.step_bwd(st, g, clip=clip)
+    conf = tw.MPMConf(steps=S)
+    sim = tw.MPMTwin(conf, 67, material=material, dtype=torch.float64, clip_grads=clip, use_position_control=False)
+    L = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    xt, vt, Ct, Ft, pp, pr = L(st["x"][0]), L(st["v"][0]), L(st["C"][0]), L(st["F"][0]), L(st["ppos"][0]), L(st["prot"][0])
+    fr, mu, la, ac = L(st["friction"]), L(st["mu"]), L(st["lamda"]), L(st["action"][0])
+    p = tw.make_prim(conf, [0.02, 0.06, 0.02], [0, 0, 0], torch.float64)._replace(position=pp, rotation=pr)
+    p = p._replace(size=p.size.clone().requires_grad_(True), friction=p.friction.clone().requires_grad_(True))
+    s2 = sim.step(tw.MPMState(xt, vt, Ct, Ft, torch.tensor(st["J"][0]), [p], fr, mu, la), ac)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    loss = (s2.x * T(g["gx"][0])).sum() + (s2.v * T(g["gv"][0])).sum() + (s2.C * T(g["gC"][0])).sum() + \
+        (s2.F * T(g["gF"][0])).sum() + (s2.primitives[0].position * T(g["gppos"][0])).sum() + \
+        (s2.primitives[0].rotation * T(g["gprot"][0])).sum()
+    loss.backward()
+    for key, ref in (("x", s2.x), ("v", s2.v), ("C", s2.C), ("F", s2.F)):
+        assert _rel(of[key][0], ref.detach().numpy()) < 1e-11, key
+    assert _rel(of["prot"][0], s2.primitives[0].rotation.detach().numpy()) < 1e-13
+    # the finite-difference normal amplifies round-off by 0.5/d = 5e5: 1e-16 * 5e5 ~ 5e-11 relative in every cotangent
+    for key, ref in (("gx", xt), ("gv", vt), ("gC", Ct), ("gF", Ft), ("gppos", pp), ("gprot", pr)):
+        assert _rel(ob[key][0], ref.grad.numpy()) < 2e-7, key
+    for key, ref in (("gfriction", fr), ("gmu", mu), ("glamda", la)):
+        assert _rel(ob[key], ref.grad.numpy()) < 2e-7, key
+    assert _rel(ob["gaction"][0], ac.grad.numpy()) < 2e-7
+    assert np.abs(ob["gaction"][0, 3:]).min() > 0 and np.abs(ob["gprot"]).max() > 0
+
+
+def test_collide_zero_rotation_action_is_nan_then_laundered(demo):
+    """w = 0: d|w|/dw = 0.5/0 * 0 -> NaN in the reference's chain rule (jnp.linalg.norm, primitives.py:86); the
+    step-boundary nan_to_num (mpm_simulator.py:403-408) turns it into 0."""
+    st, g = _collide_case(demo, 2, 40, 1, 1, w=(0, 0, 0))
+    orc = MpmOracle(67, steps=2, position_control=False)
+    raw = orc.step_bwd(st, g, clip=False)
+    assert np.isnan(raw["gaction"][0, 3:]).all() and np.isfinite(raw["gaction"][0, :3]).all()
+    assert np.isfinite(raw["gx"]).all() and np.isfinite(raw["gprot"]).all()
+    lau = orc.step_bwd(st, g, clip=True)
+    assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()

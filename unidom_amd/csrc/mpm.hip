@@ -1231,11 +1231,9 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   if (N < 1 || S < 1 || conf->n_grid < 4 || conf->res[0] < 4 || conf->res[1] < 4 || conf->res[2] < 4) {
     ud::set_error("ud_mpm_create: bad sizes (N=%d steps=%d n_grid=%d)", N, S, conf->n_grid); return UD_ERR_INVALID;
   }
-  if (!conf->use_position_control) {
-    ud::set_error("ud_mpm_create: only position-control primitives are implemented (collide_batch is a next row)");
-    return UD_ERR_UNSUPPORTED;
-  }
-  if (S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
+  // soft contact (collide_batch) runs on the many-workgroup path whatever N is: every reference env that uses it has N > 128
+  const bool large = N > 128 || !conf->use_position_control;
+  if (!large && S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
   if (conf->res[0] > 1024 || conf->res[1] > 1024 || conf->res[2] > 1024) { ud::set_error("ud_mpm_create: res > 1024"); return UD_ERR_UNSUPPORTED; }
   auto* h = new ud_mpm;
   ud::MpmConst& c = h->c;
@@ -1247,13 +1245,14 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   c.stress_c = (float)(-(double)conf->dt * (double)conf->p_vol * 4.0);   // :267
   c.dx2 = (float)(dx * dx);
   for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
+  c.position_control = conf->use_position_control ? 1 : 0;
+  c.prim_friction = conf->prim_friction; c.prim_softness = conf->prim_softness;
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
   const size_t per_particle = (N <= 96) ? 64 : 48;   // floats of LDS hand-off per particle in the adjoint (stage+ret / park)
   while (Hh > 1024 && ((size_t)16 * Hh + per_particle * c.Np + (size_t)S * 19 + 72) * sizeof(float) > 160 * 1024) { Hh /= 2; --lg; }   // LDS budget of the adjoint
   c.H = Hh; c.logH = lg;
   c.nthreads = std::max(256, (4 * std::min(N, 128) + 63) / 64 * 64);
-  const bool large = N > 128;
   h->lds_fwd = ((size_t)10 * Hh + (size_t)4 * 10 * h->c.Np + (size_t)S * 11 + 64 + 4) * sizeof(float);   // key, acc (4 doubles), list, stage/ret (10 float4 per particle), primitives + inverse rotations, scratch, count
   h->lds_bwd = ((size_t)16 * Hh + per_particle * h->c.Np + (size_t)S * 19 + 64 + 8) * sizeof(float);  // + gacc (3 doubles), gpv (doubles), stage+ret (16 float4 per particle, N <= 96) or park (12), adjoint primitive arrays
   if (!large && h->lds_bwd > 160 * 1024) { ud::set_error("ud_mpm_create: LDS cell table too large"); delete h; return UD_ERR_UNSUPPORTED; }
@@ -1321,9 +1320,9 @@ int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const floa
 
 int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, const float* friction,
                     const float* mu, const float* lamda, const float* action, const float* g_x, const float* g_v,
-                    const float* g_C, const float* g_F, const float* g_prim_position, int clip, float* g_x0,
-                    float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_friction, float* g_mu,
-                    float* g_lamda, float* g_action, int* status, void* stream) {
+                    const float* g_C, const float* g_F, const float* g_prim_position, const float* g_prim_rotation, int clip,
+                    float* g_x0, float* g_v0, float* g_C0, float* g_F0, float* g_prim_position0, float* g_prim_rotation0,
+                    float* g_friction, float* g_mu, float* g_lamda, float* g_action, int* status, void* stream) {
   if (!h || !ckpt || !prim_size || !friction || !mu || !lamda || !action || !g_x || !g_v || !g_C || !g_F ||
       !g_prim_position || !g_x0 || !g_v0 || !g_C0 || !g_F0 || !g_prim_position0 || !g_friction || !g_mu || !g_lamda ||
       !g_action) {
@@ -1332,8 +1331,10 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
   if (B < 1) { ud::set_error("ud_mpm_step_bwd: B=%d", B); return UD_ERR_INVALID; }
   if (h->large)
     return ud::mpm_large_step_bwd(h->large, B, (const float*)ckpt, prim_size, friction, mu, lamda, action, g_x, g_v, g_C, g_F,
-                                  g_prim_position, clip, g_x0, g_v0, g_C0, g_F0, g_prim_position0, g_friction, g_mu, g_lamda,
-                                  g_action, status, (hipStream_t)stream);
+                                  g_prim_position, g_prim_rotation, clip, g_x0, g_v0, g_C0, g_F0, g_prim_position0, g_prim_rotation0,
+                                  g_friction, g_mu, g_lamda, g_action, status, (hipStream_t)stream);
+  // one-workgroup path = position control: no cotangent reaches the rotation array
+  if (g_prim_rotation0) UD_HIP_CHECK(hipMemsetAsync(g_prim_rotation0, 0, (size_t)B * h->c.steps * 4 * sizeof(float), (hipStream_t)stream));
   ud::MpmBwdArgs a;
   a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B; a.ckpt = (const float*)ckpt;
   a.psize = prim_size; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;

@@ -1,0 +1,221 @@
+// Soft contact between the grid and one box primitive -- collide_batch and what it calls
+//   /root/reference/DaXBench/daxbench/core/engine/primitives/primitives.py
+//     collide_batch :154-182   sdf_batch :112-114   inv_trans_batch :105-109   normal_batch / _normal_batch :117-141
+//     collider_v_batch :144-151   qrot_batch :95-102   length :68-70
+//   /root/reference/DaXBench/daxbench/core/engine/primitives/box.py  _sdf_batch :6-18
+// and its hand-derived adjoint (the reference differentiates it with jax.grad, mpm_simulator.py:339-359).
+//
+// The contact normal is a central difference of the SDF with d = 1e-6 (:119-134): one ulp in the local position
+// moves a normal component by ~0.2 %.  Everything up to the normal therefore runs without FMA contraction and with
+// correctly rounded division / square root, in the reference's operation order; the rest follows the file's flags.
+#pragma once
+#include "mpm_device.h"
+
+namespace ud {
+
+// correctly rounded f32 sqrt / divide whatever the file's -f[no-]hip-fp32-correctly-rounded-divide-sqrt setting:
+// through f64 (53 >= 2*24 + 2 bits, so the second rounding is innocuous)
+__device__ __forceinline__ float sqrt_rte(float x) { return (float)sqrt((double)x); }
+__device__ __forceinline__ float div_rte(float a, float b) { return (float)((double)a / (double)b); }
+
+struct PrimC {            // the primitive as the grid op of substep f sees it (rows f and f + 1, clamped: Q5); uniform
+  float p0[3], r0[4], p1[3], r1[4], iq[4], nq, size[3], soft, mu;
+};
+struct PrimCGrad {        // cotangents one cell adds to the primitive's leaves
+  float p0[3], r0[4], p1[3], r1[4], size[3], mu;
+};
+constexpr int UD_PRIMC_NGRAD = 18;
+
+__device__ __forceinline__ void primc_finish(PrimC& pc) {   // inv_trans_batch :106-107
+#pragma clang fp contract(off)
+  const float c0 = pc.r0[0], c1 = -pc.r0[1], c2 = -pc.r0[2], c3 = -pc.r0[3];
+  pc.nq = sqrt_rte(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3) + 1e-12f;
+  pc.iq[0] = div_rte(c0, pc.nq); pc.iq[1] = div_rte(c1, pc.nq);
+  pc.iq[2] = div_rte(c2, pc.nq); pc.iq[3] = div_rte(c3, pc.nq);
+}
+
+__device__ __forceinline__ void qrot_x(const float* q, const float* v, float* o) {  // :95-102, no contraction
+#pragma clang fp contract(off)
+  float uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
+  float w0 = q[2] * uv2 - q[3] * uv1, w1 = q[3] * uv0 - q[1] * uv2, w2 = q[1] * uv1 - q[2] * uv0;
+  o[0] = v[0] + 2.f * (q[0] * uv0 + w0);
+  o[1] = v[1] + 2.f * (q[0] * uv1 + w1);
+  o[2] = v[2] + 2.f * (q[0] * uv2 + w2);
+}
+
+__device__ __forceinline__ float box_sdf_x(const float* size, float p0, float p1, float p2) {  // box.py:6-18
+#pragma clang fp contract(off)
+  const float q0 = clipf(fabsf(p0) - size[0], 0.f, INFINITY);
+  const float q1 = clipf(fabsf(p1) - size[1], 0.f, INFINITY);
+  const float q2 = clipf(fabsf(p2) - size[2], 0.f, INFINITY);
+  const float out = sqrt_rte(q0 * q0 + q1 * q1 + q2 * q2 + 1e-12f);
+  float tmp = q1 > q2 ? q1 : q2;
+  tmp = q0 > tmp ? q0 : tmp;
+  tmp = clipf(tmp, -INFINITY, 0.f);
+  return out + tmp;
+}
+
+// accumulates the cotangents of p and size for a cotangent gout of box_sdf(size, p)
+__device__ __forceinline__ void box_sdf_bwd(const float* size, float p0, float p1, float p2, float gout, float* gp, float* gsize) {
+  const float p[3] = {p0, p1, p2};
+  float xr[3], q[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { xr[a] = fabsf(p[a]) - size[a]; q[a] = clipf(xr[a], 0.f, INFINITY); }
+  const float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + 1e-12f);
+  const bool s12 = q[1] > q[2];
+  const float q12 = s12 ? q[1] : q[2];
+  const bool s0 = q[0] > q12;
+  const float qsel = s0 ? q[0] : q12;
+  const float gt = gout * clip_grad(qsel, -INFINITY, 0.f);
+  const bool sel[3] = {s0, !s0 && s12, !s0 && !s12};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float gq = gout * q[a] / len + (sel[a] ? gt : 0.f);
+    const float gx = gq * clip_grad(xr[a], 0.f, INFINITY);
+    const float sg = p[a] > 0.f ? 1.f : (p[a] < 0.f ? -1.f : 0.f);
+    gp[a] += gx * sg;
+    gsize[a] -= gx;
+  }
+}
+
+// qrot adjoint: accumulates into gq[4], gv[3]
+__device__ __forceinline__ void qrot_bwd(const float* q, const float* v, const float* go, float* gq, float* gv) {
+  const float uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
+  gq[0] += 2.f * (go[0] * uv0 + go[1] * uv1 + go[2] * uv2);
+  float gu0 = 2.f * q[0] * go[0], gu1 = 2.f * q[0] * go[1], gu2 = 2.f * q[0] * go[2];
+  const float h0 = 2.f * go[0], h1 = 2.f * go[1], h2 = 2.f * go[2];        // cotangent of uuv
+  gq[1] += uv1 * h2 - uv2 * h1; gq[2] += uv2 * h0 - uv0 * h2; gq[3] += uv0 * h1 - uv1 * h0;   // uv x g_uuv
+  gu0 += h1 * q[3] - h2 * q[2]; gu1 += h2 * q[1] - h0 * q[3]; gu2 += h0 * q[2] - h1 * q[1];   // g_uuv x qv
+  gq[1] += v[1] * gu2 - v[2] * gu1; gq[2] += v[2] * gu0 - v[0] * gu2; gq[3] += v[0] * gu1 - v[1] * gu0;   // v x g_uv
+  gv[0] += go[0] + (gu1 * q[3] - gu2 * q[2]);
+  gv[1] += go[1] + (gu2 * q[1] - gu0 * q[3]);
+  gv[2] += go[2] + (gu0 * q[2] - gu1 * q[1]);
+}
+
+struct CollideRec {
+  float rel[3], loc[3], e, infl, n[3], len, nl[3], D[3], cv[3], iv[3], nc, m, vt[3], vtn, arg, c, vtp[3];
+  bool flag;
+};
+
+// collide_batch (:154-182) for the cell at world position gp: v -> vo
+__device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const float* gp, const float* v, float* vo, CollideRec& r) {
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
+    qrot_x(pc.iq, r.rel, r.loc);
+    const float dist = box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2]);
+    r.e = expf(-dist * pc.soft);
+    r.infl = clipf(r.e, -INFINITY, 1.f);
+    const float d = 1.e-6f, k = 500000.f;   // (0.5 / d)
+    r.n[0] = k * (box_sdf_x(pc.size, r.loc[0] + d, r.loc[1], r.loc[2]) - box_sdf_x(pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2]));
+    r.n[1] = k * (box_sdf_x(pc.size, r.loc[0], r.loc[1] + d, r.loc[2]) - box_sdf_x(pc.size, r.loc[0], r.loc[1] + (-d), r.loc[2]));
+    r.n[2] = k * (box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2] + d) - box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2] + (-d)));
+    r.len = sqrt_rte(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + 1e-12f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r.nl[a] = div_rte(r.n[a], r.len);
+    qrot_x(pc.r0, r.nl, r.D);
+    float np_[3];
+    qrot_x(pc.r1, r.loc, np_);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) r.cv[a] = div_rte((np_[a] + pc.p1[a]) - gp[a], dt);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) r.iv[a] = v[a] - r.cv[a];
+  r.nc = r.iv[0] * r.D[0] + r.iv[1] * r.D[1] + r.iv[2] * r.D[2];
+  r.m = clipf(r.nc, -INFINITY, 0.f);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) r.vt[a] = r.iv[a] - r.m * r.D[a];
+  const float vt_dot = r.vt[0] * r.vt[0] + r.vt[1] * r.vt[1] + r.vt[2] * r.vt[2];
+  r.vtn = sqrtf(vt_dot + 1e-12f);
+  r.arg = r.vtn + r.nc * pc.mu;
+  r.c = clipf(r.arg, 1e-12f, INFINITY);
+  r.flag = (r.nc < 0.f) && (sqrtf(vt_dot) > 1e-12f);
+  const float fl = r.flag ? 1.f : 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float vtf = r.vt[a] / r.vtn * r.c;
+    r.vtp[a] = vtf * fl + r.vt[a] * (1.f - fl);
+    vo[a] = r.cv[a] + r.iv[a] * (1.f - r.infl) + r.vtp[a] * r.infl;
+  }
+}
+
+// adjoint: gout (cotangent of vo) -> gv (cotangent of v); pg receives this cell's share of the primitive's cotangents
+__device__ __forceinline__ void collide_cell_bwd(const PrimC& pc, float dt, const float* gp, const float* v, const float* gout,
+                                                 float* gv, PrimCGrad& pg) {
+  CollideRec r;
+  float vo[3];
+  collide_cell(pc, dt, gp, v, vo, r);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { pg.p0[a] = 0.f; pg.p1[a] = 0.f; pg.size[a] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { pg.r0[a] = 0.f; pg.r1[a] = 0.f; }
+  float gcv[3], giv[3], gvtp[3], ginfl = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gcv[a] = gout[a]; giv[a] = gout[a] * (1.f - r.infl); gvtp[a] = gout[a] * r.infl;
+    ginfl += gout[a] * (r.vtp[a] - r.iv[a]);
+  }
+  float gvt[3], gnc = 0.f;
+  {
+    const float fl = r.flag ? 1.f : 0.f;
+    float gc = 0.f, gu_vt = 0.f, gvtn = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float gvtf = gvtp[a] * fl;
+      gvt[a] = gvtp[a] * (1.f - fl);
+      gc += gvtf * (r.vt[a] / r.vtn);
+      const float gu = gvtf * r.c;
+      gvt[a] += gu / r.vtn;
+      gu_vt += gu * r.vt[a];
+    }
+    gvtn -= gu_vt / (r.vtn * r.vtn);
+    const float garg = gc * clip_grad(r.arg, 1e-12f, INFINITY);
+    gvtn += garg; gnc += garg * pc.mu; pg.mu = garg * r.nc;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gvt[a] += gvtn * r.vt[a] / r.vtn;
+  }
+  float gD[3], gm = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { giv[a] += gvt[a]; gm -= gvt[a] * r.D[a]; gD[a] = -r.m * gvt[a]; }
+  gnc += gm * clip_grad(r.nc, -INFINITY, 0.f);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { giv[a] += gnc * r.D[a]; gD[a] += gnc * r.iv[a]; }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gv[a] = giv[a]; gcv[a] -= giv[a]; }
+  float gloc[3] = {0.f, 0.f, 0.f}, gnp[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { gnp[a] = gcv[a] / dt; pg.p1[a] += gnp[a]; }
+  qrot_bwd(pc.r1, r.loc, gnp, pg.r1, gloc);
+  float gnl[3] = {0.f, 0.f, 0.f};
+  qrot_bwd(pc.r0, r.nl, gD, pg.r0, gnl);
+  const float dotn = gnl[0] * r.n[0] + gnl[1] * r.n[1] + gnl[2] * r.n[2];
+  const float glen = -dotn / (r.len * r.len);
+  const float d = 1.e-6f, k = 500000.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float gn = gnl[a] / r.len + glen * r.n[a] / r.len;
+    const float i0 = r.loc[0] + (a == 0 ? d : 0.f), i1 = r.loc[1] + (a == 1 ? d : 0.f), i2 = r.loc[2] + (a == 2 ? d : 0.f);
+    const float d0 = r.loc[0] + (a == 0 ? -d : 0.f), d1 = r.loc[1] + (a == 1 ? -d : 0.f), d2 = r.loc[2] + (a == 2 ? -d : 0.f);
+    box_sdf_bwd(pc.size, i0, i1, i2, k * gn, gloc, pg.size);
+    box_sdf_bwd(pc.size, d0, d1, d2, -(k * gn), gloc, pg.size);
+  }
+  const float ge = ginfl * clip_grad(r.e, -INFINITY, 1.f);
+  const float gdist = -(ge * r.e) * pc.soft;
+  box_sdf_bwd(pc.size, r.loc[0], r.loc[1], r.loc[2], gdist, gloc, pg.size);
+  float giq[4] = {0.f, 0.f, 0.f, 0.f}, grel[3] = {0.f, 0.f, 0.f};
+  qrot_bwd(pc.iq, r.rel, gloc, giq, grel);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) pg.p0[a] -= grel[a];
+  const float cq[4] = {pc.r0[0], -pc.r0[1], -pc.r0[2], -pc.r0[3]};
+  const float nrm = pc.nq - 1e-12f;
+  const float dq = giq[0] * cq[0] + giq[1] * cq[1] + giq[2] * cq[2] + giq[3] * cq[3];
+  const float gnq = -dq / (pc.nq * pc.nq);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float gcq = giq[a] / pc.nq + gnq * cq[a] / nrm;
+    pg.r0[a] += (a == 0) ? gcq : -gcq;
+  }
+}
+
+}  // namespace ud

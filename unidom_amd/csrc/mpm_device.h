@@ -13,6 +13,8 @@ struct MpmConst {
   int N, Np, n_grid, res[3], steps;
   float dt, dx, inv_dx, p_mass, p_vol, stress_c, dx2, dtg[3];
   int H, logH, nthreads;
+  int position_control;            // 1: position_control_batch, 0: collide_batch (soft contact)
+  float prim_friction, prim_softness;   // PrimitiveState.friction / .softness (collide_batch only)
 };
 
 // ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------
@@ -171,6 +173,9 @@ struct CellRec {
   bool ctrl, fric, bnd[3];
 };
 
+template <bool REC>
+__device__ __forceinline__ void grid_tail(const MpmConst& c, float friction, int ci, int cj, int ck, float* v, float* vo, CellRec* rec);
+
 // grid op of one cell (:283-313): (m, mv) -> v.  REC: keep what the adjoint needs.
 template <bool REC>
 __device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int ci, int cj, int ck, float m,
@@ -184,7 +189,14 @@ __device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int 
   const bool ctrl = box_sdf(pf.size, loc) < pf.size[0] * 1.5f;   // :232-239
 #pragma unroll
   for (int a = 0; a < 3; ++a) v[a] = ctrl ? pf.pv[a] / c.dt : v[a];
-  if (REC) { rec->ctrl = ctrl; rec->v1[0] = v[0]; rec->v1[1] = v[1]; rec->v1[2] = v[2]; }
+  if (REC) rec->ctrl = ctrl;
+  grid_tail<REC>(c, pf.friction, ci, cj, ck, v, vo, rec);
+}
+
+// ground friction (:297-307) and boundary (:310-313) of one cell: v (after the primitive op) -> vo
+template <bool REC>
+__device__ __forceinline__ void grid_tail(const MpmConst& c, float friction, int ci, int cj, int ck, float* v, float* vo, CellRec* rec) {
+  if (REC) { rec->v1[0] = v[0]; rec->v1[1] = v[1]; rec->v1[2] = v[2]; }
   const bool fric = (cj < 3) && (v[1] <= 0.f);                    // :297-307
   {
     float g0 = (float)ci, g1 = (float)cj, g2 = (float)ck;
@@ -192,7 +204,7 @@ __device__ __forceinline__ void grid_op(const MpmConst& c, const PrimF& pf, int 
     float vit0 = v[0] - lin * 0.f - g0 * 1e-30f, vit1 = v[1] - lin * 1.f - g1 * 1e-30f, vit2 = v[2] - lin * 0.f - g2 * 1e-30f;
     float e0 = vit0 + 1e-12f, e1 = vit1 + 1e-12f, e2 = vit2 + 1e-12f;
     float lit = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-    float s = clipf(1.f + pf.friction * lin / lit, 0.f, INFINITY);
+    float s = clipf(1.f + friction * lin / lit, 0.f, INFINITY);
     float f0 = s * (vit0 + g0 * 1e-30f), f2 = s * (vit2 + g2 * 1e-30f);
     v[0] = fric ? f0 : v[0];
     v[1] = fric ? 0.f : v[1];
@@ -300,6 +312,9 @@ __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, 
 }
 
 
+__device__ __forceinline__ void grid_tail_adjoint(float friction, int ci, int cj, int ck, const CellRec& rec, float* g, float& dfric);
+__device__ __forceinline__ void grid_head_adjoint(float m, const float* mvv, float* g, float& gmm);
+
 // Adjoint of grid_op for one cell: g (cotangent of the cell's output velocity, in) -> g (cotangent of mv, out),
 // gmm (cotangent of m), dfric (contribution to d state.friction), dpv (contribution to d primitive v[f], valid
 // when the function returns true = the cell is position-controlled).  Reverse of :283-313.
@@ -308,6 +323,17 @@ __device__ __forceinline__ bool grid_op_adjoint(const MpmConst& c, const PrimF& 
   float vo[3];
   CellRec rec;
   grid_op<true>(c, pf, ci, cj, ck, m, mvv, vo, &rec);
+  grid_tail_adjoint(pf.friction, ci, cj, ck, rec, g, dfric);
+  if (rec.ctrl) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { dpv[d] = g[d] / c.dt; g[d] = 0.f; }
+  }
+  grid_head_adjoint(m, mvv, g, gmm);
+  return rec.ctrl;
+}
+
+// reverse of grid_tail: g (cotangent of vo) -> cotangent of v; dfric = contribution to d state.friction
+__device__ __forceinline__ void grid_tail_adjoint(float friction, int ci, int cj, int ck, const CellRec& rec, float* g, float& dfric) {
   dfric = 0.f;
 #pragma unroll
   for (int d = 0; d < 3; ++d) g[d] = rec.bnd[d] ? 0.f : g[d];
@@ -318,24 +344,24 @@ __device__ __forceinline__ bool grid_op_adjoint(const MpmConst& c, const PrimF& 
     float vit[3] = {vv[0] - g0 * 1e-30f, vv[1] - lin - g1 * 1e-30f, vv[2] - g2 * 1e-30f};
     float e[3] = {vit[0] + 1e-12f, vit[1] + 1e-12f, vit[2] + 1e-12f};
     float lit = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-    float arg = 1.f + pf.friction * lin / lit;
+    float arg = 1.f + friction * lin / lit;
     float sc = clipf(arg, 0.f, INFINITY);
     float qv0 = vit[0] + g0 * 1e-30f, qv2 = vit[2] + g2 * 1e-30f;
     float gs_ = g[0] * qv0 + g[2] * qv2;
     float gvit[3] = {sc * g[0], 0.f, sc * g[2]};
     float garg = gs_ * clip_grad(arg, 0.f, INFINITY);
     dfric = garg * lin / lit;
-    float glin = garg * pf.friction / lit;
-    float glit = -garg * pf.friction * lin / (lit * lit);
+    float glin = garg * friction / lit;
+    float glit = -garg * friction * lin / (lit * lit);
 #pragma unroll
     for (int d = 0; d < 3; ++d) gvit[d] += glit * e[d] / lit;
     glin -= gvit[1];
     g[0] = gvit[0]; g[1] = gvit[1] + glin; g[2] = gvit[2];
   }
-  if (rec.ctrl) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { dpv[d] = g[d] / c.dt; g[d] = 0.f; }
-  }
+}
+
+// reverse of v = where(m > 0, mv / m, mv) + dt g (:283-285): g (cotangent of v) -> cotangent of mv, gmm of m
+__device__ __forceinline__ void grid_head_adjoint(float m, const float* mvv, float* g, float& gmm) {
   if (m > 0.f) {
     gmm = 0.f;
 #pragma unroll
@@ -345,7 +371,6 @@ __device__ __forceinline__ bool grid_op_adjoint(const MpmConst& c, const PrimF& 
   } else {                 // m < 0 (negative quadratic weights below dx/2, Q13): pass-through branch
     gmm = 0.f;
   }
-  return rec.ctrl;
 }
 
 // Adjoint of the particle pre-pass (:233-268) given the gathered stencil cotangents:

@@ -14,7 +14,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
                        float* prot_o, float* pv_o, float* pw_o, float* ckpt, int* status, hipStream_t st);
 int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, const float* gx, const float* gv, const float* gC, const float* gF,
-                       const float* gppos, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0, float* gfric,
-                       float* gmu, float* glam, float* gaction, int* status, hipStream_t st);
+                       const float* gppos, const float* gprot, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
+                       float* grot0, float* gfric, float* gmu, float* glam, float* gaction, int* status, hipStream_t st);
 
 }  // namespace ud

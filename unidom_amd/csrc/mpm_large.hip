@@ -13,6 +13,7 @@
 // next optimisation step for this path).
 #include "mpm_device.h"
 #include "mpm_large.h"
+#include "mpm_collide.h"
 
 namespace ud {
 
@@ -33,6 +34,9 @@ struct LargeBuf {
   float* pscr;      // [B][Np][12] bwd: per-particle gw[9], gfx[3] between kernels
   float* hist;      // [B][2][24][Np] ping-pong state when the caller passes no checkpoint
   float* gstate;    // [B][24][Np] bwd: cotangent state (gx,gv,gC,gF) SoA
+  float* grot;      // [B][S*4]  bwd, soft contact: cotangent of the rotation array
+  float* gpw;       // [B][S*3]  bwd, soft contact: cotangent of the angular velocity rows
+  float* gpsz;      // [B][4]    bwd, soft contact: cotangents of primitive size[3] and friction (enter the norm only)
 };
 
 struct LargeArgs {
@@ -75,6 +79,19 @@ __device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, 
   float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;
   pf.iq[0] = r0 / n; pf.iq[1] = r1 / n; pf.iq[2] = r2 / n; pf.iq[3] = r3 / n;
   pf.friction = a.friction[b];
+}
+
+// soft contact: rows f and f + 1 (clamped, Q5) of the primitive arrays
+__device__ __forceinline__ void load_primc(const LargeArgs& a, int b, PrimC& pc) {
+  const int S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
+  const float* pp = a.w.ppos + (long)b * S * 3;
+  const float* pr = a.w.prot + (long)b * S * 4;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { pc.p0[d] = pp[f0 * 3 + d]; pc.p1[d] = pp[f1 * 3 + d]; pc.size[d] = a.psize[b * 3 + d]; }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) { pc.r0[d] = pr[f0 * 4 + d]; pc.r1[d] = pr[f1 * 4 + d]; }
+  pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction;
+  primc_finish(pc);
 }
 
 __device__ __forceinline__ void load_state(const float* h, int Np, int p, float* x, float* v, float* Cm, float* F) {
@@ -300,13 +317,25 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
   int ci, cj, ck;
   decode_cell(a.c, key, ci, cj, ck);
   const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-  PrimF pf;
-  float pv[3];
-  load_prim(a, b, pf, pv);
   const float4 mv = a.w.val[(long)b * a.G + lin];
   const float mvv[3] = {mv.y, mv.z, mv.w};
   float vo[3];
-  grid_op<false>(a.c, pf, ci, cj, ck, mv.x, mvv, vo, nullptr);
+  if (a.c.position_control) {
+    PrimF pf;
+    float pv[3];
+    load_prim(a, b, pf, pv);
+    grid_op<false>(a.c, pf, ci, cj, ck, mv.x, mvv, vo, nullptr);
+  } else {                                                          // collide_batch (primitives.py:154-182)
+    PrimC pc;
+    load_primc(a, b, pc);
+    float v0[3], v1[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+    const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+    CollideRec cr;
+    collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+    grid_tail<false>(a.c, a.friction[b], ci, cj, ck, v1, vo, nullptr);
+  }
   if (to_vel) a.w.vel[(long)b * a.G + lin] = make_float4(vo[0], vo[1], vo[2], 0.f);
   else a.w.val[(long)b * a.G + lin] = make_float4(mv.x, vo[0], vo[1], vo[2]);
 }
@@ -456,6 +485,48 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
     if (e < S * 3) { gp[e] = val; gpv[e] += t; }
     __syncthreads();
   }
+  // soft contact: rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))  (primitives.py:190, :73-92)
+  if (!a.c.position_control && threadIdx.x == 0 && f + 1 < S) {
+    float* gr_ = a.w.grot + (long)b * S * 4;
+    const float* rr = a.w.prot + (long)b * S * 4 + f * 4;
+    float go[4], w[3];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { go[d] = gr_[(f + 1) * 4 + d]; gr_[(f + 1) * 4 + d] = 0.f; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w[d] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+    const float s2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const float nrm = sqrtf(s2), ang = nrm + 1e-12f, hh = ang / 2.f, sn = sinf(hh), cs = cosf(hh);
+    const float u[3] = {w[0] / ang, w[1] / ang, w[2] / ang};
+    const float q[4] = {cs, u[0] * sn, u[1] * sn, u[2] * sn};
+    const float o[4] = {rr[0] * q[0] - rr[1] * q[1] - rr[2] * q[2] - rr[3] * q[3],
+                        rr[0] * q[1] + rr[1] * q[0] - rr[2] * q[3] + rr[3] * q[2],
+                        rr[0] * q[2] + rr[1] * q[3] + rr[2] * q[0] - rr[3] * q[1],
+                        rr[0] * q[3] - rr[1] * q[2] + rr[2] * q[1] + rr[3] * q[0]};
+    const float oo = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    const float nn = clipf(oo, 1e-12f, INFINITY);
+    const float dot = go[0] * o[0] + go[1] * o[1] + go[2] * o[2] + go[3] * o[3];
+    const float goo = -dot / (nn * nn) * clip_grad(oo, 1e-12f, INFINITY);
+    float gO[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) gO[d] = go[d] / nn + goo * o[d] / oo;
+    gr_[f * 4 + 0] += gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3];
+    gr_[f * 4 + 1] += -gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2];
+    gr_[f * 4 + 2] += -gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1];
+    gr_[f * 4 + 3] += -gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0];
+    const float gq[4] = {gO[0] * rr[0] + gO[1] * rr[1] + gO[2] * rr[2] + gO[3] * rr[3],
+                         -gO[0] * rr[1] + gO[1] * rr[0] - gO[2] * rr[3] + gO[3] * rr[2],
+                         -gO[0] * rr[2] + gO[1] * rr[3] + gO[2] * rr[0] - gO[3] * rr[1],
+                         -gO[0] * rr[3] - gO[1] * rr[2] + gO[2] * rr[1] + gO[3] * rr[0]};
+    float gh = -sn * gq[0], gsn = 0.f, gang = 0.f, gw[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gsn += gq[1 + d] * u[d]; const float gu = gq[1 + d] * sn; gw[d] = gu / ang; gang -= gu * w[d] / (ang * ang); }
+    gh += cs * gsn;
+    gang += gh / 2.f;
+    // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule is 0.5/0 * 0 = NaN, laundered by nan_to_num at `step`
+    const float gs = gang * (0.5f / nrm);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a.w.gpw[(long)b * S * 3 + f * 3 + d] += gw[d] + gs * (2.f * w[d]);
+  }
 }
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
@@ -541,27 +612,74 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 
 // grid-op adjoint over the active cells
 __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
+  __shared__ float red[4][UD_PRIMC_NGRAD];
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int cur = a.f & 1;
-  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
-  const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
-  int ci, cj, ck;
-  decode_cell(a.c, key, ci, cj, ck);
-  const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-  PrimF pf;
-  float pv[3];
-  load_prim(a, b, pf, pv);
-  const float4 mv = a.w.val[(long)b * a.G + lin];
-  const float mvv[3] = {mv.y, mv.z, mv.w};
-  const float4 g4 = a.w.gacc[(long)b * a.G + lin];
-  float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric, dpv[3];
-  const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
-  if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-  if (ctrl) {
+  const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
+  if (a.c.position_control && !live) return;
+  float pgv[UD_PRIMC_NGRAD];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
+  for (int d = 0; d < UD_PRIMC_NGRAD; ++d) pgv[d] = 0.f;
+  if (live) {
+    const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
+    int ci, cj, ck;
+    decode_cell(a.c, key, ci, cj, ck);
+    const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
+    const float4 mv = a.w.val[(long)b * a.G + lin];
+    const float mvv[3] = {mv.y, mv.z, mv.w};
+    const float4 g4 = a.w.gacc[(long)b * a.G + lin];
+    float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric;
+    if (a.c.position_control) {
+      PrimF pf;
+      float pv[3], dpv[3];
+      load_prim(a, b, pf, pv);
+      const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
+      if (ctrl) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
+      }
+    } else {
+      PrimC pc;
+      load_primc(a, b, pc);
+      float v0[3], v1[3], vo[3], gin[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+      const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+      CollideRec cr;
+      CellRec rec;
+      collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+      grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
+      grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
+      PrimCGrad pg;
+      collide_cell_bwd(pc, a.c.dt, gp, v0, g, gin, pg);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { g[d] = gin[d]; pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
+      pgv[17] = pg.mu;
+      grid_head_adjoint(mv.x, mvv, g, gmm);
+    }
+    if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
   }
-  a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+  if (a.c.position_control) return;
+  // the primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
+#pragma unroll
+  for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
+    const float sum = wave_sum(pgv[d]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
+  }
+  __syncthreads();
+  if (threadIdx.x < UD_PRIMC_NGRAD) {
+    const int d = threadIdx.x, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
+    const float tot = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+    float* dst = (d < 3)    ? a.w.gppos + (long)b * S * 3 + f0 * 3 + d
+                 : (d < 7)  ? a.w.grot + (long)b * S * 4 + f0 * 4 + (d - 3)
+                 : (d < 10) ? a.w.gppos + (long)b * S * 3 + f1 * 3 + (d - 7)
+                 : (d < 14) ? a.w.grot + (long)b * S * 4 + f1 * 4 + (d - 10)
+                            : a.w.gpsz + b * 4 + (d - 14);
+    if (tot != 0.f) atomicAdd(dst, tot);
+  }
 }
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
@@ -637,7 +755,8 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
 }
 
 // backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
-__global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_tail, long ck_stride_b, const float* gppos) {
+__global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_tail, long ck_stride_b, const float* gppos,
+                                                 const float* gprot) {
   const int b = blockIdx.x, S = a.c.steps;
   const float* tail = ck_tail + (long)b * ck_stride_b;
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
@@ -652,24 +771,40 @@ __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_ta
     }
     a.w.gppos[(long)b * S * 3 + e] = g;
   }
-  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[(long)b * S * 4 + e] = tail[S * 3 + e];
+  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) {
+    a.w.prot[(long)b * S * 4 + e] = tail[S * 3 + e];
+    const int row = e / 4, d = e - row * 4;
+    float g = gprot ? gprot[(long)b * S * 4 + e] : 0.f;          // copy_frame adjoint: rotation[0] <- rotation[steps - 1]
+    if (S > 1 && gprot) {
+      if (row == 0) g = 0.f;
+      if (row == S - 1) g += gprot[(long)b * S * 4 + d];
+    }
+    a.w.grot[(long)b * S * 4 + e] = g;
+  }
+  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) a.w.gpw[(long)b * S * 3 + e] = 0.f;
+  if (threadIdx.x < 4) a.w.gpsz[b * 4 + threadIdx.x] = 0.f;
   if (threadIdx.x < 4) a.w.acc[b * 4 + threadIdx.x] = 0.f;
   if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
 }
 
 // backward epilogue: set_action adjoint, action clip, norm_grad / norm_grad_state, outputs (one block per env)
 __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
-                                                  float* gfric, float* gmu, float* glam, float* gaction) {
+                                                  float* gfric, float* gmu, float* glam, float* gaction, float* grot0) {
   __shared__ float red[8];
   const int b = blockIdx.x, S = a.c.steps, N = a.c.N, Np = a.c.Np, tid = threadIdx.x;
   float* gs = a.w.gstate + (long)b * 24 * Np;
   float* gp = a.w.gppos + (long)b * S * 3;
-  float ac[6], ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[3] = {0.f, 0.f, 0.f};
+  float* gr = a.w.grot + (long)b * S * 4;
+  float ac[6], ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int d = 0; d < 6; ++d) ac[d] = clipf(a.action[b * 6 + d], -1.f, 1.f);
   for (int j = 0; j < S; ++j)
 #pragma unroll
     for (int d = 0; d < 3; ++d) { const float t = a.w.gpv[(long)b * S * 3 + j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
+  if (!a.c.position_control)   // soft contact: the rotation chain reaches action[3:6] (position control: reported as 0, see unidom_hip.h)
+    for (int j = 0; j < S; ++j)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { const float t = a.w.gpw[(long)b * S * 3 + j * 3 + d]; ga[3 + d] += t * 1.f / (float)S; gscale[3 + d] += t * ac[3 + d] / (float)S; }
 #pragma unroll
   for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
   float tf = a.w.acc[b * 4 + 0], tm = a.w.acc[b * 4 + 1], tl = a.w.acc[b * 4 + 2];
@@ -689,11 +824,16 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
       if (p < N) { const float t = nan_to_num(gs[e] + 0.f); gs[e] = t; s2 += t * t; }
     }
     for (int e = tid; e < S * 3; e += blockDim.x) { const float t = nan_to_num(gp[e] + 0.f); gp[e] = t; s2 += t * t; }
+    if (!a.c.position_control)
+      for (int e = tid; e < S * 4; e += blockDim.x) { const float t = nan_to_num(gr[e] + 0.f); gr[e] = t; s2 += t * t; }
     tf = nan_to_num(tf); tm = nan_to_num(tm); tl = nan_to_num(tl);
     if (tid == 0) {
       s2 += tf * tf + tm * tm + tl * tl;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+      for (int d = 0; d < 6; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+      if (!a.c.position_control)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { const float t = nan_to_num(a.w.gpsz[b * 4 + d]); s2 += t * t; }
     }
     s2 = wave_sum(s2);
     if ((tid & 63) == 0) red[tid >> 6] = s2;
@@ -716,6 +856,8 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
     }
   }
   for (int e = tid; e < S * 3; e += blockDim.x) gppos0[(long)b * S * 3 + e] = sc ? gp[e] / sn : gp[e];
+  if (grot0)
+    for (int e = tid; e < S * 4; e += blockDim.x) grot0[(long)b * S * 4 + e] = a.c.position_control ? 0.f : (sc ? gr[e] / sn : gr[e]);
   if (tid == 0) {
     gfric[b] = sc ? tf / sn : tf; gmu[b] = sc ? tm / sn : tm; glam[b] = sc ? tl / sn : tl;
 #pragma unroll
@@ -773,6 +915,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_trq = take((size_t)B * S * 4), o_gppos = take((size_t)B * S * 3 * 4), o_gpv = take((size_t)B * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 12 * 4);
   const size_t o_hist = take((size_t)B * 2 * 24 * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
+  const size_t o_grot = take((size_t)B * S * 4 * 4), o_gpw = take((size_t)B * S * 3 * 4), o_gpsz = take((size_t)B * 4 * 4);
   hipError_t e = hipMalloc(&L->arena, off);
   if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
   e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, stamps and counters start at zero
@@ -784,6 +927,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   L->w.trq = (float*)(base + o_trq); L->w.gppos = (float*)(base + o_gppos); L->w.gpv = (float*)(base + o_gpv);
   L->w.acc = (float*)(base + o_acc); L->w.pscr = (float*)(base + o_pscr); L->w.hist = (float*)(base + o_hist);
   L->w.gstate = (float*)(base + o_gstate);
+  L->w.grot = (float*)(base + o_grot); L->w.gpw = (float*)(base + o_gpw); L->w.gpsz = (float*)(base + o_gpsz);
   L->arena_bytes = off; L->B = B; L->epoch = 1;
   return UD_OK;
 }
@@ -843,8 +987,8 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
 
 int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, const float* gx, const float* gv, const float* gC, const float* gF,
-                       const float* gppos, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0, float* gfric,
-                       float* gmu, float* glam, float* gaction, int* status, hipStream_t st) {
+                       const float* gppos, const float* gprot, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
+                       float* grot0, float* gfric, float* gmu, float* glam, float* gaction, int* status, hipStream_t st) {
   int rc = reserve(L, B, st);
   if (rc) return rc;
   const MpmConst& c = L->c;
@@ -857,7 +1001,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const long rec = (long)24 * Np;
   const long stride_b = (long)(S + 1) * rec + (long)S * 10;
   a.hist_stride_b = stride_b;
-  hipLaunchKernelGGL(lg_bwd_in, dim3(B), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos);
+  hipLaunchKernelGGL(lg_bwd_in, dim3(B), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
   hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
   for (int f = S - 1; f >= 0; --f) {
     // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
@@ -873,7 +1017,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   }
   a.f = -1; a.epoch = L->epoch++;
   hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-  hipLaunchKernelGGL(lg_bwd_out, dim3(B), blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction);
+  hipLaunchKernelGGL(lg_bwd_out, dim3(B), blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_bwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }

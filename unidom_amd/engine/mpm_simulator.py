@@ -70,7 +70,10 @@ class _Step(torch.autograd.Function):
         sim.status_log.append(status)
         ctx.sim, ctx.B = sim, B
         ctx.save_for_backward(ckpt, psize, friction, mu, lamda, action)
-        ctx.mark_non_differentiable(Jo, pro, pvo, pwo)
+        if sim.use_position_control:
+            ctx.mark_non_differentiable(Jo, pro, pvo, pwo)
+        else:                                  # soft contact: the rotation array carries gradient (collide_batch)
+            ctx.mark_non_differentiable(Jo, pvo, pwo)
         return xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo
 
     @staticmethod
@@ -83,8 +86,8 @@ class _Step(torch.autograd.Function):
         N, S, dev = sim.n_particles, sim.conf.steps, psize.device
         z = lambda t, shape: (torch.zeros(shape, device=dev) if t is None else t.to(torch.float32).contiguous())
         gx, gv, gC, gF = z(gx, (B, N, 3)), z(gv, (B, N, 3)), z(gC, (B, N, 3, 3)), z(gF, (B, N, 3, 3))
-        gppos = z(gppos, (B, S, 3))
-        ox, ov, oC, oF, opp = (torch.empty_like(t) for t in (gx, gv, gC, gF, gppos))
+        gppos, gprot = z(gppos, (B, S, 3)), z(gprot, (B, S, 4))
+        ox, ov, oC, oF, opp, opr = (torch.empty_like(t) for t in (gx, gv, gC, gF, gppos, gprot))
         ofr, omu, ola = (torch.empty((B,), device=dev) for _ in range(3))
         oa = torch.empty((B, 6), device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
@@ -92,12 +95,12 @@ class _Step(torch.autograd.Function):
         ev = sim._prof_begin("bwd")
         _lib.check(L.ud_mpm_step_bwd(
             sim._h, C.c_int(B), _lib.ptr(ckpt), *[_lib.ptr(t) for t in (psize, friction, mu, lamda, action)],
-            *[_lib.ptr(t) for t in (gx, gv, gC, gF, gppos)], C.c_int(1 if sim.clip_grad else 0),
-            *[_lib.ptr(t) for t in (ox, ov, oC, oF, opp, ofr, omu, ola, oa)], _lib.ptr(status), stream), "ud_mpm_step_bwd")
+            *[_lib.ptr(t) for t in (gx, gv, gC, gF, gppos, gprot)], C.c_int(1 if sim.clip_grad else 0),
+            *[_lib.ptr(t) for t in (ox, ov, oC, oF, opp, opr, ofr, omu, ola, oa)], _lib.ptr(status), stream), "ud_mpm_step_bwd")
         sim._prof_end(ev)
         sim.status_log.append(status)
         fs, ms, ls = ctx.pshape
-        return (None, ox, ov, oC, oF, None, opp, None, None, ofr.reshape(fs), omu.reshape(ms), ola.reshape(ls), oa)
+        return (None, ox, ov, oC, oF, None, opp, opr, None, ofr.reshape(fs), omu.reshape(ms), ola.reshape(ls), oa)
 
 
 class SimpleMPMSimulator:
@@ -121,6 +124,7 @@ class SimpleMPMSimulator:
         self.material = None
         self.h = None
         self.clip_grad = True            # norm_grad_state / norm_grad (:375-411)
+        self.prim_friction, self.prim_softness = 0.1, 666.0   # PrimitiveState.friction / .softness (collide_batch); set by create_primitive
         self.profile = None
         self.status_log = []
         self._h = None
@@ -179,6 +183,9 @@ class SimpleMPMSimulator:
             key=prng.split(key_global, B),
             friction=torch.full((B, 1), float(conf.ground_friction), device=dev),
             mu=torch.full((B, 1), float(mu_0), device=dev), lamda=torch.full((B, 1), float(lambda_0), device=dev))
+        if state.primitives:                   # constants of collide_batch (primitives.py:154-182), fixed per handle
+            self.prim_friction = float(state.primitives[0].friction.reshape(-1)[0])
+            self.prim_softness = float(state.primitives[0].softness.reshape(-1)[0])
         self._make_handle()
         return out
 
@@ -189,7 +196,8 @@ class SimpleMPMSimulator:
         g = [float(v) for v in np.asarray(conf.gravity, dtype=np.float64).reshape(3)]
         cc = _lib.ud_mpm_conf(n_particles=self.n_particles, n_grid=int(conf.n_grid), res=(C.c_int * 3)(*self.res),
                               steps=int(conf.steps), dt=float(conf.dt), p_mass=float(conf.p_mass), p_vol=float(conf.p_vol),
-                              gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)))
+                              gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)),
+                              prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness))
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
         self._h = C.c_void_p()
