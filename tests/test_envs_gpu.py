@@ -209,3 +209,79 @@ def test_unfold_cloth1_reset_folds_and_step_matches_oracle():
     np.testing.assert_array_equal(info["state"].x.cpu().numpy(), ref["x"])      # friction-heavy conf, still bit-exact
     np.testing.assert_array_equal(info["state"].v.cpu().numpy(), ref["v"])
     assert torch.isfinite(reward).all()
+
+
+def test_shape_rope_seeding_and_push_matches_oracle():
+    """shape_rope (shape_rope_env.py:153-174): 582 plastic particles reproduce the reference's goal.npy lattice; one
+    env.step pushes the rope through collide_batch -- the first scanned `step`s agree with the CPU oracle driven with
+    the same shifted state and sub-actions, and the reward carries a finite gradient back to the push action."""
+    from oracle.pyoracle import MpmOracle
+    from unidom_amd.envs.registration import env_functions
+    env = env_functions["shape_rope"](batch_size=2, seed=1)
+    env.build_reset_state()                                     # reset() without the random pushes
+    st = env.state
+    conf = env.conf
+    assert st.x.shape == (2, 582, 3) and conf.steps == 133 and tuple(conf.res) == (64, 6, 64)
+    goal = np.load(conf.goal_path)          # the reference's recorded goal: the same 582-point lattice, settled by < 2.1e-5
+    np.testing.assert_allclose(st.x[0].cpu().numpy(), goal, atol=3e-5)
+    mid = st.x[0, 291].cpu().numpy()
+    acts = np.array([[mid[0] - 0.004, 0, mid[2] - 0.02, mid[0] + 0.01, 0, mid[2] + 0.08],      # 5 mm from the rope, pushing across it
+                     [mid[0] + 0.06, 0, mid[2] + 0.022, mid[0] + 0.04, 0, mid[2] - 0.08]], np.float32)
+    a = torch.tensor(acts, device=env.device, requires_grad=True)
+    obs, reward, done, info = env.step_diff(a, st)
+    env.simulator.check_status()
+    assert obs.shape == (2, env.observation_size) and info["obs_list"].shape == (30, 2, env.observation_size)
+    assert torch.isfinite(reward).all() and int(info["state"].cur_step[0]) == 1
+    # the pusher moved (end - start) * 29/30 ... in 30 steps of 132/133 increments (Q5), y pinned to 0.01
+    # ---- oracle, first K scanned steps --------------------------------------------------------------------------
+    K = 3
+    x0 = st.x.cpu().numpy()
+    shift = (np.array(conf.res, np.float32) * np.float32(0.5) / np.float32(conf.n_grid) - x0.mean(1, dtype=np.float32)).astype(np.float32)
+    shift[:, 1] = 0
+    start = acts[:, :3] + shift
+    end = acts[:, 3:] + shift
+    start[:, 1] = 0.01
+    end[:, 1] = 0.01
+    nrm = np.linalg.norm(end - start, axis=-1, keepdims=True).astype(np.float32) + np.float32(1e-8)
+    end = start + (end - start) / nrm * np.clip(nrm, 0, 0.3)
+    push = ((end - start) / np.float32(30)).astype(np.float32)
+    push[:, 1] = 0
+    S = conf.steps
+    ppos = np.zeros((2, S, 3), np.float32)
+    ppos[:, 0] = start
+    prot = np.zeros((2, S, 4), np.float32)
+    prot[..., 0] = 1
+    mu0, la0 = conf.E / (2 * (1 + conf.nu)), conf.E * conf.nu / ((1 + conf.nu) * (1 - 2 * conf.nu))
+    ost = dict(x=x0 + shift[:, None], v=np.zeros_like(x0), C=np.zeros((2, 582, 3, 3), np.float32),
+               F=np.tile(np.eye(3, dtype=np.float32), (2, 582, 1, 1)), J=np.ones((2, 582), np.float32), ppos=ppos, prot=prot,
+               psize=np.tile(np.array([0.015, 0.06, 0.015], np.float32), (2, 1)), friction=np.full(2, 0.9, np.float32),
+               mu=np.full(2, mu0, np.float32), lamda=np.full(2, la0, np.float32),
+               action=np.concatenate([push, np.zeros_like(push)], -1))
+    orc = MpmOracle(582, n_grid=128, res=(64, 6, 64), steps=S, dt=conf.dt, position_control=False, material=np.full(582, 2),
+                    prim_friction=0.1, prim_softness=666.0)
+    sl = info["state_list"]
+    npy = lambda t: t.detach().cpu().numpy()
+    for k in range(K):
+        o = orc.step_fwd(ost, nthreads=4)
+        xk = npy(sl.x[k]) + shift[:, None]                              # post_step removed the focus shift
+        err_x = np.abs(xk - o["x"]).max()
+        err_v = np.abs(npy(sl.v[k]) - o["v"]).max() / (np.abs(o["v"]).max() + 1e-30)
+        # 133 substeps of plastic contact in f32: the oracle's own f32 and f64 runs differ by 4e-7 / 1.3e-4 here
+        assert err_x < 2e-6 and err_v < 1e-3, (k, err_x, err_v)
+        np.testing.assert_allclose(npy(sl.primitives[0].position[k, :, 0]) + shift, o["ppos"][:, 0], atol=2e-7)
+        # next step from the kernel's own state (each comparison = one `step` from identical inputs)
+        ost.update(x=xk, v=npy(sl.v[k]), C=npy(sl.C[k]), F=npy(sl.F[k]), J=npy(sl.J[k]),
+                   ppos=npy(sl.primitives[0].position[k]) + shift[:, None], prot=npy(sl.primitives[0].rotation[k]))
+    assert np.abs(o["v"]).max() > 1e-3                                # the pusher reached the rope
+    reward.sum().backward()
+    assert torch.isfinite(a.grad).all() and a.grad.abs().sum() > 0
+
+
+def test_shape_rope_hard_reset_runs():
+    from unidom_amd.envs.registration import env_functions
+    env = env_functions["shape_rope_hard"](batch_size=2, seed=0)
+    obs, st = env.reset(None)
+    env.simulator.check_status()
+    assert obs.shape == (2, env.observation_size) and torch.isfinite(obs).all()
+    assert int(st.cur_step[0]) == 10 and env.max_steps == 20        # 2 + 8 random pushes advance cur_step (shape_rope_env.py:123-130)
+    assert (st.x[0] - st.x[1]).abs().max() > 1e-4                     # each env got its own random pushes

@@ -325,3 +325,46 @@ def test_collide_zero_rotation_action_laundered(demo):
     assert np.isfinite(raw["gx"]).all() and np.isfinite(raw["gprot"]).all()
     lau = run_hip_collide(make_collide_sim(2, 1), st, g, clip=True)
     assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()
+
+
+def test_collide_shape_rope_geometry_fwd_bwd():
+    """shape_rope's sizes (582 plastic particles, 64x6x64 grid, dt 0.5e-4, ground friction 0.9; 4 lanes per particle on
+    the many-workgroup path): a pusher overlapping the rope -- forward vs the f32 oracle, adjoint vs the f64 oracle."""
+    from oracle.pyoracle import MpmOracle
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    from unidom_amd.envs.shape_rope_env import DefaultConf
+    conf = DefaultConf()
+    conf.steps = S = 4
+    B, N = 2, 582
+    sim = SimpleMPMSimulator(conf, B, use_position_control=False)
+    sim.n_particles, sim.material, sim.h = N, np.full(N, 2, np.int32), np.ones(N, np.float32)
+    sim._make_handle()
+    rng = np.random.default_rng(5)
+    x0 = np.load(conf.goal_path).astype(np.float32)
+    x = np.stack([x0, x0 + np.float32(0.003)]).astype(np.float32)
+    x[..., 1] = x0[:, 1]
+    ppos = np.zeros((B, S, 3), np.float32)
+    ppos[:, 0] = x[:, 291] + np.array([[0.002, 0.0, -0.012], [-0.003, 0.001, 0.011]], np.float32)
+    prot = np.zeros((B, S, 4), np.float32)
+    q = np.array([[0.95, 0.05, 0.3, -0.02], [1, 0, 0, 0]], np.float32)
+    prot[:] = (q / np.linalg.norm(q, axis=1, keepdims=True))[:, None]
+    mu0, la0 = conf.E / (2 * (1 + conf.nu)), conf.E * conf.nu / ((1 + conf.nu) * (1 - 2 * conf.nu))
+    st = dict(x=x, v=rng.normal(size=(B, N, 3)).astype(np.float32) * 0.05, C=rng.normal(size=(B, N, 3, 3)).astype(np.float32) * 2,
+              F=(np.eye(3) + rng.normal(size=(B, N, 3, 3)) * 0.05).astype(np.float32), J=np.ones((B, N), np.float32), ppos=ppos, prot=prot,
+              psize=np.tile(np.array([0.015, 0.06, 0.015], np.float32), (B, 1)), friction=np.full(B, 0.9, np.float32),
+              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32),
+              action=np.array([[0.002, 0, 0.012, 0.2, -0.1, 0.3], [-0.004, 0, -0.01, 0.1, 0.2, -0.2]], np.float32))
+    g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)) * 1e-3, gC=rng.normal(size=(B, N, 3, 3)) * 1e-6,
+             gF=rng.normal(size=(B, N, 3, 3)) * 1e-2, gppos=rng.normal(size=(B, S, 3)), gprot=rng.normal(size=(B, S, 4)))
+    g = {k: v.astype(np.float32) for k, v in g.items()}
+    orc = MpmOracle(N, n_grid=128, res=(64, 6, 64), steps=S, dt=conf.dt, position_control=False, material=np.full(N, 2))
+    of = orc.step_fwd(st, nthreads=2)
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()},
+                      clip=False, nthreads=2)
+    oh = run_hip_collide(sim, st, g, clip=False)
+    assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4, (_rel(oh["x"], of["x"]), _rel(oh["v"], of["v"]))
+    assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gprot", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
+    assert np.abs(ob["gprot"]).max() > 0 and np.abs(ob["gaction"][:, 3:]).min() > 0

@@ -1,7 +1,8 @@
 """Name -> env class, same keys as the reference's registry for the envs on the hot path
 (/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  fold_cloth3 / unfold_cloth1 / unfold_cloth3 are
-the same 512-particle cloth and the same kernels under other confs; the remaining reference envs (fold_tshirt --
-3573 particles, needs a multi-workgroup cloth kernel --, shape_rope, pour_water, pour_soup) are "next" rows
+the same 512-particle cloth and the same kernels under other confs; shape_rope / shape_rope_hard run the MPM kernels
+in soft-contact mode with the plastic material.  The remaining reference envs (fold_tshirt -- 3573 particles, needs a
+multi-workgroup cloth kernel --, pour_water, pour_soup -- two primitives and a container SDF) are "next" rows
  and are absent from the registry."""
 from .fold_cloth1_env import FoldCloth1Env
 from .fold_cloth1_para_env import FoldCloth1ParaEnv
@@ -18,6 +19,10 @@ env_functions = {
 
 try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
     from .whip_rope_env import WhipRopeEnv
+    from .shape_rope_env import ShapeRopeEnv
+    from .shape_rope_hard_env import ShapeRopeHardEnv
     env_functions["whip_rope"] = WhipRopeEnv
+    env_functions["shape_rope"] = ShapeRopeEnv
+    env_functions["shape_rope_hard"] = ShapeRopeHardEnv
 except ImportError:  # pragma: no cover
     pass
