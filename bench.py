@@ -300,6 +300,74 @@ def bench_mpm_scaled(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def bench_shape_rope(args, rank, world, device):
+    """shape_rope: 582 plastic particles, 64x6x64 grid, box pusher in soft-contact mode
+    (collide_batch).  One "step" = one env.step_diff -- 30 scanned simulator.steps of 133 substeps -- plus the backward
+    of the reward to the push action, for `--envs` envs per GPU (the reference's shape_rope has no training script:
+    this is the env-level loss + gradient that APG would drive)."""
+    import torch.distributed as dist
+    from unidom_amd.envs.registration import env_functions
+    B = args.envs
+    env = env_functions["shape_rope"](batch_size=B, seed=rank, device=device)
+    env.build_reset_state()
+    st = env.state
+    sim = env.simulator
+    N, S, T = sim.n_particles, env.conf.steps, env.conf.primitive_action_steps
+    g = torch.Generator(device=device).manual_seed(rank)
+    mid = st.x[:, N // 2]
+    ang = torch.rand((B,), device=device, generator=g) * 6.2831853
+    off = torch.stack([torch.cos(ang), torch.zeros_like(ang), torch.sin(ang)], -1)
+    act = torch.cat([mid - 0.02 * off, mid + 0.08 * off], -1).contiguous().requires_grad_(True)   # start 5 mm from the rope
+
+    def one():
+        act.grad = None
+        obs, reward, done, info = env.step_diff(act, st)
+        reward.sum().backward()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one()
+    sim.check_status()
+    sim.profile = {"fwd": [], "bwd": []}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, sim.profile = sim.profile, None
+    assert torch.isfinite(act.grad).all()
+    tm = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm[0])
+    if rank == 0:
+        units = world * B * T * S * args.steps
+        g_act = touched_cells(st.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
+        k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
+        dom = max(k_ms, key=k_ms.get)
+        per_launch = B * S * ((192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act))
+        achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"shape_rope (MLS-MPM plastic rope N={N}, res 64x6x64, soft contact, {T} x {S} substeps/env.step) "
+                                   f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act},
+            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
+                         "note": "launch/latency bound: 11 small kernels per substep pair on 32 x 582 particles"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,7 +375,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus", "shape_rope"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
@@ -326,6 +394,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.workload == "torus":
         return bench_torus(args, rank, world, device)
+    if args.workload == "shape_rope":
+        return bench_shape_rope(args, rank, world, device)
     if args.workload == "whip_rope" and args.n_grid != 64:
         return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
