@@ -140,12 +140,10 @@ __device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const fl
   }
 }
 
-// adjoint: gout (cotangent of vo) -> gv (cotangent of v); pg receives this cell's share of the primitive's cotangents
-__device__ __forceinline__ void collide_cell_bwd(const PrimC& pc, float dt, const float* gp, const float* v, const float* gout,
+// adjoint: gout (cotangent of vo) -> gv (cotangent of v); pg receives this cell's share of the primitive's cotangents.
+// r: the record collide_cell left for this cell
+__device__ __forceinline__ void collide_cell_bwd(const PrimC& pc, float dt, const CollideRec& r, const float* gout,
                                                  float* gv, PrimCGrad& pg) {
-  CollideRec r;
-  float vo[3];
-  collide_cell(pc, dt, gp, v, vo, r);
 #pragma unroll
   for (int a = 0; a < 3; ++a) { pg.p0[a] = 0.f; pg.p1[a] = 0.f; pg.size[a] = 0.f; }
 #pragma unroll
