@@ -106,8 +106,11 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
  * One call = one `simulator.step` = conf.steps substeps for B independent envs, ONE kernel launch.
  *   core/engine/primitives/primitives.py:105-182 (inv_trans, sdf, finite-difference normal, collider velocity,
  *   collide_batch)
- * Scope this round: one box primitive, in position-control mode (whip_rope) or soft-contact mode (collide_batch:
- * shape_rope); materials 1 (elastic), 2 (plastic clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.
+ *   core/engine/primitives/container.py:8-16 (container SDF)
+ * Scope this round: one box primitive in position-control mode (whip_rope); 1..4 box or container primitives in
+ * soft-contact mode (collide_batch: shape_rope, pour_water), applied one after the other (mpm_simulator.py:292-294).
+ * With n_primitive = P > 1 every primitive array gains a primitive axis after the env axis -- position [B,P,steps,3],
+ * rotation [B,P,steps,4], size [B,P,3], v / w [B,P,steps,3], action [B,6P] -- in both directions.  Materials 1 (elastic), 2 (plastic clamp) and 0 (liquid mu=0, la=1) in the particle pre-pass.
  * Position control with N <= 128 particles per env: one workgroup per env, the touched part of the `res` grid in an
  * LDS cell table, ONE launch per step.  N > 128, or soft contact: many workgroups per env, dense grid in HBM, a few
  * launches per substep (all on `stream`).
@@ -125,6 +128,9 @@ typedef struct {
   int use_position_control;  /* 1: position_control_batch (primitives.py:232-239), 0: collide_batch soft contact (:154-182) */
   float prim_friction;       /* PrimitiveState.friction  (create_primitive, mpm_env.py:201-207): collide_batch only */
   float prim_softness;       /* PrimitiveState.softness  (666 in every reference env): collide_batch only */
+  int n_primitive;           /* conf.n_primitive (0 = 1).  > 1 (up to 4) in soft-contact mode only: pour_water_env.py:32 */
+  int sdf_kind;              /* the SDF installed by set_sdf (primitives.py:26-28): 0 box (box.py:6-18), 1 container =
+                                cut hollow sphere, size = (r, h, t) (container.py:8-16); soft-contact mode only */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */

@@ -16,7 +16,9 @@
 // gauge-invariant products U S Vh, U Vh and S enter the dynamics.
 //     normal_batch / _normal_batch (finite-difference normal) :117-141   collider_v_batch :144-151
 //     collide_batch :154-182
-// Scope: ONE box primitive, in position-control mode (whip_rope) or soft-contact mode (collide_batch: shape_rope).
+//   /root/reference/DaXBench/daxbench/core/engine/primitives/container.py  _sdf_batch :8-16 (cut hollow sphere)
+// Scope: one box primitive in position-control mode (whip_rope); any number of primitives with the box or the
+// container SDF in soft-contact mode (collide_batch: shape_rope, pour_water).
 // The soft-contact adjoint is validated against torch.autograd on the twin in f64 (tests/test_oracle_mpm.py).
 #pragma once
 #include <algorithm>
@@ -122,21 +124,29 @@ struct MpmParams {
   T dx2;           // T(dx**2)
   T dtg[3];        // T(dt)*T(gravity) (:285)
   int position_control;
-  T prim_friction = T(0.1), prim_softness = T(666);   // PrimitiveState.friction / .softness (primitives.py:31-60)
+  int n_prim = 1, sdf_kind = 0;                       // sdf_kind: 0 box (box.py), 1 container (container.py); one per process in the reference (set_sdf)
+  T prim_friction = T(0.1), prim_softness = T(666);   // PrimitiveState.friction / .softness (primitives.py:31-60), same for all primitives
   std::vector<int> material;  // [N]
   std::vector<T> h;           // [N] hardness, clipped to [0.1,5] at use (:241)
 };
 
 template <class T>
+struct PrimS {   // one primitive: position [steps*3], rotation [steps*4] (w,x,y,z), v, w [steps*3], size[3]
+  std::vector<T> ppos, prot, pv, pw;
+  T psize[3] = {0, 0, 0};
+  void alloc(int steps) { ppos.assign(steps * 3, 0); prot.assign(steps * 4, 0); pv.assign(steps * 3, 0); pw.assign(steps * 3, 0); }
+};
+
+template <class T>
 struct MpmState {
   std::vector<T> x, v, C, F, J;                 // [N*3],[N*3],[N*9],[N*9],[N]
-  std::vector<T> ppos, prot, pv, pw;            // primitive 0: [steps*3],[steps*4],[steps*3],[steps*3]
-  T psize[3];
+  std::vector<PrimS<T>> prims;                  // PrimitiveState leaves the dynamics touch
   T friction, mu, lamda;
-  void alloc(int N, int steps) {
+  void alloc(int N, int steps, int n_prim = 1) {
     x.assign(N * 3, 0); v.assign(N * 3, 0); C.assign(N * 9, 0); F.assign(N * 9, 0); J.assign(N, 0);
-    ppos.assign(steps * 3, 0); prot.assign(steps * 4, 0); pv.assign(steps * 3, 0); pw.assign(steps * 3, 0);
-    psize[0] = psize[1] = psize[2] = 0; friction = mu = lamda = 0;
+    prims.assign(n_prim, PrimS<T>());
+    for (auto& p : prims) p.alloc(steps);
+    friction = mu = lamda = 0;
   }
 };
 
@@ -206,8 +216,42 @@ template <class T> inline void box_sdf_bwd(const T size[3], const T p[3], T gout
   }
 }
 
-// one box primitive as the grid op of substep f sees it (rows f and f+1 of position / rotation, clamped: Q5)
-template <class T> struct PrimCtx { T p0[3], r0[4], p1[3], r1[4], size[3], softness, friction; };
+// container.py:8-16 -- cut hollow sphere, size = (r, h, t)
+template <class T> inline T container_sdf(const T size[3], const T p[3]) {
+  const T r = size[0], h = size[1], t = size[2];
+  const T w = std::sqrt(r * r - h * h);
+  const T q0 = std::sqrt(p[0] * p[0] + p[2] * p[2] + T(1e-12)), q1 = p[1];
+  const bool mask = h * q0 < w * q1;
+  const T d0 = q0 - w, d1 = q1 - h;
+  const T val1 = std::sqrt(d0 * d0 + d1 * d1 + T(1e-12)) - t;
+  const T val2 = std::abs(std::sqrt(q0 * q0 + q1 * q1 + T(1e-12)) - r) - t;
+  return mask ? val1 : val2;
+}
+template <class T> inline void container_sdf_bwd(const T size[3], const T p[3], T gout, T gp[3], T gsize[3]) {
+  const T r = size[0], h = size[1], t = size[2];
+  const T w = std::sqrt(r * r - h * h);
+  const T q0 = std::sqrt(p[0] * p[0] + p[2] * p[2] + T(1e-12)), q1 = p[1];
+  const bool mask = h * q0 < w * q1;
+  T gq0, gq1, gw = 0, gr = 0, gh = 0;
+  if (mask) {
+    const T d0 = q0 - w, d1 = q1 - h, L1 = std::sqrt(d0 * d0 + d1 * d1 + T(1e-12));
+    gq0 = gout * d0 / L1; gq1 = gout * d1 / L1; gw = -gq0; gh = -gq1;
+  } else {
+    const T L2 = std::sqrt(q0 * q0 + q1 * q1 + T(1e-12)), dd = L2 - r;
+    const T sg = dd > 0 ? T(1) : (dd < 0 ? T(-1) : T(0));
+    gq0 = gout * sg * q0 / L2; gq1 = gout * sg * q1 / L2; gr = -gout * sg;
+  }
+  gr += gw * r / w; gh -= gw * h / w;
+  gp[0] += gq0 * p[0] / q0; gp[2] += gq0 * p[2] / q0; gp[1] += gq1;
+  gsize[0] += gr; gsize[1] += gh; gsize[2] -= gout;
+}
+template <class T> inline T prim_sdf(int kind, const T size[3], const T p[3]) { return kind == 1 ? container_sdf(size, p) : box_sdf(size, p); }
+template <class T> inline void prim_sdf_bwd(int kind, const T size[3], const T p[3], T gout, T gp[3], T gsize[3]) {
+  if (kind == 1) container_sdf_bwd(size, p, gout, gp, gsize); else box_sdf_bwd(size, p, gout, gp, gsize);
+}
+
+// one primitive as the grid op of substep f sees it (rows f and f+1 of position / rotation, clamped: Q5)
+template <class T> struct PrimCtx { T p0[3], r0[4], p1[3], r1[4], size[3], softness, friction; int kind; };
 template <class T> struct PrimGrad {
   T p0[3], r0[4], p1[3], r1[4], size[3], friction;
   PrimGrad() { std::memset(this, 0, sizeof(*this)); }
@@ -228,7 +272,7 @@ inline void collide_cell(const PrimCtx<T>& pc, T dt, const T gp[3], const T v[3]
   for (int a = 0; a < 4; ++a) r.iq[a] = cq[a] / r.nq;
   for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
   qrot(r.iq, r.rel, r.loc);
-  const T dist = box_sdf(pc.size, r.loc);
+  const T dist = prim_sdf(pc.kind, pc.size, r.loc);
   r.e = std::exp(-dist * pc.softness);
   r.infl = clipf(r.e, -inf, T(1));
   // _normal_batch (:117-134): central differences, d = 1e-6, in the primitive's frame
@@ -236,7 +280,7 @@ inline void collide_cell(const PrimCtx<T>& pc, T dt, const T gp[3], const T v[3]
   for (int a = 0; a < 3; ++a) {
     T inc[3] = {r.loc[0], r.loc[1], r.loc[2]}, dec[3] = {r.loc[0], r.loc[1], r.loc[2]};
     inc[a] = inc[a] + d; dec[a] = dec[a] + (-d);
-    r.n[a] = k * (box_sdf(pc.size, inc) - box_sdf(pc.size, dec));
+    r.n[a] = k * (prim_sdf(pc.kind, pc.size, inc) - prim_sdf(pc.kind, pc.size, dec));
   }
   r.len = std::sqrt(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + T(1e-12));
   for (int a = 0; a < 3; ++a) r.nl[a] = r.n[a] / r.len;
@@ -305,13 +349,13 @@ inline void collide_cell_bwd(const PrimCtx<T>& pc, T dt, const T gp[3], const T 
     const T gn = gnl[a] / r.len + glen * r.n[a] / r.len;
     T inc[3] = {r.loc[0], r.loc[1], r.loc[2]}, dec[3] = {r.loc[0], r.loc[1], r.loc[2]};
     inc[a] = inc[a] + d; dec[a] = dec[a] + (-d);
-    box_sdf_bwd(pc.size, inc, k * gn, gloc, pg.size);
-    box_sdf_bwd(pc.size, dec, -(k * gn), gloc, pg.size);
+    prim_sdf_bwd(pc.kind, pc.size, inc, k * gn, gloc, pg.size);
+    prim_sdf_bwd(pc.kind, pc.size, dec, -(k * gn), gloc, pg.size);
   }
   // influence
   const T ge = ginfl * clip_grad(r.e, -inf, T(1));
   const T gdist = -(ge * r.e) * pc.softness;
-  box_sdf_bwd(pc.size, r.loc, gdist, gloc, pg.size);
+  prim_sdf_bwd(pc.kind, pc.size, r.loc, gdist, gloc, pg.size);
   // loc = qrot(iq, gp - p0), iq = conj(r0) / (|conj(r0)| + 1e-12)
   T giq[4] = {0, 0, 0, 0}, grel[3] = {0, 0, 0};
   qrot_bwd(r.iq, r.rel, gloc, giq, grel);
@@ -328,7 +372,9 @@ inline void collide_cell_bwd(const PrimCtx<T>& pc, T dt, const T gp[3], const T 
 }
 
 // forward_kinematics (:185-194) in place on (ppos, prot)
-template <class T> void fk(int f, int steps, std::vector<T>& ppos, std::vector<T>& prot, const std::vector<T>& pv, const std::vector<T>& pw) {
+template <class T> void fk(int f, int steps, PrimS<T>& P_) {
+  std::vector<T>&ppos = P_.ppos, &prot = P_.prot;
+  const std::vector<T>&pv = P_.pv, &pw = P_.pw;
   const int fc = clampi<T>(f, steps);
   if (f + 1 < steps && f + 1 >= 0)
     for (int a = 0; a < 3; ++a) ppos[(f + 1) * 3 + a] = ppos[fc * 3 + a] + pv[fc * 3 + a];
@@ -405,13 +451,13 @@ template <class T> inline long cell_gather(const MpmParams<T>& pr, int i, int j,
   return ((long)id[0] * pr.res[1] + id[1]) * pr.res[2] + id[2];
 }
 
-template <class T, class ST>
-inline PrimCtx<T> prim_ctx(const MpmParams<T>& pr, const ST& st, int f) {
+template <class T>
+inline PrimCtx<T> prim_ctx(const MpmParams<T>& pr, const PrimS<T>& st, int f) {
   const int f0 = clampi<T>(f, pr.steps), f1 = clampi<T>(f + 1, pr.steps);
   PrimCtx<T> pc;
   for (int a = 0; a < 3; ++a) { pc.p0[a] = st.ppos[f0 * 3 + a]; pc.p1[a] = st.ppos[f1 * 3 + a]; pc.size[a] = st.psize[a]; }
   for (int a = 0; a < 4; ++a) { pc.r0[a] = st.prot[f0 * 4 + a]; pc.r1[a] = st.prot[f1 * 4 + a]; }
-  pc.softness = pr.prim_softness; pc.friction = pr.prim_friction;
+  pc.softness = pr.prim_softness; pc.friction = pr.prim_friction; pc.kind = pr.sdf_kind;
   return pc;
 }
 
@@ -434,17 +480,20 @@ inline void grid_cell_op(const MpmParams<T>& pr, const MpmState<T>& st, int f, i
   bool ctrl = false;
   if (pr.position_control) {                                        // :232-239
     const int fc = clampi<T>(f, pr.steps);
+    const PrimS<T>& P0 = st.prims[0];                               // position control: one primitive (whip_rope)
     T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx};
-    T dist = sdf_at(st.psize, &st.ppos[fc * 3], &st.prot[fc * 4], gp);
-    ctrl = dist < st.psize[0] * T(1.5);
-    if (ctrl) for (int a = 0; a < 3; ++a) v[a] = st.pv[fc * 3 + a] / pr.dt;
-  } else {                                                          // collide_batch (:154-182)
+    T dist = sdf_at(P0.psize, &P0.ppos[fc * 3], &P0.prot[fc * 4], gp);
+    ctrl = dist < P0.psize[0] * T(1.5);
+    if (ctrl) for (int a = 0; a < 3; ++a) v[a] = P0.pv[fc * 3 + a] / pr.dt;
+  } else {                                                          // collide_batch (:154-182), primitive after primitive (:292-294)
     T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx};
-    PrimCtx<T> pc = prim_ctx(pr, st, f);
-    CollideRec<T> cr;
-    T vo[3];
-    collide_cell(pc, pr.dt, gp, v, vo, cr);
-    for (int a = 0; a < 3; ++a) v[a] = vo[a];
+    for (int i = 0; i < pr.n_prim; ++i) {
+      PrimCtx<T> pc = prim_ctx(pr, st.prims[i], f);
+      CollideRec<T> cr;
+      T vo[3];
+      collide_cell(pc, pr.dt, gp, v, vo, cr);
+      for (int a = 0; a < 3; ++a) v[a] = vo[a];
+    }
   }
   if (rec) { rec->ctrl = ctrl; for (int a = 0; a < 3; ++a) rec->v1[a] = v[a]; }
   // friction (:297-307)
@@ -495,7 +544,7 @@ void mpm_substep_fwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmSt
       }
     }
   }
-  fk(f, pr.steps, out.ppos, out.prot, out.pv, out.pw);  // :277-278
+  for (auto& P_ : out.prims) fk(f, pr.steps, P_);  // :277-278
   // grid op (dense, like the source)
   for (int ci = 0; ci < pr.res[0]; ++ci) for (int cj = 0; cj < pr.res[1]; ++cj) for (int ck = 0; ck < pr.res[2]; ++ck) {
     size_t c = ((size_t)ci * pr.res[1] + cj) * pr.res[2] + ck;
@@ -533,12 +582,17 @@ void mpm_substep_fwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmSt
 // cotangents of one MPM state (same leaves the reference differentiates, :343-354; J excluded)
 template <class T>
 struct MpmGrad {
-  std::vector<T> x, v, C, F, ppos, pv, prot, pw;
+  std::vector<T> x, v, C, F;
+  struct PrimG {
+    std::vector<T> ppos, pv, prot, pw;
+    T psize[3] = {0, 0, 0}, pfriction = 0;   // primitive size / friction leaves: only their norm enters (norm_grad_state)
+  };
+  std::vector<PrimG> prims;
   T friction = 0, mu = 0, lamda = 0;
-  T psize[3] = {0, 0, 0}, pfriction = 0;   // primitive size / friction leaves: only their norm enters (norm_grad_state)
-  void alloc(int N, int steps) {
-    x.assign(N * 3, 0); v.assign(N * 3, 0); C.assign(N * 9, 0); F.assign(N * 9, 0); ppos.assign(steps * 3, 0); pv.assign(steps * 3, 0);
-    prot.assign(steps * 4, 0); pw.assign(steps * 3, 0);
+  void alloc(int N, int steps, int n_prim = 1) {
+    x.assign(N * 3, 0); v.assign(N * 3, 0); C.assign(N * 9, 0); F.assign(N * 9, 0);
+    prims.assign(n_prim, PrimG());
+    for (auto& p : prims) { p.ppos.assign(steps * 3, 0); p.pv.assign(steps * 3, 0); p.prot.assign(steps * 4, 0); p.pw.assign(steps * 3, 0); }
   }
 };
 
@@ -567,7 +621,7 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
     }
   }
   MpmState<T> mid = in;
-  fk(f, pr.steps, mid.ppos, mid.prot, mid.pv, mid.pw);
+  for (auto& P_ : mid.prims) fk(f, pr.steps, P_);
   std::vector<CellOp<T>> rec(G);
   for (int ci = 0; ci < pr.res[0]; ++ci) for (int cj = 0; cj < pr.res[1]; ++cj) for (int ck = 0; ck < pr.res[2]; ++ck) {
     size_t c = ((size_t)ci * pr.res[1] + cj) * pr.res[2] + ck;
@@ -604,8 +658,9 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
   // grid-op adjoint per cell
   const int fc = clampi<T>(f, pr.steps);
   T gpv_f[3] = {0, 0, 0};
-  const PrimCtx<T> pctx = prim_ctx(pr, mid, f);
-  PrimGrad<T> pgrad;
+  std::vector<PrimCtx<T>> pctx;
+  for (int i = 0; i < pr.n_prim; ++i) pctx.push_back(prim_ctx(pr, mid.prims[i], f));
+  std::vector<PrimGrad<T>> pgrad(pr.n_prim);
   for (int ci = 0; ci < pr.res[0]; ++ci) for (int cj = 0; cj < pr.res[1]; ++cj) for (int ck = 0; ck < pr.res[2]; ++ck) {
     size_t c = ((size_t)ci * pr.res[1] + cj) * pr.res[2] + ck;
     const CellOp<T>& r = rec[c];
@@ -638,8 +693,13 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
     }
     if (!pr.position_control) {                                     // collide_batch
       T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx}, gin[3];
-      collide_cell_bwd(pctx, pr.dt, gp, r.v0, gvv, gin, pgrad);
-      for (int a = 0; a < 3; ++a) gvv[a] = gin[a];
+      T vin[8][3];                                                  // input velocity of each primitive's collide
+      for (int a = 0; a < 3; ++a) vin[0][a] = r.v0[a];
+      for (int i = 0; i + 1 < pr.n_prim; ++i) { CollideRec<T> cr; collide_cell(pctx[i], pr.dt, gp, vin[i], vin[i + 1], cr); }
+      for (int i = pr.n_prim - 1; i >= 0; --i) {
+        collide_cell_bwd(pctx[i], pr.dt, gp, vin[i], gvv, gin, pgrad[i]);
+        for (int a = 0; a < 3; ++a) gvv[a] = gin[a];
+      }
     }
     // gravity: pass. normalise (:283-284, Q7)
     T m = gm[c];
@@ -657,18 +717,21 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
       ggm[c] = 0;
     }
   }
+  for (int ip = 0; ip < pr.n_prim; ++ip) {
+  auto& G = g.prims[ip];
+  const PrimS<T>& IN = in.prims[ip];
   if (!pr.position_control) {   // rows f and f+1 (clamped) of position / rotation as the grid op read them
     const int f1 = clampi<T>(f + 1, pr.steps);
-    for (int a = 0; a < 3; ++a) { g.ppos[fc * 3 + a] += pgrad.p0[a]; g.ppos[f1 * 3 + a] += pgrad.p1[a]; g.psize[a] += pgrad.size[a]; }
-    for (int a = 0; a < 4; ++a) { g.prot[fc * 4 + a] += pgrad.r0[a]; g.prot[f1 * 4 + a] += pgrad.r1[a]; }
-    g.pfriction += pgrad.friction;
+    for (int a = 0; a < 3; ++a) { G.ppos[fc * 3 + a] += pgrad[ip].p0[a]; G.ppos[f1 * 3 + a] += pgrad[ip].p1[a]; G.psize[a] += pgrad[ip].size[a]; }
+    for (int a = 0; a < 4; ++a) { G.prot[fc * 4 + a] += pgrad[ip].r0[a]; G.prot[f1 * 4 + a] += pgrad[ip].r1[a]; }
+    G.pfriction += pgrad[ip].friction;
     // rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))   (:190, qmul :73-81, w2quat :84-92)
     if (f + 1 < pr.steps) {
       const T inf = std::numeric_limits<T>::infinity();
       T go_[4];
-      for (int a = 0; a < 4; ++a) { go_[a] = g.prot[(f + 1) * 4 + a]; g.prot[(f + 1) * 4 + a] = 0; }
-      const T* w = &in.pw[fc * 3];
-      const T* rr = &in.prot[fc * 4];
+      for (int a = 0; a < 4; ++a) { go_[a] = G.prot[(f + 1) * 4 + a]; G.prot[(f + 1) * 4 + a] = 0; }
+      const T* w = &IN.pw[fc * 3];
+      const T* rr = &IN.prot[fc * 4];
       const T s = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
       const T nrm = std::sqrt(s), ang = nrm + T(1e-12), hh = ang / 2, sn = std::sin(hh), cs = std::cos(hh);
       const T u[3] = {w[0] / ang, w[1] / ang, w[2] / ang};
@@ -692,34 +755,35 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
                        -gO[0] * rr[1] + gO[1] * rr[0] - gO[2] * rr[3] + gO[3] * rr[2],
                        -gO[0] * rr[2] + gO[1] * rr[3] + gO[2] * rr[0] - gO[3] * rr[1],
                        -gO[0] * rr[3] - gO[1] * rr[2] + gO[2] * rr[1] + gO[3] * rr[0]};
-      for (int a = 0; a < 4; ++a) g.prot[fc * 4 + a] += gr[a];
+      for (int a = 0; a < 4; ++a) G.prot[fc * 4 + a] += gr[a];
       T gh = -sn * gq[0], gsn = 0, gang = 0, gw[3];
       for (int a = 0; a < 3; ++a) { gsn += gq[1 + a] * u[a]; const T gu = gq[1 + a] * sn; gw[a] = gu / ang; gang -= gu * w[a] / (ang * ang); }
       gh += cs * gsn;
       gang += gh / 2;
       // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule gives 0.5/0 * 0 = NaN (laundered by nan_to_num at `step`)
       const T gs = gang * (T(0.5) / nrm);
-      for (int a = 0; a < 3; ++a) g.pw[fc * 3 + a] += gw[a] + gs * (T(2) * w[a]);
+      for (int a = 0; a < 3; ++a) G.pw[fc * 3 + a] += gw[a] + gs * (T(2) * w[a]);
     }
   }
   // primitives: FK adjoint (:185-194). position' = clip(set(position, f+1, position[f]+v[f]))
   {
-    std::vector<T> gp = g.ppos;
+    std::vector<T> gp = G.ppos;
     // clip factors evaluated on the pre-clip array
-    std::vector<T> pre_clip = in.ppos;
-    if (f + 1 < pr.steps) for (int a = 0; a < 3; ++a) pre_clip[(f + 1) * 3 + a] = in.ppos[fc * 3 + a] + in.pv[fc * 3 + a];
+    std::vector<T> pre_clip = IN.ppos;
+    if (f + 1 < pr.steps) for (int a = 0; a < 3; ++a) pre_clip[(f + 1) * 3 + a] = IN.ppos[fc * 3 + a] + IN.pv[fc * 3 + a];
     for (size_t i = 0; i < gp.size(); ++i) gp[i] *= clip_grad(pre_clip[i], T(-2), T(2));
     if (f + 1 < pr.steps) {
       for (int a = 0; a < 3; ++a) {
         T t = gp[(f + 1) * 3 + a];
         gp[(f + 1) * 3 + a] = 0;
         gp[fc * 3 + a] += t;
-        g.pv[fc * 3 + a] += t;
+        G.pv[fc * 3 + a] += t;
       }
     }
-    g.ppos = gp;
-    for (int a = 0; a < 3; ++a) g.pv[fc * 3 + a] += gpv_f[a];
+    G.ppos = gp;
+    if (ip == 0) for (int a = 0; a < 3; ++a) G.pv[fc * 3 + a] += gpv_f[a];
   }
+  }   // primitives
   // p2g adjoint (gather) + particle pre-pass adjoint
   T gmu_tot = 0, gla_tot = 0;
   for (int p = 0; p < N; ++p) {

@@ -128,8 +128,9 @@ class MpmOracle:
     """CPU restatement of SimpleMPMSimulator.step (mpm_simulator.py:413-429) + adjoint, dense grid."""
 
     def __init__(self, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0),
-                 position_control=True, material=None, hardness=None, prim_friction=0.1, prim_softness=666.0):
-        self.N, self.steps, self.res, self.n_grid = N, steps, tuple(res), n_grid
+                 position_control=True, material=None, hardness=None, prim_friction=0.1, prim_softness=666.0,
+                 n_prim=1, sdf="box"):
+        self.N, self.steps, self.res, self.n_grid, self.P = N, steps, tuple(res), n_grid, n_prim
         dx = 1 / n_grid
         p_vol = (dx * 0.5) ** 2
         p_mass = p_vol * p_rho
@@ -139,7 +140,9 @@ class MpmOracle:
         g = np.ascontiguousarray(gravity, dtype=np.float64)
         self.h = C.c_void_p(lib().oc_mpm_create(
             C.c_int(N), C.c_int(n_grid), _p(r), C.c_int(steps), C.c_double(dt), C.c_double(p_mass), C.c_double(p_vol),
-            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd), C.c_double(prim_friction), C.c_double(prim_softness)))
+            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd), C.c_double(prim_friction), C.c_double(prim_softness),
+            C.c_int(n_prim), C.c_int({"box": 0, "container": 1}[sdf])))
+        assert self.h.value, "oc_mpm_create refused the configuration"
 
     def __del__(self):
         try:
@@ -152,13 +155,15 @@ class MpmOracle:
         return [c(st[k]) for k in ("x", "v", "C", "F", "J", "ppos", "prot", "psize", "friction", "mu", "lamda", "action")]
 
     def step_fwd(self, st, nthreads=1):
-        """st: dict x[B,N,3] v C[B,N,3,3] F J[B,N] ppos[B,steps,3] prot[B,steps,4] psize[B,3] friction mu lamda[B] action[B,6]"""
+        """st: dict x[B,N,3] v C[B,N,3,3] F J[B,N] ppos[B,(P,)steps,3] prot[B,(P,)steps,4] psize[B,(P,)3] friction mu lamda[B]
+        action[B,6P]; the primitive axis P is present when n_prim > 1."""
         dt = st["x"].dtype
         a = self._prep(st, dt)
         B, N, S = a[0].shape[0], self.N, self.steps
+        pa = (self.P,) if self.P > 1 else ()
         o = dict(x=np.empty((B, N, 3), dt), v=np.empty((B, N, 3), dt), C=np.empty((B, N, 3, 3), dt),
-                 F=np.empty((B, N, 3, 3), dt), J=np.empty((B, N), dt), ppos=np.empty((B, S, 3), dt),
-                 prot=np.empty((B, S, 4), dt), pv=np.empty((B, S, 3), dt), pw=np.empty((B, S, 3), dt))
+                 F=np.empty((B, N, 3, 3), dt), J=np.empty((B, N), dt), ppos=np.empty((B,) + pa + (S, 3), dt),
+                 prot=np.empty((B,) + pa + (S, 4), dt), pv=np.empty((B,) + pa + (S, 3), dt), pw=np.empty((B,) + pa + (S, 3), dt))
         getattr(lib(), "oc_mpm_step_fwd_" + _suf(dt))(
             self.h, C.c_int(B), *[_p(q) for q in a],
             *[_p(o[k]) for k in ("x", "v", "C", "F", "J", "ppos", "prot", "pv", "pw")], C.c_int(nthreads))
@@ -170,10 +175,11 @@ class MpmOracle:
         a = self._prep(st, dt)
         B, N, S = a[0].shape[0], self.N, self.steps
         c = lambda q: np.ascontiguousarray(q, dtype=dt)
-        gin = [c(g[k]) for k in ("gx", "gv", "gC", "gF", "gppos")] + [c(g["gprot"]) if "gprot" in g else np.zeros((B, S, 4), dt)]
+        pa = (self.P,) if self.P > 1 else ()
+        gin = [c(g[k]) for k in ("gx", "gv", "gC", "gF", "gppos")] + [c(g["gprot"]) if "gprot" in g else np.zeros((B,) + pa + (S, 4), dt)]
         o = dict(gx=np.empty((B, N, 3), dt), gv=np.empty((B, N, 3), dt), gC=np.empty((B, N, 3, 3), dt),
-                 gF=np.empty((B, N, 3, 3), dt), gppos=np.empty((B, S, 3), dt), gprot=np.empty((B, S, 4), dt), gfriction=np.empty((B,), dt),
-                 gmu=np.empty((B,), dt), glamda=np.empty((B,), dt), gaction=np.empty((B, 6), dt))
+                 gF=np.empty((B, N, 3, 3), dt), gppos=np.empty((B,) + pa + (S, 3), dt), gprot=np.empty((B,) + pa + (S, 4), dt),
+                 gfriction=np.empty((B,), dt), gmu=np.empty((B,), dt), glamda=np.empty((B,), dt), gaction=np.empty((B, 6 * self.P), dt))
         getattr(lib(), "oc_mpm_step_bwd_" + _suf(dt))(
             self.h, C.c_int(B), *[_p(q) for q in a], *[_p(q) for q in gin], C.c_int(int(clip)),
             *[_p(o[k]) for k in ("gx", "gv", "gC", "gF", "gppos", "gprot", "gfriction", "gmu", "glamda", "gaction")],

@@ -170,6 +170,24 @@ def box_sdf(size, grid_pos):                         # box.py:6-18
     return out + tmp
 
 
+def container_sdf(size, p):                          # container.py:8-16 (cut hollow sphere, size = (r, h, t))
+    r, h, t = size[0], size[1], size[2]
+    w = torch.sqrt(r * r - h * h)
+    q = torch.stack([length(torch.stack([p[..., 0], p[..., 2]], -1)), p[..., 1]], -1)
+    mask = h * q[..., 0] < w * q[..., 1]
+    val1 = length(q - torch.stack([w, h])) - t
+    val2 = torch.abs(length(q) - r) - t
+    return torch.where(mask, val1, val2)
+
+
+_sdf_batch = box_sdf                                 # primitives.py:5-6, 26-28: one process-global SDF
+
+
+def set_sdf(fn):
+    global _sdf_batch
+    _sdf_batch = fn
+
+
 def _gather_clamp(arr, idx):
     """JAX gather out-of-bounds = clamp (Q5)."""
     return arr[min(max(idx, 0), arr.shape[0] - 1)]
@@ -185,7 +203,7 @@ def _set_drop(arr, idx, val):
 
 def sdf_batch(f, grid_pos, p: Prim):                 # :112-114
     gp = inv_trans_batch(grid_pos, _gather_clamp(p.position, f), _gather_clamp(p.rotation, f))
-    return box_sdf(p.size, gp)
+    return _sdf_batch(p.size, gp)
 
 
 def normal_batch(f, grid_pos, p: Prim):              # :117-141
@@ -195,7 +213,7 @@ def normal_batch(f, grid_pos, p: Prim):              # :117-141
     for a in range(3):
         e = torch.zeros(3, dtype=gp.dtype)
         e[a] = d
-        comps.append((0.5 / d) * (box_sdf(p.size, gp + e) - box_sdf(p.size, gp - e)))
+        comps.append((0.5 / d) * (_sdf_batch(p.size, gp + e) - _sdf_batch(p.size, gp - e)))
     n = torch.stack(comps, -1)
     n = n / length(n)[..., None]
     return qrot_batch(_gather_clamp(p.rotation, f), n)
@@ -400,13 +418,14 @@ class MPMTwin:
         if self.clip_grads:
             st = st._replace(x=torch.nan_to_num(st.x), v=torch.nan_to_num(st.v), C=torch.nan_to_num(st.C),
                              F=torch.nan_to_num(st.F), J=torch.nan_to_num(st.J))
-            p = st.primitives[0]
-            leaves = [st.x, st.v, st.C, st.F, st.J, st.friction, st.mu, st.lamda, p.position, p.rotation, p.v, p.w,
-                      p.size, p.action_buffer, p.action_scale, p.friction]
+            leaves = [st.x, st.v, st.C, st.F, st.J, st.friction, st.mu, st.lamda]
+            for p in st.primitives:
+                leaves += [p.position, p.rotation, p.v, p.w, p.size, p.action_buffer, p.action_scale, p.friction]
             o = _NormGradTree.apply(*leaves)
-            st = st._replace(x=o[0], v=o[1], C=o[2], F=o[3], J=o[4], friction=o[5], mu=o[6], lamda=o[7],
-                             primitives=[p._replace(position=o[8], rotation=o[9], v=o[10], w=o[11], size=o[12],
-                                                    action_buffer=o[13], action_scale=o[14], friction=o[15])] + st.primitives[1:])
+            prims = [p._replace(position=o[8 + 8 * i], rotation=o[9 + 8 * i], v=o[10 + 8 * i], w=o[11 + 8 * i], size=o[12 + 8 * i],
+                                action_buffer=o[13 + 8 * i], action_scale=o[14 + 8 * i], friction=o[15 + 8 * i])
+                     for i, p in enumerate(st.primitives)]
+            st = st._replace(x=o[0], v=o[1], C=o[2], F=o[3], J=o[4], friction=o[5], mu=o[6], lamda=o[7], primitives=prims)
             action = _NormGradTree.apply(action)[0]
         action = _clip(action, -1, 1)
         prims = [set_action(c.steps, action[i * 6:(i + 1) * 6], p) for i, p in enumerate(st.primitives)]

@@ -241,3 +241,70 @@ def test_collide_zero_rotation_action_is_nan_then_laundered(demo):
     assert np.isfinite(raw["gx"]).all() and np.isfinite(raw["gprot"]).all()
     lau = orc.step_bwd(st, g, clip=True)
     assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()
+
+
+def _two_bowl_case(d, S, k, seed, dtn=np.float64, turning=True):
+    """pour_water-like: liquid particles, two container primitives (cut hollow spheres), the first one moving and turning."""
+    st, g = _adjoint_case(d, S, k, 0, seed, dtn)
+    rng = np.random.default_rng(seed + 200)
+    c = st["x"][0].mean(0)
+    ppos = np.zeros((1, 2, S, 3), dtn)
+    ppos[0, 0, 0] = c + np.array([0.01, 0.03, -0.005], dtn)          # bowl under / around the body
+    ppos[0, 1, 0] = c + np.array([-0.03, -0.02, 0.06], dtn)
+    prot = np.zeros((1, 2, S, 4), dtn)
+    q = np.array([[0.96, 0.2, -0.1, 0.05], [1, 0, 0, 0]], dtn)
+    prot[0] = (q / np.linalg.norm(q, axis=1, keepdims=True))[:, None]
+    st.update(ppos=ppos, prot=prot, psize=np.array([[[0.05, 0.0, 0.008], [0.04, 0.01, 0.008]]], dtn),
+              action=np.array([[0.3, -0.2, 0.5, 0.4, -0.3, 0.2, 0.1, 0.05, -0.1, 0.2, 0.1, -0.3]], dtn) * dtn(0.02))   # ~10 m/s colliders
+    if not turning:                                                     # upright bowls that only translate
+        st["prot"][:] = 0
+        st["prot"][..., 0] = 1
+        st["action"][0, [3, 4, 5, 9, 10, 11]] = 0
+    g["gppos"] = rng.normal(size=(1, 2, S, 3)).astype(dtn)
+    g["gprot"] = rng.normal(size=(1, 2, S, 4)).astype(dtn)
+    return st, g
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_two_container_primitives_adjoint_matches_autograd_f64(demo, clip):
+    """n_primitive = 2 with the container SDF (container.py:8-16), collide_batch applied primitive after primitive
+    (mpm_simulator.py:292-294), liquid material: forward and hand-derived adjoint == torch.autograd through the twin."""
+    S = 3
+    st, g = _two_bowl_case(demo, S, 40, 0)
+    orc = MpmOracle(67, steps=S, material=np.zeros(67), position_control=False, n_prim=2, sdf="container")
+    of, ob = orc.step_fwd(st), orc.step_bwd(st, g, clip=clip)
+    conf = tw.MPMConf(steps=S, n_primitive=2)
+    tw.set_sdf(tw.container_sdf)
+    try:
+        sim = tw.MPMTwin(conf, 67, material=0, dtype=torch.float64, clip_grads=clip, use_position_control=False)
+        L = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+        xt, vt, Ct, Ft = L(st["x"][0]), L(st["v"][0]), L(st["C"][0]), L(st["F"][0])
+        fr, mu, la, ac = L(st["friction"]), L(st["mu"]), L(st["lamda"]), L(st["action"][0])
+        pps, prs, prims = [], [], []
+        for i in range(2):
+            pp, pr = L(st["ppos"][0, i]), L(st["prot"][0, i])
+            p = tw.make_prim(conf, st["psize"][0, i], [0, 0, 0], torch.float64)._replace(position=pp, rotation=pr)
+            prims.append(p._replace(size=p.size.clone().requires_grad_(True), friction=p.friction.clone().requires_grad_(True)))
+            pps.append(pp)
+            prs.append(pr)
+        s2 = sim.step(tw.MPMState(xt, vt, Ct, Ft, torch.tensor(st["J"][0]), prims, fr, mu, la), ac)
+    finally:
+        tw.set_sdf(tw.box_sdf)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    loss = (s2.x * T(g["gx"][0])).sum() + (s2.v * T(g["gv"][0])).sum() + (s2.C * T(g["gC"][0])).sum() + (s2.F * T(g["gF"][0])).sum()
+    for i in range(2):
+        loss = loss + (s2.primitives[i].position * T(g["gppos"][0, i])).sum() + (s2.primitives[i].rotation * T(g["gprot"][0, i])).sum()
+    loss.backward()
+    for key, ref in (("x", s2.x), ("v", s2.v), ("C", s2.C), ("F", s2.F)):
+        assert _rel(of[key][0], ref.detach().numpy()) < 1e-11, key
+    for i in range(2):
+        assert _rel(of["ppos"][0, i], s2.primitives[i].position.detach().numpy()) < 1e-13
+        assert _rel(of["prot"][0, i], s2.primitives[i].rotation.detach().numpy()) < 1e-13
+    for key, ref in (("gx", xt), ("gv", vt), ("gC", Ct), ("gF", Ft)):
+        assert _rel(ob[key][0], ref.grad.numpy()) < 2e-7, key
+    for i in range(2):
+        assert _rel(ob["gppos"][0, i], pps[i].grad.numpy()) < 2e-7, i
+        assert _rel(ob["gprot"][0, i], prs[i].grad.numpy()) < 2e-7, i
+        assert np.abs(ob["gprot"][0, i]).max() > 0
+    assert _rel(ob["gfriction"], fr.grad.numpy()) < 2e-7
+    assert _rel(ob["gaction"][0], ac.grad.numpy()) < 2e-7 and np.abs(ob["gaction"][0]).min() > 0

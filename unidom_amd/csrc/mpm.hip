@@ -1231,6 +1231,13 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   if (N < 1 || S < 1 || conf->n_grid < 4 || conf->res[0] < 4 || conf->res[1] < 4 || conf->res[2] < 4) {
     ud::set_error("ud_mpm_create: bad sizes (N=%d steps=%d n_grid=%d)", N, S, conf->n_grid); return UD_ERR_INVALID;
   }
+  const int n_prim = conf->n_primitive > 0 ? conf->n_primitive : 1;
+  if (n_prim > UD_MAX_PRIM || (conf->use_position_control && n_prim != 1) || conf->sdf_kind < 0 || conf->sdf_kind > 1 ||
+      (conf->use_position_control && conf->sdf_kind != 0)) {
+    ud::set_error("ud_mpm_create: n_primitive=%d sdf_kind=%d unsupported (position control: one box primitive; soft contact: 1..%d box or container primitives)",
+                  n_prim, conf->sdf_kind, UD_MAX_PRIM);
+    return UD_ERR_UNSUPPORTED;
+  }
   // soft contact (collide_batch) runs on the many-workgroup path whatever N is: every reference env that uses it has N > 128
   const bool large = N > 128 || !conf->use_position_control;
   if (!large && S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
@@ -1247,6 +1254,8 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
   c.position_control = conf->use_position_control ? 1 : 0;
   c.prim_friction = conf->prim_friction; c.prim_softness = conf->prim_softness;
+  c.n_prim = conf->n_primitive > 0 ? conf->n_primitive : 1;   // 0 = unset = 1
+  c.sdf_kind = conf->sdf_kind;
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
   const size_t per_particle = (N <= 96) ? 64 : 48;   // floats of LDS hand-off per particle in the adjoint (stage+ret / park)
@@ -1334,7 +1343,7 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
                                   g_prim_position, g_prim_rotation, clip, g_x0, g_v0, g_C0, g_F0, g_prim_position0, g_prim_rotation0,
                                   g_friction, g_mu, g_lamda, g_action, status, (hipStream_t)stream);
   // one-workgroup path = position control: no cotangent reaches the rotation array
-  if (g_prim_rotation0) UD_HIP_CHECK(hipMemsetAsync(g_prim_rotation0, 0, (size_t)B * h->c.steps * 4 * sizeof(float), (hipStream_t)stream));
+  if (g_prim_rotation0) UD_HIP_CHECK(hipMemsetAsync(g_prim_rotation0, 0, (size_t)B * h->c.n_prim * h->c.steps * 4 * sizeof(float), (hipStream_t)stream));
   ud::MpmBwdArgs a;
   a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B; a.ckpt = (const float*)ckpt;
   a.psize = prim_size; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;

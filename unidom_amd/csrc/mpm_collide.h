@@ -3,6 +3,7 @@
 //     collide_batch :154-182   sdf_batch :112-114   inv_trans_batch :105-109   normal_batch / _normal_batch :117-141
 //     collider_v_batch :144-151   qrot_batch :95-102   length :68-70
 //   /root/reference/DaXBench/daxbench/core/engine/primitives/box.py  _sdf_batch :6-18
+//   /root/reference/DaXBench/daxbench/core/engine/primitives/container.py  _sdf_batch :8-16 (cut hollow sphere)
 // and its hand-derived adjoint (the reference differentiates it with jax.grad, mpm_simulator.py:339-359).
 //
 // The contact normal is a central difference of the SDF with d = 1e-6 (:119-134): one ulp in the local position
@@ -20,6 +21,7 @@ __device__ __forceinline__ float div_rte(float a, float b) { return (float)((dou
 
 struct PrimC {            // the primitive as the grid op of substep f sees it (rows f and f + 1, clamped: Q5); uniform
   float p0[3], r0[4], p1[3], r1[4], iq[4], nq, size[3], soft, mu;
+  int kind;               // 0 box, 1 container (the reference's process-global set_sdf, primitives.py:26-28)
 };
 struct PrimCGrad {        // cotangents one cell adds to the primitive's leaves
   float p0[3], r0[4], p1[3], r1[4], size[3], mu;
@@ -78,6 +80,46 @@ __device__ __forceinline__ void box_sdf_bwd(const float* size, float p0, float p
   }
 }
 
+// container.py:8-16 -- cut hollow sphere, size = (r, h, t)
+__device__ __forceinline__ float container_sdf_x(const float* size, float p0, float p1, float p2) {
+#pragma clang fp contract(off)
+  const float r = size[0], h = size[1], t = size[2];
+  const float w = sqrt_rte(r * r - h * h);
+  const float q0 = sqrt_rte(p0 * p0 + p2 * p2 + 1e-12f), q1 = p1;
+  const bool mask = h * q0 < w * q1;
+  const float d0 = q0 - w, d1 = q1 - h;
+  const float val1 = sqrt_rte(d0 * d0 + d1 * d1 + 1e-12f) - t;
+  const float val2 = fabsf(sqrt_rte(q0 * q0 + q1 * q1 + 1e-12f) - r) - t;
+  return mask ? val1 : val2;
+}
+
+__device__ __forceinline__ void container_sdf_bwd(const float* size, float p0, float p1, float p2, float gout, float* gp, float* gsize) {
+  const float r = size[0], h = size[1];
+  const float w = sqrtf(r * r - h * h);
+  const float q0 = sqrtf(p0 * p0 + p2 * p2 + 1e-12f), q1 = p1;
+  const bool mask = h * q0 < w * q1;
+  float gq0, gq1, gw = 0.f, gr = 0.f, gh = 0.f;
+  if (mask) {
+    const float d0 = q0 - w, d1 = q1 - h, L1 = sqrtf(d0 * d0 + d1 * d1 + 1e-12f);
+    gq0 = gout * d0 / L1; gq1 = gout * d1 / L1; gw = -gq0; gh = -gq1;
+  } else {
+    const float L2 = sqrtf(q0 * q0 + q1 * q1 + 1e-12f), dd = L2 - r;
+    const float sg = dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f);
+    gq0 = gout * sg * q0 / L2; gq1 = gout * sg * q1 / L2; gr = -gout * sg;
+  }
+  gr += gw * r / w; gh -= gw * h / w;
+  gp[0] += gq0 * p0 / q0; gp[2] += gq0 * p2 / q0; gp[1] += gq1;
+  gsize[0] += gr; gsize[1] += gh; gsize[2] -= gout;
+}
+
+__device__ __forceinline__ float prim_sdf_x(int kind, const float* size, float p0, float p1, float p2) {
+  return kind == 1 ? container_sdf_x(size, p0, p1, p2) : box_sdf_x(size, p0, p1, p2);
+}
+__device__ __forceinline__ void prim_sdf_bwd(int kind, const float* size, float p0, float p1, float p2, float gout, float* gp, float* gsize) {
+  if (kind == 1) container_sdf_bwd(size, p0, p1, p2, gout, gp, gsize);
+  else box_sdf_bwd(size, p0, p1, p2, gout, gp, gsize);
+}
+
 // qrot adjoint: accumulates into gq[4], gv[3]
 __device__ __forceinline__ void qrot_bwd(const float* q, const float* v, const float* go, float* gq, float* gv) {
   const float uv0 = q[2] * v[2] - q[3] * v[1], uv1 = q[3] * v[0] - q[1] * v[2], uv2 = q[1] * v[1] - q[2] * v[0];
@@ -104,13 +146,13 @@ __device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const fl
 #pragma unroll
     for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
     qrot_x(pc.iq, r.rel, r.loc);
-    const float dist = box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2]);
+    const float dist = prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2]);
     r.e = expf(-dist * pc.soft);
     r.infl = clipf(r.e, -INFINITY, 1.f);
     const float d = 1.e-6f, k = 500000.f;   // (0.5 / d)
-    r.n[0] = k * (box_sdf_x(pc.size, r.loc[0] + d, r.loc[1], r.loc[2]) - box_sdf_x(pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2]));
-    r.n[1] = k * (box_sdf_x(pc.size, r.loc[0], r.loc[1] + d, r.loc[2]) - box_sdf_x(pc.size, r.loc[0], r.loc[1] + (-d), r.loc[2]));
-    r.n[2] = k * (box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2] + d) - box_sdf_x(pc.size, r.loc[0], r.loc[1], r.loc[2] + (-d)));
+    r.n[0] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0] + d, r.loc[1], r.loc[2]) - prim_sdf_x(pc.kind, pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2]));
+    r.n[1] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1] + d, r.loc[2]) - prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1] + (-d), r.loc[2]));
+    r.n[2] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + d) - prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + (-d)));
     r.len = sqrt_rte(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + 1e-12f);
 #pragma unroll
     for (int a = 0; a < 3; ++a) r.nl[a] = div_rte(r.n[a], r.len);
@@ -195,12 +237,12 @@ __device__ __forceinline__ void collide_cell_bwd(const PrimC& pc, float dt, cons
     const float gn = gnl[a] / r.len + glen * r.n[a] / r.len;
     const float i0 = r.loc[0] + (a == 0 ? d : 0.f), i1 = r.loc[1] + (a == 1 ? d : 0.f), i2 = r.loc[2] + (a == 2 ? d : 0.f);
     const float d0 = r.loc[0] + (a == 0 ? -d : 0.f), d1 = r.loc[1] + (a == 1 ? -d : 0.f), d2 = r.loc[2] + (a == 2 ? -d : 0.f);
-    box_sdf_bwd(pc.size, i0, i1, i2, k * gn, gloc, pg.size);
-    box_sdf_bwd(pc.size, d0, d1, d2, -(k * gn), gloc, pg.size);
+    prim_sdf_bwd(pc.kind, pc.size, i0, i1, i2, k * gn, gloc, pg.size);
+    prim_sdf_bwd(pc.kind, pc.size, d0, d1, d2, -(k * gn), gloc, pg.size);
   }
   const float ge = ginfl * clip_grad(r.e, -INFINITY, 1.f);
   const float gdist = -(ge * r.e) * pc.soft;
-  box_sdf_bwd(pc.size, r.loc[0], r.loc[1], r.loc[2], gdist, gloc, pg.size);
+  prim_sdf_bwd(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2], gdist, gloc, pg.size);
   float giq[4] = {0.f, 0.f, 0.f, 0.f}, grel[3] = {0.f, 0.f, 0.f};
   qrot_bwd(pc.iq, r.rel, gloc, giq, grel);
 #pragma unroll

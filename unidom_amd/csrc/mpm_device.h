@@ -7,6 +7,8 @@
 #define UD_MPM_ABLATE 0   // timing-only diagnostic builds (never shipped): bit0 no SVD, bit1 no scatter, bit2 no grid op, bit3 no g2p, bit4 no clear, bit5 no insert
 #endif
 
+#define UD_MAX_PRIM 4
+
 namespace ud {
 
 struct MpmConst {
@@ -15,6 +17,7 @@ struct MpmConst {
   int H, logH, nthreads;
   int position_control;            // 1: position_control_batch, 0: collide_batch (soft contact)
   float prim_friction, prim_softness;   // PrimitiveState.friction / .softness (collide_batch only)
+  int n_prim, sdf_kind;            // primitives per env (collide_batch: 1..UD_MAX_PRIM); 0 box SDF, 1 container SDF
 };
 
 // ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------

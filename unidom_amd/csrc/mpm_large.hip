@@ -24,19 +24,20 @@ struct LargeBuf {
   int* stamp;       // [B][G]
   int* list;        // [2][B][cap]
   int* count;       // [2][B]
-  float* ppos;      // [B][S*3]  primitive position (evolving)
-  float* prot;      // [B][S*4]
-  float* ppin;      // [B][S*3]  input position array (bwd clip factors)
+  // primitive arrays carry a primitive axis: [B][P][...], P = c.n_prim (1 in position-control mode)
+  float* ppos;      // [B][P][S*3]  primitive position (evolving)
+  float* prot;      // [B][P][S*4]
+  float* ppin;      // [B][P][S*3]  input position array (bwd clip factors)
   float* trq;       // [B][S]    Q6 scalar per substep
-  float* gppos;     // [B][S*3]  bwd
-  float* gpv;       // [B][S*3]  bwd
+  float* gppos;     // [B][P][S*3]  bwd
+  float* gpv;       // [B][P][S*3]  bwd
   float* acc;       // [B][4]    bwd: friction, mu, lamda accumulators
   float* pscr;      // [B][Np][12] bwd: per-particle gw[9], gfx[3] between kernels
   float* hist;      // [B][2][24][Np] ping-pong state when the caller passes no checkpoint
   float* gstate;    // [B][24][Np] bwd: cotangent state (gx,gv,gC,gF) SoA
-  float* grot;      // [B][S*4]  bwd, soft contact: cotangent of the rotation array
-  float* gpw;       // [B][S*3]  bwd, soft contact: cotangent of the angular velocity rows
-  float* gpsz;      // [B][4]    bwd, soft contact: cotangents of primitive size[3] and friction (enter the norm only)
+  float* grot;      // [B][P][S*4]  bwd, soft contact: cotangent of the rotation array
+  float* gpw;       // [B][P][S*3]  bwd, soft contact: cotangent of the angular velocity rows
+  float* gpsz;      // [B][P][4]    bwd, soft contact: cotangents of primitive size[3] and friction (enter the norm only)
 };
 
 struct LargeArgs {
@@ -82,16 +83,25 @@ __device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, 
 }
 
 // soft contact: rows f and f + 1 (clamped, Q5) of the primitive arrays
-__device__ __forceinline__ void load_primc(const LargeArgs& a, int b, PrimC& pc) {
+__device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, PrimC& pc) {
   const int S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
-  const float* pp = a.w.ppos + (long)b * S * 3;
-  const float* pr = a.w.prot + (long)b * S * 4;
+  const long bp = (long)b * a.c.n_prim + ip;
+  const float* pp = a.w.ppos + bp * S * 3;
+  const float* pr = a.w.prot + bp * S * 4;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) { pc.p0[d] = pp[f0 * 3 + d]; pc.p1[d] = pp[f1 * 3 + d]; pc.size[d] = a.psize[b * 3 + d]; }
+  for (int d = 0; d < 3; ++d) { pc.p0[d] = pp[f0 * 3 + d]; pc.p1[d] = pp[f1 * 3 + d]; pc.size[d] = a.psize[bp * 3 + d]; }
 #pragma unroll
   for (int d = 0; d < 4; ++d) { pc.r0[d] = pr[f0 * 4 + d]; pc.r1[d] = pr[f1 * 4 + d]; }
-  pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction;
+  pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction; pc.kind = a.c.sdf_kind;
   primc_finish(pc);
+}
+
+// vin[ip][d] without dynamic register indexing
+__device__ __forceinline__ float sel4(const float (*v)[3], int ip, int d) {
+  float r = v[0][d];
+#pragma unroll
+  for (int k = 1; k < UD_MAX_PRIM; ++k) r = (ip == k) ? v[k][d] : r;
+  return r;
 }
 
 __device__ __forceinline__ void load_state(const float* h, int Np, int p, float* x, float* v, float* Cm, float* F) {
@@ -190,15 +200,17 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
   if (blockIdx.x == 0) {
     const int S = a.c.steps, f = a.f, tid = threadIdx.x;
     if (tid == 0) a.w.count[cur * a.B + b] = 0;
-    if (do_fk) {
-      float* pp = a.w.ppos + (long)b * S * 3;
-      float* pr = a.w.prot + (long)b * S * 4;
+    if (do_fk)
+    for (int ip = 0; ip < a.c.n_prim; ++ip) {
+      const long bp = (long)b * a.c.n_prim + ip;
+      float* pp = a.w.ppos + bp * S * 3;
+      float* pr = a.w.prot + bp * S * 4;
       for (int e0 = 0; e0 < S * 3; e0 += blockDim.x) {   // read all, then write all (one block per env)
         const int e = e0 + tid;
         float pending = 0.f;
         if (e < S * 3) {
           const int row = e / 3, d = e - row * 3;
-          const float pva = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+          const float pva = clipf(a.action[bp * 6 + d], -1.f, 1.f) * 1.f / (float)S;
           pending = (row == f + 1) ? (pp[min(f, S - 1) * 3 + d] + pva) : pp[e];
         }
         __syncthreads();
@@ -208,7 +220,7 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
       if (tid == 0 && f + 1 < S) {
         float pw[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) pw[d] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+        for (int d = 0; d < 3; ++d) pw[d] = clipf(a.action[bp * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
         float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;
         float sn = sinf(ang / 2.f);
         float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
@@ -327,14 +339,18 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
     load_prim(a, b, pf, pv);
     grid_op<false>(a.c, pf, ci, cj, ck, mv.x, mvv, vo, nullptr);
   } else {                                                          // collide_batch (primitives.py:154-182)
-    PrimC pc;
-    load_primc(a, b, pc);
     float v0[3], v1[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
     const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
-    CollideRec cr;
-    collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+    for (int ip = 0; ip < a.c.n_prim; ++ip) {                       // primitive after primitive (mpm_simulator.py:292-294)
+      PrimC pc;
+      load_primc(a, b, ip, pc);
+      CollideRec cr;
+      collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v0[d] = v1[d];
+    }
     grid_tail<false>(a.c, a.friction[b], ci, cj, ck, v1, vo, nullptr);
   }
   if (to_vel) a.w.vel[(long)b * a.G + lin] = make_float4(vo[0], vo[1], vo[2], 0.f);
@@ -425,34 +441,39 @@ __global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int B, const float*
 
 // forward prologue / epilogue for the primitive arrays, J and the outputs set_action writes
 __global__ void __launch_bounds__(256) lg_prim_in(LargeArgs a, const float* ppos, const float* prot) {
-  const int b = blockIdx.x, S = a.c.steps;
-  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) { a.w.ppos[(long)b * S * 3 + e] = ppos[(long)b * S * 3 + e]; a.w.ppin[(long)b * S * 3 + e] = ppos[(long)b * S * 3 + e]; }
-  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[(long)b * S * 4 + e] = prot[(long)b * S * 4 + e];
+  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
+  const long bp = (long)b * a.c.n_prim + ip;
+  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) { a.w.ppos[bp * S * 3 + e] = ppos[bp * S * 3 + e]; a.w.ppin[bp * S * 3 + e] = ppos[bp * S * 3 + e]; }
+  for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[bp * S * 4 + e] = prot[bp * S * 4 + e];
+  if (ip != 0) return;
   for (int e = threadIdx.x; e < S; e += blockDim.x) a.w.trq[(long)b * S + e] = 0.f;
   if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
 }
 
 __global__ void __launch_bounds__(256) lg_fwd_out(LargeArgs a, const float* J, float* Jo, float* ppos_o, float* prot_o, float* pv_o,
                                                   float* pw_o, float* ck_tail, long ck_stride_b) {
-  const int b = blockIdx.x, S = a.c.steps, N = a.c.N;
-  for (int p = threadIdx.x; p < N; p += blockDim.x) {
-    float Jp = nan_to_num(J[(long)b * N + p]);
-    for (int f = 0; f < S; ++f) Jp = Jp * (1.f + a.c.dt * a.w.trq[(long)b * S + f]);   // :327
-    Jo[(long)b * N + p] = Jp;
-  }
+  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps, N = a.c.N;   // grid (B, n_prim)
+  const long bp = (long)b * a.c.n_prim + ip;
+  if (ip == 0)
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+      float Jp = nan_to_num(J[(long)b * N + p]);
+      for (int f = 0; f < S; ++f) Jp = Jp * (1.f + a.c.dt * a.w.trq[(long)b * S + f]);   // :327
+      Jo[(long)b * N + p] = Jp;
+    }
+  float* tail = ck_tail ? ck_tail + (long)b * ck_stride_b + (long)ip * S * 10 : nullptr;   // per primitive: position, rotation, input position
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
     const int row = e / 3, d = e - row * 3;
-    const float* pp = a.w.ppos + (long)b * S * 3;
-    ppos_o[(long)b * S * 3 + e] = (row == 0) ? pp[(S - 1) * 3 + d] : pp[e];       // copy_frame(steps, 0), Q5
-    pv_o[(long)b * S * 3 + e] = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
-    pw_o[(long)b * S * 3 + e] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
-    if (ck_tail) { ck_tail[(long)b * ck_stride_b + e] = pp[e]; ck_tail[(long)b * ck_stride_b + S * 7 + e] = a.w.ppin[(long)b * S * 3 + e]; }
+    const float* pp = a.w.ppos + bp * S * 3;
+    ppos_o[bp * S * 3 + e] = (row == 0) ? pp[(S - 1) * 3 + d] : pp[e];       // copy_frame(steps, 0), Q5
+    pv_o[bp * S * 3 + e] = clipf(a.action[bp * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+    pw_o[bp * S * 3 + e] = clipf(a.action[bp * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+    if (tail) { tail[e] = pp[e]; tail[S * 7 + e] = a.w.ppin[bp * S * 3 + e]; }
   }
   for (int e = threadIdx.x; e < S * 4; e += blockDim.x) {
     const int row = e / 4, d = e - row * 4;
-    const float* pr = a.w.prot + (long)b * S * 4;
-    prot_o[(long)b * S * 4 + e] = (row == 0) ? pr[(S - 1) * 4 + d] : pr[e];
-    if (ck_tail) ck_tail[(long)b * ck_stride_b + S * 3 + e] = pr[e];
+    const float* pr = a.w.prot + bp * S * 4;
+    prot_o[bp * S * 4 + e] = (row == 0) ? pr[(S - 1) * 4 + d] : pr[e];
+    if (tail) tail[S * 3 + e] = pr[e];
   }
 }
 
@@ -465,11 +486,12 @@ __device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pi
 
 // FK adjoint of substep f (one block per env)
 __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
-  const int b = blockIdx.x, S = a.c.steps, f = a.f;
-  const float* pp = a.w.ppos + (long)b * S * 3;
-  const float* pin = a.w.ppin + (long)b * S * 3;
-  float* gp = a.w.gppos + (long)b * S * 3;
-  float* gpv = a.w.gpv + (long)b * S * 3;
+  const int S = a.c.steps, f = a.f;                             // grid (B, n_prim)
+  const long b = (long)blockIdx.x * a.c.n_prim + blockIdx.y;    // (env, primitive) row of the primitive arrays
+  const float* pp = a.w.ppos + b * S * 3;
+  const float* pin = a.w.ppin + b * S * 3;
+  float* gp = a.w.gppos + b * S * 3;
+  float* gpv = a.w.gpv + b * S * 3;
   for (int e0 = 0; e0 < S * 3; e0 += blockDim.x) {
     const int e = e0 + threadIdx.x;
     float val = 0.f, t = 0.f;
@@ -488,8 +510,8 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
   }
   // soft contact: rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))  (primitives.py:190, :73-92)
   if (!a.c.position_control && threadIdx.x == 0 && f + 1 < S) {
-    float* gr_ = a.w.grot + (long)b * S * 4;
-    const float* rr = a.w.prot + (long)b * S * 4 + f * 4;
+    float* gr_ = a.w.grot + b * S * 4;
+    const float* rr = a.w.prot + b * S * 4 + f * 4;
     float go[4], w[3];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { go[d] = gr_[(f + 1) * 4 + d]; gr_[(f + 1) * 4 + d] = 0.f; }
@@ -526,7 +548,7 @@ __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
     // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule is 0.5/0 * 0 = NaN, laundered by nan_to_num at `step`
     const float gs = gang * (0.5f / nrm);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) a.w.gpw[(long)b * S * 3 + f * 3 + d] += gw[d] + gs * (2.f * w[d]);
+    for (int d = 0; d < 3; ++d) a.w.gpw[b * S * 3 + f * 3 + d] += gw[d] + gs * (2.f * w[d]);
   }
 }
 
@@ -617,11 +639,8 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int cur = a.f & 1;
   const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
-  if (a.c.position_control && !live) return;
-  float pgv[UD_PRIMC_NGRAD];
-#pragma unroll
-  for (int d = 0; d < UD_PRIMC_NGRAD; ++d) pgv[d] = 0.f;
-  if (live) {
+  if (a.c.position_control) {
+    if (!live) return;
     const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
     int ci, cj, ck;
     decode_cell(a.c, key, ci, cj, ck);
@@ -629,57 +648,99 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     const float4 mv = a.w.val[(long)b * a.G + lin];
     const float mvv[3] = {mv.y, mv.z, mv.w};
     const float4 g4 = a.w.gacc[(long)b * a.G + lin];
-    float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric;
-    if (a.c.position_control) {
-      PrimF pf;
-      float pv[3], dpv[3];
-      load_prim(a, b, pf, pv);
-      const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
-      if (ctrl) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
-      }
-    } else {
-      PrimC pc;
-      load_primc(a, b, pc);
-      float v0[3], v1[3], vo[3], gin[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
-      const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
-      CollideRec cr;
-      CellRec rec;
-      collide_cell(pc, a.c.dt, gp, v0, v1, cr);
-      grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
-      grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
-      PrimCGrad pg;
-      collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { g[d] = gin[d]; pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
-#pragma unroll
-      for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
-      pgv[17] = pg.mu;
-      grid_head_adjoint(mv.x, mvv, g, gmm);
-    }
+    float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric, pv[3], dpv[3];
+    PrimF pf;
+    load_prim(a, b, pf, pv);
+    const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
     if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
-  }
-  if (a.c.position_control) return;
-  // the primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
+    if (ctrl) {
 #pragma unroll
-  for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
-    const float sum = wave_sum(pgv[d]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
+      for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
+    }
+    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+    return;
   }
-  __syncthreads();
-  if (threadIdx.x < UD_PRIMC_NGRAD) {
-    const int d = threadIdx.x, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
-    const float tot = red[0][d] + red[1][d] + red[2][d] + red[3][d];
-    float* dst = (d < 3)    ? a.w.gppos + (long)b * S * 3 + f0 * 3 + d
-                 : (d < 7)  ? a.w.grot + (long)b * S * 4 + f0 * 4 + (d - 3)
-                 : (d < 10) ? a.w.gppos + (long)b * S * 3 + f1 * 3 + (d - 7)
-                 : (d < 14) ? a.w.grot + (long)b * S * 4 + f1 * 4 + (d - 10)
-                            : a.w.gpsz + b * 4 + (d - 14);
-    if (tot != 0.f) atomicAdd(dst, tot);
+  // ---- soft contact: collide_batch of each primitive in turn (forward), reversed here --------------------------------
+  const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
+  int ci = 0, cj = 0, ck = 0;
+  long lin = 0;
+  float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+  float g[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f}, vin[UD_MAX_PRIM][3];
+  if (live) {
+    const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
+    decode_cell(a.c, key, ci, cj, ck);
+    lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
+    mv = a.w.val[(long)b * a.G + lin];
+    const float4 g4 = a.w.gacc[(long)b * a.G + lin];
+    g[0] = g4.x; g[1] = g4.y; g[2] = g4.z;
+    gp[0] = (float)ci * a.c.dx; gp[1] = (float)cj * a.c.dx; gp[2] = (float)ck * a.c.dx;
+  }
+  const float mvv[3] = {mv.y, mv.z, mv.w};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) vin[0][d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+  // forward chain up to the last primitive's input, then the tail
+  CollideRec cr;
+  float v1[3], vo[3], dfric = 0.f;
+#pragma unroll
+  for (int ip = 0; ip < UD_MAX_PRIM; ++ip) {
+    if (ip >= P) break;
+    PrimC pc;
+    load_primc(a, b, ip, pc);
+    collide_cell(pc, a.c.dt, gp, vin[ip], v1, cr);
+    if (ip + 1 < UD_MAX_PRIM) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) vin[ip + 1][d] = v1[d];
+    }
+  }
+  if (live) {
+    CellRec rec;
+    grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
+    grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
+    if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+  }
+#pragma unroll
+  for (int ipr = 0; ipr < UD_MAX_PRIM; ++ipr) {
+    const int ip = P - 1 - ipr;
+    if (ip < 0) break;
+    PrimC pc;
+    load_primc(a, b, ip, pc);
+    if (ipr > 0) {   // cr still holds the last primitive's record on the first turn
+      float tmp[3];
+      const float vi[3] = {sel4(vin, ip, 0), sel4(vin, ip, 1), sel4(vin, ip, 2)};
+      collide_cell(pc, a.c.dt, gp, vi, tmp, cr);
+    }
+    PrimCGrad pg;
+    float gin[3], pgv[UD_PRIMC_NGRAD];
+    collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { g[d] = gin[d]; pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
+    pgv[17] = pg.mu;
+    // this primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
+#pragma unroll
+    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
+      const float sum = wave_sum(live ? pgv[d] : 0.f);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < UD_PRIMC_NGRAD) {
+      const int d = threadIdx.x;
+      const long bp = (long)b * P + ip;
+      const float tot = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+      float* dst = (d < 3)    ? a.w.gppos + bp * S * 3 + f0 * 3 + d
+                   : (d < 7)  ? a.w.grot + bp * S * 4 + f0 * 4 + (d - 3)
+                   : (d < 10) ? a.w.gppos + bp * S * 3 + f1 * 3 + (d - 7)
+                   : (d < 14) ? a.w.grot + bp * S * 4 + f1 * 4 + (d - 10)
+                              : a.w.gpsz + bp * 4 + (d - 14);
+      if (tot != 0.f) atomicAdd(dst, tot);
+    }
+    __syncthreads();
+  }
+  if (live) {
+    float gmm;
+    grid_head_adjoint(mv.x, mvv, g, gmm);
+    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
   }
 }
 
@@ -758,32 +819,34 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
 // backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
 __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_tail, long ck_stride_b, const float* gppos,
                                                  const float* gprot) {
-  const int b = blockIdx.x, S = a.c.steps;
-  const float* tail = ck_tail + (long)b * ck_stride_b;
+  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
+  const long bp = (long)b * a.c.n_prim + ip;
+  const float* tail = ck_tail + (long)b * ck_stride_b + (long)ip * S * 10;
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
-    a.w.ppos[(long)b * S * 3 + e] = tail[e];
-    a.w.ppin[(long)b * S * 3 + e] = tail[S * 7 + e];
-    a.w.gpv[(long)b * S * 3 + e] = 0.f;
+    a.w.ppos[bp * S * 3 + e] = tail[e];
+    a.w.ppin[bp * S * 3 + e] = tail[S * 7 + e];
+    a.w.gpv[bp * S * 3 + e] = 0.f;
+    a.w.gpw[bp * S * 3 + e] = 0.f;
     const int row = e / 3, d = e - row * 3;
-    float g = gppos[(long)b * S * 3 + e];
+    float g = gppos[bp * S * 3 + e];
     if (S > 1) {
       if (row == 0) g = 0.f;
-      if (row == S - 1) g += gppos[(long)b * S * 3 + d];
+      if (row == S - 1) g += gppos[bp * S * 3 + d];
     }
-    a.w.gppos[(long)b * S * 3 + e] = g;
+    a.w.gppos[bp * S * 3 + e] = g;
   }
   for (int e = threadIdx.x; e < S * 4; e += blockDim.x) {
-    a.w.prot[(long)b * S * 4 + e] = tail[S * 3 + e];
+    a.w.prot[bp * S * 4 + e] = tail[S * 3 + e];
     const int row = e / 4, d = e - row * 4;
-    float g = gprot ? gprot[(long)b * S * 4 + e] : 0.f;          // copy_frame adjoint: rotation[0] <- rotation[steps - 1]
+    float g = gprot ? gprot[bp * S * 4 + e] : 0.f;          // copy_frame adjoint: rotation[0] <- rotation[steps - 1]
     if (S > 1 && gprot) {
       if (row == 0) g = 0.f;
-      if (row == S - 1) g += gprot[(long)b * S * 4 + d];
+      if (row == S - 1) g += gprot[bp * S * 4 + d];
     }
-    a.w.grot[(long)b * S * 4 + e] = g;
+    a.w.grot[bp * S * 4 + e] = g;
   }
-  for (int e = threadIdx.x; e < S * 3; e += blockDim.x) a.w.gpw[(long)b * S * 3 + e] = 0.f;
-  if (threadIdx.x < 4) a.w.gpsz[b * 4 + threadIdx.x] = 0.f;
+  if (threadIdx.x < 4) a.w.gpsz[bp * 4 + threadIdx.x] = 0.f;
+  if (ip != 0) return;
   if (threadIdx.x < 4) a.w.acc[b * 4 + threadIdx.x] = 0.f;
   if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
 }
@@ -791,50 +854,46 @@ __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_ta
 // backward epilogue: set_action adjoint, action clip, norm_grad / norm_grad_state, outputs (one block per env)
 __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
                                                   float* gfric, float* gmu, float* glam, float* gaction, float* grot0) {
-  __shared__ float red[8];
-  const int b = blockIdx.x, S = a.c.steps, N = a.c.N, Np = a.c.Np, tid = threadIdx.x;
+  __shared__ float red[8], sga[6 * UD_MAX_PRIM], sgs[6 * UD_MAX_PRIM];
+  const int b = blockIdx.x, S = a.c.steps, N = a.c.N, Np = a.c.Np, P = a.c.n_prim, tid = threadIdx.x;
   float* gs = a.w.gstate + (long)b * 24 * Np;
-  float* gp = a.w.gppos + (long)b * S * 3;
-  float* gr = a.w.grot + (long)b * S * 4;
-  float ac[6], ga[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gscale[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int d = 0; d < 6; ++d) ac[d] = clipf(a.action[b * 6 + d], -1.f, 1.f);
-  for (int j = 0; j < S; ++j)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { const float t = a.w.gpv[(long)b * S * 3 + j * 3 + d]; ga[d] += t * 1.f / (float)S; gscale[d] += t * ac[d] / (float)S; }
-  if (!a.c.position_control)   // soft contact: the rotation chain reaches action[3:6] (position control: reported as 0, see unidom_hip.h)
-    for (int j = 0; j < S; ++j)
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { const float t = a.w.gpw[(long)b * S * 3 + j * 3 + d]; ga[3 + d] += t * 1.f / (float)S; gscale[3 + d] += t * ac[3 + d] / (float)S; }
-#pragma unroll
-  for (int d = 0; d < 6; ++d) ga[d] *= clip_grad(a.action[b * 6 + d], -1.f, 1.f);
+  float* gp = a.w.gppos + (long)b * P * S * 3;     // all primitives of this env, contiguous
+  float* gr = a.w.grot + (long)b * P * S * 4;
+  // set_action adjoint (primitives.py:212-229): thread (ip, d) sums its component over the substeps
+  if (tid < 6 * P) {
+    const int ip = tid / 6, d = tid - ip * 6;
+    const long bp = (long)b * P + ip;
+    const float ac = clipf(a.action[bp * 6 + d], -1.f, 1.f);
+    float g1 = 0.f, g2 = 0.f;
+    // position control: nothing reaches the rotation chain and action[3:6] is reported as 0 (see unidom_hip.h)
+    const float* src = (d < 3) ? a.w.gpv + bp * S * 3 + d : (a.c.position_control ? nullptr : a.w.gpw + bp * S * 3 + (d - 3));
+    if (src)
+      for (int j = 0; j < S; ++j) { const float t = src[j * 3]; g1 += t * 1.f / (float)S; g2 += t * ac / (float)S; }
+    g1 *= clip_grad(a.action[bp * 6 + d], -1.f, 1.f);
+    if (clip) { g1 = nan_to_num(g1 + 0.f); g2 = nan_to_num(g2); }
+    sga[tid] = g1; sgs[tid] = g2;
+  }
+  __syncthreads();
   float tf = a.w.acc[b * 4 + 0], tm = a.w.acc[b * 4 + 1], tl = a.w.acc[b * 4 + 2];
-  float sn = 0.f;
+  float sn = 0.f, anrm = 0.f;
   if (clip) {
     float n2 = 0.f;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) { ga[d] = nan_to_num(ga[d] + 0.f); n2 += ga[d] * ga[d]; }
-    const float nrm = sqrtf(n2);
-    if (!(nrm < 1.f)) {
-#pragma unroll
-      for (int d = 0; d < 6; ++d) ga[d] = ga[d] / nrm;
-    }
+    for (int d = 0; d < 6 * P; ++d) n2 += sga[d] * sga[d];
+    anrm = sqrtf(n2);
     float s2 = 0.f;
     for (int e = tid; e < 24 * Np; e += blockDim.x) {
       const int p = e % Np;
       if (p < N) { const float t = nan_to_num(gs[e] + 0.f); gs[e] = t; s2 += t * t; }
     }
-    for (int e = tid; e < S * 3; e += blockDim.x) { const float t = nan_to_num(gp[e] + 0.f); gp[e] = t; s2 += t * t; }
+    for (int e = tid; e < P * S * 3; e += blockDim.x) { const float t = nan_to_num(gp[e] + 0.f); gp[e] = t; s2 += t * t; }
     if (!a.c.position_control)
-      for (int e = tid; e < S * 4; e += blockDim.x) { const float t = nan_to_num(gr[e] + 0.f); gr[e] = t; s2 += t * t; }
+      for (int e = tid; e < P * S * 4; e += blockDim.x) { const float t = nan_to_num(gr[e] + 0.f); gr[e] = t; s2 += t * t; }
     tf = nan_to_num(tf); tm = nan_to_num(tm); tl = nan_to_num(tl);
     if (tid == 0) {
       s2 += tf * tf + tm * tm + tl * tl;
-#pragma unroll
-      for (int d = 0; d < 6; ++d) { const float t = nan_to_num(gscale[d]); s2 += t * t; }
+      for (int d = 0; d < 6 * P; ++d) s2 += sgs[d] * sgs[d];
       if (!a.c.position_control)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { const float t = nan_to_num(a.w.gpsz[b * 4 + d]); s2 += t * t; }
+        for (int d = 0; d < 4 * P; ++d) { const float t = nan_to_num(a.w.gpsz[(long)b * P * 4 + d]); s2 += t * t; }
     }
     s2 = wave_sum(s2);
     if ((tid & 63) == 0) red[tid >> 6] = s2;
@@ -856,14 +915,11 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
       gF0[((long)b * N + p) * 9 + d] = sc ? gs[(15 + d) * Np + p] / sn : gs[(15 + d) * Np + p];
     }
   }
-  for (int e = tid; e < S * 3; e += blockDim.x) gppos0[(long)b * S * 3 + e] = sc ? gp[e] / sn : gp[e];
+  for (int e = tid; e < P * S * 3; e += blockDim.x) gppos0[(long)b * P * S * 3 + e] = sc ? gp[e] / sn : gp[e];
   if (grot0)
-    for (int e = tid; e < S * 4; e += blockDim.x) grot0[(long)b * S * 4 + e] = a.c.position_control ? 0.f : (sc ? gr[e] / sn : gr[e]);
-  if (tid == 0) {
-    gfric[b] = sc ? tf / sn : tf; gmu[b] = sc ? tm / sn : tm; glam[b] = sc ? tl / sn : tl;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) gaction[b * 6 + d] = ga[d];
-  }
+    for (int e = tid; e < P * S * 4; e += blockDim.x) grot0[(long)b * P * S * 4 + e] = a.c.position_control ? 0.f : (sc ? gr[e] / sn : gr[e]);
+  if (tid == 0) { gfric[b] = sc ? tf / sn : tf; gmu[b] = sc ? tm / sn : tm; glam[b] = sc ? tl / sn : tl; }
+  if (tid < 6 * P) gaction[(long)b * P * 6 + tid] = (clip && !(anrm < 1.f)) ? sga[tid] / anrm : sga[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -900,7 +956,7 @@ void mpm_large_destroy(MpmLarge* L) {
 }
 
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B) {
-  return (size_t)B * ((size_t)(L->c.steps + 1) * 24 * L->c.Np + (size_t)L->c.steps * 10) * sizeof(float);
+  return (size_t)B * ((size_t)(L->c.steps + 1) * 24 * L->c.Np + (size_t)L->c.n_prim * L->c.steps * 10) * sizeof(float);
 }
 
 static int reserve(MpmLarge* L, int B, hipStream_t stream) {
@@ -908,15 +964,16 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   if (L->arena) { (void)hipStreamSynchronize(stream); (void)hipFree(L->arena); L->arena = nullptr; }
   const MpmConst& c = L->c;
   const long G = L->G, S = c.steps;
+  const size_t BP = (size_t)B * c.n_prim;   // rows of the primitive arrays
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_val = take((size_t)B * G * 16), o_vel = take((size_t)B * G * 16), o_gacc = take((size_t)B * G * 16);
   const size_t o_stamp = take((size_t)B * G * 4), o_list = take((size_t)2 * B * L->cap * 4), o_count = take((size_t)2 * B * 4);
-  const size_t o_ppos = take((size_t)B * S * 3 * 4), o_prot = take((size_t)B * S * 4 * 4), o_ppin = take((size_t)B * S * 3 * 4);
-  const size_t o_trq = take((size_t)B * S * 4), o_gppos = take((size_t)B * S * 3 * 4), o_gpv = take((size_t)B * S * 3 * 4);
+  const size_t o_ppos = take(BP * S * 3 * 4), o_prot = take(BP * S * 4 * 4), o_ppin = take(BP * S * 3 * 4);
+  const size_t o_trq = take((size_t)B * S * 4), o_gppos = take(BP * S * 3 * 4), o_gpv = take(BP * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 12 * 4);
   const size_t o_hist = take((size_t)B * 2 * 24 * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
-  const size_t o_grot = take((size_t)B * S * 4 * 4), o_gpw = take((size_t)B * S * 3 * 4), o_gpsz = take((size_t)B * 4 * 4);
+  const size_t o_grot = take(BP * S * 4 * 4), o_gpw = take(BP * S * 3 * 4), o_gpsz = take(BP * 4 * 4);
   hipError_t e = hipMalloc(&L->arena, off);
   if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
   e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, stamps and counters start at zero
@@ -960,9 +1017,9 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
   float* hist = ckpt ? ckpt : L->w.hist;
   const long rec = (long)24 * Np;
-  const long stride_b = ckpt ? ((long)(S + 1) * rec + (long)S * 10) : 2 * rec;
+  const long stride_b = ckpt ? ((long)(S + 1) * rec + (long)c.n_prim * S * 10) : 2 * rec;
   a.hist_stride_b = stride_b;
-  hipLaunchKernelGGL(lg_prim_in, dim3(B), blk, 0, st, a, ppos, prot);
+  hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
   hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, x, v, C, F, hist, stride_b, 1);
   for (int f = 0; f < S; ++f) {
     a.f = f; a.epoch = L->epoch++;
@@ -979,7 +1036,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
   hipLaunchKernelGGL(lg_unpack, gp, blk, 0, st, c, B, last, stride_b, xo, vo, Co, Fo);
   float* tail = ckpt ? ckpt + (long)(S + 1) * rec : nullptr;
-  hipLaunchKernelGGL(lg_fwd_out, dim3(B), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+  hipLaunchKernelGGL(lg_fwd_out, dim3(B, c.n_prim), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_fwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
@@ -1000,9 +1057,9 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const dim3 gq((lanes * N + 255) / 256, B);                                               // gather kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   const long rec = (long)24 * Np;
-  const long stride_b = (long)(S + 1) * rec + (long)S * 10;
+  const long stride_b = (long)(S + 1) * rec + (long)c.n_prim * S * 10;
   a.hist_stride_b = stride_b;
-  hipLaunchKernelGGL(lg_bwd_in, dim3(B), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
+  hipLaunchKernelGGL(lg_bwd_in, dim3(B, c.n_prim), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
   hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
   for (int f = S - 1; f >= 0; --f) {
     // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
@@ -1014,7 +1071,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), st, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), st, a);
     hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, st, a);
-    hipLaunchKernelGGL(lg_fk_adj, dim3(B), blk, 0, st, a);
+    hipLaunchKernelGGL(lg_fk_adj, dim3(B, c.n_prim), blk, 0, st, a);
   }
   a.f = -1; a.epoch = L->epoch++;
   hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);

@@ -49,13 +49,16 @@ class _Step(torch.autograd.Function):
         x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action = map(
             f32, (x, v, Cm, F, J, ppos, prot, psize, friction, mu, lamda, action))
         assert x.shape == (B, N, 3) and Cm.shape == (B, N, 3, 3) and J.shape == (B, N)
-        assert ppos.shape == (B, S, 3) and prot.shape == (B, S, 4) and psize.shape == (B, 3) and action.shape == (B, 6)
+        P = sim.n_primitive
+        pa = (P,) if P > 1 else ()          # primitive axis after the env axis when there are several primitives
+        assert ppos.shape == (B,) + pa + (S, 3) and prot.shape == (B,) + pa + (S, 4) and psize.shape == (B,) + pa + (3,)
+        assert action.shape == (B, 6 * P)
         ctx.pshape = (tuple(friction.shape), tuple(mu.shape), tuple(lamda.shape))
         friction, mu, lamda = friction.reshape(B).contiguous(), mu.reshape(B).contiguous(), lamda.reshape(B).contiguous()
         dev = x.device
         xo, vo, Co, Fo, Jo = (torch.empty_like(t) for t in (x, v, Cm, F, J))
         ppo, pro = torch.empty_like(ppos), torch.empty_like(prot)
-        pvo, pwo = torch.empty((B, S, 3), device=dev), torch.empty((B, S, 3), device=dev)
+        pvo, pwo = torch.empty_like(ppos), torch.empty_like(ppos)
         ckpt = None
         if any(ctx.needs_input_grad):
             ckpt = torch.empty((L.ud_mpm_ckpt_bytes(sim._h, C.c_int(B)) // 4,), dtype=torch.float32, device=dev)
@@ -86,10 +89,11 @@ class _Step(torch.autograd.Function):
         N, S, dev = sim.n_particles, sim.conf.steps, psize.device
         z = lambda t, shape: (torch.zeros(shape, device=dev) if t is None else t.to(torch.float32).contiguous())
         gx, gv, gC, gF = z(gx, (B, N, 3)), z(gv, (B, N, 3)), z(gC, (B, N, 3, 3)), z(gF, (B, N, 3, 3))
-        gppos, gprot = z(gppos, (B, S, 3)), z(gprot, (B, S, 4))
+        pa = (sim.n_primitive,) if sim.n_primitive > 1 else ()
+        gppos, gprot = z(gppos, (B,) + pa + (S, 3)), z(gprot, (B,) + pa + (S, 4))
         ox, ov, oC, oF, opp, opr = (torch.empty_like(t) for t in (gx, gv, gC, gF, gppos, gprot))
         ofr, omu, ola = (torch.empty((B,), device=dev) for _ in range(3))
-        oa = torch.empty((B, 6), device=dev)
+        oa = torch.empty((B, 6 * sim.n_primitive), device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ev = sim._prof_begin("bwd")
@@ -125,6 +129,7 @@ class SimpleMPMSimulator:
         self.h = None
         self.clip_grad = True            # norm_grad_state / norm_grad (:375-411)
         self.prim_friction, self.prim_softness = 0.1, 666.0   # PrimitiveState.friction / .softness (collide_batch); set by create_primitive
+        self.n_primitive, self.sdf_kind = 1, "box"             # fixed at reset_jax (state.primitives, primitives.set_sdf)
         self.profile = None
         self.status_log = []
         self._h = None
@@ -186,6 +191,12 @@ class SimpleMPMSimulator:
         if state.primitives:                   # constants of collide_batch (primitives.py:154-182), fixed per handle
             self.prim_friction = float(state.primitives[0].friction.reshape(-1)[0])
             self.prim_softness = float(state.primitives[0].softness.reshape(-1)[0])
+            for q in state.primitives[1:]:
+                if float(q.friction.reshape(-1)[0]) != self.prim_friction or float(q.softness.reshape(-1)[0]) != self.prim_softness:
+                    raise NotImplementedError("primitives with different friction / softness (every reference env uses 0.1 / 666)")
+            self.n_primitive = len(state.primitives)
+        from .primitives.primitives import get_sdf_kind
+        self.sdf_kind = get_sdf_kind()
         self._make_handle()
         return out
 
@@ -197,7 +208,8 @@ class SimpleMPMSimulator:
         cc = _lib.ud_mpm_conf(n_particles=self.n_particles, n_grid=int(conf.n_grid), res=(C.c_int * 3)(*self.res),
                               steps=int(conf.steps), dt=float(conf.dt), p_mass=float(conf.p_mass), p_vol=float(conf.p_vol),
                               gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)),
-                              prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness))
+                              prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness),
+                              n_primitive=int(self.n_primitive), sdf_kind={"box": 0, "container": 1}[self.sdf_kind])
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
         self._h = C.c_void_p()
@@ -237,15 +249,24 @@ class SimpleMPMSimulator:
         """One `step` for the batch: (state, action[B, 6*n_primitive]) -> (state, state)   (:413-429)."""
         if self._h is None:
             raise _lib.UnidomError("reset_jax() must run before step_jax() (it fixes n_particles / material / h)")
-        if len(state.primitives) != 1:
-            raise NotImplementedError("exactly one primitive is supported this round")
-        p = state.primitives[0]
+        P = self.n_primitive
+        if len(state.primitives) != P:
+            raise _lib.UnidomError(f"state has {len(state.primitives)} primitives, the kernel handle was built for {P}")
         if len(self.status_log) > 256:
             self.status_log = self.status_log[-8:]
+        prims = state.primitives
+        if P == 1:
+            pos, rot, size = prims[0].position, prims[0].rotation, prims[0].size
+        else:                                  # [B, P, ...]: primitive axis after the env axis (include/unidom_hip.h)
+            pos, rot, size = (torch.stack([getattr(q, k) for q in prims], 1) for k in ("position", "rotation", "size"))
         xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo = _Step.apply(
-            self, state.x, state.v, state.C, state.F, state.J, p.position, p.rotation, p.size, state.friction,
-            state.mu, state.lamda, action[:, :6])
-        a = action[:, :6].clamp(-1, 1)
-        p2 = p._replace(position=ppo, rotation=pro, v=pvo, w=pwo, action_buffer=a)
-        new = state._replace(x=xo, v=vo, C=Co, F=Fo, J=Jo, primitives=[p2])
+            self, state.x, state.v, state.C, state.F, state.J, pos, rot, size, state.friction,
+            state.mu, state.lamda, action[:, :6 * P])
+        a = action[:, :6 * P].clamp(-1, 1)
+        if P == 1:
+            new_prims = [prims[0]._replace(position=ppo, rotation=pro, v=pvo, w=pwo, action_buffer=a)]
+        else:
+            new_prims = [q._replace(position=ppo[:, i], rotation=pro[:, i], v=pvo[:, i], w=pwo[:, i], action_buffer=a[:, 6 * i:6 * i + 6])
+                         for i, q in enumerate(prims)]
+        new = state._replace(x=xo, v=vo, C=Co, F=Fo, J=Jo, primitives=new_prims)
         return new, new

@@ -1,8 +1,10 @@
 """PrimitiveState / create_primitive -- mirrors the state container of
 /root/reference/DaXBench/daxbench/core/engine/primitives/primitives.py:9-60 (torch tensors instead of jnp arrays).
 The primitive dynamics themselves (forward_kinematics :185-194, set_action :212-229, position_control_batch
-:232-239, box SDF box.py:6-18) run inside the MPM kernels (csrc/mpm.hip).  The SDF kind is a per-simulator
-constant (box) instead of the reference's process-global `_sdf_batch` function pointer (:5-6, :26-28)."""
+:232-239, collide_batch :154-182, box SDF box.py:6-18, container SDF container.py:8-16) run inside the MPM kernels
+(csrc/mpm.hip, mpm_large.hip, mpm_collide.h).  set_sdf records the SDF kind, which each simulator copies into its kernel
+handle at reset -- a per-handle constant instead of the reference's process-global `_sdf_batch` function pointer
+(:5-6, :26-28), so two envs with different SDFs can live in one process."""
 from __future__ import annotations
 
 from typing import NamedTuple
@@ -31,12 +33,19 @@ _SDF_KIND = "box"
 
 
 def set_sdf(kind):
-    """Kept for interface parity (whip_rope_env.py:122 calls set_sdf(box_sdf)); only the box SDF exists here."""
+    """whip_rope_env.py:122 / shape_rope_env.py:158 call set_sdf(box_sdf), pour_water_env.py:119 set_sdf(container_sdf)."""
     global _SDF_KIND
     name = kind if isinstance(kind, str) else getattr(kind, "__name__", "box")
-    if "box" not in name:
-        raise NotImplementedError("only the box SDF is implemented (container SDF: next row)")
-    _SDF_KIND = "box"
+    if "container" in name:
+        _SDF_KIND = "container"
+    elif "box" in name:
+        _SDF_KIND = "box"
+    else:
+        raise NotImplementedError(f"unknown SDF {name!r}: box (box.py) and container (container.py) are implemented")
+
+
+def get_sdf_kind():
+    return _SDF_KIND
 
 
 def create_primitive(conf, friction, softness, color, size, init_pos, device="cpu"):   # :31-60
