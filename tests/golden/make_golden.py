@@ -123,7 +123,7 @@ def main():
         shutil.copyfile(src, f"{dst}/goal.npy")
         print(task, "goal", np.load(src).shape)
     # goals of the sibling envs on the same kernels (data files: inputs of their reward)
-    for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "shape_rope"):
+    for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "shape_rope", "pour_water"):
         src = f"{REF}/core/envs/goals/{task}/goal.npy"
         dst = f"{REPO}/unidom_amd/envs/goals/{task}"
         os.makedirs(dst, exist_ok=True)

@@ -1,9 +1,9 @@
 """Name -> env class, same keys as the reference's registry for the envs on the hot path
 (/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  fold_cloth3 / unfold_cloth1 / unfold_cloth3 are
 the same 512-particle cloth and the same kernels under other confs; shape_rope / shape_rope_hard run the MPM kernels
-in soft-contact mode with the plastic material.  The remaining reference envs (fold_tshirt -- 3573 particles, needs a
-multi-workgroup cloth kernel --, pour_water, pour_soup -- two primitives and a container SDF) are "next" rows
- and are absent from the registry."""
+in soft-contact mode with the plastic material.  pour_water adds the liquid material, two primitives and the container SDF.
+The remaining reference envs (fold_tshirt -- 3573 particles, needs a multi-workgroup cloth kernel --, pour_soup -- needs
+an open3d point-cloud asset the reference loads at reset) are "next" rows and are absent from the registry."""
 from .fold_cloth1_env import FoldCloth1Env
 from .fold_cloth1_para_env import FoldCloth1ParaEnv
 from .fold_cloth3_env import FoldCloth3Env
@@ -21,8 +21,10 @@ try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
     from .whip_rope_env import WhipRopeEnv
     from .shape_rope_env import ShapeRopeEnv
     from .shape_rope_hard_env import ShapeRopeHardEnv
+    from .pour_water_env import PourWaterEnv
     env_functions["whip_rope"] = WhipRopeEnv
     env_functions["shape_rope"] = ShapeRopeEnv
     env_functions["shape_rope_hard"] = ShapeRopeHardEnv
+    env_functions["pour_water"] = PourWaterEnv
 except ImportError:  # pragma: no cover
     pass
