@@ -11,6 +11,8 @@
 //   * no host synchronisation: all launches go to the caller's stream in order.
 // First version: one lane per particle, plain global atomics (the Morton-sorted, LDS-tiled p2g of north_star is the
 // next optimisation step for this path).
+#include <cstdlib>
+
 #include "mpm_device.h"
 #include "mpm_large.h"
 #include "mpm_collide.h"
@@ -46,6 +48,7 @@ struct LargeArgs {
   const int* material;
   const float* hard;
   int B, f, epoch, cap;
+  int b0;                 // first env of this launch (env groups on separate streams)
   long G;
   const float* hist_in;   // state at substep f      [B][*][24][Np] with stride
   float* hist_out;        // state at substep f + 1
@@ -94,14 +97,6 @@ __device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, Pr
   for (int d = 0; d < 4; ++d) { pc.r0[d] = pr[f0 * 4 + d]; pc.r1[d] = pr[f1 * 4 + d]; }
   pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction; pc.kind = a.c.sdf_kind;
   primc_finish(pc);
-}
-
-// vin[ip][d] without dynamic register indexing
-__device__ __forceinline__ float sel4(const float (*v)[3], int ip, int d) {
-  float r = v[0][d];
-#pragma unroll
-  for (int k = 1; k < UD_MAX_PRIM; ++k) r = (ip == k) ? v[k][d] : r;
-  return r;
 }
 
 __device__ __forceinline__ void load_state(const float* h, int Np, int p, float* x, float* v, float* Cm, float* F) {
@@ -189,7 +184,7 @@ __device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, 
 // ---- forward kernels ---------------------------------------------------------------------------------
 // clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
 __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
-  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int prev = (a.f + 1) & 1, cur = a.f & 1;   // works for f ascending (forward) and descending (backward)
   const int n = min(a.w.count[prev * a.B + b], a.cap);
   if (t < n) {
@@ -242,7 +237,7 @@ template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) {
   constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
   const BlockTable bt = bt_make<TH>();
-  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   bt_clear<TH>(bt);
   __syncthreads();
@@ -323,7 +318,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
 
 // grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
 __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
-  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int cur = a.f & 1;
   if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
@@ -343,6 +338,7 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
     const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+#pragma unroll 1
     for (int ip = 0; ip < a.c.n_prim; ++ip) {                       // primitive after primitive (mpm_simulator.py:292-294)
       PrimC pc;
       load_primc(a, b, ip, pc);
@@ -360,7 +356,7 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
 // g2p + advect (:196-221, :318-328)
 template <int LANES>
 __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
-  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   if (p >= c.N) return;   // whole quads leave together
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
@@ -409,9 +405,9 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
 }
 
 // AoS boundary <-> SoA history; nan_to_num on the way in (norm_grad_state fwd, :377-381)
-__global__ void __launch_bounds__(256) lg_pack(MpmConst c, int B, const float* x, const float* v, const float* Cm, const float* F,
+__global__ void __launch_bounds__(256) lg_pack(MpmConst c, int b0, const float* x, const float* v, const float* Cm, const float* F,
                                                float* hist, long stride_b, int sanitize) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + b0, p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= c.N) return;
   float* h = hist + (long)b * stride_b;
   const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
@@ -427,9 +423,9 @@ __global__ void __launch_bounds__(256) lg_pack(MpmConst c, int B, const float* x
   }
 }
 
-__global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int B, const float* hist, long stride_b, float* x, float* v, float* Cm,
+__global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int b0, const float* hist, long stride_b, float* x, float* v, float* Cm,
                                                  float* F) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + b0, p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= c.N) return;
   const float* h = hist + (long)b * stride_b;
   const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
@@ -441,7 +437,7 @@ __global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int B, const float*
 
 // forward prologue / epilogue for the primitive arrays, J and the outputs set_action writes
 __global__ void __launch_bounds__(256) lg_prim_in(LargeArgs a, const float* ppos, const float* prot) {
-  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
+  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
   const long bp = (long)b * a.c.n_prim + ip;
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) { a.w.ppos[bp * S * 3 + e] = ppos[bp * S * 3 + e]; a.w.ppin[bp * S * 3 + e] = ppos[bp * S * 3 + e]; }
   for (int e = threadIdx.x; e < S * 4; e += blockDim.x) a.w.prot[bp * S * 4 + e] = prot[bp * S * 4 + e];
@@ -452,7 +448,7 @@ __global__ void __launch_bounds__(256) lg_prim_in(LargeArgs a, const float* ppos
 
 __global__ void __launch_bounds__(256) lg_fwd_out(LargeArgs a, const float* J, float* Jo, float* ppos_o, float* prot_o, float* pv_o,
                                                   float* pw_o, float* ck_tail, long ck_stride_b) {
-  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps, N = a.c.N;   // grid (B, n_prim)
+  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps, N = a.c.N;   // grid (B, n_prim)
   const long bp = (long)b * a.c.n_prim + ip;
   if (ip == 0)
     for (int p = threadIdx.x; p < N; p += blockDim.x) {
@@ -487,7 +483,7 @@ __device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pi
 // FK adjoint of substep f (one block per env)
 __global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
   const int S = a.c.steps, f = a.f;                             // grid (B, n_prim)
-  const long b = (long)blockIdx.x * a.c.n_prim + blockIdx.y;    // (env, primitive) row of the primitive arrays
+  const long b = (long)(blockIdx.x + a.b0) * a.c.n_prim + blockIdx.y;    // (env, primitive) row of the primitive arrays
   const float* pp = a.w.ppos + b * S * 3;
   const float* pin = a.w.ppin + b * S * 3;
   float* gp = a.w.gppos + b * S * 3;
@@ -557,7 +553,7 @@ template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
   const BlockTable bt = bt_make<TH>();
-  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   bt_clear<TH>(bt);
   __syncthreads();
@@ -636,7 +632,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 // grid-op adjoint over the active cells
 __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   __shared__ float red[4][UD_PRIMC_NGRAD];
-  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int cur = a.f & 1;
   const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
   if (a.c.position_control) {
@@ -665,7 +661,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   int ci = 0, cj = 0, ck = 0;
   long lin = 0;
   float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
-  float g[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f}, vin[UD_MAX_PRIM][3];
+  float g[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f};
   if (live) {
     const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
     decode_cell(a.c, key, ci, cj, ck);
@@ -676,38 +672,28 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     gp[0] = (float)ci * a.c.dx; gp[1] = (float)cj * a.c.dx; gp[2] = (float)ck * a.c.dx;
   }
   const float mvv[3] = {mv.y, mv.z, mv.w};
+  float v0[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) vin[0][d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
-  // forward chain up to the last primitive's input, then the tail
-  CollideRec cr;
-  float v1[3], vo[3], dfric = 0.f;
-#pragma unroll
-  for (int ip = 0; ip < UD_MAX_PRIM; ++ip) {
-    if (ip >= P) break;
+  for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+  // Reverse walk over the primitives.  Primitive ip's input velocity is recomputed by running the chain 0..ip again
+  // (one extra collide for two primitives) -- loops are kept rolled: one copy of the collide code in the kernel.
+#pragma unroll 1
+  for (int ip = P - 1; ip >= 0; --ip) {
     PrimC pc;
-    load_primc(a, b, ip, pc);
-    collide_cell(pc, a.c.dt, gp, vin[ip], v1, cr);
-    if (ip + 1 < UD_MAX_PRIM) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) vin[ip + 1][d] = v1[d];
+    CollideRec cr;
+    float vi[3] = {v0[0], v0[1], v0[2]}, v1[3];
+#pragma unroll 1
+    for (int j = 0; j <= ip; ++j) {
+      load_primc(a, b, j, pc);
+      collide_cell(pc, a.c.dt, gp, vi, v1, cr);
+      if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
     }
-  }
-  if (live) {
-    CellRec rec;
-    grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
-    grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
-    if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-  }
-#pragma unroll
-  for (int ipr = 0; ipr < UD_MAX_PRIM; ++ipr) {
-    const int ip = P - 1 - ipr;
-    if (ip < 0) break;
-    PrimC pc;
-    load_primc(a, b, ip, pc);
-    if (ipr > 0) {   // cr still holds the last primitive's record on the first turn
-      float tmp[3];
-      const float vi[3] = {sel4(vin, ip, 0), sel4(vin, ip, 1), sel4(vin, ip, 2)};
-      collide_cell(pc, a.c.dt, gp, vi, tmp, cr);
+    if (ip == P - 1 && live) {   // v1 = velocity after the last primitive: ground friction + boundary, reversed first
+      CellRec rec;
+      float vo[3], dfric;
+      grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
+      grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
+      if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
     }
     PrimCGrad pg;
     float gin[3], pgv[UD_PRIMC_NGRAD];
@@ -747,7 +733,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
 template <int LANES>
 __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
-  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   if (p >= c.N) return;   // whole quads leave together
   float x[3], v[3], Cm[9], F[9];
@@ -819,7 +805,7 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
 // backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
 __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_tail, long ck_stride_b, const float* gppos,
                                                  const float* gprot) {
-  const int b = blockIdx.x, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
+  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps;   // grid (B, n_prim)
   const long bp = (long)b * a.c.n_prim + ip;
   const float* tail = ck_tail + (long)b * ck_stride_b + (long)ip * S * 10;
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
@@ -855,7 +841,7 @@ __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_ta
 __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
                                                   float* gfric, float* gmu, float* glam, float* gaction, float* grot0) {
   __shared__ float red[8], sga[6 * UD_MAX_PRIM], sgs[6 * UD_MAX_PRIM];
-  const int b = blockIdx.x, S = a.c.steps, N = a.c.N, Np = a.c.Np, P = a.c.n_prim, tid = threadIdx.x;
+  const int b = blockIdx.x + a.b0, S = a.c.steps, N = a.c.N, Np = a.c.Np, P = a.c.n_prim, tid = threadIdx.x;
   float* gs = a.w.gstate + (long)b * 24 * Np;
   float* gp = a.w.gppos + (long)b * P * S * 3;     // all primitives of this env, contiguous
   float* gr = a.w.grot + (long)b * P * S * 4;
@@ -934,7 +920,24 @@ struct MpmLarge {
   LargeBuf w{};
   void* arena = nullptr;
   size_t arena_bytes = 0;
+  // Small launches (a few hundred workgroups of latency-bound work) leave most of the chip idle and every kernel waits
+  // for the previous one: the envs are split into groups that run the same kernel sequence on separate streams, forked
+  // from and joined back into the caller's stream with events (no host synchronisation).
+  static constexpr int MAX_GROUPS = 4;
+  hipStream_t side[MAX_GROUPS - 1] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS - 1] = {};
 };
+
+#ifndef LG_GROUPS
+#define LG_GROUPS 2
+#endif
+// number of env groups for a launch of B envs
+static int lg_groups(const MpmLarge* L, int B) {
+  static const int want = [] { const char* e = getenv("UD_LG_GROUPS"); return e ? atoi(e) : LG_GROUPS; }();   // diagnostic override
+  const long lanes = (long)B * L->c.N * 4;
+  if (want <= 1 || B < 2 * want || lanes > 200000 || !L->ev_fork) return 1;
+  return want < MpmLarge::MAX_GROUPS ? want : MpmLarge::MAX_GROUPS;
+}
 
 MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard) {
   auto* L = new MpmLarge;
@@ -946,12 +949,23 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   (void)hipFuncSetAttribute((const void*)lg_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+  bool ok = hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
+    ok = ok && hipStreamCreateWithFlags(&L->side[g], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&L->ev_join[g], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) { if (L->ev_fork) (void)hipEventDestroy(L->ev_fork); L->ev_fork = nullptr; (void)hipGetLastError(); }   // single-stream fallback
   return L;
 }
 
 void mpm_large_destroy(MpmLarge* L) {
   if (!L) return;
   if (L->arena) (void)hipFree(L->arena);
+  for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
+    if (L->side[g]) (void)hipStreamDestroy(L->side[g]);
+    if (L->ev_join[g]) (void)hipEventDestroy(L->ev_join[g]);
+  }
+  if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
   delete L;
 }
 
@@ -994,10 +1008,31 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
                            const float* action) {
   LargeArgs a;
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.epoch = 0; a.cap = L->cap; a.G = L->G;
-  a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0;
+  a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
   return a;
+}
+
+// env groups: group g covers envs [b0, b0 + Bg) on stream s (group 0 = the caller's stream)
+struct LgGroup { int b0, Bg; hipStream_t s; };
+static int lg_fork(MpmLarge* L, int B, hipStream_t st, LgGroup* grp) {
+  const int G = lg_groups(L, B);
+  for (int g = 0; g < G; ++g) {
+    const int b0 = (int)((long)B * g / G), b1 = (int)((long)B * (g + 1) / G);
+    grp[g] = LgGroup{b0, b1 - b0, g == 0 ? st : L->side[g - 1]};
+  }
+  if (G > 1) {
+    (void)hipEventRecord(L->ev_fork, st);
+    for (int g = 1; g < G; ++g) (void)hipStreamWaitEvent(grp[g].s, L->ev_fork, 0);
+  }
+  return G;
+}
+static void lg_join(MpmLarge* L, int G, hipStream_t st, const LgGroup* grp) {
+  for (int g = 1; g < G; ++g) {
+    (void)hipEventRecord(L->ev_join[g - 1], grp[g].s);
+    (void)hipStreamWaitEvent(st, L->ev_join[g - 1], 0);
+  }
 }
 
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
@@ -1008,10 +1043,8 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   if (rc) return rc;
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
-  const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  const dim3 blk(256), blks(LG_SCATTER_T);
   const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
-  const dim3 gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);   // scatter kernels
-  const dim3 gq((lanes * N + 255) / 256, B);                                               // gather kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
@@ -1019,24 +1052,40 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const long rec = (long)24 * Np;
   const long stride_b = ckpt ? ((long)(S + 1) * rec + (long)c.n_prim * S * 10) : 2 * rec;
   a.hist_stride_b = stride_b;
-  hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
-  hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, x, v, C, F, hist, stride_b, 1);
-  for (int f = 0; f < S; ++f) {
-    a.f = f; a.epoch = L->epoch++;
+  const int e0 = L->epoch;            // one epoch per substep, shared by the groups (stamps are per env)
+  L->epoch += S + 1;
+  LgGroup grp[MpmLarge::MAX_GROUPS];
+  const int G = lg_fork(L, B, st, grp);
+  for (int g = 0; g < G; ++g) {
+    a.b0 = grp[g].b0;
+    hipLaunchKernelGGL(lg_prim_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ppos, prot);
+    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1);
+  }
+  for (int f = 0; f <= S; ++f) {
+    a.f = f; a.epoch = e0 + f;
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
-    hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 1, 0);
-    if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), st, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), st, a, 1);
-    hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 0);
-    if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, st, a);
+    for (int g = 0; g < G; ++g) {
+      const int Bg = grp[g].Bg;
+      hipStream_t s = grp[g].s;
+      a.b0 = grp[g].b0;
+      const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
+      if (f == S) { hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 0); continue; }   // restore the all-zero grid invariant
+      hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 1, 0);
+      if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
+      hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0);
+      if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, s, a);
+    }
   }
-  // restore the all-zero grid invariant (cells of the last substep)
-  a.f = S; a.epoch = L->epoch++;
-  hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 0);
+  a.f = S;
   const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
-  hipLaunchKernelGGL(lg_unpack, gp, blk, 0, st, c, B, last, stride_b, xo, vo, Co, Fo);
   float* tail = ckpt ? ckpt + (long)(S + 1) * rec : nullptr;
-  hipLaunchKernelGGL(lg_fwd_out, dim3(B, c.n_prim), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+  for (int g = 0; g < G; ++g) {
+    a.b0 = grp[g].b0;
+    hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, last, stride_b, xo, vo, Co, Fo);
+    hipLaunchKernelGGL(lg_fwd_out, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+  }
+  lg_join(L, G, st, grp);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_fwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
@@ -1051,31 +1100,46 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   if (rc) return rc;
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
-  const dim3 gp((N + 255) / 256, B), gc((L->cap + 255) / 256, B), blk(256);
+  const dim3 blk(256), blks(LG_SCATTER_T);
   const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
-  const dim3 gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, B), blks(LG_SCATTER_T);   // scatter kernels
-  const dim3 gq((lanes * N + 255) / 256, B);                                               // gather kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   const long rec = (long)24 * Np;
   const long stride_b = (long)(S + 1) * rec + (long)c.n_prim * S * 10;
   a.hist_stride_b = stride_b;
-  hipLaunchKernelGGL(lg_bwd_in, dim3(B, c.n_prim), blk, 0, st, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
-  hipLaunchKernelGGL(lg_pack, gp, blk, 0, st, c, B, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
-  for (int f = S - 1; f >= 0; --f) {
-    // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
-    a.f = f; a.epoch = L->epoch++;
-    a.hist_in = ckpt + (long)f * rec;
-    hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-    if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), st, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), st, a, 0);
-    hipLaunchKernelGGL(lg_grid, gc, blk, 0, st, a, 1);
-    if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), st, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), st, a);
-    hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, st, a);
-    if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, st, a);
-    hipLaunchKernelGGL(lg_fk_adj, dim3(B, c.n_prim), blk, 0, st, a);
+  const int e0 = L->epoch;
+  L->epoch += S + 1;
+  LgGroup grp[MpmLarge::MAX_GROUPS];
+  const int G = lg_fork(L, B, st, grp);
+  for (int g = 0; g < G; ++g) {
+    a.b0 = grp[g].b0;
+    hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
+    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
   }
-  a.f = -1; a.epoch = L->epoch++;
-  hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, st, a, 0, 1);
-  hipLaunchKernelGGL(lg_bwd_out, dim3(B), blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
+  for (int f = S - 1; f >= -1; --f) {
+    // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
+    a.f = f; a.epoch = e0 + (S - 1 - f);
+    a.hist_in = ckpt + (long)max(f, 0) * rec;
+    for (int g = 0; g < G; ++g) {
+      const int Bg = grp[g].Bg;
+      hipStream_t s = grp[g].s;
+      a.b0 = grp[g].b0;
+      const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
+      hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 1);
+      if (f < 0) continue;
+      if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 0);
+      hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 1);
+      if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
+      hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, s, a);
+      if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, s, a);
+      hipLaunchKernelGGL(lg_fk_adj, dim3(Bg, c.n_prim), blk, 0, s, a);
+    }
+  }
+  a.f = -1;
+  for (int g = 0; g < G; ++g) {
+    a.b0 = grp[g].b0;
+    hipLaunchKernelGGL(lg_bwd_out, dim3(grp[g].Bg), blk, 0, grp[g].s, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
+  }
+  lg_join(L, G, st, grp);
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_bwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
