@@ -114,10 +114,15 @@ __device__ __forceinline__ void container_sdf_bwd(const float* size, float p0, f
 
 // (kind as a template parameter of the collide code was tried: no faster, and `#pragma clang fp contract(off)` stopped
 // being honoured inside the instantiations -- the upright-bowl test, which needs the SDF path bit-faithful, failed)
+#ifndef UD_DIAG_BOX_ONLY
+#define UD_DIAG_BOX_ONLY 0   // timing-only diagnostic build (never shipped): drop the container branch at every SDF call site
+#endif
 __device__ __forceinline__ float prim_sdf_x(int kind, const float* size, float p0, float p1, float p2) {
+  if (UD_DIAG_BOX_ONLY) return box_sdf_x(size, p0, p1, p2);
   return kind == 1 ? container_sdf_x(size, p0, p1, p2) : box_sdf_x(size, p0, p1, p2);
 }
 __device__ __forceinline__ void prim_sdf_bwd(int kind, const float* size, float p0, float p1, float p2, float gout, float* gp, float* gsize) {
+  if (UD_DIAG_BOX_ONLY) { box_sdf_bwd(size, p0, p1, p2, gout, gp, gsize); return; }
   if (kind == 1) container_sdf_bwd(size, p0, p1, p2, gout, gp, gsize);
   else box_sdf_bwd(size, p0, p1, p2, gout, gp, gsize);
 }

@@ -657,6 +657,9 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     return;
   }
   // ---- soft contact: collide_batch of each primitive in turn (forward), reversed here --------------------------------
+  // The grid covers `cap` cells per env, most blocks hold no active cell: leave block-uniformly (safe for the barriers
+  // below) before any of the collide arithmetic.
+  if ((int)(blockIdx.x * blockDim.x) >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
   int ci = 0, cj = 0, ck = 0;
   long lin = 0;
@@ -679,34 +682,39 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   // (one extra collide for two primitives) -- loops are kept rolled: one copy of the collide code in the kernel.
 #pragma unroll 1
   for (int ip = P - 1; ip >= 0; --ip) {
-    PrimC pc;
-    CollideRec cr;
-    float vi[3] = {v0[0], v0[1], v0[2]}, v1[3];
+    float pgv[UD_PRIMC_NGRAD];
+#pragma unroll
+    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) pgv[d] = 0.f;
+    if (live) {                  // lanes past the env's active list only take part in the reductions below
+      PrimC pc;
+      CollideRec cr;
+      float vi[3] = {v0[0], v0[1], v0[2]}, v1[3];
 #pragma unroll 1
-    for (int j = 0; j <= ip; ++j) {
-      load_primc(a, b, j, pc);
-      collide_cell(pc, a.c.dt, gp, vi, v1, cr);
-      if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
-    }
-    if (ip == P - 1 && live) {   // v1 = velocity after the last primitive: ground friction + boundary, reversed first
-      CellRec rec;
-      float vo[3], dfric;
-      grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
-      grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
-      if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-    }
-    PrimCGrad pg;
-    float gin[3], pgv[UD_PRIMC_NGRAD];
-    collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
+      for (int j = 0; j <= ip; ++j) {
+        load_primc(a, b, j, pc);
+        collide_cell(pc, a.c.dt, gp, vi, v1, cr);
+        if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
+      }
+      if (ip == P - 1) {         // v1 = velocity after the last primitive: ground friction + boundary, reversed first
+        CellRec rec;
+        float vo[3], dfric;
+        grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
+        grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
+        if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+      }
+      PrimCGrad pg;
+      float gin[3];
+      collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { g[d] = gin[d]; pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
+      for (int d = 0; d < 3; ++d) { g[d] = gin[d]; pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
-    pgv[17] = pg.mu;
+      for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
+      pgv[17] = pg.mu;
+    }
     // this primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
 #pragma unroll
     for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
-      const float sum = wave_sum(live ? pgv[d] : 0.f);
+      const float sum = wave_sum(pgv[d]);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
     }
     __syncthreads();
