@@ -300,6 +300,50 @@ def bench_mpm_scaled(args, rank, world, device):
         dist.destroy_process_group()
 
 
+def cpu_baseline_shape_rope(env, st, act, sample_envs=8, steps=6):   # ~11 s of host work
+    """Oracle (CPU restatement, dense 64x6x64 grid, NOT JAX-CPU) on the host cores: `steps` scanned simulator.steps
+    (133 substeps each) forward + adjoint for `sample_envs` of the bench's envs.  Checker only, never the product path."""
+    from oracle.pyoracle import MpmOracle
+    conf = env.conf
+    N, S = st.x.shape[1], conf.steps
+    npy = lambda t: t.detach().cpu().numpy()[:sample_envs]
+    x0 = npy(st.x)
+    shift = (np.array(conf.res, np.float32) * np.float32(0.5) / np.float32(conf.n_grid) - x0.mean(1, dtype=np.float32)).astype(np.float32)
+    shift[:, 1] = 0
+    a = npy(act)
+    start, end = a[:, :3] + shift, a[:, 3:] + shift
+    start[:, 1] = end[:, 1] = 0.01
+    nrm = np.linalg.norm(end - start, axis=-1, keepdims=True).astype(np.float32) + np.float32(1e-8)
+    push = ((end - start) / nrm * np.clip(nrm, 0, 0.3) / np.float32(conf.primitive_action_steps)).astype(np.float32)
+    push[:, 1] = 0
+    ppos = np.zeros((sample_envs, S, 3), np.float32)
+    ppos[:, 0] = start
+    prot = np.zeros((sample_envs, S, 4), np.float32)
+    prot[..., 0] = 1
+    ost = dict(x=x0 + shift[:, None], v=npy(st.v), C=npy(st.C), F=npy(st.F), J=npy(st.J), ppos=ppos, prot=prot,
+               psize=npy(st.primitives[0].size), friction=npy(st.friction).reshape(-1), mu=npy(st.mu).reshape(-1),
+               lamda=npy(st.lamda).reshape(-1), action=np.concatenate([push, np.zeros_like(push)], -1))
+    orc = MpmOracle(N, n_grid=conf.n_grid, res=conf.res, steps=S, dt=conf.dt, position_control=False, material=np.full(N, 2))
+    rng = np.random.default_rng(0)
+    g = dict(gx=rng.normal(size=x0.shape).astype(np.float32), gv=np.zeros_like(x0), gC=np.zeros((sample_envs, N, 3, 3), np.float32),
+             gF=np.zeros((sample_envs, N, 3, 3), np.float32), gppos=np.zeros((sample_envs, S, 3), np.float32))
+    threads = min(sample_envs, os.cpu_count() or 1)
+    t_f = t_b = 0.0
+    for _ in range(steps):
+        t0 = time.time()
+        o = orc.step_fwd(ost, nthreads=threads)
+        t_f += time.time() - t0
+        t0 = time.time()
+        orc.step_bwd(ost, g, clip=True, nthreads=threads)
+        t_b += time.time() - t0
+        ost.update(x=o["x"], v=o["v"], C=o["C"], F=o["F"], J=o["J"], ppos=o["ppos"], prot=o["prot"])
+    n = sample_envs * steps * S
+    return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
+            "sample": f"CPU restatement (C++ -O2, f32, dense res grid like the reference; not JAX-CPU): {sample_envs} envs x {steps} "
+                      f"simulator.steps x {S} substeps, forward {t_f:.2f}s + adjoint (with its own state recompute) {t_b:.2f}s, "
+                      f"OpenMP over envs ({threads} threads)"}
+
+
 def bench_shape_rope(args, rank, world, device):
     """shape_rope: 582 plastic particles, 64x6x64 grid, box pusher in soft-contact mode
     (collide_batch).  One "step" = one env.step_diff -- 30 scanned simulator.steps of 133 substeps -- plus the backward
@@ -348,6 +392,7 @@ def bench_shape_rope(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         units = world * B * T * S * args.steps
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_shape_rope(env, st, act)
         g_act = touched_cells(st.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
@@ -362,7 +407,8 @@ def bench_shape_rope(args, rank, world, device):
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
-                         "note": "launch/latency bound: 11 small kernels per substep pair on 32 x 582 particles"}}), flush=True)
+                         "note": "latency bound: 11 small kernels per substep pair on 32 x 582 particles, two env groups on two streams"},
+            **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
