@@ -131,6 +131,11 @@ typedef struct {
   int n_primitive;           /* conf.n_primitive (0 = 1).  > 1 (up to 4) in soft-contact mode only: pour_water_env.py:32 */
   int sdf_kind;              /* the SDF installed by set_sdf (primitives.py:26-28): 0 box (box.py:6-18), 1 container =
                                 cut hollow sphere, size = (r, h, t) (container.py:8-16); soft-contact mode only */
+  int grid_ckpt_cells;       /* many-workgroup path only.  0: the backward recomputes p2g + grid op per substep (the reference
+                                rematerialises the whole substep, mpm_simulator.py:332-359).  K > 0: the forward also
+                                checkpoints the active grid cells (32 B each) into a pool of K * n_particles records per
+                                substep on average, inside the caller's checkpoint (ud_mpm_ckpt_bytes grows accordingly),
+                                and the backward restores them.  A pool that runs out flags the env in status[] (1) */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */

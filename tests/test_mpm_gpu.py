@@ -206,11 +206,12 @@ class ScaledConf(LegacyConf):
     E, nu = 100, 0.1
 
 
-def _scaled_case(S, seed, B=1):
+def _scaled_case(S, seed, B=1, grid_ckpt_cells=0):
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
     conf = ScaledConf()
     conf.steps = S
     sim = SimpleMPMSimulator(conf, B, use_position_control=True)
+    sim.grid_ckpt_cells = grid_ckpt_cells
     st0 = sim.add_box(conf, None, size=[0.38, 0.006, 0.006], init_pos=[0.25, 0.01, 0.25], z_rotation_angle=np.pi / 2,
                       material=1, density=2.75, hardness=1.0)
     x = st0.x.cpu().numpy()
@@ -234,10 +235,12 @@ def _scaled_case(S, seed, B=1):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
-def test_large_path_matches_oracle_n798():
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
+def test_large_path_matches_oracle_n798(grid_ckpt_cells):
+    """grid_ckpt_cells = 0: the backward recomputes p2g + grid op; 6: it restores the grid from the forward's checkpoint."""
     from oracle.pyoracle import MpmOracle
     S = 5   # dt=1e-4 at dx=1/128 is 4x the CFL number of the default config (SURVEY.md 8d): keep the window short
-    sim, st, g, N = _scaled_case(S, 0, B=2)
+    sim, st, g, N = _scaled_case(S, 0, B=2, grid_ckpt_cells=grid_ckpt_cells)
     assert N == 798
     st["action"][1] = np.float32([-0.3, 0.2, 0.1, 0, 0, 0]) / 50
     orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
@@ -259,6 +262,18 @@ def test_large_path_matches_oracle_n798():
     # a second call on the same handle (persistent grid arena must be back to all-zero)
     oh2 = run_hip(sim, st)
     assert _rel(oh2["x"], of["x"]) < 5e-6 and _rel(oh2["v"], of["v"]) < 1e-4
+
+
+def test_grid_checkpoint_pool_overflow_is_reported():
+    """A pool of 1 record per particle and substep holds the compact rope (measured 0.58 active cells per particle) but not the
+    same particles scattered through the volume (up to 27 cells each): the env is flagged (UD_ERR_OVERFLOW) and check_status raises
+    instead of returning gradients built on a truncated grid."""
+    from unidom_amd._lib import UnidomError
+    sim, st, g, N = _scaled_case(3, 0, B=1, grid_ckpt_cells=1)
+    run_hip(sim, st, g=g, clip=True)                                   # the rope fits
+    st["x"] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"].shape).astype(np.float32)
+    with pytest.raises(UnidomError, match="UD_ERR_OVERFLOW"):
+        run_hip(sim, st, g=g, clip=True)
 
 
 # ---- soft contact (collide_batch, primitives.py:154-182) -- the mode shape_rope / pour_* use --------------------------
@@ -338,6 +353,7 @@ def test_collide_shape_rope_geometry_fwd_bwd():
     B, N = 2, 582
     sim = SimpleMPMSimulator(conf, B, use_position_control=False)
     sim.n_particles, sim.material, sim.h = N, np.full(N, 2, np.int32), np.ones(N, np.float32)
+    assert sim.grid_ckpt_cells == conf.grid_ckpt_cells == 2          # the env runs with the grid checkpoint
     sim._make_handle()
     rng = np.random.default_rng(5)
     x0 = np.load(conf.goal_path).astype(np.float32)

@@ -18,6 +18,7 @@ struct MpmConst {
   int position_control;            // 1: position_control_batch, 0: collide_batch (soft contact)
   float prim_friction, prim_softness;   // PrimitiveState.friction / .softness (collide_batch only)
   int n_prim, sdf_kind;            // primitives per env (collide_batch: 1..UD_MAX_PRIM); 0 box SDF, 1 container SDF
+  int gck;                         // many-workgroup path: grid-checkpoint records per particle and substep (0 = recompute in the backward)
 };
 
 // ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------

@@ -50,6 +50,13 @@ struct LargeArgs {
   int B, f, epoch, cap;
   int b0;                 // first env of this launch (env groups on separate streams)
   long G;
+  // grid checkpoint (ud_mpm_conf.grid_ckpt_cells > 0): the forward appends one record {key, m, mv[3], v[3]} per active
+  // cell and substep to a per-env pool inside the caller's checkpoint, the backward restores from it instead of running
+  // p2g + grid op again.  gck_idx[f] = first record of substep f ([S+1] ints per env), pool holds gck_budget records.
+  float* gck_base;        // = checkpoint base (env stride hist_stride_b); nullptr = off
+  long gck_off_idx, gck_off_pool;
+  int gck_budget;
+  int* status;
   const float* hist_in;   // state at substep f      [B][*][24][Np] with stride
   float* hist_out;        // state at substep f + 1
   long hist_stride_b;     // floats between envs
@@ -61,6 +68,9 @@ __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   decode_cell(c, key, ci, cj, ck);
   return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
 }
+
+__device__ __forceinline__ int* gck_idx(const LargeArgs& a, int b) { return (int*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_idx); }
+__device__ __forceinline__ float4* gck_pool(const LargeArgs& a, int b) { return (float4*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_pool); }
 
 __device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long lin) {
   const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
@@ -195,6 +205,10 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
   if (blockIdx.x == 0) {
     const int S = a.c.steps, f = a.f, tid = threadIdx.x;
     if (tid == 0) a.w.count[cur * a.B + b] = 0;
+    if (tid == 0 && a.gck_base && !clear_bwd) {   // forward: records of substep f start where those of f - 1 end
+      int* idx = gck_idx(a, b);
+      idx[f] = (f == 0) ? 0 : idx[f - 1] + n;
+    }
     if (do_fk)
     for (int ip = 0; ip < a.c.n_prim; ++ip) {
       const long bp = (long)b * a.c.n_prim + ip;
@@ -283,7 +297,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   }
   // flush: one global atomic per distinct cell and component.  Cells this substep sees for the first time (epoch stamp)
   // join the env's active list; the appends of a block are aggregated -- one atomicAdd on the env's counter per block
-  // instead of one per cell (20 k same-address atomics per env-substep at n_grid 256 were 80 % of the whole step).
+  // instead of one per cell (~2 k same-address atomics per env-substep at n_grid 256, one per active cell, were 80 % of the whole step).
   __shared__ int s_new, s_base;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
@@ -351,6 +365,16 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
   }
   if (to_vel) a.w.vel[(long)b * a.G + lin] = make_float4(vo[0], vo[1], vo[2], 0.f);
   else a.w.val[(long)b * a.G + lin] = make_float4(mv.x, vo[0], vo[1], vo[2]);
+  if (!to_vel && a.gck_base) {
+    const int pos = gck_idx(a, b)[a.f] + t;
+    if (pos < a.gck_budget) {
+      float4* r = gck_pool(a, b) + (long)pos * 2;
+      r[0] = make_float4(__builtin_bit_cast(float, key), mv.x, mv.y, mv.z);
+      r[1] = make_float4(mv.w, vo[0], vo[1], vo[2]);
+    } else if (a.status) {
+      a.status[b] = 1;   // pool exhausted: the backward of this env is invalid (UD_ERR_OVERFLOW, reported like the LDS table's)
+    }
+  }
 }
 
 // g2p + advect (:196-221, :318-328)
@@ -629,6 +653,33 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   }
 }
 
+// grid checkpoint -> dense arrays of the backward for substep f: velocity after the grid op, zeroed cotangent, the cell list
+__global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
+  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cur = a.f & 1;
+  const int* idx = gck_idx(a, b);
+  const int first = idx[a.f], n = min(min(idx[a.f + 1], a.gck_budget) - first, a.cap);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = max(n, 0);
+  if (t >= n) return;
+  const float4* r = gck_pool(a, b) + (long)(first + t) * 2;
+  const float4 r0 = r[0], r1 = r[1];
+  const int key = __builtin_bit_cast(int, r0.x);
+  const long lin = cell_lin(a.c, key);
+  a.w.list[((long)cur * a.B + b) * a.cap + t] = key;
+  a.w.vel[(long)b * a.G + lin] = make_float4(r1.y, r1.z, r1.w, 0.f);
+  a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// (m, mv) of active cell t of substep f: from the grid checkpoint when there is one, else from the recomputed dense grid
+__device__ __forceinline__ float4 cell_mass_momentum(const LargeArgs& a, int b, int t, long lin) {
+  if (a.gck_base) {
+    const float4* r = gck_pool(a, b) + (long)(gck_idx(a, b)[a.f] + t) * 2;
+    const float4 r0 = r[0], r1 = r[1];
+    return make_float4(r0.y, r0.z, r0.w, r1.x);
+  }
+  return a.w.val[(long)b * a.G + lin];
+}
+
 // grid-op adjoint over the active cells
 __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   __shared__ float red[4][UD_PRIMC_NGRAD];
@@ -641,7 +692,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     int ci, cj, ck;
     decode_cell(a.c, key, ci, cj, ck);
     const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-    const float4 mv = a.w.val[(long)b * a.G + lin];
+    const float4 mv = cell_mass_momentum(a, b, t, lin);
     const float mvv[3] = {mv.y, mv.z, mv.w};
     const float4 g4 = a.w.gacc[(long)b * a.G + lin];
     float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric, pv[3], dpv[3];
@@ -669,7 +720,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
     decode_cell(a.c, key, ci, cj, ck);
     lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-    mv = a.w.val[(long)b * a.G + lin];
+    mv = cell_mass_momentum(a, b, t, lin);
     const float4 g4 = a.w.gacc[(long)b * a.G + lin];
     g[0] = g4.x; g[1] = g4.y; g[2] = g4.z;
     gp[0] = (float)ci * a.c.dx; gp[1] = (float)cj * a.c.dx; gp[2] = (float)ck * a.c.dx;
@@ -977,8 +1028,26 @@ void mpm_large_destroy(MpmLarge* L) {
   delete L;
 }
 
+// checkpoint layout per env (floats): particle history [(S+1)][24][Np] | primitive tail [P][S*10] | grid checkpoint:
+// record index [S+1] (ints, padded to 4) and the record pool [budget][8]
+struct CkLayout { long rec, off_tail, off_idx, off_pool, stride; int budget; };
+static CkLayout ck_layout(const MpmConst& c) {
+  CkLayout k;
+  const long S = c.steps;
+  k.rec = (long)24 * c.Np;
+  k.off_tail = (S + 1) * k.rec;
+  k.off_idx = k.off_tail + (long)c.n_prim * S * 10;
+  k.off_idx = (k.off_idx + 3) / 4 * 4;                         // float4 alignment of the pool behind it
+  const long nidx = c.gck > 0 ? (S + 1 + 3) / 4 * 4 : 0;
+  k.off_pool = k.off_idx + nidx;
+  const long budget = c.gck > 0 ? S * (long)c.gck * c.N : 0;   // records per env and launch: gck cells per particle and substep on average
+  k.budget = (int)std::min<long>(budget, 0x7fffffff / 2);
+  k.stride = k.off_pool + (long)k.budget * 8;
+  return k;
+}
+
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B) {
-  return (size_t)B * ((size_t)(L->c.steps + 1) * 24 * L->c.Np + (size_t)L->c.n_prim * L->c.steps * 10) * sizeof(float);
+  return (size_t)B * (size_t)ck_layout(L->c).stride * sizeof(float);
 }
 
 static int reserve(MpmLarge* L, int B, hipStream_t stream) {
@@ -1017,6 +1086,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   LargeArgs a;
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.epoch = 0; a.cap = L->cap; a.G = L->G;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
+  a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
   return a;
@@ -1050,16 +1120,19 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   int rc = reserve(L, B, st);
   if (rc) return rc;
   const MpmConst& c = L->c;
-  const int S = c.steps, N = c.N, Np = c.Np;
+  const int S = c.steps, N = c.N;
   const dim3 blk(256), blks(LG_SCATTER_T);
   const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
   float* hist = ckpt ? ckpt : L->w.hist;
-  const long rec = (long)24 * Np;
-  const long stride_b = ckpt ? ((long)(S + 1) * rec + (long)c.n_prim * S * 10) : 2 * rec;
+  const CkLayout ck = ck_layout(c);
+  const long rec = ck.rec;
+  const long stride_b = ckpt ? ck.stride : 2 * rec;
   a.hist_stride_b = stride_b;
+  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
+  if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
   const int e0 = L->epoch;            // one epoch per substep, shared by the groups (stamps are per env)
   L->epoch += S + 1;
   LgGroup grp[MpmLarge::MAX_GROUPS];
@@ -1087,14 +1160,13 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   }
   a.f = S;
   const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
-  float* tail = ckpt ? ckpt + (long)(S + 1) * rec : nullptr;
+  float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, last, stride_b, xo, vo, Co, Fo);
     hipLaunchKernelGGL(lg_fwd_out, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
   }
   lg_join(L, G, st, grp);
-  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_fwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;
@@ -1111,16 +1183,19 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const dim3 blk(256), blks(LG_SCATTER_T);
   const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
-  const long rec = (long)24 * Np;
-  const long stride_b = (long)(S + 1) * rec + (long)c.n_prim * S * 10;
+  const CkLayout ck = ck_layout(c);
+  const long rec = ck.rec;
+  const long stride_b = ck.stride;
   a.hist_stride_b = stride_b;
+  const bool gck = ck.budget > 0;   // restore the grid from the checkpoint instead of recomputing p2g + grid op
+  if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   const int e0 = L->epoch;
   L->epoch += S + 1;
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
-    hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + (long)(S + 1) * rec, stride_b, gppos, gprot);
+    hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
   }
   for (int f = S - 1; f >= -1; --f) {
@@ -1132,10 +1207,15 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
       const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 1);
-      if (f < 0) continue;
-      if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 0);
-      hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 1);
+      if (gck) {          // the dense val grid is never touched: nothing to clear, nothing to recompute
+        if (f < 0) continue;
+        hipLaunchKernelGGL(lg_restore, gc, blk, 0, s, a);
+      } else {
+        hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 1);
+        if (f < 0) continue;
+        if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 0);
+        hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 1);
+      }
       if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
       hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, s, a);
       if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, s, a);

@@ -130,6 +130,7 @@ class SimpleMPMSimulator:
         self.clip_grad = True            # norm_grad_state / norm_grad (:375-411)
         self.prim_friction, self.prim_softness = 0.1, 666.0   # PrimitiveState.friction / .softness (collide_batch); set by create_primitive
         self.n_primitive, self.sdf_kind = 1, "box"             # fixed at reset_jax (state.primitives, primitives.set_sdf)
+        self.grid_ckpt_cells = int(getattr(conf, "grid_ckpt_cells", 0))   # include/unidom_hip.h: 0 = recompute the grid in the backward
         self.profile = None
         self.status_log = []
         self._h = None
@@ -209,7 +210,8 @@ class SimpleMPMSimulator:
                               steps=int(conf.steps), dt=float(conf.dt), p_mass=float(conf.p_mass), p_vol=float(conf.p_vol),
                               gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)),
                               prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness),
-                              n_primitive=int(self.n_primitive), sdf_kind={"box": 0, "container": 1}[self.sdf_kind])
+                              n_primitive=int(self.n_primitive), sdf_kind={"box": 0, "container": 1}[self.sdf_kind],
+                              grid_ckpt_cells=int(self.grid_ckpt_cells))
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
         self._h = C.c_void_p()
@@ -242,7 +244,8 @@ class SimpleMPMSimulator:
             bad = torch.stack(self.status_log).sum().item()
             self.status_log = []
             if bad:
-                raise _lib.UnidomError("MPM LDS cell table overflow (UD_ERR_OVERFLOW): particle cloud too spread out")
+                raise _lib.UnidomError("MPM device-side capacity exceeded (UD_ERR_OVERFLOW): LDS cell table (one-workgroup path) or "
+                                       "grid-checkpoint pool (conf.grid_ckpt_cells too small) -- particle cloud too spread out")
 
     # -- the hot path --------------------------------------------------------------------------------------
     def step_jax(self, state: MPMState, action):
