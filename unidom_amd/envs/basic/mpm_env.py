@@ -22,7 +22,11 @@ from ...utils.util import calc_l2
 
 
 def _where_done(done, new, old):
-    """jnp.where(right_broadcasting(done, x), y, x) over a (nested) state (mpm_env.py:161)."""
+    """jnp.where(right_broadcasting(done, x), y, x) over a (nested) state (mpm_env.py:161).
+    Leaves that auto_reset handed back untouched (the same object) select between two identical values: returned as is,
+    which spares a launch for each of the ~20 constant primitive fields on every step."""
+    if new is old:
+        return old
     if torch.is_tensor(old):
         d = done.reshape(done.shape + (1,) * (old.dim() - done.dim()))
         return torch.where(d, new.to(old.dtype), old)
@@ -122,6 +126,16 @@ class MPMEnv:
 
         def stack_states(states):
             first = states[0]
+            if len(states) == 1:               # one scanned step (whip_rope, pour_water): a leading axis, not a copy
+                lead = lambda v: v.unsqueeze(0) if torch.is_tensor(v) else np.asarray(v)[None]
+                fields = {}
+                for name in first._fields:
+                    val = getattr(first, name)
+                    if name == "primitives":
+                        fields[name] = [type(q)(*[lead(t) for t in q]) for q in val]
+                    else:
+                        fields[name] = lead(val)
+                return type(first)(**fields)
             fields = {}
             for name in first._fields:
                 vals = [getattr(s, name) for s in states]
