@@ -117,7 +117,9 @@ static void step_bwd(const OcMpm* h, int B, StepIO<T> io, const T* gx, const T* 
       auto& G = g.prims[ip];
       const size_t bp = (size_t)b * P + ip;
       for (int i = 0; i < S * 3; ++i) G.ppos[i] = gppos[bp * S * 3 + i];
-      if (gprot) for (int i = 0; i < S * 4; ++i) G.prot[i] = gprot[bp * S * 4 + i];
+      // position control: nothing downstream reads the rotation array, the boundary's contract is a zero incoming cotangent
+      // (include/unidom_hip.h) -- ignored here too, so that it cannot leak into the clip norm
+      if (gprot && !pr.position_control) for (int i = 0; i < S * 4; ++i) G.prot[i] = gprot[bp * S * 4 + i];
       // copy_frame adjoint: position[0] <- position[steps-1], rotation likewise
       if (S - 1 != 0) for (int a = 0; a < 3; ++a) { G.ppos[(S - 1) * 3 + a] += G.ppos[a]; G.ppos[a] = 0; }
       if (S - 1 != 0) for (int a = 0; a < 4; ++a) { G.prot[(S - 1) * 4 + a] += G.prot[a]; G.prot[a] = 0; }

@@ -456,3 +456,61 @@ def test_two_upright_containers_forward_tracks_f32_oracle(demo):
     oh = {k: o.cpu().numpy() for k, o in zip(("x", "v", "C", "F"), out)}
     assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4, (_rel(oh["x"], of["x"]), _rel(oh["v"], of["v"]))
     assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
+
+
+@pytest.mark.parametrize("case", ["one_substep", "n129_just_over_the_one_workgroup_limit", "body_at_the_domain_corner", "four_box_primitives"])
+def test_large_path_edge_cases(demo, case):
+    """Edges of the many-workgroup path vs the oracle (forward f32, adjoint f64): a single substep per step (copy_frame and
+    the primitive recurrences degenerate, Q5), the smallest particle count that takes this path, a body pressed into the
+    domain corner (truncating base -> index wrap for the scatter, clamp for the gather, negative weights: Q9 / Q13), and
+    the maximum of four primitives in soft-contact mode."""
+    from oracle.pyoracle import MpmOracle
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    rng = np.random.default_rng(11)
+    S, N, P, pc = 4, 160, 1, True
+    if case == "one_substep":
+        S = 1
+    elif case == "n129_just_over_the_one_workgroup_limit":
+        N = 129
+    elif case == "four_box_primitives":
+        P, pc = 4, False
+    conf = LegacyConf()
+    conf.steps = S
+    sim = SimpleMPMSimulator(conf, 2, use_position_control=pc)
+    sim.n_particles, sim.material, sim.h = N, np.full(N, 1, np.int32), np.ones(N, np.float32)
+    sim.n_primitive = P
+    sim.grid_ckpt_cells = 0 if case == "body_at_the_domain_corner" else 8
+    sim._make_handle()
+    B = 2
+    lo = 0.004 if case == "body_at_the_domain_corner" else 0.15       # dx = 1/64: x * inv_dx < 0.5 below 0.0078
+    x = (lo + rng.uniform(0, 0.06, size=(B, N, 3))).astype(np.float32)
+    pa = (P,) if P > 1 else ()
+    ppos = np.zeros((B,) + pa + (S, 3), np.float32)
+    ppos[..., 0, :] = (x.mean(1)[:, None] if P > 1 else x.mean(1)) + rng.normal(size=(B,) + pa + (3,)).astype(np.float32) * 0.01
+    prot = np.zeros((B,) + pa + (S, 4), np.float32)
+    prot[..., 0] = 1
+    mu0, la0 = 100 / (2 * 1.1), 100 * 0.1 / (1.1 * 0.8)
+    st = dict(x=x, v=(rng.normal(size=(B, N, 3)) * 0.3).astype(np.float32), C=(rng.normal(size=(B, N, 3, 3)) * 2).astype(np.float32),
+              F=(np.eye(3) + rng.normal(size=(B, N, 3, 3)) * 0.03).astype(np.float32), J=np.ones((B, N), np.float32), ppos=ppos, prot=prot,
+              psize=np.tile(np.float32([0.02, 0.02, 0.02]), (B,) + pa + (1,)), friction=np.full(B, 0.3, np.float32),
+              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32),
+              action=(rng.normal(size=(B, 6 * P)) * 0.01).astype(np.float32))
+    g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)) * 0.01, gC=rng.normal(size=(B, N, 3, 3)) * 1e-4,
+             gF=rng.normal(size=(B, N, 3, 3)) * 0.01, gppos=rng.normal(size=(B,) + pa + (S, 3)), gprot=rng.normal(size=(B,) + pa + (S, 4)))
+    g = {k: v.astype(np.float32) for k, v in g.items()}
+    if pc:
+        del g["gprot"]        # position control: no rotation cotangent crosses the boundary (run_hip does not feed one either)
+    orc = MpmOracle(N, steps=S, position_control=pc, n_prim=P)
+    of = orc.step_fwd(st)
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()}, clip=True)
+    oh = run_hip_collide(sim, st, g, clip=True) if not pc else run_hip(sim, st, g=g, clip=True)
+    assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4, (_rel(oh["x"], of["x"]), _rel(oh["v"], of["v"]))
+    assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
+    for key in ("ppos", "prot", "pv", "pw"):
+        np.testing.assert_allclose(oh[key], of[key], rtol=0, atol=2e-7)
+    keys = ("gx", "gv", "gC", "gF", "gppos", "gaction") + (() if pc else ("gprot",))
+    for key in keys:
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
+    if case == "body_at_the_domain_corner":
+        assert (x * 64 < 0.5).any()                                      # the negative-weight regime is really exercised
