@@ -458,17 +458,20 @@ def test_two_upright_containers_forward_tracks_f32_oracle(demo):
     assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5
 
 
-@pytest.mark.parametrize("case", ["one_substep", "n129_just_over_the_one_workgroup_limit", "body_at_the_domain_corner", "four_box_primitives"])
-def test_large_path_edge_cases(demo, case):
-    """Edges of the many-workgroup path vs the oracle (forward f32, adjoint f64): a single substep per step (copy_frame and
-    the primitive recurrences degenerate, Q5), the smallest particle count that takes this path, a body pressed into the
-    domain corner (truncating base -> index wrap for the scatter, clamp for the gather, negative weights: Q9 / Q13), and
-    the maximum of four primitives in soft-contact mode."""
+@pytest.mark.parametrize("case", ["one_substep", "n129_just_over_the_one_workgroup_limit", "body_at_the_domain_corner", "four_box_primitives",
+                                  "one_workgroup_one_substep", "one_workgroup_domain_corner"])
+def test_mpm_step_edge_cases(demo, case):
+    """Edges vs the oracle (forward f32, adjoint f64), on the many-workgroup path and (one_workgroup_*) the one-workgroup
+    path: a single substep per step (copy_frame and the primitive recurrences degenerate, Q5), the smallest particle count
+    that takes the many-workgroup path, a body pressed into the domain corner (base truncates to 0, every cell sits in the
+    friction and boundary bands of all three axes), and the maximum of four primitives in soft-contact mode."""
     from oracle.pyoracle import MpmOracle
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
     rng = np.random.default_rng(11)
     S, N, P, pc = 4, 160, 1, True
-    if case == "one_substep":
+    if case.startswith("one_workgroup"):                             # N <= 128, position control: the one-workgroup kernels
+        N = 100
+    if case.endswith("one_substep"):
         S = 1
     elif case == "n129_just_over_the_one_workgroup_limit":
         N = 129
@@ -479,10 +482,10 @@ def test_large_path_edge_cases(demo, case):
     sim = SimpleMPMSimulator(conf, 2, use_position_control=pc)
     sim.n_particles, sim.material, sim.h = N, np.full(N, 1, np.int32), np.ones(N, np.float32)
     sim.n_primitive = P
-    sim.grid_ckpt_cells = 0 if case == "body_at_the_domain_corner" else 8
+    sim.grid_ckpt_cells = 0 if case.endswith("domain_corner") else 8
     sim._make_handle()
     B = 2
-    lo = 0.004 if case == "body_at_the_domain_corner" else 0.15       # dx = 1/64: x * inv_dx < 0.5 below 0.0078
+    lo = 0.004 if case.endswith("domain_corner") else 0.15            # dx = 1/64: x * inv_dx < 0.5 below 0.0078
     x = (lo + rng.uniform(0, 0.06, size=(B, N, 3))).astype(np.float32)
     pa = (P,) if P > 1 else ()
     ppos = np.zeros((B,) + pa + (S, 3), np.float32)
@@ -512,5 +515,5 @@ def test_large_path_edge_cases(demo, case):
     for key in keys:
         assert np.isfinite(oh[key]).all(), key
         assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
-    if case == "body_at_the_domain_corner":
-        assert (x * 64 < 0.5).any()                                      # the negative-weight regime is really exercised
+    if case.endswith("domain_corner"):
+        assert (x * 64 < 0.5).any()                                      # base truncates to 0 with fx < 0.5 for some particles
