@@ -11,6 +11,7 @@
 // global_atomic_add_f64 per distinct cell and component; the grid lives dense in HBM (n_grid^3 x 4 doubles per env)
 // but only cells on the per-env active list are ever read, written or cleared.  No MFMA (scatter / stencil work).
 // ti.svd (third party) is replaced by a one-sided Jacobi SVD in registers.  Parity: UNPINNED (see the header).
+#include <cstdlib>
 #include "common.h"
 
 #include <vector>
@@ -155,10 +156,29 @@ __device__ __forceinline__ unsigned plb_hash(int cell) {
 }
 
 // compute_F_tmp + svd + von Mises + p2g (:91-99, :133-195)
+// LANES lanes per particle (as in mpm_large.hip): 4 while the launch is too small to fill the chip -- the quad splits the 27
+// stencil cells 7/7/7/6 (every lane repeats the particle pre-pass on otherwise idle SIMDs) -- 1 once it is full.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int LANES>
+__device__ __forceinline__ double plb_quad_sum(double v) {
+  if (LANES == 4) {
+    v += dpp_d<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);  // quad_perm [2,3,0,1]
+  }
+  return v;
+}
+
+template <int LANES>
 __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   __shared__ int s_key[PLB_H];
   __shared__ double s_val[PLB_H * 4];
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
   for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s * 4] = 0; s_val[s * 4 + 1] = 0; s_val[s * 4 + 2] = 0; s_val[s * 4 + 3] = 0; }
   __syncthreads();
@@ -208,8 +228,10 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
       }
       dm_mul(US, Vh, nF);
     }
+    if (qi == 0) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = nF[d];
+      for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = nF[d];
+    }
     const double J = nF[0] * (nF[4] * nF[8] - nF[5] * nF[7]) - nF[1] * (nF[3] * nF[8] - nF[5] * nF[6]) + nF[2] * (nF[3] * nF[7] - nF[4] * nF[6]);
     double R[9], A[9], St[9], aff[9];
     dm_mul(U, Vh, R);
@@ -220,7 +242,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
 #pragma unroll 1
-    for (int cidx = 0; cidx < 27; ++cidx) {
+    for (int cidx = qi; cidx < 27; cidx += LANES) {
       const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
       const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
       const double dp0 = ((double)i - fx[0]) * c.dx, dp1 = ((double)j - fx[1]) * c.dx, dp2 = ((double)k - fx[2]) * c.dx;
@@ -329,10 +351,11 @@ __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
 }
 
 // g2p (:234-253)
+template <int LANES>
 __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  if (p >= c.N) return;
+  if (p >= c.N) return;   // whole quads leave together
   const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
   double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
   double x[3];
@@ -350,7 +373,7 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   const double* val = a.w.val + (long)b * a.G * 4;
   double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
+  for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
     const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
@@ -364,6 +387,11 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
       for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4 * c.inv_dx * weight * g[r] * dp[s2];
     }
   }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) nv[d] = plb_quad_sum<LANES>(nv[d]);
+#pragma unroll
+  for (int d = 0; d < 9; ++d) nC[d] = plb_quad_sum<LANES>(nC[d]);
+  if (qi != 0) return;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     ho[(3 + d) * c.Np + p] = nv[d];
@@ -474,14 +502,17 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
+  static const int force_lanes = [] { const char* e = getenv("UD_PLB_LANES"); return e ? atoi(e) : 0; }();   // diagnostic override
+  const int lanes = force_lanes ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);   // lanes per particle in p2g / g2p
+  const dim3 gq((4 * h->c.N + 255) / 256, B);
   hipLaunchKernelGGL(ud::plb_prologue, dim3((B + 63) / 64), dim3(64), 0, st, a, prim_pos, action);
   hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F);
   for (int f = 0; f < h->c.S; ++f) {
     a.f = f; a.epoch = h->epoch++;
     hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(ud::plb_p2g, gp, blk, 0, st, a);
+    if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
     hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(ud::plb_g2p, gp, blk, 0, st, a);
+    if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
   }
   a.f = h->c.S; a.epoch = h->epoch++;
   hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);   // back to the all-zero grid invariant
