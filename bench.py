@@ -111,13 +111,15 @@ def touched_cells(x, n_grid=64):
     return len(cells)
 
 
-def bench_whip_rope(args, rank, world, device):
-    """Secondary line: MPM path (whip_rope, N=67, res 32^3, 70 substeps/step), 32 envs per GPU, ep_len 3."""
+def bench_whip_rope(args, rank, world, device, name="whip_rope"):
+    """Secondary lines: the APG update (policy, ep_len x step_diff, loss, backward, clip, Adam) on an MPM env, 32 envs per GPU,
+    ep_len 3.  whip_rope: N=67, res 32^3, 70 substeps/step, one workgroup per env.  pour_water: 702 liquid particles, two bowls
+    with the container SDF in soft-contact mode, res 26x20x26, 23 substeps/step, many-workgroup path."""
     from unidom_amd.algorithms.apg.core import APG
     from unidom_amd.envs.registration import env_functions
     from unidom_amd.utils import prng
     B, ep = 32, EP_LEN
-    env = env_functions["whip_rope"](batch_size=B, seed=0, aux_reward=True, device=device)
+    env = env_functions[name](batch_size=B, seed=0, aux_reward=True, device=device)
     _, state = env.reset(prng.split(prng.PRNGKey(0), world)[rank])
     learner = APG(env, ep, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
 
@@ -146,7 +148,7 @@ def bench_whip_rope(args, rank, world, device):
     if rank == 0:
         S, N = env.conf.steps, env.simulator.n_particles
         units = world * B * ep * S * args.steps
-        g_act = touched_cells(state.x[0].detach().cpu().numpy() + 0.0)
+        g_act = touched_cells(state.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
         per_sub = (192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act)
@@ -156,13 +158,15 @@ def bench_whip_rope(args, rank, world, device):
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"whip_rope (MLS-MPM, N={N}, res 32^3, {S} substeps/step) APG loss+grad+update: "
+            "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": "mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel"),
+            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)" if env.simulator.n_primitive > 1 or N > 128 else
+                         ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
-                         "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers"}}), flush=True)
+                         "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
+                         else "latency bound: small kernels on 32 x 702 particles, two env groups on two streams"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -422,7 +426,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus", "shape_rope"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus", "shape_rope", "pour_water"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
@@ -449,6 +453,8 @@ def main():
         return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
         return bench_whip_rope(args, rank, world, device)
+    if args.workload == "pour_water":
+        return bench_whip_rope(args, rank, world, device, name="pour_water")
 
     global NUM_ENVS_PER_GPU
     para = args.workload == "fold_cloth1_para"

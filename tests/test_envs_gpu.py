@@ -78,7 +78,7 @@ def test_whip_rope_reset_and_step():
     assert torch.isfinite(a.grad).all() and a.grad[:, :3].abs().sum() > 0 and a.grad[:, 3:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("name,num_envs,ep_len", [("fold_cloth1", 2, 2), ("whip_rope", 4, 2)])
+@pytest.mark.parametrize("name,num_envs,ep_len", [("fold_cloth1", 2, 2), ("whip_rope", 4, 2), ("pour_water", 3, 2)])
 def test_apg_update_runs(name, num_envs, ep_len):
     from unidom_amd.algorithms.apg.core import APG
     from unidom_amd.envs.registration import env_functions
