@@ -136,6 +136,10 @@ typedef struct {
                                 checkpoints the active grid cells (32 B each) into a pool of K * n_particles records per
                                 substep on average, inside the caller's checkpoint (ud_mpm_ckpt_bytes grows accordingly),
                                 and the backward restores them.  A pool that runs out flags the env in status[] (1) */
+  int sort_particles;        /* many-workgroup path only.  != 0: at every step the handle re-orders the particles by grid cell
+                                (Morton key) internally, for bodies whose particles come in no spatial order (uniformly
+                                sampled liquids, mpm_simulator.py:87-91).  Invisible at this boundary: inputs, outputs and
+                                gradients stay in the caller's order; only the summation order of the scatters changes */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */

@@ -517,3 +517,51 @@ def test_mpm_step_edge_cases(demo, case):
         assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
     if case.endswith("domain_corner"):
         assert (x * 64 < 0.5).any()                                      # base truncates to 0 with fx < 0.5 for some particles
+
+
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 8])
+def test_internal_spatial_order_is_invisible(demo, grid_ckpt_cells):
+    """ud_mpm_conf.sort_particles: a body whose particles arrive shuffled (mixed materials and hardness, so the per-particle
+    tables and the Q6 trace over the caller's particles 0..2 must follow the permutation) gives the same step and the same
+    gradients, in the caller's order, with and without the internal re-ordering -- and both match the oracle."""
+    from oracle.pyoracle import MpmOracle
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    rng = np.random.default_rng(21)
+    S, N, B = 4, 300, 2
+    mat = rng.integers(1, 3, size=N).astype(np.int32)                  # elastic and plastic particles interleaved
+    hard = rng.uniform(0.5, 2.0, size=N).astype(np.float32)
+    x = (0.2 + rng.uniform(0, 0.09, size=(B, N, 3))).astype(np.float32)   # no spatial order at all
+    ppos = np.zeros((B, S, 3), np.float32)
+    ppos[:, 0] = x.mean(1)
+    prot = np.zeros((B, S, 4), np.float32)
+    prot[..., 0] = 1
+    mu0, la0 = 100 / (2 * 1.1), 100 * 0.1 / (1.1 * 0.8)
+    st = dict(x=x, v=(rng.normal(size=(B, N, 3)) * 0.2).astype(np.float32), C=(rng.normal(size=(B, N, 3, 3)) * 2).astype(np.float32),
+              F=(np.eye(3) + rng.normal(size=(B, N, 3, 3)) * 0.03).astype(np.float32), J=np.ones((B, N), np.float32), ppos=ppos, prot=prot,
+              psize=np.tile(np.float32([0.02, 0.02, 0.02]), (B, 1)), friction=np.full(B, 0.3, np.float32),
+              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32), action=(rng.normal(size=(B, 6)) * 0.01).astype(np.float32))
+    g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)) * 0.01, gC=rng.normal(size=(B, N, 3, 3)) * 1e-4,
+             gF=rng.normal(size=(B, N, 3, 3)) * 0.01, gppos=rng.normal(size=(B, S, 3)))
+    g = {k: v.astype(np.float32) for k, v in g.items()}
+    outs = []
+    for sort in (0, 1):
+        conf = LegacyConf()
+        conf.steps = S
+        sim = SimpleMPMSimulator(conf, B, use_position_control=True)
+        sim.n_particles, sim.material, sim.h = N, mat, hard
+        sim.grid_ckpt_cells, sim.sort_particles = grid_ckpt_cells, sort
+        sim._make_handle()
+        outs.append(run_hip(sim, st, g=g, clip=True))
+        outs.append(run_hip(sim, st))                                   # the no-checkpoint forward keeps its order in the handle
+    plain, plain_nograd, srt, srt_nograd = outs
+    for key in ("x", "v", "C", "F", "J", "gx", "gv", "gC", "gF", "gppos", "gaction", "gmu", "glamda", "gfriction"):
+        assert _rel(srt[key], plain[key]) < 2e-5, (key, _rel(srt[key], plain[key]))     # only the atomics' summation order differs
+    for key in ("x", "v", "C", "F", "J"):
+        assert _rel(srt_nograd[key], plain_nograd[key]) < 2e-5, key
+    orc = MpmOracle(N, steps=S, material=mat, hardness=hard)
+    of = orc.step_fwd(st)
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()}, clip=True)
+    assert _rel(srt["x"], of["x"]) < 5e-6 and _rel(srt["v"], of["v"]) < 1e-4 and _rel(srt["F"], of["F"]) < 5e-5
+    np.testing.assert_allclose(srt["J"], of["J"], rtol=1e-5)           # Q6: the trace runs over the caller's particles 0, 1, 2
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert _rel(srt[key], ob[key]) < 5e-3, (key, _rel(srt[key], ob[key]))

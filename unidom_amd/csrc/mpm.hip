@@ -1257,6 +1257,7 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   c.n_prim = conf->n_primitive > 0 ? conf->n_primitive : 1;   // 0 = unset = 1
   c.sdf_kind = conf->sdf_kind;
   c.gck = conf->grid_ckpt_cells > 0 ? conf->grid_ckpt_cells : 0;
+  c.sort = conf->sort_particles ? 1 : 0;
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
   const size_t per_particle = (N <= 96) ? 64 : 48;   // floats of LDS hand-off per particle in the adjoint (stage+ret / park)

@@ -19,6 +19,7 @@ struct MpmConst {
   float prim_friction, prim_softness;   // PrimitiveState.friction / .softness (collide_batch only)
   int n_prim, sdf_kind;            // primitives per env (collide_batch: 1..UD_MAX_PRIM); 0 box SDF, 1 container SDF
   int gck;                         // many-workgroup path: grid-checkpoint records per particle and substep (0 = recompute in the backward)
+  int sort;                        // many-workgroup path: re-order the particles by cell inside the handle at every step
 };
 
 // ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------

@@ -40,6 +40,7 @@ struct LargeBuf {
   float* grot;      // [B][P][S*4]  bwd, soft contact: cotangent of the rotation array
   float* gpw;       // [B][P][S*3]  bwd, soft contact: cotangent of the angular velocity rows
   float* gpsz;      // [B][P][4]    bwd, soft contact: cotangents of primitive size[3] and friction (enter the norm only)
+  int* perm;        // [B][Np]      spatial order of a forward without checkpoint (sort_particles)
 };
 
 struct LargeArgs {
@@ -57,6 +58,9 @@ struct LargeArgs {
   long gck_off_idx, gck_off_pool;
   int gck_budget;
   int* status;
+  // spatial order (ud_mpm_conf.sort_particles): slot p of the SoA history holds the caller's particle perm[p]; nullptr = as given
+  const int* perm;        // [B][perm_stride]
+  long perm_stride;
   const float* hist_in;   // state at substep f      [B][*][24][Np] with stride
   float* hist_out;        // state at substep f + 1
   long hist_stride_b;     // floats between envs
@@ -68,6 +72,9 @@ __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   decode_cell(c, key, ci, cj, ck);
   return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
 }
+
+// caller's index of the particle in slot p
+__device__ __forceinline__ int user_index(const LargeArgs& a, int b, int p) { return a.perm ? a.perm[(long)b * a.perm_stride + p] : p; }
 
 __device__ __forceinline__ int* gck_idx(const LargeArgs& a, int b) { return (int*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_idx); }
 __device__ __forceinline__ float4* gck_pool(const LargeArgs& a, int b) { return (float4*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_pool); }
@@ -260,7 +267,8 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     float x[3], v[3], Cm[9], F[9];
     load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
     Pre q;
-    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[p], a.hard[p], q, nullptr);
+    const int up = user_index(a, b, p);
+    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr);
     if (store_F && qi == 0) {
       float* ho = a.hist_out + (long)b * a.hist_stride_b;
 #pragma unroll
@@ -422,19 +430,68 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
   for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = x[d] + c.dt * nv[d]; ho[(3 + d) * c.Np + p] = nv[d]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
-  if (p < 3) {   // Q6: row p of particle p; three adds per substep on a zero-initialised word
+  const int up = user_index(a, b, p);
+  if (up < 3) {   // Q6: row p of (the caller's) particle p; three adds per substep on a zero-initialised word
     const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
-    atomicAdd(&a.w.trq[(long)b * c.steps + a.f], (p == 0) ? r0 : ((p == 1) ? r1 : r2));
+    atomicAdd(&a.w.trq[(long)b * c.steps + a.f], (up == 0) ? r0 : ((up == 1) ? r1 : r2));
   }
+}
+
+// Spatial order for bodies whose particles arrive in no particular order (the uniformly sampled liquid of pour_water: the
+// block-level staging of p2g only pays when consecutive particles share cells -- lg_p2g 77 us there against 23 us for a
+// lattice-seeded rope).  One workgroup per env: Morton key of each particle's base cell, bitonic sort of (key, index) in LDS,
+// perm[slot] = caller's index.  Purely internal: pack / unpack / material lookups / the Q6 trace go through perm, the
+// caller sees its own order; only the summation order of the scatters changes.
+__device__ __forceinline__ unsigned morton10(unsigned v) {   // spread the low 10 bits: b9..b0 -> bits 27,24,...,0
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+constexpr int LG_SORT_MAX = 8192;   // particles per env the LDS sort holds (64 KB of 8-byte entries)
+__global__ void __launch_bounds__(1024) lg_sort(MpmConst c, int b0, const float* x, int* perm, long perm_stride, int npow2) {
+  extern __shared__ unsigned long long lg_sk[];
+  const int b = blockIdx.x + b0, tid = threadIdx.x;
+  for (int i = tid; i < npow2; i += blockDim.x) {
+    unsigned long long e = ~0ull;
+    if (i < c.N) {
+      unsigned key = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float xv = nan_to_num(x[((long)b * c.N + i) * 3 + d]);
+        const int cell = min(max((int)(xv * c.inv_dx - 0.5f), 0), 1023);
+        key |= morton10((unsigned)cell) << d;
+      }
+      e = ((unsigned long long)key << 32) | (unsigned)i;
+    }
+    lg_sk[i] = e;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long ei = lg_sk[i], el = lg_sk[l];
+          const bool up = (i & k) == 0;
+          if ((ei > el) == up) { lg_sk[i] = el; lg_sk[l] = ei; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < c.N; i += blockDim.x) perm[(long)b * perm_stride + i] = (int)(lg_sk[i] & 0xffffffffu);
 }
 
 // AoS boundary <-> SoA history; nan_to_num on the way in (norm_grad_state fwd, :377-381)
 __global__ void __launch_bounds__(256) lg_pack(MpmConst c, int b0, const float* x, const float* v, const float* Cm, const float* F,
-                                               float* hist, long stride_b, int sanitize) {
+                                               float* hist, long stride_b, int sanitize, const int* perm, long perm_stride) {
   const int b = blockIdx.y + b0, p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= c.N) return;
   float* h = hist + (long)b * stride_b;
-  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+  const int up = perm ? perm[(long)b * perm_stride + p] : p;
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     h[d * c.Np + p] = sanitize ? nan_to_num(x[o3 + d]) : x[o3 + d];
@@ -448,11 +505,12 @@ __global__ void __launch_bounds__(256) lg_pack(MpmConst c, int b0, const float* 
 }
 
 __global__ void __launch_bounds__(256) lg_unpack(MpmConst c, int b0, const float* hist, long stride_b, float* x, float* v, float* Cm,
-                                                 float* F) {
+                                                 float* F, const int* perm, long perm_stride) {
   const int b = blockIdx.y + b0, p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= c.N) return;
   const float* h = hist + (long)b * stride_b;
-  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+  const int up = perm ? perm[(long)b * perm_stride + p] : p;
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { x[o3 + d] = h[d * c.Np + p]; v[o3 + d] = h[(3 + d) * c.Np + p]; }
 #pragma unroll
@@ -799,8 +857,9 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
   load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
   Pre q;
   PreB kb;
-  const int material = a.material[p];
-  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[p], q, &kb);
+  const int up = user_index(a, b, p);
+  const int material = a.material[up];
+  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb);
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9], gF[9];
 #pragma unroll
@@ -851,7 +910,7 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
   float gmu_p, gla_p;
   particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
-    const float h = clipf(a.hard[p], 0.1f, 5.f);
+    const float h = clipf(a.hard[up], 0.1f, 5.f);
     atomicAdd(&a.w.acc[b * 4 + 1], gmu_p * h);
     atomicAdd(&a.w.acc[b * 4 + 2], gla_p * h);
   }
@@ -949,15 +1008,16 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
   }
   const bool sc = clip && !(sn < 1.f);
   for (int p = tid; p < N; p += blockDim.x) {
+    const int up = user_index(a, b, p);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      gx0[((long)b * N + p) * 3 + d] = sc ? gs[d * Np + p] / sn : gs[d * Np + p];
-      gv0[((long)b * N + p) * 3 + d] = sc ? gs[(3 + d) * Np + p] / sn : gs[(3 + d) * Np + p];
+      gx0[((long)b * N + up) * 3 + d] = sc ? gs[d * Np + p] / sn : gs[d * Np + p];
+      gv0[((long)b * N + up) * 3 + d] = sc ? gs[(3 + d) * Np + p] / sn : gs[(3 + d) * Np + p];
     }
 #pragma unroll
     for (int d = 0; d < 9; ++d) {
-      gC0[((long)b * N + p) * 9 + d] = sc ? gs[(6 + d) * Np + p] / sn : gs[(6 + d) * Np + p];
-      gF0[((long)b * N + p) * 9 + d] = sc ? gs[(15 + d) * Np + p] / sn : gs[(15 + d) * Np + p];
+      gC0[((long)b * N + up) * 9 + d] = sc ? gs[(6 + d) * Np + p] / sn : gs[(6 + d) * Np + p];
+      gF0[((long)b * N + up) * 9 + d] = sc ? gs[(15 + d) * Np + p] / sn : gs[(15 + d) * Np + p];
     }
   }
   for (int e = tid; e < P * S * 3; e += blockDim.x) gppos0[(long)b * P * S * 3 + e] = sc ? gp[e] / sn : gp[e];
@@ -1008,6 +1068,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   (void)hipFuncSetAttribute((const void*)lg_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)lg_sort, hipFuncAttributeMaxDynamicSharedMemorySize, LG_SORT_MAX * 8);
   bool ok = hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
     ok = ok && hipStreamCreateWithFlags(&L->side[g], hipStreamNonBlocking) == hipSuccess;
@@ -1029,8 +1090,8 @@ void mpm_large_destroy(MpmLarge* L) {
 }
 
 // checkpoint layout per env (floats): particle history [(S+1)][24][Np] | primitive tail [P][S*10] | grid checkpoint:
-// record index [S+1] (ints, padded to 4) and the record pool [budget][8]
-struct CkLayout { long rec, off_tail, off_idx, off_pool, stride; int budget; };
+// record index [S+1] (ints, padded to 4) and the record pool [budget][8] | spatial order [Np] (ints)
+struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int budget; };
 static CkLayout ck_layout(const MpmConst& c) {
   CkLayout k;
   const long S = c.steps;
@@ -1042,7 +1103,8 @@ static CkLayout ck_layout(const MpmConst& c) {
   k.off_pool = k.off_idx + nidx;
   const long budget = c.gck > 0 ? S * (long)c.gck * c.N : 0;   // records per env and launch: gck cells per particle and substep on average
   k.budget = (int)std::min<long>(budget, 0x7fffffff / 2);
-  k.stride = k.off_pool + (long)k.budget * 8;
+  k.off_perm = k.off_pool + (long)k.budget * 8;                // [Np] ints: the spatial order of this launch (sort_particles)
+  k.stride = k.off_perm + (c.sort ? (long)c.Np : 0);
   return k;
 }
 
@@ -1065,6 +1127,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 12 * 4);
   const size_t o_hist = take((size_t)B * 2 * 24 * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
   const size_t o_grot = take(BP * S * 4 * 4), o_gpw = take(BP * S * 3 * 4), o_gpsz = take(BP * 4 * 4);
+  const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&L->arena, off);
   if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
   e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, stamps and counters start at zero
@@ -1077,6 +1140,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   L->w.acc = (float*)(base + o_acc); L->w.pscr = (float*)(base + o_pscr); L->w.hist = (float*)(base + o_hist);
   L->w.gstate = (float*)(base + o_gstate);
   L->w.grot = (float*)(base + o_grot); L->w.gpw = (float*)(base + o_gpw); L->w.gpsz = (float*)(base + o_gpsz);
+  L->w.perm = (int*)(base + o_perm);
   L->arena_bytes = off; L->B = B; L->epoch = 1;
   return UD_OK;
 }
@@ -1087,6 +1151,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.epoch = 0; a.cap = L->cap; a.G = L->G;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr;
+  a.perm = nullptr; a.perm_stride = 0;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
   return a;
@@ -1135,12 +1200,24 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
   const int e0 = L->epoch;            // one epoch per substep, shared by the groups (stamps are per env)
   L->epoch += S + 1;
+  // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
+  const bool sort = c.sort && N <= LG_SORT_MAX;
+  int* perm = nullptr;
+  long perm_stride = 0;
+  if (sort) {
+    perm = ckpt ? (int*)(ckpt + ck.off_perm) : L->w.perm;
+    perm_stride = ckpt ? stride_b : c.Np;
+    a.perm = perm; a.perm_stride = perm_stride;
+  }
+  int npow2 = 64;
+  while (npow2 < N) npow2 <<= 1;
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_prim_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ppos, prot);
-    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1);
+    if (sort) hipLaunchKernelGGL(lg_sort, dim3(grp[g].Bg), dim3(1024), (size_t)npow2 * 8, grp[g].s, c, a.b0, x, perm, perm_stride, npow2);
+    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
   }
   for (int f = 0; f <= S; ++f) {
     a.f = f; a.epoch = e0 + f;
@@ -1163,7 +1240,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
-    hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, last, stride_b, xo, vo, Co, Fo);
+    hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, last, stride_b, xo, vo, Co, Fo, (const int*)perm, perm_stride);
     hipLaunchKernelGGL(lg_fwd_out, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
   }
   lg_join(L, G, st, grp);
@@ -1191,12 +1268,13 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   const int e0 = L->epoch;
   L->epoch += S + 1;
+  if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
-    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0);
+    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
   }
   for (int f = S - 1; f >= -1; --f) {
     // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward

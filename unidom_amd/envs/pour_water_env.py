@@ -39,6 +39,10 @@ class DefaultConf:
     p_mass = p_vol * p_rho
     gravity = (0, -9.8, 0)
 
+    # kernel option, not a reference field (include/unidom_hip.h): the liquid is sampled uniformly (no spatial order), the
+    # kernels re-order it by grid cell internally at every step
+    sort_particles = 1
+
     task = "pour_water"
     goal_path = f"{my_path}/goals/{task}/goal.npy"
 
