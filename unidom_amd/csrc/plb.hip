@@ -30,6 +30,7 @@ struct PlbBuf {
   int* count;     // [2][B]
   double* pos;    // [B][S+1][np][3] primitive positions of this step
   double* hist;   // [B][2][24][Np]
+  int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
 };
 
 struct PlbArgs {
@@ -401,26 +402,73 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
 }
 
-__global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, const double* v, const double* Cm, const double* F) {
+// Spatial order (as lg_sort in mpm_large.hip): the Torus body is sampled with np.random (shape_maker.py:21,57), consecutive
+// particles share no cells and the block-level staging of p2g does not aggregate.  One workgroup per env sorts (Morton key of
+// the base cell, index) in LDS; pack / unpack go through the permutation, the caller keeps its own order.
+__device__ __forceinline__ unsigned plb_morton10(unsigned v) {
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+constexpr int PLB_SORT_MAX = 8192;
+__global__ void __launch_bounds__(1024) plb_sort(PlbArgs a, const double* x, int npow2) {
+  extern __shared__ unsigned long long plb_sk[];
+  const PlbConst& c = a.c;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < npow2; i += blockDim.x) {
+    unsigned long long e = ~0ull;
+    if (i < c.N) {
+      unsigned key = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int cell = min(max((int)(x[((long)b * c.N + i) * 3 + d] * c.inv_dx - 0.5), 0), 1023);
+        key |= plb_morton10((unsigned)cell) << d;
+      }
+      e = ((unsigned long long)key << 32) | (unsigned)i;
+    }
+    plb_sk[i] = e;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long ei = plb_sk[i], el = plb_sk[l];
+          const bool up = (i & k) == 0;
+          if ((ei > el) == up) { plb_sk[i] = el; plb_sk[l] = ei; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < c.N; i += blockDim.x) a.w.perm[(long)b * c.Np + i] = (int)(plb_sk[i] & 0xffffffffu);
+}
+
+__global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, const double* v, const double* Cm, const double* F, int sorted) {
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
   if (p >= c.N) return;
   double* h = a.w.hist + (long)b * 2 * 24 * c.Np;
-  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+  const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { h[d * c.Np + p] = x[o3 + d]; h[(3 + d) * c.Np + p] = v[o3 + d]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) { h[(6 + d) * c.Np + p] = Cm[o9 + d]; h[(15 + d) * c.Np + p] = F[o9 + d]; }
 }
 
-__global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x, double* v, double* Cm, double* F, double* prim_o) {
+__global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x, double* v, double* Cm, double* F, double* prim_o, int sorted) {
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
   if (blockIdx.x == 0 && threadIdx.x < c.np * 3)
     prim_o[(long)b * c.np * 3 + threadIdx.x] = a.w.pos[((long)b * (c.S + 1) + c.S) * c.np * 3 + threadIdx.x];   // copyframe(cur, 0)
   if (p >= c.N) return;
   const double* h = a.w.hist + ((long)b * 2 + slot) * 24 * c.Np;
-  const long o3 = ((long)b * c.N + p) * 3, o9 = ((long)b * c.N + p) * 9;
+  const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { x[o3 + d] = h[d * c.Np + p]; v[o3 + d] = h[(3 + d) * c.Np + p]; }
 #pragma unroll
@@ -448,6 +496,7 @@ static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_val = take((size_t)B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
   const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
+  const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&h->arena, off);
   if (e != hipSuccess) { ud::set_error("ud_plb: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); h->B = 0; return UD_ERR_HIP; }
   e = hipMemsetAsync(h->arena, 0, off, st);
@@ -455,6 +504,7 @@ static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
   char* base = (char*)h->arena;
   h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
   h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
+  h->w.perm = (int*)(base + o_perm);
   h->B = B; h->epoch = 1;
   return UD_OK;
 }
@@ -476,6 +526,7 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
   c.radius[0] = conf->radius[0]; c.radius[1] = conf->radius[1];
   h->G = (long)c.n_grid * c.n_grid * c.n_grid;
   h->cap = (int)std::min<long>(h->G, (long)27 * c.N);
+  (void)hipFuncSetAttribute((const void*)ud::plb_sort, hipFuncAttributeMaxDynamicSharedMemorySize, ud::PLB_SORT_MAX * 8);
   *out = h;
   return UD_OK;
 }
@@ -506,7 +557,14 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   const int lanes = force_lanes ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);   // lanes per particle in p2g / g2p
   const dim3 gq((4 * h->c.N + 255) / 256, B);
   hipLaunchKernelGGL(ud::plb_prologue, dim3((B + 63) / 64), dim3(64), 0, st, a, prim_pos, action);
-  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F);
+  static const int no_sort = [] { const char* e = getenv("UD_PLB_NO_SORT"); return e ? atoi(e) : 0; }();   // diagnostic override
+  const int sorted = (!no_sort && h->c.N <= ud::PLB_SORT_MAX) ? 1 : 0;
+  if (sorted) {
+    int npow2 = 64;
+    while (npow2 < h->c.N) npow2 <<= 1;
+    hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, a, x, npow2);
+  }
+  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted);
   for (int f = 0; f < h->c.S; ++f) {
     a.f = f; a.epoch = h->epoch++;
     hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
@@ -516,7 +574,7 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   }
   a.f = h->c.S; a.epoch = h->epoch++;
   hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);   // back to the all-zero grid invariant
-  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S & 1, x_out, v_out, C_out, F_out, prim_pos_out);
+  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S & 1, x_out, v_out, C_out, F_out, prim_pos_out, sorted);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ud::set_error("ud_plb_step_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;
