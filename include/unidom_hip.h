@@ -167,8 +167,10 @@ int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const floa
  * the reference yields NaN there for w = 0 and launders it with nan_to_num at this boundary.
  * Soft contact: rotation and action[3:6] carry the chain rule as the reference writes it, NaN at w = 0 included
  * (d|w|/dw, primitives.py:86); clip != 0 launders it exactly like the reference.
- * clip != 0 applies norm_grad_state / norm_grad (nan_to_num + global-norm clip to 1, :389-408); in soft-contact
- * mode the norm also covers the cotangents of the primitive's rotation, size, friction and action_scale leaves. */
+ * clip bit 0 applies norm_grad_state / norm_grad (nan_to_num + global-norm clip to 1, :389-408); in soft-contact
+ * mode the norm also covers the cotangents of the primitive's rotation, size, friction and action_scale leaves.
+ * clip bit 1 (many-workgroup path with grid_ckpt_cells > 0): ignore the grid checkpoint and recompute p2g + grid op --
+ * for a step whose forward flagged a pool overflow in status[]; the particle history in the checkpoint is always complete. */
 int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, const float* friction,
                     const float* mu, const float* lamda, const float* action, const float* g_x, const float* g_v,
                     const float* g_C, const float* g_F, const float* g_prim_position, const float* g_prim_rotation, int clip,

@@ -264,16 +264,21 @@ def test_large_path_matches_oracle_n798(grid_ckpt_cells):
     assert _rel(oh2["x"], of["x"]) < 5e-6 and _rel(oh2["v"], of["v"]) < 1e-4
 
 
-def test_grid_checkpoint_pool_overflow_is_reported():
+def test_grid_checkpoint_pool_overflow_falls_back_to_recompute():
     """A pool of 1 record per particle and substep holds the compact rope (measured 0.58 active cells per particle) but not the
-    same particles scattered through the volume (up to 27 cells each): the env is flagged (UD_ERR_OVERFLOW) and check_status raises
-    instead of returning gradients built on a truncated grid."""
-    from unidom_amd._lib import UnidomError
-    sim, st, g, N = _scaled_case(3, 0, B=1, grid_ckpt_cells=1)
+    same particles scattered through the volume (up to 27 cells each): the forward flags the env in status[], the host mirror
+    sees the flag without a sync and asks that step's backward to recompute the grid (clip bit 1) -- same gradients as a
+    handle that never checkpoints the grid."""
+    sim, st, g, N = _scaled_case(3, 0, B=2, grid_ckpt_cells=1)
     run_hip(sim, st, g=g, clip=True)                                   # the rope fits
-    st["x"] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"].shape).astype(np.float32)
-    with pytest.raises(UnidomError, match="UD_ERR_OVERFLOW"):
-        run_hip(sim, st, g=g, clip=True)
+    assert sim.grid_ckpt_overflows == 0
+    st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)   # env 1 scattered
+    got = run_hip(sim, st, g=g, clip=True)
+    assert sim.grid_ckpt_overflows == 1
+    ref_sim, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=0)
+    ref = run_hip(ref_sim, st, g=g, clip=True)
+    for key in ("x", "v", "gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
 
 
 # ---- soft contact (collide_batch, primitives.py:154-182) -- the mode shape_rope / pour_* use --------------------------

@@ -711,11 +711,22 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   }
 }
 
-// grid checkpoint -> dense arrays of the backward for substep f: velocity after the grid op, zeroed cotangent, the cell list
+// grid checkpoint -> dense arrays of the backward for substep f: velocity after the grid op, zeroed cotangent, the cell list.
+// It also zeroes the cotangent cells of substep f + 1 (just consumed by its p2g adjoint), and a last call with f = -1 does
+// only that for substep 0: the handle's gacc grid is all-zero again afterwards, which the recomputing backward relies on
+// (a handle may serve both modes: a step whose pool overflowed falls back to recomputing).
 __global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
-  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cur = a.f & 1;
+  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x, S = a.c.steps;
   const int* idx = gck_idx(a, b);
+  if (a.f + 1 < S) {                                  // cells of substep f + 1: done with
+    const int first = idx[a.f + 1], n = min(min(idx[a.f + 2], a.gck_budget) - first, a.cap);
+    if (t < n) {
+      const int key = __builtin_bit_cast(int, gck_pool(a, b)[(long)(first + t) * 2].x);
+      a.w.gacc[(long)b * a.G + cell_lin(a.c, key)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (a.f < 0) return;
+  const int cur = a.f & 1;
   const int first = idx[a.f], n = min(min(idx[a.f + 1], a.gck_budget) - first, a.cap);
   if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = max(n, 0);
   if (t >= n) return;
@@ -1264,7 +1275,10 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const long rec = ck.rec;
   const long stride_b = ck.stride;
   a.hist_stride_b = stride_b;
-  const bool gck = ck.budget > 0;   // restore the grid from the checkpoint instead of recomputing p2g + grid op
+  // restore the grid from the checkpoint instead of recomputing p2g + grid op -- unless the caller saw the forward flag a
+  // pool overflow and asks for the recomputing backward (clip bit 1)
+  const bool gck = ck.budget > 0 && !(clip & 2);
+  clip &= 1;
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   const int e0 = L->epoch;
   L->epoch += S + 1;
@@ -1285,9 +1299,9 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
       const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      if (gck) {          // the dense val grid is never touched: nothing to clear, nothing to recompute
-        if (f < 0) continue;
+      if (gck) {          // the dense val grid is never touched: nothing to recompute; gacc is handed back all-zero
         hipLaunchKernelGGL(lg_restore, gc, blk, 0, s, a);
+        if (f < 0) continue;
       } else {
         hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 1);
         if (f < 0) continue;

@@ -70,7 +70,13 @@ class _Step(torch.autograd.Function):
             *[_lib.ptr(t) for t in (xo, vo, Co, Fo, Jo, ppo, pro, pvo, pwo)], _lib.ptr(ckpt), _lib.ptr(status), stream),
             "ud_mpm_step_fwd")
         sim._prof_end(ev)
-        sim.status_log.append(status)
+        ctx.overflow = None
+        if ckpt is not None and sim.grid_ckpt_cells > 0 and sim._h_large:
+            # the only flag this path raises is "grid-checkpoint pool exhausted": not an error -- that step's backward recomputes
+            # the grid instead.  The flags travel to pinned host memory on a side stream, so the backward reads them without a sync.
+            ctx.overflow = sim._stage_flags(status)
+        else:
+            sim.status_log.append(status)
         ctx.sim, ctx.B = sim, B
         ctx.save_for_backward(ckpt, psize, friction, mu, lamda, action)
         if sim.use_position_control:
@@ -99,7 +105,7 @@ class _Step(torch.autograd.Function):
         ev = sim._prof_begin("bwd")
         _lib.check(L.ud_mpm_step_bwd(
             sim._h, C.c_int(B), _lib.ptr(ckpt), *[_lib.ptr(t) for t in (psize, friction, mu, lamda, action)],
-            *[_lib.ptr(t) for t in (gx, gv, gC, gF, gppos, gprot)], C.c_int(1 if sim.clip_grad else 0),
+            *[_lib.ptr(t) for t in (gx, gv, gC, gF, gppos, gprot)], C.c_int((1 if sim.clip_grad else 0) | (2 if sim._overflowed(ctx.overflow) else 0)),
             *[_lib.ptr(t) for t in (ox, ov, oC, oF, opp, opr, ofr, omu, ola, oa)], _lib.ptr(status), stream), "ud_mpm_step_bwd")
         sim._prof_end(ev)
         sim.status_log.append(status)
@@ -135,6 +141,9 @@ class SimpleMPMSimulator:
         self.profile = None
         self.status_log = []
         self._h = None
+        self._h_large = False            # the handle runs the many-workgroup path (N > 128 or soft contact)
+        self._flag_stream = None
+        self.grid_ckpt_overflows = 0     # steps whose backward fell back to recomputing the grid
 
     # -- particle seeding (:65-145) ----------------------------------------------------------------------
     def add_box(self, conf, state, size, init_pos, hardness=1, z_rotation_angle=0, material=0, density=1):
@@ -219,6 +228,7 @@ class SimpleMPMSimulator:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ud_mpm_create(C.byref(cc), mat.ctypes.data_as(C.c_void_p),
                                                 hh.ctypes.data_as(C.c_void_p), C.byref(self._h)), "ud_mpm_create")
+        self._h_large = self.n_particles > 128 or not self.use_position_control
 
     def __del__(self):
         try:
@@ -226,6 +236,28 @@ class SimpleMPMSimulator:
                 _lib.lib().ud_mpm_destroy(self._h)
         except Exception:
             pass
+
+    # -- grid-checkpoint overflow flags (include/unidom_hip.h: status[] of the many-workgroup path) -------------------
+    def _stage_flags(self, status):
+        if self._flag_stream is None:
+            self._flag_stream = torch.cuda.Stream(self.device)
+        host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+        done = torch.cuda.Event()
+        self._flag_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._flag_stream):
+            host.copy_(status, non_blocking=True)
+            done.record(self._flag_stream)
+        status.record_stream(self._flag_stream)
+        return host, done
+
+    def _overflowed(self, staged):
+        if staged is None:
+            return False
+        host, done = staged
+        done.synchronize()            # long complete by the time the backward of this step runs
+        over = bool(host.any())
+        self.grid_ckpt_overflows += int(over)
+        return over
 
     def _prof_begin(self, kind):
         if self.profile is None:

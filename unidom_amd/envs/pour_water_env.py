@@ -42,6 +42,9 @@ class DefaultConf:
     # kernel option, not a reference field (include/unidom_hip.h): the liquid is sampled uniformly (no spatial order), the
     # kernels re-order it by grid cell internally at every step
     sort_particles = 1
+    # the forward checkpoints the active grid cells for the backward (measured 0.97 cells per particle at rest); a step in
+    # which the splashing liquid needs more than the pool holds falls back to recomputing the grid, silently
+    grid_ckpt_cells = 4
 
     task = "pour_water"
     goal_path = f"{my_path}/goals/{task}/goal.npy"
