@@ -47,3 +47,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no fallback" in str(e).lower()
     else:
         raise AssertionError("expected UnidomError")
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """include/unidom_hip.h is the contract; unidom_amd/_lib.py re-declares its structs for ctypes.  A field added on one side
+    only would corrupt the conf silently: compile the header with gcc and compare sizeof / offsetof of every field."""
+    import ctypes as C
+    import subprocess
+
+    from unidom_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"ud_cloth_conf": _lib.ud_cloth_conf, "ud_mpm_conf": _lib.ud_mpm_conf, "ud_plb_conf": _lib.ud_plb_conf}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "unidom_hip.h"', "int main(void) {"]
+    for name, st in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in st._fields_:
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, st in structs.items():
+        assert int(got[name]) == C.sizeof(st), (name, got[name], C.sizeof(st))
+        for field, _ in st._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(st, field).offset, (name, field)

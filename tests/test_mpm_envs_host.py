@@ -1,0 +1,88 @@
+"""CPU: host-side arithmetic of the MPM envs above the kernels (no GPU, no library calls): the action expansion of
+shape_rope (shape_rope_env.py:91-121) and pour_water (pour_water_env.py:77-90), restated here in numpy line by line, and the
+state plumbing helpers of MPMEnv (mpm_env.py:161)."""
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from unidom_amd.engine.mpm_simulator import MPMState
+from unidom_amd.engine.primitives.primitives import PrimitiveState, create_primitive, get_sdf_kind, set_sdf
+from unidom_amd.envs.basic.mpm_env import _where_done
+from unidom_amd.envs.pour_water_env import PourWaterEnv
+from unidom_amd.envs.shape_rope_env import DefaultConf as RopeConf
+from unidom_amd.envs.shape_rope_env import ShapeRopeEnv
+
+
+def _state(B, conf, n_prim=1):
+    prims = []
+    for i in range(n_prim):
+        p = create_primitive(conf, friction=0.1, softness=666, color=[0.5] * 3, size=[0.02, 0.06, 0.02], init_pos=[0.5, 0.01, 0.45 + 0.1 * i])
+        prims.append(PrimitiveState(*[t[None].repeat((B,) + (1,) * t.dim()) for t in p]))
+    return MPMState(x=torch.zeros((B, 5, 3)), primitives=prims)
+
+
+def test_shape_rope_push_expansion_matches_the_reference_lines():
+    rng = np.random.default_rng(0)
+    B = 5
+    acts = rng.uniform(0.2, 0.8, size=(B, 6)).astype(np.float32)
+    acts[0, 3:] = acts[0, :3] + 0.9            # longer than the 0.3 cap
+    acts[1, 3:] = acts[1, :3]                  # zero-length push: norm = 1e-8
+    st = _state(B, RopeConf())
+    sub, st2 = ShapeRopeEnv.get_primitive_actions(torch.tensor(acts), st)
+    assert sub.shape == (30, B, 6)
+    for b in range(B):                         # :92-115, one env at a time like the vmapped original
+        start, end = acts[b, :3].copy(), acts[b, 3:].copy()
+        start[1] = 0.01
+        end[1] = 0.01
+        norm = np.float32(np.linalg.norm(end - start)) + np.float32(1e-8)
+        vec = (end - start) / norm
+        end = start + vec * np.clip(norm, 0.0, 0.3)
+        push = np.repeat(((end - start))[None], 30, 0) / np.float32(30)
+        push[:, 1] = 0
+        want = np.concatenate([push, np.zeros_like(push)], -1)
+        np.testing.assert_allclose(sub[:, b].numpy(), want, rtol=0, atol=1e-8)
+        np.testing.assert_array_equal(st2.primitives[0].position[b, 0].numpy(), start)     # position.at[0].set(start)
+        np.testing.assert_array_equal(st2.primitives[0].position[b, 1:].numpy(), st.primitives[0].position[b, 1:].numpy())
+    assert np.linalg.norm(sub[:, 0, :3].sum(0).numpy()) <= 0.3 * (1 + 1e-5)               # the cap held
+    shift = torch.tensor([[0.1, 0.0, -0.2]] * B)
+    moved = ShapeRopeEnv.process_pre_step_actions(torch.tensor(acts), shift)              # :85-89: both end points shift
+    np.testing.assert_allclose(moved.numpy(), acts + np.tile(shift.numpy(), (1, 2)), atol=1e-7)
+
+
+def test_pour_water_action_expansion_matches_the_reference_lines():
+    rng = np.random.default_rng(1)
+    acts = rng.normal(size=(4, 6)).astype(np.float32)
+    sub, _ = PourWaterEnv.get_primitive_actions(torch.tensor(acts), None)
+    assert sub.shape == (1, 4, 12)
+    for b in range(4):                          # :79-88
+        a = np.concatenate([acts[b], np.zeros(6, np.float32)])[None]
+        a[..., :3] = a[..., :3] / np.float32(500.0)
+        a[..., 3:6] = a[..., 3:6] / np.float32(500.0)
+        a = a + np.float32(1e-12)
+        a[..., 1] = 0
+        np.testing.assert_array_equal(sub[:, b].numpy(), a)
+    assert (sub[0, :, 6:] == np.float32(1e-12)).all()          # the second bowl: zeros + 1e-12
+
+
+def test_where_done_keeps_untouched_leaves_and_selects_the_rest():
+    T = namedtuple("T", "a b c")
+    done = torch.tensor([True, False, True])
+    old = T(torch.zeros(3, 2), torch.arange(3.0), np.array([1, 2, 3]))
+    new = T(torch.ones(3, 2), old.b, np.array([7, 8, 9]))      # b handed back untouched
+    out = _where_done(done, new, old)
+    assert out.b is old.b                                        # no launch, no copy
+    np.testing.assert_array_equal(out.a.numpy(), [[1, 1], [0, 0], [1, 1]])
+    np.testing.assert_array_equal(out.c, [7, 2, 9])
+
+
+def test_set_sdf_records_the_kind_per_reset():
+    from unidom_amd.engine.primitives.box import _sdf_batch as box_sdf
+    from unidom_amd.engine.primitives.container import _sdf_batch as container_sdf
+    try:
+        set_sdf(container_sdf)
+        assert get_sdf_kind() == "container"
+        set_sdf(box_sdf)
+        assert get_sdf_kind() == "box"
+    finally:
+        set_sdf(box_sdf)
