@@ -154,6 +154,10 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
         per_sub = (192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act)
         per_launch = B * S * per_sub
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        traffic = None          # PMC passes exist for the default whip_rope shape only (32 envs, one workgroup per env)
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if name == "whip_rope" and B == 32 and os.path.exists(tj):
+            traffic = json.load(open(tj)).get("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", {}).get("hbm_bytes_per_launch")
         print(json.dumps({
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -163,7 +167,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)" if env.simulator.n_primitive > 1 or N > 128 else
                          ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
                          "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
                          else "latency bound: small kernels on 32 x 702 particles, two env groups on two streams"}}), flush=True)
