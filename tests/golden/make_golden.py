@@ -122,6 +122,27 @@ def main():
         os.makedirs(dst, exist_ok=True)
         shutil.copyfile(src, f"{dst}/goal.npy")
         print(task, "goal", np.load(src).shape)
+    # ---- fold_tshirt cloth mask (input of the simulator's constructor) ---------------------------------------------
+    # The reference builds it from others/t-shirt.jpg with cv2 (fold_cloth_tshirt_env.py:50-67); cv2 is not available here, but
+    # the recorded reset state of expert_demo/fold_tshirt/demo_0.pkl (y = 0, lattice positions) holds the same information:
+    # particle p sits at lattice point (round(x / cell), N - round(z / cell)), in row-major order of the mask (cloth_simulator.py:52).
+    class _Legacy(_Stub):                       # these demos predate ClothState.stiffness / .mu: 8 fields
+        def find_class(self, module, name):
+            if name == "ClothState":
+                return type("LegacyClothState", (tuple,), {"__new__": lambda cls, *a: tuple.__new__(cls, a)})
+            return super().find_class(module, name)
+    with open(f"{REF}/algorithms/expert_demo/fold_tshirt/demo_0.pkl", "rb") as f:
+        x0 = np.asarray(_Legacy(f).load()["state"][0][0])[0]
+    N = 180
+    assert x0.shape == (3573, 3) and np.all(x0[:, 1] == 0)
+    ii, jj = np.round(x0[:, 0] * N).astype(int), N - np.round(x0[:, 2] * N).astype(int)
+    tmask = np.zeros((N, N), np.uint8)
+    tmask[ii, jj] = 1
+    assert tmask.sum() == 3573 and np.array_equal(np.stack(np.nonzero(tmask), 1), np.stack([ii, jj], 1))
+    os.makedirs(f"{REPO}/unidom_amd/envs/others", exist_ok=True)
+    np.save(f"{REPO}/unidom_amd/envs/others/tshirt_mask.npy", tmask)
+    print("fold_tshirt mask", tmask.shape, int(tmask.sum()))
+
     # goals of the sibling envs on the same kernels (data files: inputs of their reward)
     for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "shape_rope", "pour_water"):
         src = f"{REF}/core/envs/goals/{task}/goal.npy"

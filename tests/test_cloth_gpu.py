@@ -341,3 +341,52 @@ def test_mask_touching_border_is_refused():
     mask[0:4, 10:20] = 1
     with pytest.raises(_lib.UnidomError, match="border"):
         ClothSimulator(Conf(), 1, lambda x, v, i, j: v, mask)
+
+
+class BigConf(Conf):  # fold_cloth_tshirt_env.py:19-33
+    N = 180
+    stiffness = 5000
+    dt = 0.5e-3
+    mu = 0.9
+
+
+def _big_case(mask, B, T, seed):
+    from conftest import cloth_reset_x
+    rng = np.random.default_rng(seed)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T, P_x=cloth_reset_x(180, mask), deform=0.0003, v_scale=0.01)
+    k = rng.uniform(3000, 6000, size=B).astype(np.float32)
+    return rng, (x, v, prim, k, mu, actions)
+
+
+@pytest.mark.parametrize("which", ["disk", "tshirt"])
+def test_big_body_kernels_match_oracle(which):
+    """Bodies above 1024 particles (fold_tshirt: 3573): one workgroup per env, four particles per lane.  Forward bit-exact
+    against the reference-order oracle (grasp sets included), adjoint within the usual tolerance."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    N = 180
+    if which == "disk":
+        ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+        mask = (((ii - 90) ** 2 + (jj - 87) ** 2) <= 30.3 ** 2).astype(np.float32)
+    else:
+        import os
+        import unidom_amd.envs as envs
+        mask = np.load(os.path.join(os.path.dirname(envs.__file__), "others", "tshirt_mask.npy")).astype(np.float32)
+    P = int(mask.sum())
+    assert 1024 < P <= 4096 and P % 64 != 0
+    B, T = 2, 2
+    sim = ClothSimulator(BigConf(), B, lambda x, v, i, j: v, mask)
+    orc = ClothOracle(mask, N=N, **{k: getattr(BigConf, k) for k in ("gravity", "damping", "dt", "max_v", "small_num")})
+    assert sim.n_particles == orc.P == P
+    rng, case = _big_case(mask, B, T, 7)
+    o = orc.rollout_fwd(*case, want_lists=True, want_grasp=True, nthreads=2)
+    g = _grads(rng, B, T, P)
+    ob = orc.rollout_bwd(*case, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"], g["gprim_list"], nthreads=2)
+    h = _run_hip(sim, *case, g=g)
+    assert o["grasp"].sum() > 0
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert np.isfinite(h[key]).all(), key
+        assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))

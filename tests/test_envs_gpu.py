@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 def test_registry_names():
     from unidom_amd.envs.registration import env_functions
-    assert {"fold_cloth1", "fold_cloth1_para", "whip_rope"} <= set(env_functions)
+    assert {"fold_cloth1", "fold_cloth1_para", "fold_cloth3", "unfold_cloth1", "unfold_cloth3", "fold_tshirt", "whip_rope", "shape_rope",
+            "shape_rope_hard", "pour_water"} == set(env_functions)   # the reference registry minus pour_soup (registration.py:13-27)
 
 
 def test_fold_cloth1_step_diff_reproduces_recorded_primitives_and_keys():
@@ -338,3 +339,32 @@ def test_pour_water_reset_step_matches_oracle_and_grad():
     reward.sum().backward()
     assert torch.isfinite(a.grad).all() and a.grad[:, [0, 2]].abs().min() > 0 and a.grad[:, 3:].abs().sum() > 0
     assert (a.grad[:, 1] == 0).all()                                    # vertical motion is overwritten (pour_water_env.py:88)
+
+
+def test_fold_tshirt_step_matches_oracle_and_grad():
+    """fold_tshirt (fold_cloth_tshirt_env.py): 3573 particles from the recovered T-shirt mask, observation = every tenth
+    particle + grippers (1082).  One step_diff (2000 substeps at k = 5000, dt = 0.5e-3) is bit-exact against the reference-order
+    CPU restatement; the reward's gradient reaches the pick-and-place action."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.envs.basic import _fused
+    from unidom_amd.envs.registration import env_functions
+    env = env_functions["fold_tshirt"](batch_size=2, aux_reward=True)
+    obs, st = env.reset(np.array([0, 5], np.uint32))
+    conf = env.conf
+    assert st.x.shape == (2, 3573, 3) and obs.shape == (2, 1082) == (2, env.observation_size) and env.max_steps == 5
+    xm = st.x[0].mean(0).cpu().numpy()
+    a = torch.tensor([[xm[0] - 0.08, 0.0, xm[2] + 0.05, xm[0] + 0.1, 0.0, xm[2] - 0.02],
+                      [xm[0] + 0.1, 0.0, xm[2] - 0.1, xm[0] - 0.05, 0.0, xm[2] + 0.08]], device=env.device, requires_grad=True)
+    obs2, reward, done, info = env.step_diff(a, st)
+    assert obs2.shape == (2, 1082) and torch.isfinite(reward).all()
+    macro = _fused.pnp_and_contact(a.detach(), st.primitive0, st.x)[0].cpu().numpy()
+    orc = ClothOracle(np.asarray(env.cloth_mask), N=conf.N, gravity=conf.gravity, damping=conf.damping, dt=conf.dt,
+                      max_v=conf.max_v, small_num=conf.small_num)
+    prim = torch.stack([st.primitive0, st.primitive1], 1).cpu().numpy()
+    ref = orc.rollout_fwd(st.x.cpu().numpy(), st.v.cpu().numpy(), prim, st.stiffness.float().cpu().numpy(),
+                          st.mu.cpu().numpy(), macro, nthreads=2)
+    np.testing.assert_array_equal(info["state"].x.detach().cpu().numpy(), ref["x"])
+    np.testing.assert_array_equal(info["state"].v.detach().cpu().numpy(), ref["v"])
+    assert float((info["state"].x.detach() - st.x).abs().max()) > 1e-3        # the pick-and-place moved the shirt
+    reward.sum().backward()
+    assert torch.isfinite(a.grad).all() and a.grad.abs().sum() > 0

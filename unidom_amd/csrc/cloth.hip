@@ -453,6 +453,371 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Bodies of more than 1024 particles (fold_tshirt: 3573, fold_cloth_tshirt_env.py:19-50): still one workgroup per env,
+// 1024 lanes, each lane owns particles tid, tid + 1024, ... (at most UD_BIG_PPT of them).  Same device functions, same
+// operation order per particle as the kernels above; neighbour tables are re-read from L2 every substep instead of living
+// in registers, and the adjoint parks the per-particle intermediates of the recomputed forward in a scratch arena (global,
+// SoA) between its barrier-separated phases.  x stays in LDS (2 x 3 x Pp floats forward, X + G planes in the adjoint).
+// ------------------------------------------------------------------------------------------------
+#define UD_BIG_T 1024
+#define UD_BIG_PPT 4
+#define UD_BIG_PARK 21   // floats parked per particle: F1 cF muF xV yV sV dm Ax Az sF zm nz R v3[3] v4[3] m0 m1
+
+__global__ void __launch_bounds__(UD_BIG_T) cloth_big_fwd_kernel(ClothFwdArgs a) {
+  extern __shared__ float lds[];  // [2][3][Pp]
+  const ClothConst c = a.c;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  float x[UD_BIG_PPT][3], v[UD_BIG_PPT][3];
+#pragma unroll
+  for (int q = 0; q < UD_BIG_PPT; ++q) {
+    const int i = tid + q * UD_BIG_T;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool live = i < P;
+      x[q][d] = live ? a.x[((size_t)b * P + i) * 3 + d] : 0.f;
+      v[q][d] = live ? a.v[((size_t)b * P + i) * 3 + d] : 0.f;
+    }
+  }
+  float ps[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ps[d] = a.prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  const size_t rec = (size_t)6 * Pp + 8;
+  unsigned step = 0;
+  for (int t = 0; t < T; ++t) {
+    float act[8];
+    macro_action(a.actions + ((size_t)t * B + b) * 8, act);
+    for (int s = 0; s < S; ++s, ++step) {
+      float* X = lds + (step & 1u) * 3 * Pp;
+      float* r = a.ckpt ? a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)t * S + s) * rec : nullptr;
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) {
+          X[i] = x[q][0]; X[Pp + i] = x[q][1]; X[2 * Pp + i] = x[q][2];
+          if (r) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[q][d]; r[(3 + d) * Pp + i] = v[q][d]; }
+          }
+        }
+      }
+      if (r && tid == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) {
+          int nb[8];
+          float L0[8];
+#pragma unroll
+          for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
+          float xo[3], vo[3];
+          Inter in;
+          substep_fwd<false>(c, i, nb, L0, X, k, mu, x[q], v[q], ps, act, xo, vo, &in);
+          if (a.grasp && i < P) {
+            uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
+            g[i] = in.m0; g[P + i] = in.m1;
+          }
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { x[q][d] = xo[d]; v[q][d] = vo[d]; }
+        }
+      }
+      float po[8];
+      prim_update(ps, act, po);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ps[d] = po[d];
+    }
+#pragma unroll
+    for (int q = 0; q < UD_BIG_PPT; ++q) {
+      const int i = tid + q * UD_BIG_T;
+      if (i < P) {
+        const size_t o = (((size_t)t * B + b) * P + i) * 3;
+        if (a.x_list) { a.x_list[o] = x[q][0]; a.x_list[o + 1] = x[q][1]; a.x_list[o + 2] = x[q][2]; }
+        if (a.v_list) { a.v_list[o] = v[q][0]; a.v_list[o + 1] = v[q][1]; a.v_list[o + 2] = v[q][2]; }
+      }
+    }
+    if (a.prim_list && tid == 0) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) a.prim_list[((size_t)t * B + b) * 8 + d] = ps[d];
+    }
+  }
+  float* r = a.ckpt ? a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)T * S) * rec : nullptr;   // final record
+#pragma unroll
+  for (int q = 0; q < UD_BIG_PPT; ++q) {
+    const int i = tid + q * UD_BIG_T;
+    if (i < P) {
+      const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { a.x_out[o + d] = x[q][d]; a.v_out[o + d] = v[q][d]; }
+    }
+    if (r && i < Pp) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[q][d]; r[(3 + d) * Pp + i] = v[q][d]; }
+    }
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.prim_out[b * 8 + d] = ps[d];
+    if (r) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
+    }
+  }
+}
+
+// adjoint; `park` = scratch [B][UD_BIG_PARK][Pp]
+__global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a, float* park) {
+  extern __shared__ float lds[];  // X [3][Pp] | G [3][Pp] | red [6][32] + [16][8]
+  const ClothConst c = a.c;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
+  const int nw = UD_BIG_T >> 6;
+  const bool norm = a.normalize != 0;
+  float* X = lds;
+  float* G = lds + 3 * Pp;
+  float* red = lds + 6 * Pp;
+  float* pk = park + (size_t)b * UD_BIG_PARK * Pp;
+  float gx[UD_BIG_PPT][3], gv[UD_BIG_PPT][3];
+#pragma unroll
+  for (int q = 0; q < UD_BIG_PPT; ++q) {
+    const int i = tid + q * UD_BIG_T;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      gx[q][d] = (i < P) ? a.g_x[((size_t)b * P + i) * 3 + d] : 0.f;
+      gv[q][d] = (i < P) ? a.g_v[((size_t)b * P + i) * 3 + d] : 0.f;
+    }
+  }
+  float gp[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) gp[d] = a.g_prim[b * 8 + d];
+  const float k = a.k[b], mu = a.mu[b];
+  float gk = 0.f, gmu = 0.f;
+  const size_t rec = (size_t)6 * Pp + 8;
+  const float* ck = a.ckpt + (size_t)b * ((size_t)T * S + 1) * rec;
+  unsigned step = 0;
+  for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+    for (int q = 0; q < UD_BIG_PPT; ++q) {
+      const int i = tid + q * UD_BIG_T;
+      if (i < P) {
+        const size_t o = (((size_t)t * B + b) * P + i) * 3;
+        if (a.g_x_list) { gx[q][0] += a.g_x_list[o]; gx[q][1] += a.g_x_list[o + 1]; gx[q][2] += a.g_x_list[o + 2]; }
+        if (a.g_v_list) { gv[q][0] += a.g_v_list[o]; gv[q][1] += a.g_v_list[o + 1]; gv[q][2] += a.g_v_list[o + 2]; }
+      }
+    }
+    if (a.g_prim_list) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d) gp[d] += a.g_prim_list[((size_t)t * B + b) * 8 + d];
+    }
+    const float* a8 = a.actions + ((size_t)t * B + b) * 8;
+    float act[8], ga[8];
+    macro_action(a8, act);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) ga[d] = 0.f;
+    for (int s = S - 1; s >= 0; --s, ++step) {
+      const float* r = ck + ((size_t)t * S + s) * rec;
+      float ps[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) ps[d] = r[6 * Pp + d];
+      float* rd = red + (step & 1u) * 96;
+      // -- stage x; round 1: |g_x|, |g_v| (:331-332) -- its barrier also publishes X
+      float n0 = 0.f, n1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) { X[i] = r[i]; X[Pp + i] = r[Pp + i]; X[2 * Pp + i] = r[2 * Pp + i]; }
+        n0 += gx[q][0] * gx[q][0] + gx[q][1] * gx[q][1] + gx[q][2] * gx[q][2];
+        n1 += gv[q][0] * gv[q][0] + gv[q][1] * gv[q][1] + gv[q][2] * gv[q][2];
+      }
+      block_sum2(n0, n1, rd, nw);
+      if (norm) {
+#pragma unroll
+        for (int q = 0; q < UD_BIG_PPT; ++q) { norm3(gx[q], n0, c.n_mask); norm3(gv[q], n1, c.n_mask); }
+        norm4(gp, c.n_mask);      // :333-334
+        norm4(gp + 4, c.n_mask);
+      }
+      // -- recomputed forward of every particle; x_out = clip(x2) + dt*clip(v5) (:326-329); park what the later phases need
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) {
+          int nb[8];
+          float L0[8];
+#pragma unroll
+          for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
+          const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
+          const float v[3] = {r[3 * Pp + i], r[4 * Pp + i], r[5 * Pp + i]};
+          float xo[3], vo[3];
+          Inter in;
+          substep_fwd<true>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const float gxc = gx[q][d];
+            const float gvc = gv[q][d] + c.dt * gx[q][d];
+            gx[q][d] = gxc * clip_grad(in.x2[d], 0.f, 1.f);
+            gv[q][d] = gvc * clip_grad(in.v5[d], -c.max_v, c.max_v);
+          }
+          const float vals[UD_BIG_PARK] = {in.F1, in.cF, in.muF, in.xV, in.yV, in.sV, in.dm, in.Ax, in.Az, in.sF, in.zm, in.nz, in.R,
+                                           in.v3[0], in.v3[1], in.v3[2], in.v4[0], in.v4[1], in.v4[2], in.m0 ? 1.f : 0.f, in.m1 ? 1.f : 0.f};
+#pragma unroll
+          for (int e = 0; e < UD_BIG_PARK; ++e) pk[(size_t)e * Pp + i] = vals[e];
+        }
+      }
+      // primitives (:322-323); uniform across lanes, counted once (lane 0) in the action accumulators
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float add = d < 3 ? act[g * 4 + d] : 0.f;
+          const float tt = gp[g * 4 + d] * clip_grad(ps[g * 4 + d] + add, 0.f, 1.f);
+          gp[g * 4 + d] = tt;
+          if (d < 3) ga[g * 4 + d] += (tid == 0) ? tt : 0.f;
+        }
+      // grippers in reverse order (:313-314, :198-226)
+#pragma unroll
+      for (int g = 1; g >= 0; --g) {
+        n0 = 0.f; n1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < UD_BIG_PPT; ++q) {
+          n0 += gx[q][0] * gx[q][0] + gx[q][1] * gx[q][1] + gx[q][2] * gx[q][2];
+          n1 += gv[q][0] * gv[q][0] + gv[q][1] * gv[q][1] + gv[q][2] * gv[q][2];
+        }
+        block_sum2(n0, n1, rd + 32 * (2 - g), nw);
+        const float suction = act[g * 4 + 3];
+#pragma unroll
+        for (int q = 0; q < UD_BIG_PPT; ++q) {
+          const int i = tid + q * UD_BIG_T;
+          if (norm) { norm3(gx[q], n0, c.n_mask); norm3(gv[q], n1, c.n_mask); }  // :223-224
+          if (i < Pp) {
+            const bool m = (pk[(size_t)(19 + g) * Pp + i] != 0.f) && i < P;
+            const float* vinp = pk + (size_t)(g ? 16 : 13) * Pp + i;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const float gvo = gv[q][d], gxo = gx[q][d];
+              const float vin = vinp[(size_t)d * Pp];
+              ga[g * 4 + 3] += m ? (vin * gvo - gxo * act[g * 4 + d]) : 0.f;
+              ga[g * 4 + d] += m ? gxo * (1.f - suction) : 0.f;
+              gv[q][d] = m ? suction * gvo : gvo;
+            }
+          }
+        }
+      }
+      // v3 = (v1 + F*dt)*damp (:308-309); friction block (:281-306) -> gF into the G planes
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) {
+          const bool live = i < P;
+          const float F1 = pk[i], cF = pk[(size_t)Pp + i], muF = pk[(size_t)2 * Pp + i], xV = pk[(size_t)3 * Pp + i], yV = pk[(size_t)4 * Pp + i],
+                      sV = pk[(size_t)5 * Pp + i], dm = pk[(size_t)6 * Pp + i], Ax = pk[(size_t)7 * Pp + i], Az = pk[(size_t)8 * Pp + i],
+                      sF = pk[(size_t)9 * Pp + i], zm = pk[(size_t)10 * Pp + i], nz = pk[(size_t)11 * Pp + i], R = pk[(size_t)12 * Pp + i];
+          float gv2[3], gFf[3], gF[3];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { gv2[d] = gv[q][d] * c.damp; gFf[d] = gv2[d] * c.dt; }
+          const float gCx = gFf[0], gCz = gFf[2];
+          const float gBx = gCx * (1.f - nz), gBz = gCz * (1.f - nz);
+          const float gR = gCx * nz * Ax + gCz * nz * Az;
+          float gAx = gCx * nz * R + gBx * (1.f - zm);
+          float gAz = gCz * nz * R + gBz * (1.f - zm);
+          float gmuF = -gR / sF;
+          const float gsF = gR * muF / (sF * sF);
+          gAx += gsF * Ax / sF;
+          gAz += gsF * Az / sF;
+          gmuF += -(gAx * dm * xV / sV + gAz * dm * yV / sV);
+          float gxV = -gAx * dm * muF / sV, gyV = -gAz * dm * muF / sV;
+          const float gsV = (gAx * dm * muF * xV + gAz * dm * muF * yV) / (sV * sV);
+          gxV += gsV * xV / sV;
+          gyV += gsV * yV / sV;
+          gmu += live ? -gmuF * cF : 0.f;
+          const float gcF = -gmuF * mu;
+          gF[0] = gAx;
+          gF[1] = gFf[1] + gcF * clip_grad(F1, -INFINITY, 0.f);
+          gF[2] = gAz;
+          gv[q][0] = gv2[0] + gxV;
+          gv[q][1] = gv2[1];
+          gv[q][2] = gv2[2] + gyV;
+          if (!live) { gF[0] = gF[1] = gF[2] = 0.f; }
+          G[i] = gF[0]; G[Pp + i] = gF[1]; G[2 * Pp + i] = gF[2];
+        }
+      }
+      __syncthreads();
+      // spring forces (:262-277), gather form: g_x_i += sum_l J_il (gF_j - gF_i)
+#pragma unroll
+      for (int q = 0; q < UD_BIG_PPT; ++q) {
+        const int i = tid + q * UD_BIG_T;
+        if (i < Pp) {
+          const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
+          const float gF[3] = {G[i], G[Pp + i], G[2 * Pp + i]};
+#pragma unroll
+          for (int l = 0; l < 8; ++l) {
+            const int j = a.nbr[l * Pp + i];
+            const bool ok = j >= 0;
+            const int jj = ok ? j : i;
+            const float r0 = X[jj] - x[0], r1 = X[Pp + jj] - x[1], r2 = X[2 * Pp + jj] - x[2];
+            const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+            const float cf = clip_grad(s2, 1e-12f, INFINITY);
+            const float len = sqrtf(clipf(s2, 1e-12f, INFINITY));
+            const float L = a.L0[l * Pp + i];
+            const float d0 = G[jj] - gF[0], d1 = G[Pp + jj] - gF[1], d2 = G[2 * Pp + jj] - gF[2];
+            const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
+            const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
+            const float c1 = (k / L) * (1.f - L / len);
+            const float c2 = (k / L) * cf * L / (len * len * len) * rd_;
+            gk += ok ? rg / len * (len - L) / L : 0.f;
+            gx[q][0] += ok ? c1 * d0 + c2 * r0 : 0.f;
+            gx[q][1] += ok ? c1 * d1 + c2 * r1 : 0.f;
+            gx[q][2] += ok ? c1 * d2 + c2 * r2 : 0.f;
+          }
+        }
+      }
+      __syncthreads();   // X / G are rewritten by the next substep
+    }
+    // macro-step boundary: robot_step's action transform (:168-169)
+    {
+      float* rd = red + 192;
+      float part[8];
+#pragma unroll
+      for (int d = 0; d < 8; ++d) part[d] = wave_sum(ga[d]);
+      const int lane = tid & 63, w = tid >> 6;
+      if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) rd[w * 8 + d] = part[d];
+      }
+      __syncthreads();
+      if (tid < 8) {
+        float tot = 0.f;
+        for (int qq = 0; qq < nw; ++qq) tot += rd[qq * 8 + tid];
+        const int d = tid & 3;
+        a.g_actions[((size_t)t * B + b) * 8 + tid] = (d < 3) ? tot / 50.0f * clip_grad(a8[tid], -2.0f, 2.0f) : tot;
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < UD_BIG_PPT; ++q) {
+    const int i = tid + q * UD_BIG_T;
+    if (i < P) {
+      const size_t o = ((size_t)b * P + i) * 3;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { a.g_x0[o + d] = gx[q][d]; a.g_v0[o + d] = gv[q][d]; }
+    }
+  }
+  float rk = gk, rmu = gmu;
+  block_sum2(rk, rmu, red + 192, nw);
+  if (tid == 0) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.g_prim0[b * 8 + d] = gp[d];
+    a.g_k[b] = rk;
+    a.g_mu[b] = rmu;
+  }
+}
+
 }  // namespace ud
 
 // ------------------------------------------------------------------------------------------------
@@ -468,6 +833,8 @@ struct ud_cloth {
   int device = 0;
   int* d_nbr = nullptr;
   float* d_L0 = nullptr;
+  float* d_park = nullptr;   // P > 1024 only: adjoint scratch [B][UD_BIG_PARK][Pp]
+  int park_B = 0;
 };
 
 extern "C" {
@@ -488,7 +855,7 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
         pid[i * N + j] = (int)gi.size(); gi.push_back(i); gj.push_back(j);
       }
   const int P = (int)gi.size();
-  if (P < 1 || P > 1024) { ud::set_error("ud_cloth_create: P=%d outside 1..1024 (one workgroup per env)", P); return UD_ERR_UNSUPPORTED; }
+  if (P < 1 || P > UD_BIG_T * UD_BIG_PPT) { ud::set_error("ud_cloth_create: P=%d outside 1..%d (one workgroup per env)", P, UD_BIG_T * UD_BIG_PPT); return UD_ERR_UNSUPPORTED; }
   const int Pp = (P + 63) / 64 * 64;
   std::vector<int> nbr((size_t)8 * Pp, -1);
   std::vector<float> L0((size_t)8 * Pp, 1.0f);
@@ -519,6 +886,10 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_L0, L0.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_L0, L0.data(), L0.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && Pp > 1024) {   // the kernels for big bodies need more than the default 64 KB of dynamic LDS
+    e = hipFuncSetAttribute((const void*)ud::cloth_big_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)6 * Pp * sizeof(float)));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::cloth_big_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)6 * Pp + 192 + 128) * sizeof(float)));
+  }
   if (e != hipSuccess) {
     ud::set_error("ud_cloth_create: %s", hipGetErrorString(e));
     if (h->d_nbr) (void)hipFree(h->d_nbr);
@@ -533,6 +904,7 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
 void ud_cloth_destroy(ud_cloth* h) {
   if (!h) return;
   (void)hipFree(h->d_nbr);
+  if (h->d_park) (void)hipFree(h->d_park);
   (void)hipFree(h->d_L0);
   delete h;
 }
@@ -558,7 +930,9 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   a.x_out = x_out; a.v_out = v_out; a.prim_out = prim_out; a.x_list = x_list; a.v_list = v_list;
   a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
-  if (h->mode == 2 && h->c.Pp <= 512)
+  if (h->c.Pp > 1024)
+    hipLaunchKernelGGL(ud::cloth_big_fwd_kernel, dim3(B), dim3(UD_BIG_T), shmem, (hipStream_t)stream, a);
+  else if (h->mode == 2 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
   else if (h->mode == 0 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_v2(a, (hipStream_t)stream);
@@ -587,7 +961,16 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
   a.g_prim_list = g_prim_list; a.normalize = normalize;
   a.g_x0 = g_x0; a.g_v0 = g_v0; a.g_prim0 = g_prim0; a.g_actions = g_actions; a.g_k = g_stiffness; a.g_mu = g_mu;
   const size_t shmem = ((size_t)6 * h->c.Pp + 192 + 128) * sizeof(float);
-  if (h->mode != 1 && h->c.Pp <= 512)
+  if (h->c.Pp > 1024) {
+    if (h->park_B < B) {   // scratch of the big-body adjoint, grown on demand
+      if (h->d_park) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(h->d_park); h->d_park = nullptr; h->park_B = 0; }
+      if (hipMalloc((void**)&h->d_park, (size_t)B * UD_BIG_PARK * h->c.Pp * sizeof(float)) != hipSuccess) {
+        ud::set_error("ud_cloth_rollout_bwd: scratch allocation failed"); return UD_ERR_HIP;
+      }
+      h->park_B = B;
+    }
+    hipLaunchKernelGGL(ud::cloth_big_bwd_kernel, dim3(B), dim3(UD_BIG_T), shmem, (hipStream_t)stream, a, h->d_park);
+  } else if (h->mode != 1 && h->c.Pp <= 512)
     ud::cloth_launch_bwd_fast(a, (hipStream_t)stream);
   else if (h->c.Pp <= 512)
     hipLaunchKernelGGL(ud::cloth_rollout_bwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);

@@ -2,11 +2,12 @@
 (/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  fold_cloth3 / unfold_cloth1 / unfold_cloth3 are
 the same 512-particle cloth and the same kernels under other confs; shape_rope / shape_rope_hard run the MPM kernels
 in soft-contact mode with the plastic material.  pour_water adds the liquid material, two primitives and the container SDF.
-The remaining reference envs (fold_tshirt -- 3573 particles, needs a multi-workgroup cloth kernel --, pour_soup -- needs
-an open3d point-cloud asset the reference loads at reset) are "next" rows and are absent from the registry."""
+fold_tshirt (3573 particles) runs the several-particles-per-lane cloth kernels.  The one remaining reference env, pour_soup,
+needs an open3d point-cloud asset the reference loads at reset and is absent from the registry."""
 from .fold_cloth1_env import FoldCloth1Env
 from .fold_cloth1_para_env import FoldCloth1ParaEnv
 from .fold_cloth3_env import FoldCloth3Env
+from .fold_cloth_tshirt_env import FoldTshirtEnv
 from .unfold_cloth1_env import UnfoldCloth1Env, UnfoldCloth3Env
 
 env_functions = {
@@ -15,6 +16,7 @@ env_functions = {
     "fold_cloth3": FoldCloth3Env,
     "unfold_cloth1": UnfoldCloth1Env,
     "unfold_cloth3": UnfoldCloth3Env,
+    "fold_tshirt": FoldTshirtEnv,
 }
 
 try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
