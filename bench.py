@@ -353,6 +353,67 @@ def cpu_baseline_shape_rope(env, st, act, sample_envs=8, steps=6):   # ~11 s of 
                       f"OpenMP over envs ({threads} threads)"}
 
 
+def bench_fold_tshirt(args, rank, world, device):
+    """fold_tshirt: 3573-particle T-shirt, k = 5000, dt = 0.5e-3, 4 envs per GPU like the headline.
+    One "step" = one env.step_diff (40 x 50 substeps) + the backward of the reward to the pick-and-place action."""
+    import torch.distributed as dist
+    from unidom_amd.envs.registration import env_functions
+    B = args.cloth_envs or 4
+    env = env_functions["fold_tshirt"](batch_size=B, aux_reward=True, device=device)
+    _, st = env.reset(np.array([0, 5 + rank], np.uint32))
+    g = torch.Generator(device=device).manual_seed(rank)
+    xm = st.x.mean(1)
+    off = (torch.rand((B, 2), device=device, generator=g) - 0.5) * 0.2
+    act = torch.stack([xm[:, 0] + off[:, 0], torch.zeros_like(off[:, 0]), xm[:, 2] + off[:, 1],
+                       xm[:, 0] - off[:, 0], torch.zeros_like(off[:, 0]), xm[:, 2] - off[:, 1]], -1).contiguous().requires_grad_(True)
+
+    def one():
+        act.grad = None
+        _, reward, _, _ = env.step_diff(act, st)
+        reward.sum().backward()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one()
+    env.simulator.profile = {"fwd": [], "bwd": []}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, env.simulator.profile = env.simulator.profile, None
+    assert torch.isfinite(act.grad).all()
+    tm = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm[0])
+    if rank == 0:
+        P = st.x.shape[1]
+        units = world * B * MACRO * SUBSTEPS * args.steps
+        k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
+        dom = max(k_ms, key=k_ms.get)
+        per_launch = B * MACRO * SUBSTEPS * P * (72 if dom == "bwd" else 48)     # 48 / 72 B per particle-substep (SURVEY.md 8d)
+        achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"fold_tshirt (mass-spring cloth, P={P} on a 180x180 lattice) step_diff + backward to the action, {B} envs per GPU"},
+            "roofline": {"bound": "hbm", "kernel": "cloth_big_bwd_kernel" if dom == "bwd" else "cloth_big_fwd_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": per_launch,
+                         "note": "one workgroup of 1024 lanes per env, 4 particles per lane, 2000 sequential substeps per launch"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_shape_rope(args, rank, world, device):
     """shape_rope: 582 plastic particles, 64x6x64 grid, box pusher in soft-contact mode
     (collide_batch).  One "step" = one env.step_diff -- 30 scanned simulator.steps of 133 substeps -- plus the backward
@@ -430,7 +491,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "whip_rope", "torus", "shape_rope", "pour_water"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
@@ -453,6 +514,8 @@ def main():
         return bench_torus(args, rank, world, device)
     if args.workload == "shape_rope":
         return bench_shape_rope(args, rank, world, device)
+    if args.workload == "fold_tshirt":
+        return bench_fold_tshirt(args, rank, world, device)
     if args.workload == "whip_rope" and args.n_grid != 64:
         return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
