@@ -463,22 +463,28 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a)
 // ------------------------------------------------------------------------------------------------
 #define UD_BIG_T 1024
 #define UD_BIG_PPT 4
-#define UD_BIG_PARK 21   // floats parked per particle: F1 cF muF xV yV sV dm Ax Az sF zm nz R v3[3] v4[3] m0 m1
+#define UD_BIG_PARK 27   // floats per particle in the adjoint's scratch: F1 cF muF xV yV sV dm Ax Az sF zm nz R v3[3] v4[3] m0 m1 | gx[3] gv[3]
+
+// The per-particle loops below are kept rolled (#pragma unroll 1) and the per-particle state lives in LDS (forward: x
+// double-buffered + v) or in the scratch arena (adjoint: cotangents): unrolled four-wide, the same code needed 0.7 KB
+// (forward) / 2.4 KB (adjoint) of scratch per lane under the 128-VGPR budget of a 1024-lane workgroup.
+__device__ __forceinline__ void big_tables(const ClothConst& c, const int* nbr, int Pp, int i, int* nb, float* L0) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) { nb[l] = nbr[l * Pp + i]; L0[l] = (l < 4) ? c.Ls : c.Ld; }   // = the L0 table: :61-63 depend on the link only
+}
 
 __global__ void __launch_bounds__(UD_BIG_T) cloth_big_fwd_kernel(ClothFwdArgs a) {
-  extern __shared__ float lds[];  // [2][3][Pp]
+  extern __shared__ float lds[];  // X [2][3][Pp] | V [3][Pp]
   const ClothConst c = a.c;
   const int tid = threadIdx.x, b = blockIdx.x;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
-  float x[UD_BIG_PPT][3], v[UD_BIG_PPT][3];
-#pragma unroll
-  for (int q = 0; q < UD_BIG_PPT; ++q) {
-    const int i = tid + q * UD_BIG_T;
+  float* V = lds + 6 * Pp;
+#pragma unroll 1
+  for (int i = tid; i < Pp; i += UD_BIG_T) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const bool live = i < P;
-      x[q][d] = live ? a.x[((size_t)b * P + i) * 3 + d] : 0.f;
-      v[q][d] = live ? a.v[((size_t)b * P + i) * 3 + d] : 0.f;
+      lds[d * Pp + i] = (i < P) ? a.x[((size_t)b * P + i) * 3 + d] : 0.f;
+      V[d * Pp + i] = (i < P) ? a.v[((size_t)b * P + i) * 3 + d] : 0.f;
     }
   }
   float ps[8];
@@ -487,78 +493,69 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_fwd_kernel(ClothFwdArgs a)
   const float k = a.k[b], mu = a.mu[b];
   const size_t rec = (size_t)6 * Pp + 8;
   unsigned step = 0;
+  __syncthreads();
   for (int t = 0; t < T; ++t) {
     float act[8];
     macro_action(a.actions + ((size_t)t * B + b) * 8, act);
     for (int s = 0; s < S; ++s, ++step) {
-      float* X = lds + (step & 1u) * 3 * Pp;
+      const float* X = lds + (step & 1u) * 3 * Pp;
+      float* Xn = lds + ((step + 1) & 1u) * 3 * Pp;
       float* r = a.ckpt ? a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)t * S + s) * rec : nullptr;
-#pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) {
-          X[i] = x[q][0]; X[Pp + i] = x[q][1]; X[2 * Pp + i] = x[q][2];
-          if (r) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[q][d]; r[(3 + d) * Pp + i] = v[q][d]; }
-          }
-        }
-      }
       if (r && tid == 0) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) r[6 * Pp + d] = ps[d];
       }
-      __syncthreads();
+#pragma unroll 1
+      for (int i = tid; i < Pp; i += UD_BIG_T) {
+        const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
+        const float v[3] = {V[i], V[Pp + i], V[2 * Pp + i]};
+        if (r) {
 #pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) {
-          int nb[8];
-          float L0[8];
-#pragma unroll
-          for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
-          float xo[3], vo[3];
-          Inter in;
-          substep_fwd<false>(c, i, nb, L0, X, k, mu, x[q], v[q], ps, act, xo, vo, &in);
-          if (a.grasp && i < P) {
-            uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
-            g[i] = in.m0; g[P + i] = in.m1;
-          }
-#pragma unroll
-          for (int d = 0; d < 3; ++d) { x[q][d] = xo[d]; v[q][d] = vo[d]; }
+          for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[d]; r[(3 + d) * Pp + i] = v[d]; }
         }
+        int nb[8];
+        float L0[8];
+        big_tables(c, a.nbr, Pp, i, nb, L0);
+        float xo[3], vo[3];
+        Inter in;
+        substep_fwd<false>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
+        if (a.grasp && i < P) {
+          uint8_t* g = a.grasp + ((((size_t)t * S + s) * B + b) * 2) * P;
+          g[i] = in.m0; g[P + i] = in.m1;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { Xn[d * Pp + i] = xo[d]; V[d * Pp + i] = vo[d]; }
       }
       float po[8];
       prim_update(ps, act, po);
 #pragma unroll
       for (int d = 0; d < 8; ++d) ps[d] = po[d];
+      __syncthreads();   // Xn complete; nobody reads X any more
     }
-#pragma unroll
-    for (int q = 0; q < UD_BIG_PPT; ++q) {
-      const int i = tid + q * UD_BIG_T;
-      if (i < P) {
-        const size_t o = (((size_t)t * B + b) * P + i) * 3;
-        if (a.x_list) { a.x_list[o] = x[q][0]; a.x_list[o + 1] = x[q][1]; a.x_list[o + 2] = x[q][2]; }
-        if (a.v_list) { a.v_list[o] = v[q][0]; a.v_list[o + 1] = v[q][1]; a.v_list[o + 2] = v[q][2]; }
-      }
+    const float* X = lds + (step & 1u) * 3 * Pp;
+#pragma unroll 1
+    for (int i = tid; i < P; i += UD_BIG_T) {
+      const size_t o = (((size_t)t * B + b) * P + i) * 3;
+      if (a.x_list) { a.x_list[o] = X[i]; a.x_list[o + 1] = X[Pp + i]; a.x_list[o + 2] = X[2 * Pp + i]; }
+      if (a.v_list) { a.v_list[o] = V[i]; a.v_list[o + 1] = V[Pp + i]; a.v_list[o + 2] = V[2 * Pp + i]; }
     }
     if (a.prim_list && tid == 0) {
 #pragma unroll
       for (int d = 0; d < 8; ++d) a.prim_list[((size_t)t * B + b) * 8 + d] = ps[d];
     }
   }
+  const float* X = lds + (step & 1u) * 3 * Pp;
   float* r = a.ckpt ? a.ckpt + ((size_t)b * ((size_t)T * S + 1) + (size_t)T * S) * rec : nullptr;   // final record
-#pragma unroll
-  for (int q = 0; q < UD_BIG_PPT; ++q) {
-    const int i = tid + q * UD_BIG_T;
+#pragma unroll 1
+  for (int i = tid; i < Pp; i += UD_BIG_T) {
     if (i < P) {
       const size_t o = ((size_t)b * P + i) * 3;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { a.x_out[o + d] = x[q][d]; a.v_out[o + d] = v[q][d]; }
+      for (int d = 0; d < 3; ++d) { a.x_out[o + d] = X[d * Pp + i]; a.v_out[o + d] = V[d * Pp + i]; }
     }
-    if (r && i < Pp) {
+    if (r) {
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { r[d * Pp + i] = x[q][d]; r[(3 + d) * Pp + i] = v[q][d]; }
+      for (int d = 0; d < 3; ++d) { r[d * Pp + i] = X[d * Pp + i]; r[(3 + d) * Pp + i] = V[d * Pp + i]; }
     }
   }
   if (tid == 0) {
@@ -583,14 +580,14 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
   float* G = lds + 3 * Pp;
   float* red = lds + 6 * Pp;
   float* pk = park + (size_t)b * UD_BIG_PARK * Pp;
-  float gx[UD_BIG_PPT][3], gv[UD_BIG_PPT][3];
-#pragma unroll
-  for (int q = 0; q < UD_BIG_PPT; ++q) {
-    const int i = tid + q * UD_BIG_T;
+  float* GX = pk + (size_t)21 * Pp;   // cotangent planes gx[3][Pp], gv[3][Pp]: each lane touches only its own particles
+  float* GV = pk + (size_t)24 * Pp;
+#pragma unroll 1
+  for (int i = tid; i < Pp; i += UD_BIG_T) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      gx[q][d] = (i < P) ? a.g_x[((size_t)b * P + i) * 3 + d] : 0.f;
-      gv[q][d] = (i < P) ? a.g_v[((size_t)b * P + i) * 3 + d] : 0.f;
+      GX[(size_t)d * Pp + i] = (i < P) ? a.g_x[((size_t)b * P + i) * 3 + d] : 0.f;
+      GV[(size_t)d * Pp + i] = (i < P) ? a.g_v[((size_t)b * P + i) * 3 + d] : 0.f;
     }
   }
   float gp[8];
@@ -602,13 +599,15 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
   const float* ck = a.ckpt + (size_t)b * ((size_t)T * S + 1) * rec;
   unsigned step = 0;
   for (int t = T - 1; t >= 0; --t) {
-#pragma unroll
-    for (int q = 0; q < UD_BIG_PPT; ++q) {
-      const int i = tid + q * UD_BIG_T;
-      if (i < P) {
+    if (a.g_x_list || a.g_v_list) {
+#pragma unroll 1
+      for (int i = tid; i < P; i += UD_BIG_T) {
         const size_t o = (((size_t)t * B + b) * P + i) * 3;
-        if (a.g_x_list) { gx[q][0] += a.g_x_list[o]; gx[q][1] += a.g_x_list[o + 1]; gx[q][2] += a.g_x_list[o + 2]; }
-        if (a.g_v_list) { gv[q][0] += a.g_v_list[o]; gv[q][1] += a.g_v_list[o + 1]; gv[q][2] += a.g_v_list[o + 2]; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (a.g_x_list) GX[(size_t)d * Pp + i] += a.g_x_list[o + d];
+          if (a.g_v_list) GV[(size_t)d * Pp + i] += a.g_v_list[o + d];
+        }
       }
     }
     if (a.g_prim_list) {
@@ -628,46 +627,48 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
       float* rd = red + (step & 1u) * 96;
       // -- stage x; round 1: |g_x|, |g_v| (:331-332) -- its barrier also publishes X
       float n0 = 0.f, n1 = 0.f;
+#pragma unroll 1
+      for (int i = tid; i < Pp; i += UD_BIG_T) {
 #pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) { X[i] = r[i]; X[Pp + i] = r[Pp + i]; X[2 * Pp + i] = r[2 * Pp + i]; }
-        n0 += gx[q][0] * gx[q][0] + gx[q][1] * gx[q][1] + gx[q][2] * gx[q][2];
-        n1 += gv[q][0] * gv[q][0] + gv[q][1] * gv[q][1] + gv[q][2] * gv[q][2];
+        for (int d = 0; d < 3; ++d) {
+          X[d * Pp + i] = r[d * Pp + i];
+          const float gxd = GX[(size_t)d * Pp + i], gvd = GV[(size_t)d * Pp + i];
+          n0 += gxd * gxd; n1 += gvd * gvd;
+        }
       }
       block_sum2(n0, n1, rd, nw);
       if (norm) {
-#pragma unroll
-        for (int q = 0; q < UD_BIG_PPT; ++q) { norm3(gx[q], n0, c.n_mask); norm3(gv[q], n1, c.n_mask); }
         norm4(gp, c.n_mask);      // :333-334
         norm4(gp + 4, c.n_mask);
       }
-      // -- recomputed forward of every particle; x_out = clip(x2) + dt*clip(v5) (:326-329); park what the later phases need
+      // -- recomputed forward of every particle; x_out = clip(x2) + dt*clip(v5) (:326-329); park what the later phases need.
+      //    The same pass accumulates the norms gripper 1 needs (round 2).
+      float m0s = 0.f, m1s = 0.f;
+#pragma unroll 1
+      for (int i = tid; i < Pp; i += UD_BIG_T) {
+        float gx[3] = {GX[i], GX[(size_t)Pp + i], GX[(size_t)2 * Pp + i]}, gv[3] = {GV[i], GV[(size_t)Pp + i], GV[(size_t)2 * Pp + i]};
+        if (norm) { norm3(gx, n0, c.n_mask); norm3(gv, n1, c.n_mask); }
+        int nb[8];
+        float L0[8];
+        big_tables(c, a.nbr, Pp, i, nb, L0);
+        const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
+        const float v[3] = {r[3 * Pp + i], r[4 * Pp + i], r[5 * Pp + i]};
+        float xo[3], vo[3];
+        Inter in;
+        substep_fwd<true>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
 #pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) {
-          int nb[8];
-          float L0[8];
-#pragma unroll
-          for (int l = 0; l < 8; ++l) { nb[l] = a.nbr[l * Pp + i]; L0[l] = a.L0[l * Pp + i]; }
-          const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
-          const float v[3] = {r[3 * Pp + i], r[4 * Pp + i], r[5 * Pp + i]};
-          float xo[3], vo[3];
-          Inter in;
-          substep_fwd<true>(c, i, nb, L0, X, k, mu, x, v, ps, act, xo, vo, &in);
-#pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const float gxc = gx[q][d];
-            const float gvc = gv[q][d] + c.dt * gx[q][d];
-            gx[q][d] = gxc * clip_grad(in.x2[d], 0.f, 1.f);
-            gv[q][d] = gvc * clip_grad(in.v5[d], -c.max_v, c.max_v);
-          }
-          const float vals[UD_BIG_PARK] = {in.F1, in.cF, in.muF, in.xV, in.yV, in.sV, in.dm, in.Ax, in.Az, in.sF, in.zm, in.nz, in.R,
-                                           in.v3[0], in.v3[1], in.v3[2], in.v4[0], in.v4[1], in.v4[2], in.m0 ? 1.f : 0.f, in.m1 ? 1.f : 0.f};
-#pragma unroll
-          for (int e = 0; e < UD_BIG_PARK; ++e) pk[(size_t)e * Pp + i] = vals[e];
+        for (int d = 0; d < 3; ++d) {
+          const float gxc = gx[d];
+          const float gvc = gv[d] + c.dt * gx[d];
+          gx[d] = gxc * clip_grad(in.x2[d], 0.f, 1.f);
+          gv[d] = gvc * clip_grad(in.v5[d], -c.max_v, c.max_v);
+          GX[(size_t)d * Pp + i] = gx[d]; GV[(size_t)d * Pp + i] = gv[d];
+          m0s += gx[d] * gx[d]; m1s += gv[d] * gv[d];
         }
+        const float vals[21] = {in.F1, in.cF, in.muF, in.xV, in.yV, in.sV, in.dm, in.Ax, in.Az, in.sF, in.zm, in.nz, in.R,
+                                in.v3[0], in.v3[1], in.v3[2], in.v4[0], in.v4[1], in.v4[2], in.m0 ? 1.f : 0.f, in.m1 ? 1.f : 0.f};
+#pragma unroll
+        for (int e = 0; e < 21; ++e) pk[(size_t)e * Pp + i] = vals[e];
       }
       // primitives (:322-323); uniform across lanes, counted once (lane 0) in the action accumulators
 #pragma unroll
@@ -679,102 +680,95 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
           gp[g * 4 + d] = tt;
           if (d < 3) ga[g * 4 + d] += (tid == 0) ? tt : 0.f;
         }
-      // grippers in reverse order (:313-314, :198-226)
+      // grippers in reverse order (:313-314, :198-226); the pass of gripper g accumulates the norms of the next round
+      n0 = m0s; n1 = m1s;
 #pragma unroll
       for (int g = 1; g >= 0; --g) {
-        n0 = 0.f; n1 = 0.f;
-#pragma unroll
-        for (int q = 0; q < UD_BIG_PPT; ++q) {
-          n0 += gx[q][0] * gx[q][0] + gx[q][1] * gx[q][1] + gx[q][2] * gx[q][2];
-          n1 += gv[q][0] * gv[q][0] + gv[q][1] * gv[q][1] + gv[q][2] * gv[q][2];
-        }
         block_sum2(n0, n1, rd + 32 * (2 - g), nw);
         const float suction = act[g * 4 + 3];
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll 1
+        for (int i = tid; i < Pp; i += UD_BIG_T) {
+          float gx[3] = {GX[i], GX[(size_t)Pp + i], GX[(size_t)2 * Pp + i]}, gv[3] = {GV[i], GV[(size_t)Pp + i], GV[(size_t)2 * Pp + i]};
+          if (norm) { norm3(gx, n0, c.n_mask); norm3(gv, n1, c.n_mask); }  // :223-224
+          const bool m = (pk[(size_t)(19 + g) * Pp + i] != 0.f) && i < P;
+          const float* vinp = pk + (size_t)(g ? 16 : 13) * Pp + i;
 #pragma unroll
-        for (int q = 0; q < UD_BIG_PPT; ++q) {
-          const int i = tid + q * UD_BIG_T;
-          if (norm) { norm3(gx[q], n0, c.n_mask); norm3(gv[q], n1, c.n_mask); }  // :223-224
-          if (i < Pp) {
-            const bool m = (pk[(size_t)(19 + g) * Pp + i] != 0.f) && i < P;
-            const float* vinp = pk + (size_t)(g ? 16 : 13) * Pp + i;
+          for (int d = 0; d < 3; ++d) {
+            const float gvo = gv[d], gxo = gx[d];
+            const float vin = vinp[(size_t)d * Pp];
+            ga[g * 4 + 3] += m ? (vin * gvo - gxo * act[g * 4 + d]) : 0.f;
+            ga[g * 4 + d] += m ? gxo * (1.f - suction) : 0.f;
+            gv[d] = m ? suction * gvo : gvo;
+            a0 += gx[d] * gx[d]; a1 += gv[d] * gv[d];
+          }
+          if (g == 1) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-              const float gvo = gv[q][d], gxo = gx[q][d];
-              const float vin = vinp[(size_t)d * Pp];
-              ga[g * 4 + 3] += m ? (vin * gvo - gxo * act[g * 4 + d]) : 0.f;
-              ga[g * 4 + d] += m ? gxo * (1.f - suction) : 0.f;
-              gv[q][d] = m ? suction * gvo : gvo;
-            }
+            for (int d = 0; d < 3; ++d) { GX[(size_t)d * Pp + i] = gx[d]; GV[(size_t)d * Pp + i] = gv[d]; }
+          } else {
+            // v3 = (v1 + F*dt)*damp (:308-309); friction block (:281-306) -> gF into the G planes
+            const bool live = i < P;
+            const float F1 = pk[i], cF = pk[(size_t)Pp + i], muF = pk[(size_t)2 * Pp + i], xV = pk[(size_t)3 * Pp + i], yV = pk[(size_t)4 * Pp + i],
+                        sV = pk[(size_t)5 * Pp + i], dm = pk[(size_t)6 * Pp + i], Ax = pk[(size_t)7 * Pp + i], Az = pk[(size_t)8 * Pp + i],
+                        sF = pk[(size_t)9 * Pp + i], zm = pk[(size_t)10 * Pp + i], nz = pk[(size_t)11 * Pp + i], R = pk[(size_t)12 * Pp + i];
+            float gv2[3], gFf[3], gF[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { gv2[d] = gv[d] * c.damp; gFf[d] = gv2[d] * c.dt; }
+            const float gCx = gFf[0], gCz = gFf[2];
+            const float gBx = gCx * (1.f - nz), gBz = gCz * (1.f - nz);
+            const float gR = gCx * nz * Ax + gCz * nz * Az;
+            float gAx = gCx * nz * R + gBx * (1.f - zm);
+            float gAz = gCz * nz * R + gBz * (1.f - zm);
+            float gmuF = -gR / sF;
+            const float gsF = gR * muF / (sF * sF);
+            gAx += gsF * Ax / sF;
+            gAz += gsF * Az / sF;
+            gmuF += -(gAx * dm * xV / sV + gAz * dm * yV / sV);
+            float gxV = -gAx * dm * muF / sV, gyV = -gAz * dm * muF / sV;
+            const float gsV = (gAx * dm * muF * xV + gAz * dm * muF * yV) / (sV * sV);
+            gxV += gsV * xV / sV;
+            gyV += gsV * yV / sV;
+            gmu += live ? -gmuF * cF : 0.f;
+            const float gcF = -gmuF * mu;
+            gF[0] = gAx;
+            gF[1] = gFf[1] + gcF * clip_grad(F1, -INFINITY, 0.f);
+            gF[2] = gAz;
+            if (!live) { gF[0] = gF[1] = gF[2] = 0.f; }
+            G[i] = gF[0]; G[Pp + i] = gF[1]; G[2 * Pp + i] = gF[2];
+            GX[i] = gx[0]; GX[(size_t)Pp + i] = gx[1]; GX[(size_t)2 * Pp + i] = gx[2];
+            GV[i] = gv2[0] + gxV; GV[(size_t)Pp + i] = gv2[1]; GV[(size_t)2 * Pp + i] = gv2[2] + gyV;
           }
         }
-      }
-      // v3 = (v1 + F*dt)*damp (:308-309); friction block (:281-306) -> gF into the G planes
-#pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) {
-          const bool live = i < P;
-          const float F1 = pk[i], cF = pk[(size_t)Pp + i], muF = pk[(size_t)2 * Pp + i], xV = pk[(size_t)3 * Pp + i], yV = pk[(size_t)4 * Pp + i],
-                      sV = pk[(size_t)5 * Pp + i], dm = pk[(size_t)6 * Pp + i], Ax = pk[(size_t)7 * Pp + i], Az = pk[(size_t)8 * Pp + i],
-                      sF = pk[(size_t)9 * Pp + i], zm = pk[(size_t)10 * Pp + i], nz = pk[(size_t)11 * Pp + i], R = pk[(size_t)12 * Pp + i];
-          float gv2[3], gFf[3], gF[3];
-#pragma unroll
-          for (int d = 0; d < 3; ++d) { gv2[d] = gv[q][d] * c.damp; gFf[d] = gv2[d] * c.dt; }
-          const float gCx = gFf[0], gCz = gFf[2];
-          const float gBx = gCx * (1.f - nz), gBz = gCz * (1.f - nz);
-          const float gR = gCx * nz * Ax + gCz * nz * Az;
-          float gAx = gCx * nz * R + gBx * (1.f - zm);
-          float gAz = gCz * nz * R + gBz * (1.f - zm);
-          float gmuF = -gR / sF;
-          const float gsF = gR * muF / (sF * sF);
-          gAx += gsF * Ax / sF;
-          gAz += gsF * Az / sF;
-          gmuF += -(gAx * dm * xV / sV + gAz * dm * yV / sV);
-          float gxV = -gAx * dm * muF / sV, gyV = -gAz * dm * muF / sV;
-          const float gsV = (gAx * dm * muF * xV + gAz * dm * muF * yV) / (sV * sV);
-          gxV += gsV * xV / sV;
-          gyV += gsV * yV / sV;
-          gmu += live ? -gmuF * cF : 0.f;
-          const float gcF = -gmuF * mu;
-          gF[0] = gAx;
-          gF[1] = gFf[1] + gcF * clip_grad(F1, -INFINITY, 0.f);
-          gF[2] = gAz;
-          gv[q][0] = gv2[0] + gxV;
-          gv[q][1] = gv2[1];
-          gv[q][2] = gv2[2] + gyV;
-          if (!live) { gF[0] = gF[1] = gF[2] = 0.f; }
-          G[i] = gF[0]; G[Pp + i] = gF[1]; G[2 * Pp + i] = gF[2];
-        }
+        n0 = a0; n1 = a1;
       }
       __syncthreads();
       // spring forces (:262-277), gather form: g_x_i += sum_l J_il (gF_j - gF_i)
+#pragma unroll 1
+      for (int i = tid; i < Pp; i += UD_BIG_T) {
+        const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
+        const float gF[3] = {G[i], G[Pp + i], G[2 * Pp + i]};
+        float gx[3] = {GX[i], GX[(size_t)Pp + i], GX[(size_t)2 * Pp + i]};
 #pragma unroll
-      for (int q = 0; q < UD_BIG_PPT; ++q) {
-        const int i = tid + q * UD_BIG_T;
-        if (i < Pp) {
-          const float x[3] = {X[i], X[Pp + i], X[2 * Pp + i]};
-          const float gF[3] = {G[i], G[Pp + i], G[2 * Pp + i]};
-#pragma unroll
-          for (int l = 0; l < 8; ++l) {
-            const int j = a.nbr[l * Pp + i];
-            const bool ok = j >= 0;
-            const int jj = ok ? j : i;
-            const float r0 = X[jj] - x[0], r1 = X[Pp + jj] - x[1], r2 = X[2 * Pp + jj] - x[2];
-            const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
-            const float cf = clip_grad(s2, 1e-12f, INFINITY);
-            const float len = sqrtf(clipf(s2, 1e-12f, INFINITY));
-            const float L = a.L0[l * Pp + i];
-            const float d0 = G[jj] - gF[0], d1 = G[Pp + jj] - gF[1], d2 = G[2 * Pp + jj] - gF[2];
-            const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
-            const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
-            const float c1 = (k / L) * (1.f - L / len);
-            const float c2 = (k / L) * cf * L / (len * len * len) * rd_;
-            gk += ok ? rg / len * (len - L) / L : 0.f;
-            gx[q][0] += ok ? c1 * d0 + c2 * r0 : 0.f;
-            gx[q][1] += ok ? c1 * d1 + c2 * r1 : 0.f;
-            gx[q][2] += ok ? c1 * d2 + c2 * r2 : 0.f;
-          }
+        for (int l = 0; l < 8; ++l) {
+          const int j = a.nbr[l * Pp + i];
+          const bool ok = j >= 0;
+          const int jj = ok ? j : i;
+          const float r0 = X[jj] - x[0], r1 = X[Pp + jj] - x[1], r2 = X[2 * Pp + jj] - x[2];
+          const float s2 = r0 * r0 + r1 * r1 + r2 * r2;
+          const float cf = clip_grad(s2, 1e-12f, INFINITY);
+          const float len = sqrtf(clipf(s2, 1e-12f, INFINITY));
+          const float L = (l < 4) ? c.Ls : c.Ld;
+          const float d0 = G[jj] - gF[0], d1 = G[Pp + jj] - gF[1], d2 = G[2 * Pp + jj] - gF[2];
+          const float rd_ = r0 * d0 + r1 * d1 + r2 * d2;
+          const float rg = r0 * gF[0] + r1 * gF[1] + r2 * gF[2];
+          const float c1 = (k / L) * (1.f - L / len);
+          const float c2 = (k / L) * cf * L / (len * len * len) * rd_;
+          gk += ok ? rg / len * (len - L) / L : 0.f;
+          gx[0] += ok ? c1 * d0 + c2 * r0 : 0.f;
+          gx[1] += ok ? c1 * d1 + c2 * r1 : 0.f;
+          gx[2] += ok ? c1 * d2 + c2 * r2 : 0.f;
         }
+        GX[i] = gx[0]; GX[(size_t)Pp + i] = gx[1]; GX[(size_t)2 * Pp + i] = gx[2];
       }
       __syncthreads();   // X / G are rewritten by the next substep
     }
@@ -799,14 +793,11 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
       __syncthreads();
     }
   }
+#pragma unroll 1
+  for (int i = tid; i < P; i += UD_BIG_T) {
+    const size_t o = ((size_t)b * P + i) * 3;
 #pragma unroll
-  for (int q = 0; q < UD_BIG_PPT; ++q) {
-    const int i = tid + q * UD_BIG_T;
-    if (i < P) {
-      const size_t o = ((size_t)b * P + i) * 3;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { a.g_x0[o + d] = gx[q][d]; a.g_v0[o + d] = gv[q][d]; }
-    }
+    for (int d = 0; d < 3; ++d) { a.g_x0[o + d] = GX[(size_t)d * Pp + i]; a.g_v0[o + d] = GV[(size_t)d * Pp + i]; }
   }
   float rk = gk, rmu = gmu;
   block_sum2(rk, rmu, red + 192, nw);
@@ -887,7 +878,7 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   if (e == hipSuccess) e = hipMemcpy(h->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_L0, L0.data(), L0.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess && Pp > 1024) {   // the kernels for big bodies need more than the default 64 KB of dynamic LDS
-    e = hipFuncSetAttribute((const void*)ud::cloth_big_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)6 * Pp * sizeof(float)));
+    e = hipFuncSetAttribute((const void*)ud::cloth_big_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)9 * Pp * sizeof(float)));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::cloth_big_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)6 * Pp + 192 + 128) * sizeof(float)));
   }
   if (e != hipSuccess) {
@@ -931,7 +922,7 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
   if (h->c.Pp > 1024)
-    hipLaunchKernelGGL(ud::cloth_big_fwd_kernel, dim3(B), dim3(UD_BIG_T), shmem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ud::cloth_big_fwd_kernel, dim3(B), dim3(UD_BIG_T), (size_t)9 * h->c.Pp * sizeof(float), (hipStream_t)stream, a);
   else if (h->mode == 2 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
   else if (h->mode == 0 && h->c.Pp <= 512)
