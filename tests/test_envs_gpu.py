@@ -368,3 +368,29 @@ def test_fold_tshirt_step_matches_oracle_and_grad():
     assert float((info["state"].x.detach() - st.x).abs().max()) > 1e-3        # the pick-and-place moved the shirt
     reward.sum().backward()
     assert torch.isfinite(a.grad).all() and a.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("name,steps", [("pour_water", 60), ("shape_rope", 4), ("whip_rope", 80)])
+def test_long_rollouts_stay_finite_and_in_the_domain(name, steps):
+    """Many env.steps in a row with random actions (through auto_reset where the episode is shorter): states stay finite, particles
+    stay inside the unit box, no device-side capacity flag is left standing (the grid-checkpoint fallback absorbs pool overflows)."""
+    from unidom_amd.envs.registration import env_functions
+    torch.manual_seed(0)
+    np.random.seed(0)
+    env = env_functions[name](batch_size=3, seed=2)
+    _, st = env.reset(np.array([0, 9], np.uint32))
+    for k in range(steps):
+        if name == "shape_rope":
+            a = torch.tensor(env.random_policy(3), dtype=torch.float32, device=env.device)
+            a[:, 1] = 0
+        else:
+            a = torch.rand((3, 6), device=env.device) * 2 - 1
+        with torch.no_grad():
+            obs, reward, done, info = env.step_diff(a, st)
+        st = info["state"]
+        env.state = st
+    env.simulator.check_status()
+    for t in (st.x, st.v, st.C, st.F, obs, reward):
+        assert torch.isfinite(t).all()
+    assert float(st.x.min()) > -1e-3 and float(st.x.max()) < 1.0 + 1e-3
+    assert int(st.cur_step.max()) <= env.max_steps
