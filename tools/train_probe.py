@@ -9,7 +9,12 @@ import torch
 from unidom_amd.algorithms.apg.core import APG
 from unidom_amd.envs.registration import env_functions
 
-for name, num_envs, ep_len, iters, lr in (("fold_cloth1", 4, 3, 150, 1e-4), ("whip_rope", 32, 3, 150, 1e-4), ("pour_water", 8, 3, 60, 1e-4)):
+import os
+import sys
+
+LONG = "--long" in sys.argv      # one long run on the headline env, curve written to gpurun_out/train_fold_cloth1.csv
+RUNS = (("fold_cloth1", 4, 3, 1000, 1e-4),) if LONG else (("fold_cloth1", 4, 3, 150, 1e-4), ("whip_rope", 32, 3, 150, 1e-4), ("pour_water", 8, 3, 60, 1e-4))
+for name, num_envs, ep_len, iters, lr in RUNS:
     torch.manual_seed(0)
     np.random.seed(0)
     env = env_functions[name](batch_size=num_envs, seed=0, aux_reward=True)
@@ -20,6 +25,11 @@ for name, num_envs, ep_len, iters, lr in (("fold_cloth1", 4, 3, 150, 1e-4), ("wh
         m = learner.minimize(st)
         rewards.append(float(m["reward"].mean()))
         assert np.isfinite(rewards[-1]) and bool(torch.isfinite(m["grad_norm"]))
+    if LONG:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/train_fold_cloth1.csv", "w") as f:
+            f.write("iteration,mean_reward_over_ep_len_and_envs\n")
+            f.writelines(f"{i},{r:.6f}\n" for i, r in enumerate(rewards))
     k = max(iters // 10, 1)
     print(f"{name}: {iters} APG iterations ({num_envs} envs, ep_len {ep_len}) in {time.time() - t0:.1f}s; mean reward first {k}: "
           f"{np.mean(rewards[:k]):.4f}  last {k}: {np.mean(rewards[-k:]):.4f}  (max {max(rewards):.4f})", flush=True)
