@@ -2,15 +2,16 @@
 // n_grid 128 / 256 -> N = 798 / 6675): many workgroups per env, the `res` grid dense in HBM, a handful of small
 // kernels per substep.  Same arithmetic (shared device functions, mpm_device.h) and the same C ABI as mpm.hip.
 //
-// Per substep the forward runs  clear+FK -> p2g -> grid op -> g2p  and the backward
-// clear+FK-adjoint -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint:
+// Per substep the forward runs  clear+FK -> p2g -> grid op -> g2p  and the backward either
+// clear -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint in extra blocks)
+// or, with the grid checkpoint,  restore -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint):
 //   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells with an
 //     epoch stamp; the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
 //     the next substep visit only touched cells (never the 32^3..128^3 dense volume the reference sweeps ~10x);
 //   * particle state history (24 floats/particle/substep, SoA) doubles as the backward's checkpoint;
 //   * no host synchronisation: all launches go to the caller's stream in order.
-// First version: one lane per particle, plain global atomics (the Morton-sorted, LDS-tiled p2g of north_star is the
-// next optimisation step for this path).
+// Scatters are staged per workgroup in an LDS cell table; particles can be kept in Morton order inside the handle (lg_sort);
+// small launches split the envs over two streams.
 #include <cstdlib>
 
 #include "mpm_device.h"
@@ -563,9 +564,10 @@ __device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pi
 }
 
 // FK adjoint of substep f (one block per env)
-__global__ void __launch_bounds__(256) lg_fk_adj(LargeArgs a) {
-  const int S = a.c.steps, f = a.f;                             // grid (B, n_prim)
-  const long b = (long)(blockIdx.x + a.b0) * a.c.n_prim + blockIdx.y;    // (env, primitive) row of the primitive arrays
+// Runs in the extra blocks of lg_p2g_adj (one 256-thread block per env and primitive): both only need the grid-op adjoint
+// of this substep, neither needs the other, and a launch of its own cost 5 us per reverse substep for microseconds of work.
+__device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env, primitive) row of the primitive arrays */) {
+  const int S = a.c.steps, f = a.f;
   const float* pp = a.w.ppos + b * S * 3;
   const float* pin = a.w.ppin + b * S * 3;
   float* gp = a.w.gppos + b * S * 3;
@@ -860,7 +862,11 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
 template <int LANES>
-__global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a) {
+__global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_blocks) {
+  if ((int)blockIdx.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
+    fk_adj_block(a, (long)(blockIdx.y + a.b0) * a.c.n_prim + ((int)blockIdx.x - particle_blocks));
+    return;
+  }
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   if (p >= c.N) return;   // whole quads leave together
@@ -1310,8 +1316,8 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       }
       if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
       hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, s, a);
-      if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_p2g_adj<1>, gq, blk, 0, s, a);
-      hipLaunchKernelGGL(lg_fk_adj, dim3(Bg, c.n_prim), blk, 0, s, a);
+      const dim3 gqf(gq.x + c.n_prim, Bg);   // + one block per primitive: the FK adjoint
+      if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gqf, blk, 0, s, a, (int)gq.x); else hipLaunchKernelGGL(lg_p2g_adj<1>, gqf, blk, 0, s, a, (int)gq.x);
     }
   }
   a.f = -1;
