@@ -1,5 +1,6 @@
 """fold_cloth1_para -- mirrors /root/reference/DaXBench/daxbench/core/envs/fold_cloth1_para_env.py:15-53
 (parameter-aware observation: normalised stiffness appended, cloth_env_para.py:130)."""
+from .basic.cloth_conf import patch_mask
 from .basic.cloth_env import ClothEnv
 from .fold_cloth1_env import DefaultConf as _Base
 
@@ -22,8 +23,4 @@ class FoldCloth1ParaEnv(ClothEnv):
         self.observation_size = 1545
 
     def create_cloth_mask(self, conf):
-        import numpy as np
-        N, size = conf.N, conf.size
-        cloth_mask = np.zeros((N, N), dtype=np.float32)
-        cloth_mask[size * 2:size * 3, size * 2:size * 4] = 1
-        return cloth_mask
+        return patch_mask(conf)

@@ -6,34 +6,19 @@ The reference reads the mask from others/t-shirt.jpg with cv2 (resize, rotate, t
 others/tshirt_mask.npy, recovered from the recorded reset state of the reference's expert_demo/fold_tshirt/demo_0.pkl
 (tests/golden/make_golden.py).  The reference ships no goal for this task (goals/fold_tshirt/ is empty: it warns and uses
 zeros), and neither does this repo.  Bodies above 1024 particles run the several-particles-per-lane kernels of csrc/cloth.hip."""
-import os
-from dataclasses import dataclass
-
 import numpy as np
 import torch
 
+from .basic.cloth_conf import ENVS_DIR, ClothConfBase
 from .basic.cloth_env import ClothEnv
 
-my_path = os.path.dirname(os.path.abspath(__file__))
 
-
-@dataclass
-class DefaultConf:            # fold_cloth_tshirt_env.py:19-40
+class DefaultConf(ClothConfBase):            # fold_cloth_tshirt_env.py:19-40
     N = 180
-    cell_size = 1.0 / N
-    gravity = 0.5
     stiffness = 5000
-    damping = 2
     dt = 0.5e-3
-    max_v = 2.
-    small_num = 1e-8
-    mu = 0.9  # friction
-    seed = 1
-    size = int(N / 5.0)
-    mem_saving_level = 2      # interface parity only: the HIP path checkpoints per substep (DESIGN.md)
+    mu = 0.9
     task = "fold_tshirt"
-    goal_path = f"{my_path}/goals/{task}/goal.npy"
-    use_substep_obs = True
 
 
 FoldTshirtConfig = DefaultConf
@@ -48,7 +33,7 @@ class FoldTshirtEnv(ClothEnv):
         self.observation_size = 1082                                       # 358 sampled particles x 3 + 2 x 4
 
     def create_cloth_mask(self, conf):   # :50-67 (see the module docstring)
-        mask = np.load(f"{my_path}/others/tshirt_mask.npy")
+        mask = np.load(f"{ENVS_DIR}/others/tshirt_mask.npy")
         assert mask.shape == (conf.N, conf.N)
         return mask.astype(np.float32)
 

@@ -2,35 +2,19 @@
 unfold_cloth3_env.py (identical but for the number of random folds applied at reset, 1 vs 3): the fold_cloth1 cloth
 with friction mu = 3, 15 steps per episode, no substep observations, and a reset that jitters the particles
 (normal * 1e-4) and then folds the cloth with random pick-and-place actions through step_diff itself."""
-import os
-from dataclasses import dataclass
-
 import numpy as np
 import torch
 
 from ..utils import prng
+from .basic.cloth_conf import ClothConfBase, patch_mask
 from .basic.cloth_env import ClothEnv
 
-my_path = os.path.dirname(os.path.abspath(__file__))
 
-
-@dataclass
-class DefaultConf:            # unfold_cloth1_env.py:15-35
-    N = 80
-    cell_size = 1.0 / N
-    gravity = 0.5
+class DefaultConf(ClothConfBase):            # unfold_cloth1_env.py:15-35
     stiffness = 900
-    damping = 2
-    dt = 2e-3
-    max_v = 2.
-    small_num = 1e-8
-    mu = 3  # friction
-    seed = 1
-    size = int(N / 5.0)
-    mem_saving_level = 2      # interface parity only
-    task = "unfold_cloth1"
-    goal_path = f"{my_path}/goals/{task}/goal.npy"
+    mu = 3                    # a sticky table
     use_substep_obs = False
+    task = "unfold_cloth1"
 
 
 UnfoldCloth1Config = DefaultConf
@@ -46,11 +30,8 @@ class UnfoldCloth1Env(ClothEnv):
         self.observation_size = 1544
         self.reset = self.build_reset()                                    # :47
 
-    def create_cloth_mask(self, conf):   # :49-54
-        N, size = conf.N, conf.size
-        cloth_mask = np.zeros((N, N), dtype=np.float32)
-        cloth_mask[size * 2:size * 3, size * 2:size * 4] = 1
-        return cloth_mask
+    def create_cloth_mask(self, conf):
+        return patch_mask(conf)
 
     def random_fold(self, state, key, step=10):   # :56-66 (draws from numpy's global stream, as the reference does)
         num_particle = state.x.shape[1]
@@ -81,10 +62,8 @@ class UnfoldCloth1Env(ClothEnv):
         return reset
 
 
-@dataclass
 class DefaultConf3(DefaultConf):   # unfold_cloth3_env.py:15-35
     task = "unfold_cloth3"
-    goal_path = f"{my_path}/goals/{task}/goal.npy"
 
 
 UnfoldCloth3Config = DefaultConf3
