@@ -1,7 +1,6 @@
 """Diagnostic: which term of the norm_grad_state global norm differs between the many-workgroup adjoint and the oracle?
 usage (GPU box): PYTHONPATH=$PWD:$PWD/tests python tools/debug_norm.py"""
 import numpy as np
-import torch
 
 from oracle.pyoracle import MpmOracle
 from test_mpm_gpu import LegacyConf, run_hip

@@ -15,7 +15,6 @@ from __future__ import annotations
 import math
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn.functional as Fn

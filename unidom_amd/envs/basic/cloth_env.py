@@ -11,7 +11,6 @@ Rendering (pyrender) is out of scope: step_with_render / render raise NotImpleme
 """
 from __future__ import annotations
 
-import math
 import os
 
 import numpy as np
@@ -19,7 +18,6 @@ import torch
 
 from ...engine.cloth_simulator import ClothSimulator, ClothState
 from ...utils import prng
-from ...utils.util import calc_chamfer
 from . import _fused
 
 
