@@ -308,3 +308,59 @@ def test_two_container_primitives_adjoint_matches_autograd_f64(demo, clip):
         assert np.abs(ob["gprot"][0, i]).max() > 0
     assert _rel(ob["gfriction"], fr.grad.numpy()) < 2e-7
     assert _rel(ob["gaction"][0], ac.grad.numpy()) < 2e-7 and np.abs(ob["gaction"][0]).min() > 0
+
+
+@pytest.mark.parametrize("sdf,n_prim", [("box", 1), ("container", 2)])
+def test_collide_adjoint_vs_finite_differences_f64(demo, sdf, n_prim):
+    """Soft contact, independent of autograd: central differences of the oracle's own f64 forward against its hand-derived
+    adjoint, for particle state, material parameters, primitive position / rotation rows and the action (translation and
+    rotation parts) -- box with one primitive, container with two."""
+    S = 2
+    if sdf == "box":
+        st, g = _collide_case(demo, S, 40, 1, 3)
+        orc = MpmOracle(67, steps=S, position_control=False)
+    else:
+        st, g = _two_bowl_case(demo, S, 40, 3)
+        orc = MpmOracle(67, steps=S, material=np.zeros(67), position_control=False, n_prim=2, sdf="container")
+
+    def Lf(s):
+        o = orc.step_fwd(s)
+        return (o["x"] * g["gx"]).sum() + (o["v"] * g["gv"]).sum() + (o["C"] * g["gC"]).sum() + (o["F"] * g["gF"]).sum() + \
+            (o["ppos"] * g["gppos"]).sum() + (o["prot"] * g["gprot"]).sum()
+
+    b = orc.step_bwd(st, g, clip=False)
+    rng = np.random.default_rng(0)
+    # The forward contains a finite-difference normal of step 1e-6 (primitives.py:119-134) that amplifies f64 round-off by 5e5:
+    # an outer difference of step h carries ~5e-11 / h of noise (5e-5 at h = 1e-6), while a larger h starts crossing the kinks of
+    # the SDFs (measured: 1.5e-4 at h = 1e-5).  So this check is a coarse, autograd-independent one at 2e-4; the tight one is
+    # the comparison with the twin above (2e-7).
+    tol = 2e-4
+    names = [("x", "gx"), ("v", "gv"), ("C", "gC"), ("F", "gF"), ("friction", "gfriction"), ("action", "gaction")]
+    if sdf == "box":
+        names += [("mu", "gmu"), ("lamda", "glamda")]          # the liquid of the container case has mu = 0, la = 1 whatever the state says
+    for name, gname in names:
+        for _ in range(4):
+            a = st[name]
+            idx = tuple(rng.integers(0, n) for n in a.shape)
+            h = 1e-6 * max(1.0, abs(a[idx]))
+            sp, sm = dict(st), dict(st)
+            sp[name], sm[name] = a.copy(), a.copy()
+            sp[name][idx] += h
+            sm[name][idx] -= h
+            fd = (Lf(sp) - Lf(sm)) / (2 * h)
+            an = b[gname][idx]
+            assert abs(fd - an) <= tol * max(1.0, abs(fd), abs(an)), (name, idx, fd, an)
+    # primitive rows: only row 0 of position / rotation is an input that matters (rows >= 1 are overwritten by FK)
+    for name, gname, width in (("ppos", "gppos", 3), ("prot", "gprot", 4)):
+        for ip in range(n_prim):
+            for d in range(width):
+                idx = (0, ip, 0, d) if n_prim > 1 else (0, 0, d)
+                a = st[name]
+                h = 1e-6
+                sp, sm = dict(st), dict(st)
+                sp[name], sm[name] = a.copy(), a.copy()
+                sp[name][idx] += h
+                sm[name][idx] -= h
+                fd = (Lf(sp) - Lf(sm)) / (2 * h)
+                an = b[gname][idx]
+                assert abs(fd - an) <= tol * max(1.0, abs(fd), abs(an)), (name, idx, fd, an)
