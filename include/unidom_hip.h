@@ -138,7 +138,8 @@ typedef struct {
                                 and the backward restores them.  A pool that runs out flags the env in status[] (1) */
   int sort_particles;        /* many-workgroup path only.  != 0: at every step the handle re-orders the particles by grid cell
                                 (Morton key) internally, for bodies whose particles come in no spatial order (uniformly
-                                sampled liquids, mpm_simulator.py:87-91).  Invisible at this boundary: inputs, outputs and
+                                sampled liquids, mpm_simulator.py:87-91); bodies above 8192 particles keep their order (the
+                                sort runs in the LDS of one workgroup per env).  Invisible at this boundary: inputs, outputs and
                                 gradients stay in the caller's order; only the summation order of the scatters changes */
 } ud_mpm_conf;
 
