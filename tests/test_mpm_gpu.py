@@ -464,7 +464,9 @@ def test_two_upright_containers_forward_tracks_f32_oracle(demo):
 
 
 @pytest.mark.parametrize("case", ["one_substep", "n129_just_over_the_one_workgroup_limit", "body_at_the_domain_corner", "four_box_primitives",
-                                  "one_workgroup_one_substep", "one_workgroup_domain_corner"])
+                                  "one_workgroup_one_substep", "one_workgroup_domain_corner",
+                                  "across_the_upper_grid_edge", "one_workgroup_across_the_upper_grid_edge",
+                                  "negative_weights", "one_workgroup_negative_weights"])
 def test_mpm_step_edge_cases(demo, case):
     """Edges vs the oracle (forward f32, adjoint f64), on the many-workgroup path and (one_workgroup_*) the one-workgroup
     path: a single substep per step (copy_frame and the primitive recurrences degenerate, Q5), the smallest particle count
@@ -487,11 +489,15 @@ def test_mpm_step_edge_cases(demo, case):
     sim = SimpleMPMSimulator(conf, 2, use_position_control=pc)
     sim.n_particles, sim.material, sim.h = N, np.full(N, 1, np.int32), np.ones(N, np.float32)
     sim.n_primitive = P
-    sim.grid_ckpt_cells = 0 if case.endswith("domain_corner") else 8
+    sim.grid_ckpt_cells = 0 if case.endswith(("domain_corner", "negative_weights")) else 8
     sim._make_handle()
     B = 2
     lo = 0.004 if case.endswith("domain_corner") else 0.15            # dx = 1/64: x * inv_dx < 0.5 below 0.0078
     x = (lo + rng.uniform(0, 0.06, size=(B, N, 3))).astype(np.float32)
+    if case.endswith("upper_grid_edge"):      # res = 32 cells of dx = 1/64 end at 0.5: stencil cells beyond it are dropped by the
+        x[..., 0] += np.float32(0.30)          # scatter and clamped by the gather (Q5 / Q9); x in [0.45, 0.51]
+    if case.endswith("negative_weights"):     # x * inv_dx < 0.134: w[1] = 0.75 - (fx - 1)^2 < 0, cells with m < 0 (Q13)
+        x[..., 1] = (0.0002 + rng.uniform(0, 0.004, size=(B, N))).astype(np.float32)
     pa = (P,) if P > 1 else ()
     ppos = np.zeros((B,) + pa + (S, 3), np.float32)
     ppos[..., 0, :] = (x.mean(1)[:, None] if P > 1 else x.mean(1)) + rng.normal(size=(B,) + pa + (3,)).astype(np.float32) * 0.01
@@ -522,6 +528,10 @@ def test_mpm_step_edge_cases(demo, case):
         assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
     if case.endswith("domain_corner"):
         assert (x * 64 < 0.5).any()                                      # base truncates to 0 with fx < 0.5 for some particles
+    if case.endswith("upper_grid_edge"):
+        assert ((x[..., 0] * 64 - 0.5).astype(np.int32) + 2 >= 32).any() and ((x[..., 0] * 64 - 0.5).astype(np.int32) + 2 < 32).any()
+    if case.endswith("negative_weights"):
+        assert (x[..., 1] * 64 < 0.134).any()
 
 
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 8])
