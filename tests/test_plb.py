@@ -101,3 +101,35 @@ def test_hip_matches_restatement_full_torus_state():
     s2 = sim.step(s, act * 0)
     cur2 = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act * 0, E, nu, ys, nthreads=3)
     assert _rel(s2.x.cpu().numpy(), cur2["x"]) < 1e-9 and _rel(s2.v.cpu().numpy(), cur2["v"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_hip_matches_restatement_quality_2():
+    """The same path at quality 2 (n_grid 128, dt 0.5e-4 / 1 -> 40 substeps per step, bench.py --workload torus --n-grid 128):
+    ~1 particle per cell, the regime where the internal spatial order and the four-lane mapping matter most."""
+    import torch
+    from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
+    cfg = PlbConf()
+    cfg.quality = 2
+    sim = PlbSimulator(cfg, batch_size=2)
+    st = sim.reset()
+    assert sim.n_grid == 128
+    rng = np.random.default_rng(3)
+    x0 = st.x.cpu().numpy()
+    v0 = rng.normal(size=x0.shape) * 0.01
+    C0 = rng.normal(size=(2, 1000, 3, 3)) * 0.1
+    F0 = np.eye(3)[None, None] + rng.normal(size=(2, 1000, 3, 3)) * 0.002
+    prim = st.prim_pos.cpu().numpy().copy()
+    prim[:, 0] = x0[:, 11]
+    soft = np.full((2, 2), 666.0)
+    E, nu, ys = np.array([5e3, 4e3]), np.array([0.35, 0.3]), np.array([1762.2, 20.0])
+    act = np.array([[0.004, 0.003, 0.0], [-0.002, 0.001, 0.002]])
+    T = lambda a: torch.tensor(a, dtype=torch.float64, device=sim.device)
+    s = st._replace(v=T(v0), C=T(C0), F=T(F0), prim_pos=T(prim), softness=T(soft), E=T(E), nu=T(nu), yield_stress=T(ys))
+    orc = PlbOracle(N=1000, n_grid=128, substeps=sim.substeps, dt=sim.dt)
+    cur = dict(x=x0, v=v0, C=C0, F=F0, prim_pos=prim)
+    for step in range(2):
+        s = sim.step(s, act)
+        cur = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act, E, nu, ys, nthreads=2)
+    for key, t in (("x", s.x), ("v", s.v), ("C", s.C), ("F", s.F)):
+        assert _rel(t.cpu().numpy(), cur[key]) < 1e-9, (key, _rel(t.cpu().numpy(), cur[key]))
