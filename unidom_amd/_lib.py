@@ -21,6 +21,7 @@ SYMBOLS = [
     "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
     "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd",
     "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
+    "ud_mpm_focus_fwd", "ud_mpm_focus_bwd", "ud_mpm_finish_fwd", "ud_mpm_finish_bwd",
 ]
 
 

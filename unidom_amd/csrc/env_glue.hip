@@ -2,6 +2,8 @@
 // chamfer reward, the contact distance and the 6-vector -> 40 x 8 macro-action expansion into a handful of fused
 // kernels; done op by op on the device they are ~180 tiny launches (and a dense [B,P,Q] autograd graph) per
 // step_diff.  Here each piece is one forward and one backward kernel, one workgroup per environment.
+// The MPM envs' counterpart (focus shift before the step; un-shift, nan_to_num, reward and observation after it) is the
+// second half of this file.
 //   chamfer        core/utils/util.py:138-153     d(p,q) = sqrt(mean_xyz((x_p - y_q)^2)); mean_p min_q + mean_q min_p
 //   pnp / contact  core/envs/basic/cloth_env.py:134-173 (get_pnp_actions), :206-209 (contact_distance)
 // The backward kernels return what jax.grad / torch.autograd return for the same expressions: the minimum passes its
@@ -182,6 +184,171 @@ __global__ void __launch_bounds__(GLUE_T) pnp_bwd_kernel(int B, int P, const flo
   }
 }
 
+
+// ---- MPM envs: focus shift, and the tail of step_diff ----------------------------------------------
+//   focus   core/envs/basic/mpm_env.py:99-114  shift = (res / 2 / n_grid - mean_n x) * (1,0,1); x and every primitive
+//           trajectory move by it before the step, and back afterwards (:116-125)
+//   finish  :116-125 (x, primitive positions - shift), :150-154 (nan_to_num on x v C F J), :90-94 reward
+//           e ** (-10 * mean_n sqrt(mean_xyz((x - goal)^2))), :57-76 obs = x | v | primitive 0 trajectory
+// One workgroup per env.  Cotangent pointers may be null (that output was not used).
+constexpr int MG_MAXPRIM = 4;   // = UD_MAX_PRIM of the simulator
+struct PrimIn { const float* p[MG_MAXPRIM]; };
+struct PrimOut { float* p[MG_MAXPRIM]; };
+
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float (*red)[GLUE_T / 64]) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[0][wv] = a; red[1][wv] = b; red[2][wv] = c; }
+  __syncthreads();
+  a = b = c = 0.f;
+  for (int q = 0; q < GLUE_T / 64; ++q) { a += red[0][q]; b += red[1][q]; c += red[2][q]; }
+}
+
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) < INFINITY; }   // false for NaN and +-inf
+
+__global__ void __launch_bounds__(GLUE_T) mpm_focus_fwd_kernel(int N, int S, int n_prim, float cx, float cz, const float* __restrict__ x,
+                                                               PrimIn pin, float* __restrict__ xo, PrimOut pout, float* __restrict__ shift) {
+  __shared__ float red[3][GLUE_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * N * 3;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int n = tid; n < N; n += GLUE_T) { sx += xb[n * 3]; sz += xb[n * 3 + 2]; }
+  block_sum3(sx, sy, sz, red);
+  const float sh[3] = {cx - sx / (float)N, 0.f, cz - sz / (float)N};
+  float* xob = xo + (size_t)b * N * 3;
+  for (int i = tid; i < N * 3; i += GLUE_T) xob[i] = xb[i] + sh[i % 3];
+  for (int p = 0; p < n_prim; ++p) {
+    const float* src = pin.p[p] + (size_t)b * S * 3;
+    float* dst = pout.p[p] + (size_t)b * S * 3;
+    for (int i = tid; i < S * 3; i += GLUE_T) dst[i] = src[i] + sh[i % 3];
+  }
+  if (tid < 3) shift[b * 3 + tid] = sh[tid];
+}
+
+// x_out = x + shift(x), shift = c - mean(x) on the x and z axes: g_x = g_xo - (1/N) (g_shift + sum_n g_xo + sum g_pos_out)
+__global__ void __launch_bounds__(GLUE_T) mpm_focus_bwd_kernel(int N, int S, int n_prim, const float* __restrict__ g_xo, PrimIn g_pout,
+                                                               const float* __restrict__ g_shift, float* __restrict__ g_x) {
+  __shared__ float red[3][GLUE_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* gb = g_xo ? g_xo + (size_t)b * N * 3 : nullptr;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (gb)
+    for (int n = tid; n < N; n += GLUE_T) { sx += gb[n * 3]; sz += gb[n * 3 + 2]; }
+  for (int p = 0; p < n_prim; ++p) {
+    if (!g_pout.p[p]) continue;
+    const float* g = g_pout.p[p] + (size_t)b * S * 3;
+    for (int s = tid; s < S; s += GLUE_T) { sx += g[s * 3]; sz += g[s * 3 + 2]; }
+  }
+  block_sum3(sx, sy, sz, red);
+  if (g_shift) { sx += g_shift[b * 3]; sz += g_shift[b * 3 + 2]; }
+  const float t[3] = {sx / (float)N, 0.f, sz / (float)N};
+  float* o = g_x + (size_t)b * N * 3;
+  for (int i = tid; i < N * 3; i += GLUE_T) o[i] = (gb ? gb[i] : 0.f) - t[i % 3];
+}
+
+__global__ void __launch_bounds__(GLUE_T) mpm_finish_fwd_kernel(int N, int S, int n_prim, const float* __restrict__ x, const float* __restrict__ v,
+                                                                const float* __restrict__ Cm, const float* __restrict__ F,
+                                                                const float* __restrict__ J, const float* __restrict__ shift, PrimIn pin,
+                                                                const float* __restrict__ goal, float* __restrict__ xo, float* __restrict__ vo,
+                                                                float* __restrict__ Co, float* __restrict__ Fo, float* __restrict__ Jo,
+                                                                PrimOut pout, float* __restrict__ reward, float* __restrict__ obs) {
+  __shared__ float scratch[GLUE_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t o3 = (size_t)b * N * 3, o9 = (size_t)b * N * 9;
+  float sh[3] = {0.f, 0.f, 0.f};
+  if (shift) { sh[0] = shift[b * 3]; sh[1] = shift[b * 3 + 1]; sh[2] = shift[b * 3 + 2]; }
+  float* ob = obs + (size_t)b * (6 * N + 3 * S);
+  float acc = 0.f;
+  for (int n = tid; n < N; n += GLUE_T) {
+    float m = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float xv = nan_to_num(x[o3 + n * 3 + d] - sh[d]);
+      xo[o3 + n * 3 + d] = xv; ob[n * 3 + d] = xv;
+      const float df = xv - goal[n * 3 + d];
+      m += df * df;
+      const float vv = nan_to_num(v[o3 + n * 3 + d]);
+      vo[o3 + n * 3 + d] = vv; ob[3 * N + n * 3 + d] = vv;
+    }
+    acc += sqrtf(m / 3.0f);
+    Jo[(size_t)b * N + n] = nan_to_num(J[(size_t)b * N + n]);
+  }
+  for (int i = tid; i < N * 9; i += GLUE_T) { Co[o9 + i] = nan_to_num(Cm[o9 + i]); Fo[o9 + i] = nan_to_num(F[o9 + i]); }
+  for (int p = 0; p < n_prim; ++p) {
+    const float* src = pin.p[p] + (size_t)b * S * 3;
+    float* dst = pout.p[p] + (size_t)b * S * 3;
+    for (int i = tid; i < S * 3; i += GLUE_T) {
+      const float q = src[i] - sh[i % 3];
+      dst[i] = q;
+      if (p == 0) ob[6 * N + i] = q;
+    }
+  }
+  const float tot = block_sum(acc, scratch);
+  if (tid == 0) reward[b] = powf(2.718281828459045f, -(tot / (float)N) * 10.0f);
+}
+
+// nan_to_num passes the cotangent where its argument was finite and nothing elsewhere (jnp.where selection: a NaN
+// cotangent does not leak through a replaced entry)
+__global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, int n_prim, const float* __restrict__ x, const float* __restrict__ v,
+                                                                const float* __restrict__ Cm, const float* __restrict__ F,
+                                                                const float* __restrict__ shift, const float* __restrict__ goal,
+                                                                const float* __restrict__ reward, const float* __restrict__ g_xo,
+                                                                const float* __restrict__ g_vo, const float* __restrict__ g_Co,
+                                                                const float* __restrict__ g_Fo, PrimIn g_pout, const float* __restrict__ g_reward,
+                                                                const float* __restrict__ g_obs, float* __restrict__ g_x, float* __restrict__ g_v,
+                                                                float* __restrict__ g_C, float* __restrict__ g_F, PrimOut g_pin,
+                                                                float* __restrict__ g_shift) {
+  __shared__ float red[3][GLUE_T / 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t o3 = (size_t)b * N * 3, o9 = (size_t)b * N * 9;
+  float sh[3] = {0.f, 0.f, 0.f};
+  if (shift) { sh[0] = shift[b * 3]; sh[1] = shift[b * 3 + 1]; sh[2] = shift[b * 3 + 2]; }
+  const float* gob = g_obs ? g_obs + (size_t)b * (6 * N + 3 * S) : nullptr;
+  // reward = e^t, t = -10 * l2, l2 = (1/N) sum_n sqrt(m_n), m_n = |x - goal|^2 / 3
+  const float gr = g_reward ? g_reward[b] * reward[b] * (-10.0f) / (float)N : 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int n = tid; n < N; n += GLUE_T) {
+    float xs[3], df[3], m = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      xs[d] = x[o3 + n * 3 + d] - sh[d];
+      df[d] = nan_to_num(xs[d]) - goal[n * 3 + d];
+      m += df[d] * df[d];
+    }
+    const float dn = sqrtf(m / 3.0f);
+    float g[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float t = (g_xo ? g_xo[o3 + n * 3 + d] : 0.f) + (gob ? gob[n * 3 + d] : 0.f);
+      if (g_reward) t += gr * (df[d] / (3.0f * dn));     // 0/0 at a particle sitting on its goal, as in the reference
+      g[d] = finitef(xs[d]) ? t : 0.f;
+      g_x[o3 + n * 3 + d] = g[d];
+      const float tv = (g_vo ? g_vo[o3 + n * 3 + d] : 0.f) + (gob ? gob[3 * N + n * 3 + d] : 0.f);
+      g_v[o3 + n * 3 + d] = finitef(v[o3 + n * 3 + d]) ? tv : 0.f;
+    }
+    s0 += g[0]; s1 += g[1]; s2 += g[2];
+  }
+  for (int i = tid; i < N * 9; i += GLUE_T) {
+    g_C[o9 + i] = (g_Co && finitef(Cm[o9 + i])) ? g_Co[o9 + i] : 0.f;
+    g_F[o9 + i] = (g_Fo && finitef(F[o9 + i])) ? g_Fo[o9 + i] : 0.f;
+  }
+  for (int p = 0; p < n_prim; ++p) {
+    const float* src = g_pout.p[p] ? g_pout.p[p] + (size_t)b * S * 3 : nullptr;
+    float* dst = g_pin.p[p] + (size_t)b * S * 3;
+    for (int i = tid; i < S * 3; i += GLUE_T) {
+      const float q = (src ? src[i] : 0.f) + ((p == 0 && gob) ? gob[6 * N + i] : 0.f);
+      dst[i] = q;
+      const int d = i % 3;
+      if (d == 0) s0 += q; else if (d == 1) s1 += q; else s2 += q;
+    }
+  }
+  if (g_shift) {    // every shifted quantity is (value - shift)
+    block_sum3(s0, s1, s2, red);
+    if (tid == 0) { g_shift[b * 3] = -s0; g_shift[b * 3 + 1] = -s1; g_shift[b * 3 + 2] = -s2; }
+  }
+}
+
 }  // namespace ud
 
 using namespace ud;
@@ -229,6 +396,73 @@ int ud_cloth_pnp_bwd(int B, int P, const float* actions, const float* x, const f
   }
   hipLaunchKernelGGL(pnp_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, B, P, actions, x, contact_distance, contact_idx,
                      g_macro_actions, g_contact_distance, g_actions, g_primitive0, g_x);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+
+static bool prim_args_ok(int n_prim, const float* const* a, bool allow_null_entries) {
+  if (n_prim < 0 || n_prim > MG_MAXPRIM) return false;
+  if (n_prim > 0 && !a) return false;
+  if (!allow_null_entries)
+    for (int p = 0; p < n_prim; ++p)
+      if (!a[p]) return false;
+  return true;
+}
+
+int ud_mpm_focus_fwd(int B, int N, int n_prim, int S, float cx, float cz, const float* x, const float* const* prim_pos, float* x_out,
+                     float* const* prim_pos_out, float* shift, void* stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !x || !x_out || !shift || !prim_args_ok(n_prim, prim_pos, false) ||
+      !prim_args_ok(n_prim, (const float* const*)prim_pos_out, false)) {
+    set_error("ud_mpm_focus_fwd: bad argument"); return UD_ERR_INVALID;
+  }
+  PrimIn pi{}; PrimOut po{};
+  for (int p = 0; p < n_prim; ++p) { pi.p[p] = prim_pos[p]; po.p[p] = prim_pos_out[p]; }
+  hipLaunchKernelGGL(mpm_focus_fwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, cx, cz, x, pi, x_out, po, shift);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+int ud_mpm_focus_bwd(int B, int N, int n_prim, int S, const float* g_x_out, const float* const* g_prim_pos_out, const float* g_shift,
+                     float* g_x, void* stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !g_x || !prim_args_ok(n_prim, g_prim_pos_out, true)) {
+    set_error("ud_mpm_focus_bwd: bad argument"); return UD_ERR_INVALID;
+  }
+  PrimIn gi{};
+  for (int p = 0; p < n_prim; ++p) gi.p[p] = g_prim_pos_out[p];
+  hipLaunchKernelGGL(mpm_focus_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, g_x_out, gi, g_shift, g_x);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+int ud_mpm_finish_fwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F, const float* J,
+                      const float* shift, const float* const* prim_pos, const float* goal, float* x_out, float* v_out, float* C_out,
+                      float* F_out, float* J_out, float* const* prim_pos_out, float* reward, float* obs, void* stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !x || !v || !C || !F || !J || !goal || !x_out || !v_out || !C_out || !F_out || !J_out || !reward ||
+      !obs || n_prim < 1 || !prim_args_ok(n_prim, prim_pos, false) || !prim_args_ok(n_prim, (const float* const*)prim_pos_out, false)) {
+    set_error("ud_mpm_finish_fwd: bad argument"); return UD_ERR_INVALID;
+  }
+  PrimIn pi{}; PrimOut po{};
+  for (int p = 0; p < n_prim; ++p) { pi.p[p] = prim_pos[p]; po.p[p] = prim_pos_out[p]; }
+  hipLaunchKernelGGL(mpm_finish_fwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, x, v, C, F, J, shift, pi, goal,
+                     x_out, v_out, C_out, F_out, J_out, po, reward, obs);
+  UD_HIP_CHECK(hipGetLastError());
+  return UD_OK;
+}
+
+int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F, const float* shift,
+                      const float* goal, const float* reward, const float* g_x_out, const float* g_v_out, const float* g_C_out,
+                      const float* g_F_out, const float* const* g_prim_pos_out, const float* g_reward, const float* g_obs, float* g_x,
+                      float* g_v, float* g_C, float* g_F, float* const* g_prim_pos, float* g_shift, void* stream) {
+  if (B <= 0 || N <= 0 || S <= 0 || !x || !v || !C || !F || !goal || !reward || !g_x || !g_v || !g_C || !g_F || n_prim < 1 ||
+      !prim_args_ok(n_prim, g_prim_pos_out, true) || !prim_args_ok(n_prim, (const float* const*)g_prim_pos, false) ||
+      ((shift == nullptr) != (g_shift == nullptr))) {
+    set_error("ud_mpm_finish_bwd: bad argument"); return UD_ERR_INVALID;
+  }
+  PrimIn gi{}; PrimOut go{};
+  for (int p = 0; p < n_prim; ++p) { gi.p[p] = g_prim_pos_out[p]; go.p[p] = g_prim_pos[p]; }
+  hipLaunchKernelGGL(mpm_finish_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, x, v, C, F, shift, goal, reward,
+                     g_x_out, g_v_out, g_C_out, g_F_out, gi, g_reward, g_obs, g_x, g_v, g_C, g_F, go, g_shift);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;
 }

@@ -85,3 +85,96 @@ def chamfer(x, goal):
 
 def pnp_and_contact(actions, primitive0, x):
     return PnpContactFn.apply(actions, primitive0, x)
+
+
+# ---- MPM envs (csrc/env_glue.hip, second half) ---------------------------------------------------------------------
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr_array(tensors):
+    """HOST array of device pointers (include/unidom_hip.h: prim_pos arguments); None entries become NULL."""
+    arr = (C.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else _lib.ptr(t).value
+    return arr
+
+
+class FocusFn(torch.autograd.Function):
+    """pre_step (mpm_env.py:99-114): (x [B,N,3], *primitive positions [B,S,3]) -> (x + shift, shift [B,3], *positions + shift)."""
+
+    @staticmethod
+    def forward(ctx, center, x, *pos):
+        x = _f32(x)
+        pos = [_f32(p) for p in pos]
+        B, N, S = x.shape[0], x.shape[1], pos[0].shape[1] if pos else 1
+        xo, po = torch.empty_like(x), [torch.empty_like(p) for p in pos]
+        shift = torch.empty((B, 3), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ud_mpm_focus_fwd(C.c_int(B), C.c_int(N), C.c_int(len(pos)), C.c_int(S), C.c_float(center[0]),
+                                               C.c_float(center[2]), _lib.ptr(x), _ptr_array(pos), _lib.ptr(xo), _ptr_array(po),
+                                               _lib.ptr(shift), _stream(x.device)), "ud_mpm_focus_fwd")
+        ctx.dims = (B, N, len(pos), S, x.device)
+        ctx.set_materialize_grads(False)
+        return (xo, shift, *po)
+
+    @staticmethod
+    def backward(ctx, g_xo, g_shift, *g_po):
+        B, N, P, S, dev = ctx.dims
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_xo, g_shift, g_po = c(g_xo), c(g_shift), [c(g) for g in g_po]
+        gx = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().ud_mpm_focus_bwd(C.c_int(B), C.c_int(N), C.c_int(P), C.c_int(S), _lib.ptr(g_xo), _ptr_array(g_po),
+                                               _lib.ptr(g_shift), _lib.ptr(gx), _stream(dev)), "ud_mpm_focus_bwd")
+        return (None, gx, *g_po)
+
+
+class FinishFn(torch.autograd.Function):
+    """Tail of step_diff (mpm_env.py:116-125, :150-154, :90-94, :57-76):
+    (x, v, C, F, J, shift | None, goal [N,3], *positions) -> (x, v, C, F, J, reward [B], obs [B, 6N+3S], *positions)."""
+
+    @staticmethod
+    def forward(ctx, x, v, Cm, F, J, shift, goal, *pos):
+        x, v, Cm, F, J, goal = map(_f32, (x, v, Cm, F, J, goal))
+        shift = None if shift is None else _f32(shift)
+        pos = [_f32(p) for p in pos]
+        B, N, S = x.shape[0], x.shape[1], pos[0].shape[1]
+        if goal.shape != (N, 3):
+            raise _lib.UnidomError(f"reward_func: goal {tuple(goal.shape)} does not match the {N} particles of the state")
+        xo, vo, Co, Fo, Jo = (torch.empty_like(t) for t in (x, v, Cm, F, J))
+        po = [torch.empty_like(p) for p in pos]
+        reward = torch.empty((B,), dtype=torch.float32, device=x.device)
+        obs = torch.empty((B, 6 * N + 3 * S), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ud_mpm_finish_fwd(
+            C.c_int(B), C.c_int(N), C.c_int(len(pos)), C.c_int(S), *[_lib.ptr(t) for t in (x, v, Cm, F, J, shift)], _ptr_array(pos),
+            _lib.ptr(goal), *[_lib.ptr(t) for t in (xo, vo, Co, Fo, Jo)], _ptr_array(po), _lib.ptr(reward), _lib.ptr(obs),
+            _stream(x.device)), "ud_mpm_finish_fwd")
+        ctx.save_for_backward(x, v, Cm, F, shift, goal, reward)
+        ctx.dims = (B, N, len(pos), S)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(Jo)
+        return (xo, vo, Co, Fo, Jo, reward, obs, *po)
+
+    @staticmethod
+    def backward(ctx, g_x, g_v, g_C, g_F, g_J, g_reward, g_obs, *g_po):
+        x, v, Cm, F, shift, goal, reward = ctx.saved_tensors
+        B, N, P, S = ctx.dims
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_x, g_v, g_C, g_F, g_reward, g_obs, g_po = c(g_x), c(g_v), c(g_C), c(g_F), c(g_reward), c(g_obs), [c(g) for g in g_po]
+        ox, ov, oC, oF = (torch.empty_like(t) for t in (x, v, Cm, F))
+        opos = [torch.empty((B, S, 3), dtype=torch.float32, device=x.device) for _ in range(P)]
+        osh = None if shift is None else torch.empty((B, 3), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().ud_mpm_finish_bwd(
+            C.c_int(B), C.c_int(N), C.c_int(P), C.c_int(S), *[_lib.ptr(t) for t in (x, v, Cm, F, shift, goal, reward)],
+            *[_lib.ptr(t) for t in (g_x, g_v, g_C, g_F)], _ptr_array(g_po), _lib.ptr(g_reward), _lib.ptr(g_obs),
+            *[_lib.ptr(t) for t in (ox, ov, oC, oF)], _ptr_array(opos), _lib.ptr(osh), _stream(x.device)), "ud_mpm_finish_bwd")
+        return (ox, ov, oC, oF, None, osh, None, *opos)
+
+
+def mpm_focus(center, x, positions):
+    out = FocusFn.apply(tuple(float(c) for c in center), x, *positions)
+    return out[0], out[1], list(out[2:])
+
+
+def mpm_finish(x, v, Cm, F, J, shift, goal, positions):
+    out = FinishFn.apply(x, v, Cm, F, J, shift, goal, *positions)
+    return out[:5], out[5], out[6], list(out[7:])
