@@ -114,7 +114,8 @@ def touched_cells(x, n_grid=64):
 def bench_whip_rope(args, rank, world, device, name="whip_rope"):
     """Secondary lines: the APG update (policy, ep_len x step_diff, loss, backward, clip, Adam) on an MPM env, 32 envs per GPU,
     ep_len 3.  whip_rope: N=67, res 32^3, 70 substeps/step, one workgroup per env.  pour_water: 702 liquid particles, two bowls
-    with the container SDF in soft-contact mode, res 26x20x26, 23 substeps/step, many-workgroup path."""
+    with the container SDF in soft-contact mode, res 26x20x26, 23 substeps/step, many-workgroup path.  pour_soup: the same bowls at
+    n_grid 128 (res 128x64x128, 25 substeps/step) with 7631 particles of mixed material per env."""
     from unidom_amd.algorithms.apg.core import APG
     from unidom_amd.envs.registration import env_functions
     from unidom_amd.utils import prng
@@ -170,7 +171,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
                          "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
-                         else "latency bound: small kernels on 32 x 702 particles, two env groups on two streams"}}), flush=True)
+                         else f"latency bound: small kernels on {B} x {N} particles" + (", two env groups on two streams" if B * N <= 200000 else "")}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -491,7 +492,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water", "pour_soup"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
@@ -520,8 +521,8 @@ def main():
         return bench_mpm_scaled(args, rank, world, device)
     if args.workload == "whip_rope":
         return bench_whip_rope(args, rank, world, device)
-    if args.workload == "pour_water":
-        return bench_whip_rope(args, rank, world, device, name="pour_water")
+    if args.workload in ("pour_water", "pour_soup"):
+        return bench_whip_rope(args, rank, world, device, name=args.workload)
 
     global NUM_ENVS_PER_GPU
     para = args.workload == "fold_cloth1_para"

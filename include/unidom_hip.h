@@ -236,7 +236,8 @@ int ud_cloth_pnp_bwd(int B, int P, const float* actions, const float* x, const f
  *                    x_out = x + shift; prim_pos_out[p] = prim_pos[p] + shift for the n_prim (<= 4) primitive
  *                    trajectories [B,S,3].  prim_pos / prim_pos_out are HOST arrays of n_prim device pointers.
  *   ud_mpm_finish_*  post_step :116-125 (x - shift, prim_pos - shift; shift NULL = no focus), nan_to_num on x v C F J
- *                    :150-154, reward_func :90-94 = e ** (-10 * mean_n sqrt(mean_xyz((x - goal)^2))) with goal [N,3],
+ *                    :150-154, reward_func :90-94 = e ** (-10 * mean_n sqrt(mean_xyz((x - goal)^2))) with goal [Q,3], Q = N or 1
+ *                    (calc_l2 broadcasts; a missing goal file is zeros((1,3)), mpm_env.py:46-48),
  *                    get_obs :57-76: obs [B, 6N + 3S] = x | v | primitive 0 trajectory.
  * Backward entry points: any cotangent pointer (and any entry of g_prim_pos_out) may be NULL = that output was unused.
  * nan_to_num passes a cotangent only where its argument was finite (jnp.where selection).  ud_mpm_focus_bwd does not
@@ -246,12 +247,12 @@ int ud_mpm_focus_fwd(int B, int N, int n_prim, int S, float cx, float cz, const 
                      float* x_out, float* const* prim_pos_out, float* shift, void* stream);
 int ud_mpm_focus_bwd(int B, int N, int n_prim, int S, const float* g_x_out, const float* const* g_prim_pos_out,
                      const float* g_shift, float* g_x, void* stream);
-int ud_mpm_finish_fwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F,
+int ud_mpm_finish_fwd(int B, int N, int n_prim, int S, int Q, const float* x, const float* v, const float* C, const float* F,
                       const float* J, const float* shift, const float* const* prim_pos, const float* goal, float* x_out,
                       float* v_out, float* C_out, float* F_out, float* J_out, float* const* prim_pos_out, float* reward,
                       float* obs, void* stream);
 /* shift and g_shift are both NULL or both given; g_shift [B,3] = -(sum of every shifted cotangent) */
-int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F,
+int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, int Q, const float* x, const float* v, const float* C, const float* F,
                       const float* shift, const float* goal, const float* reward, const float* g_x_out, const float* g_v_out,
                       const float* g_C_out, const float* g_F_out, const float* const* g_prim_pos_out, const float* g_reward,
                       const float* g_obs, float* g_x, float* g_v, float* g_C, float* g_F, float* const* g_prim_pos,

@@ -143,6 +143,17 @@ def main():
     np.save(f"{REPO}/unidom_amd/envs/others/tshirt_mask.npy", tmask)
     print("fold_tshirt mask", tmask.shape, int(tmask.sum()))
 
+    # ---- pour_soup vegetable point cloud (input of reset: pour_soup_env.py:152-159) -----------------------------------
+    # core/engine/pyrender/models/veg/model.pcd, PCD v0.7 binary: 8161 points x {rgb, normal xyz, x y z, 4 pad bytes}.  The env reads
+    # it with open3d; here the xyz columns are kept as a data file and the env restates open3d's voxel_down_sample in numpy.
+    raw = open(f"{REF}/core/engine/pyrender/models/veg/model.pcd", "rb").read()
+    start = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    assert b"FIELDS rgb normal_x normal_y normal_z x y z _" in raw[:start] and b"POINTS 8161" in raw[:start]
+    rec = np.dtype([("rgb", "<f4"), ("n", "<f4", 3), ("xyz", "<f4", 3), ("pad", "u1", 4)])
+    veg = np.frombuffer(raw[start:start + 8161 * rec.itemsize], dtype=rec)["xyz"].copy()
+    np.save(f"{REPO}/unidom_amd/envs/others/veg_points.npy", veg)
+    print("pour_soup veg cloud", veg.shape, veg.min(0), veg.max(0))
+
     # goals of the sibling envs on the same kernels (data files: inputs of their reward)
     for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "shape_rope", "pour_water"):
         src = f"{REF}/core/envs/goals/{task}/goal.npy"

@@ -86,3 +86,25 @@ def test_set_sdf_records_the_kind_per_reset():
         assert get_sdf_kind() == "box"
     finally:
         set_sdf(box_sdf)
+
+
+def test_pour_soup_vegetable_voxel_down_sample():
+    """pour_soup_env.py:152-159: open3d's voxel_down_sample(0.5) restated in numpy.  The reference hard-codes observation_size
+    45861 = N*6 + 25*3 -> N = 7631 = 2877 (soup) + 2*343 (tofu) + 4068: the vegetable must come out as 4068 points."""
+    from unidom_amd.envs.pour_soup_env import DefaultConf, voxel_down_sample
+    conf = DefaultConf()
+    assert conf.steps == 25 and tuple(conf.res) == (128, 64, 128)
+    pts = np.load(conf.veg_path)
+    assert pts.shape == (8161, 3) and pts.dtype == np.float32
+    out = voxel_down_sample(pts, 0.5)
+    assert out.shape == (4068, 3) and out.dtype == np.float64
+    assert (45861 - conf.steps * 3) // 6 == int(0.07 ** 3 * conf.n_grid ** 3 * 4) + 2 * 7 ** 3 + out.shape[0]
+    # each output is the mean of the points of one voxel of the grid anchored at min_bound - voxel/2
+    origin = pts.astype(np.float64).min(0) - 0.25
+    vo = np.floor((out - origin) / 0.5).astype(np.int64)
+    assert len(np.unique(vo, axis=0)) == len(vo)                                  # one point per voxel, each inside its own voxel
+    vi = np.floor((pts.astype(np.float64) - origin) / 0.5).astype(np.int64)
+    k = 1234
+    np.testing.assert_allclose(out[k], pts[(vi == vo[k]).all(1)].astype(np.float64).mean(0), rtol=0, atol=1e-12)
+    tiny = voxel_down_sample(np.array([[0.0, 0, 0], [0.1, 0, 0], [0.9, 0, 0]]), 0.5)   # voxels [-.25,.25) and [.75,1.25) along x
+    np.testing.assert_allclose(tiny, [[0.05, 0, 0], [0.9, 0, 0]])

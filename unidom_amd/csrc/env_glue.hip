@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(GLUE_T) mpm_focus_bwd_kernel(int N, int S, int
   for (int i = tid; i < N * 3; i += GLUE_T) o[i] = (gb ? gb[i] : 0.f) - t[i % 3];
 }
 
-__global__ void __launch_bounds__(GLUE_T) mpm_finish_fwd_kernel(int N, int S, int n_prim, const float* __restrict__ x, const float* __restrict__ v,
+__global__ void __launch_bounds__(GLUE_T) mpm_finish_fwd_kernel(int N, int S, int n_prim, int Q, const float* __restrict__ x, const float* __restrict__ v,
                                                                 const float* __restrict__ Cm, const float* __restrict__ F,
                                                                 const float* __restrict__ J, const float* __restrict__ shift, PrimIn pin,
                                                                 const float* __restrict__ goal, float* __restrict__ xo, float* __restrict__ vo,
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_fwd_kernel(int N, int S, in
     for (int d = 0; d < 3; ++d) {
       const float xv = nan_to_num(x[o3 + n * 3 + d] - sh[d]);
       xo[o3 + n * 3 + d] = xv; ob[n * 3 + d] = xv;
-      const float df = xv - goal[n * 3 + d];
+      const float df = xv - goal[(Q == 1 ? 0 : n) * 3 + d];   // calc_l2 broadcasts a one-row goal
       m += df * df;
       const float vv = nan_to_num(v[o3 + n * 3 + d]);
       vo[o3 + n * 3 + d] = vv; ob[3 * N + n * 3 + d] = vv;
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_fwd_kernel(int N, int S, in
 
 // nan_to_num passes the cotangent where its argument was finite and nothing elsewhere (jnp.where selection: a NaN
 // cotangent does not leak through a replaced entry)
-__global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, int n_prim, const float* __restrict__ x, const float* __restrict__ v,
+__global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, int n_prim, int Q, const float* __restrict__ x, const float* __restrict__ v,
                                                                 const float* __restrict__ Cm, const float* __restrict__ F,
                                                                 const float* __restrict__ shift, const float* __restrict__ goal,
                                                                 const float* __restrict__ reward, const float* __restrict__ g_xo,
@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, in
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       xs[d] = x[o3 + n * 3 + d] - sh[d];
-      df[d] = nan_to_num(xs[d]) - goal[n * 3 + d];
+      df[d] = nan_to_num(xs[d]) - goal[(Q == 1 ? 0 : n) * 3 + d];
       m += df[d] * df[d];
     }
     const float dn = sqrtf(m / 3.0f);
@@ -435,33 +435,33 @@ int ud_mpm_focus_bwd(int B, int N, int n_prim, int S, const float* g_x_out, cons
   return UD_OK;
 }
 
-int ud_mpm_finish_fwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F, const float* J,
+int ud_mpm_finish_fwd(int B, int N, int n_prim, int S, int Q, const float* x, const float* v, const float* C, const float* F, const float* J,
                       const float* shift, const float* const* prim_pos, const float* goal, float* x_out, float* v_out, float* C_out,
                       float* F_out, float* J_out, float* const* prim_pos_out, float* reward, float* obs, void* stream) {
   if (B <= 0 || N <= 0 || S <= 0 || !x || !v || !C || !F || !J || !goal || !x_out || !v_out || !C_out || !F_out || !J_out || !reward ||
-      !obs || n_prim < 1 || !prim_args_ok(n_prim, prim_pos, false) || !prim_args_ok(n_prim, (const float* const*)prim_pos_out, false)) {
+      !obs || n_prim < 1 || (Q != N && Q != 1) || !prim_args_ok(n_prim, prim_pos, false) || !prim_args_ok(n_prim, (const float* const*)prim_pos_out, false)) {
     set_error("ud_mpm_finish_fwd: bad argument"); return UD_ERR_INVALID;
   }
   PrimIn pi{}; PrimOut po{};
   for (int p = 0; p < n_prim; ++p) { pi.p[p] = prim_pos[p]; po.p[p] = prim_pos_out[p]; }
-  hipLaunchKernelGGL(mpm_finish_fwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, x, v, C, F, J, shift, pi, goal,
+  hipLaunchKernelGGL(mpm_finish_fwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, Q, x, v, C, F, J, shift, pi, goal,
                      x_out, v_out, C_out, F_out, J_out, po, reward, obs);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;
 }
 
-int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, const float* x, const float* v, const float* C, const float* F, const float* shift,
+int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, int Q, const float* x, const float* v, const float* C, const float* F, const float* shift,
                       const float* goal, const float* reward, const float* g_x_out, const float* g_v_out, const float* g_C_out,
                       const float* g_F_out, const float* const* g_prim_pos_out, const float* g_reward, const float* g_obs, float* g_x,
                       float* g_v, float* g_C, float* g_F, float* const* g_prim_pos, float* g_shift, void* stream) {
-  if (B <= 0 || N <= 0 || S <= 0 || !x || !v || !C || !F || !goal || !reward || !g_x || !g_v || !g_C || !g_F || n_prim < 1 ||
+  if (B <= 0 || N <= 0 || S <= 0 || !x || !v || !C || !F || !goal || !reward || !g_x || !g_v || !g_C || !g_F || n_prim < 1 || (Q != N && Q != 1) ||
       !prim_args_ok(n_prim, g_prim_pos_out, true) || !prim_args_ok(n_prim, (const float* const*)g_prim_pos, false) ||
       ((shift == nullptr) != (g_shift == nullptr))) {
     set_error("ud_mpm_finish_bwd: bad argument"); return UD_ERR_INVALID;
   }
   PrimIn gi{}; PrimOut go{};
   for (int p = 0; p < n_prim; ++p) { gi.p[p] = g_prim_pos_out[p]; go.p[p] = g_prim_pos[p]; }
-  hipLaunchKernelGGL(mpm_finish_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, x, v, C, F, shift, goal, reward,
+  hipLaunchKernelGGL(mpm_finish_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, Q, x, v, C, F, shift, goal, reward,
                      g_x_out, g_v_out, g_C_out, g_F_out, gi, g_reward, g_obs, g_x, g_v, g_C, g_F, go, g_shift);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;

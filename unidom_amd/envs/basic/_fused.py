@@ -138,14 +138,15 @@ class FinishFn(torch.autograd.Function):
         shift = None if shift is None else _f32(shift)
         pos = [_f32(p) for p in pos]
         B, N, S = x.shape[0], x.shape[1], pos[0].shape[1]
-        if goal.shape != (N, 3):
-            raise _lib.UnidomError(f"reward_func: goal {tuple(goal.shape)} does not match the {N} particles of the state")
+        if goal.shape not in ((N, 3), (1, 3)):
+            raise _lib.UnidomError(f"reward_func: goal {tuple(goal.shape)} does not broadcast against the {N} particles of the state")
+        Q = goal.shape[0]
         xo, vo, Co, Fo, Jo = (torch.empty_like(t) for t in (x, v, Cm, F, J))
         po = [torch.empty_like(p) for p in pos]
         reward = torch.empty((B,), dtype=torch.float32, device=x.device)
         obs = torch.empty((B, 6 * N + 3 * S), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().ud_mpm_finish_fwd(
-            C.c_int(B), C.c_int(N), C.c_int(len(pos)), C.c_int(S), *[_lib.ptr(t) for t in (x, v, Cm, F, J, shift)], _ptr_array(pos),
+            C.c_int(B), C.c_int(N), C.c_int(len(pos)), C.c_int(S), C.c_int(Q), *[_lib.ptr(t) for t in (x, v, Cm, F, J, shift)], _ptr_array(pos),
             _lib.ptr(goal), *[_lib.ptr(t) for t in (xo, vo, Co, Fo, Jo)], _ptr_array(po), _lib.ptr(reward), _lib.ptr(obs),
             _stream(x.device)), "ud_mpm_finish_fwd")
         ctx.save_for_backward(x, v, Cm, F, shift, goal, reward)
@@ -164,7 +165,7 @@ class FinishFn(torch.autograd.Function):
         opos = [torch.empty((B, S, 3), dtype=torch.float32, device=x.device) for _ in range(P)]
         osh = None if shift is None else torch.empty((B, 3), dtype=torch.float32, device=x.device)
         _lib.check(_lib.lib().ud_mpm_finish_bwd(
-            C.c_int(B), C.c_int(N), C.c_int(P), C.c_int(S), *[_lib.ptr(t) for t in (x, v, Cm, F, shift, goal, reward)],
+            C.c_int(B), C.c_int(N), C.c_int(P), C.c_int(S), C.c_int(goal.shape[0]), *[_lib.ptr(t) for t in (x, v, Cm, F, shift, goal, reward)],
             *[_lib.ptr(t) for t in (g_x, g_v, g_C, g_F)], _ptr_array(g_po), _lib.ptr(g_reward), _lib.ptr(g_obs),
             *[_lib.ptr(t) for t in (ox, ov, oC, oF)], _ptr_array(opos), _lib.ptr(osh), _stream(x.device)), "ud_mpm_finish_bwd")
         return (ox, ov, oC, oF, None, osh, None, *opos)

@@ -2,8 +2,8 @@
 (/root/reference/DaXBench/daxbench/core/envs/registration.py:13-27).  fold_cloth3 / unfold_cloth1 / unfold_cloth3 are
 the same 512-particle cloth and the same kernels under other confs; shape_rope / shape_rope_hard run the MPM kernels
 in soft-contact mode with the plastic material.  pour_water adds the liquid material, two primitives and the container SDF.
-fold_tshirt (3573 particles) runs the several-particles-per-lane cloth kernels.  The one remaining reference env, pour_soup,
-needs an open3d point-cloud asset the reference loads at reset and is absent from the registry."""
+fold_tshirt (3573 particles) runs the several-particles-per-lane cloth kernels.  pour_soup is pour_water at n_grid 128 with a mixed
+cloud of 7631 particles (liquid, two tofu blocks, a vegetable point cloud).  That is every key of the reference's registry."""
 from .fold_cloth1_env import FoldCloth1Env
 from .fold_cloth1_para_env import FoldCloth1ParaEnv
 from .fold_cloth3_env import FoldCloth3Env
@@ -24,9 +24,11 @@ try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
     from .shape_rope_env import ShapeRopeEnv
     from .shape_rope_hard_env import ShapeRopeHardEnv
     from .pour_water_env import PourWaterEnv
+    from .pour_soup_env import PourSoupEnv
     env_functions["whip_rope"] = WhipRopeEnv
-    env_functions["shape_rope"] = ShapeRopeEnv
-    env_functions["shape_rope_hard"] = ShapeRopeHardEnv
+    env_functions["shape_rope"] = env_functions["push_rope"] = ShapeRopeEnv                  # both names, registration.py:18-21
+    env_functions["shape_rope_hard"] = env_functions["push_rope_hard"] = ShapeRopeHardEnv
     env_functions["pour_water"] = PourWaterEnv
+    env_functions["pour_soup"] = PourSoupEnv
 except ImportError:  # pragma: no cover
     pass
