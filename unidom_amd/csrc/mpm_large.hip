@@ -139,7 +139,8 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
 // it avoids (measured, n_grid 256: 2048 slots 47.8 k substeps/s, 512 slots 69 k).
 template <int LANES> struct LgTable { static constexpr int LOGH = LANES == 4 ? 9 : LG_LOGH1, H = 1 << LOGH; };
 // staged values are float64: ds_add_f32 retires ~20x slower than ds_add_f64 on gfx950 (tools/ubench_lds_atomic.hip)
-struct BlockTable { int* key; double* val; };   // key[H], val[H*4]
+// val is component-major ([4][H]): slot-major rows of 4 doubles (32 B) put the 64 lanes of one ds_add_f64 on 8 of the 64 banks
+struct BlockTable { int* key; double* val; };   // key[H], val[4][H]
 
 // The particle kernels use the small path's lane mapping: lane = 4*particle + q, the quad splits the 27 stencil cells
 // 7/7/7/6 and reduces with DPP.  One lane per particle left the chip mostly idle (N = 798, 32 envs: 400 waves on
@@ -172,7 +173,7 @@ template <int H>
 __device__ __forceinline__ void bt_clear(const BlockTable& t) {
   for (int s = threadIdx.x; s < H; s += blockDim.x) {
     t.key[s] = -1;
-    t.val[s * 4] = 0.0; t.val[s * 4 + 1] = 0.0; t.val[s * 4 + 2] = 0.0; t.val[s * 4 + 3] = 0.0;
+    t.val[s] = 0.0; t.val[H + s] = 0.0; t.val[2 * H + s] = 0.0; t.val[3 * H + s] = 0.0;
   }
 }
 
@@ -195,7 +196,7 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
 template <int H, int LOGH>
 __device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, int cell, int comp, float v) {
   const int s = bt_slot<H, LOGH>(t, cell);
-  if (s >= 0) __hip_atomic_fetch_add(&t.val[s * 4 + comp], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (s >= 0) __hip_atomic_fetch_add(&t.val[comp * H + s], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else atomicAdd(global_cell + comp, v);
 }
 
@@ -275,15 +276,20 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
 #pragma unroll
       for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
     }
+    // Sorted (or lattice-seeded) neighbours share their base cell: walking the stencil in the same order, the lanes of such a run
+    // would hit ONE table slot at a time, and same-address LDS atomics serialise (pour_soup's vegetable cloud has ~26 particles
+    // per cell: the 27-cell walk was 128 of this kernel's 158 us).  Each particle starts its walk at a different cell instead.
+    const int rot = (p * LANES) % 27;
 #pragma unroll 1
-    for (int cidx = qi; cidx < ((UD_MPM_ABLATE & 64) ? 1 : 27); cidx += LANES) {
+    for (int it = qi; it < ((UD_MPM_ABLATE & 64) ? 1 : 27); it += LANES) {
+      const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
       const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
       const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
       const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
       const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
       if (sc >= 0) {
         const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-        const int sl = bt_slot<TH, TLOG>(bt, sc);
+        const int sl = (UD_MPM_ABLATE & 512) ? (int)lg_hash<TLOG>(sc) : bt_slot<TH, TLOG>(bt, sc);   // 512: timing only, no probing
         float contrib[4];
         contrib[0] = weight * c.p_mass;
 #pragma unroll
@@ -291,9 +297,11 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
           const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
           contrib[1 + r] = weight * (c.p_mass * v[r] + ad);
         }
-        if (sl >= 0) {
+        if (UD_MPM_ABLATE & 256) {          // timing only: the arithmetic without the LDS atomics
+          if (contrib[0] + contrib[1] + contrib[2] + contrib[3] == 1.2345e30f) bt.val[sl] = 1.0;
+        } else if (sl >= 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&bt.val[sl * 4 + r], (double)contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&bt.val[r * TH + sl], (double)contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         } else {   // block table full: straight to HBM
           float* cell = (float*)(val + cell_lin(c, sc));
 #pragma unroll
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     const long lin = cell_lin(c, key);
     float* cell = (float*)(val + lin);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[sl * 4 + r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
     if (atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
   }
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
@@ -665,8 +673,10 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 #pragma unroll
   for (int d = 0; d < 9; ++d) gw[d] = 0.f;
   const float4* vel = a.w.vel + (long)b * a.G;
+  const int rot = (p * LANES) % 27;   // staggered stencil walk, as in lg_p2g: no two lanes of a run on the same table slot
 #pragma unroll 1
-  for (int cidx = qi; cidx < 27; cidx += LANES) {
+  for (int it = qi; it < 27; it += LANES) {
+    const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
     const float weight = wi * wj * wk;
@@ -709,7 +719,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     if (key < 0) continue;
     float* cell = (float*)(gacc + cell_lin(c, key));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, (float)bt.val[sl * 4 + r]);
+    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
   }
 }
 

@@ -178,10 +178,10 @@ __device__ __forceinline__ double plb_quad_sum(double v) {
 template <int LANES>
 __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   __shared__ int s_key[PLB_H];
-  __shared__ double s_val[PLB_H * 4];
+  __shared__ double s_val[PLB_H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s * 4] = 0; s_val[s * 4 + 1] = 0; s_val[s * 4 + 2] = 0; s_val[s * 4 + 3] = 0; }
+  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
   __syncthreads();
   double* val = a.w.val + (long)b * a.G * 4;
   if (p < c.N) {
@@ -242,8 +242,10 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
     const double sc = -c.dt * c.p_vol * 4 * c.inv_dx * c.inv_dx;
 #pragma unroll
     for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
+    const int rot = (p * LANES) % 27;   // staggered stencil walk (see lg_p2g, mpm_large.hip): neighbours never on the same slot at once
 #pragma unroll 1
-    for (int cidx = qi; cidx < 27; cidx += LANES) {
+    for (int it = qi; it < 27; it += LANES) {
+      const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
       const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
       const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
       const double dp0 = ((double)i - fx[0]) * c.dx, dp1 = ((double)j - fx[1]) * c.dx, dp2 = ((double)k - fx[2]) * c.dx;
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
       }
       if (slot >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&s_val[slot * 4 + r], contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&s_val[r * PLB_H + slot], contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) atomicAdd(val + lin * 4 + r, contrib[r]);
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
     const int key = s_key[threadIdx.x + u * 256];
     if (key < 0) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[(threadIdx.x + u * 256) * 4 + r]);
+    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[r * PLB_H + threadIdx.x + u * 256]);
     if (atomicExch(&a.w.stamp[(long)b * a.G + key], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
   }
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
