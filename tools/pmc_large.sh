@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 counter passes over a large-path workload (one counter group per pass, kernel trace only), summarised per kernel.
+# usage (GPU box): W=pour_soup bash tools/pmc_large.sh
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+W=${W:-pour_soup}
+i=0
+for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1)); rm -rf gpurun_out/pmc_$i; mkdir -p gpurun_out/pmc_$i
+  timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace -d gpurun_out/pmc_$i -o p -f csv -- python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i/log 2>&1 || echo "pass $i ($G) failed"
+done
+python3 - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc_*/p_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ud::", "")
+        if k.startswith("lg_"):
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE"]
+with open("gpurun_out/pmc_large_summary.csv", "w") as o:
+    o.write("kernel,launches," + ",".join(names) + "\n")
+    for k in sorted(acc):
+        n = max(len(v) for v in acc[k].values())
+        o.write(k + "," + str(n) + "," + ",".join("%.4g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in names) + "\n")
+print(open("gpurun_out/pmc_large_summary.csv").read())
+PY

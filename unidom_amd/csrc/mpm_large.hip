@@ -193,11 +193,52 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
   return -1;
 }
 
+// ---- block window: the table addressed directly --------------------------------------------------------
+// The particles of a block are spatial neighbours (lattice order, or sort_particles), so their stencils often fit a small box:
+// when the block's base cells span at most 6 per axis the table IS the 8x8x8 cells starting at the smallest base cell,
+// slot = offset inside it -- no key compare, no CAS, nothing returned from LDS inside the walk.  A block whose particles are
+// spread wider keeps the open-addressing table above.  Measured (tools/abl_p2g.sh, window forced on / off): n_grid-256 rope
+// lg_p2g 83.8 us with the hash only, 76.9 us adaptive; pour_soup 107 either way (few of its blocks qualify), and 161 us with the
+// window forced on (cells outside it go to HBM atomics) -- hence the per-block choice.
+struct BlockWin { int on, ox, oy, oz; };
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
+  return v;
+}
+// every thread of the block calls this (it holds the barrier that also publishes bt_clear)
+__device__ __forceinline__ BlockWin bt_window(const MpmConst& c, bool live, const int* base) {
+  __shared__ int s_lo[3], s_hi[3];
+  if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = 0x7fffffff; }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int bw = base[d] + ((base[d] < 0) ? c.res[d] : 0);     // negatives wrap (Q9): far from the rest, such a block keeps the hash
+    const int lo = wave_min_i(live ? bw : 0x7fffffff), nhi = wave_min_i(live ? -bw : 0x7fffffff);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&s_lo[d], lo); atomicMin(&s_hi[d], nhi); }
+  }
+  __syncthreads();
+  BlockWin w;
+  w.ox = s_lo[0]; w.oy = s_lo[1]; w.oz = s_lo[2];
+  w.on = (s_lo[0] != 0x7fffffff) && (-s_hi[0] - s_lo[0] <= 5) && (-s_hi[1] - s_lo[1] <= 5) && (-s_hi[2] - s_lo[2] <= 5);
+  if (UD_MPM_ABLATE & 1024) w.on = 1;   // timing only: window forced on (outside cells go to HBM atomics) / off
+  if (UD_MPM_ABLATE & 2048) w.on = 0;
+  return w;
+}
+// slot of a packed cell key inside the window (LgTable<>::H == 512), or -1 outside (clamped / wrapped stencil cells)
+__device__ __forceinline__ int bt_win_slot(const BlockWin& w, int key) {
+  const unsigned rx = (unsigned)((key & 1023) - w.ox), ry = (unsigned)(((key >> 10) & 1023) - w.oy), rz = (unsigned)(((key >> 20) & 1023) - w.oz);
+  return ((rx | ry | rz) < 8u) ? (int)(rx | (ry << 3) | (rz << 6)) : -1;
+}
 template <int H, int LOGH>
-__device__ __forceinline__ void bt_add(const BlockTable& t, float* global_cell, int cell, int comp, float v) {
-  const int s = bt_slot<H, LOGH>(t, cell);
-  if (s >= 0) __hip_atomic_fetch_add(&t.val[comp * H + s], (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else atomicAdd(global_cell + comp, v);
+__device__ __forceinline__ int bt_find(const BlockTable& t, const BlockWin& w, int cell) {
+  static_assert(H == 512, "the block window is 8x8x8 slots");
+  if (w.on) {
+    const int s = bt_win_slot(w, cell);
+    if (s >= 0) t.key[s] = cell;           // every writer stores the same value; the flush reads it after the barrier
+    return s;
+  }
+  return bt_slot<H, LOGH>(t, cell);
 }
 
 // ---- forward kernels ---------------------------------------------------------------------------------
@@ -263,12 +304,14 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   bt_clear<TH>(bt);
-  __syncthreads();
   float4* val = a.w.val + (long)b * a.G;
-  if (p < c.N) {
-    float x[3], v[3], Cm[9], F[9];
+  const bool live = p < c.N;
+  Pre q;
+  float v[3] = {0.f, 0.f, 0.f};
+  q.base[0] = q.base[1] = q.base[2] = 0;
+  if (live) {
+    float x[3], Cm[9], F[9];
     load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
-    Pre q;
     const int up = user_index(a, b, p);
     particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr);
     if (store_F && qi == 0) {
@@ -276,9 +319,59 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
 #pragma unroll
       for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
     }
-    // Sorted (or lattice-seeded) neighbours share their base cell: walking the stencil in the same order, the lanes of such a run
-    // would hit ONE table slot at a time, and same-address LDS atomics serialise (pour_soup's vegetable cloud has ~26 particles
-    // per cell: the 27-cell walk was 128 of this kernel's 158 us).  Each particle starts its walk at a different cell instead.
+  }
+  const BlockWin win = bt_window(c, live, q.base);
+  if (live) {
+    // The walk is staggered -- each particle starts at a different cell / column -- so that the lanes of a run of particles
+    // sharing a base cell (sorted or lattice-seeded neighbours; pour_soup's vegetable cloud has ~26 per cell) never add to the
+    // same table slot at once.
+    // Measured on pour_soup, 32 envs x 7631 particles (tools/abl_p2g.sh, tools/pmc_large.sh, profiles/r01i_pmc_large_pour_soup.csv):
+    // with one stencil cell instead of 27 this kernel takes 30 us, with 27 it took 158: staggering the walk and the
+    // component-major table brought 107, the block window nothing here (the liquid's blocks span more than 6 cells and keep the
+    // hash) but 8 % on the lattice-seeded ropes, the fast walk below 97 (rope at n_grid 256: step forward 9.2 -> 8.5 ms).
+    // Of the 97 us the table atomics are ~4 and the flush ~19; the counters say 3.1 k VALU + 1.4 k SALU + 244 LDS instructions per
+    // wave -- VALU issue is about a quarter of the duration, LDS busy + bank conflicts about a fifth.  What bounds the rest
+    // (3.75 waves per SIMD in a single round: latency of the state loads, the SVD chain and the flush's HBM atomics) is not
+    // separated yet.
+    // Fast walk: when the block window is on and the particle's stencil is interior (no wrap, drop or clamp on any axis), the
+    // 27 cells are slot0 + i + 8 j + 64 k / key0 + i + (j << 10) + (k << 20): nine (i, j) columns walked dynamically, the three k
+    // cells of a column unrolled with their weights and affine terms hoisted.
+    const bool interior = win.on && !(UD_MPM_ABLATE & 64) && q.base[0] >= 0 && q.base[1] >= 0 && q.base[2] >= 0 &&
+                          q.base[0] + 2 < c.res[0] && q.base[1] + 2 < c.res[1] && q.base[2] + 2 < c.res[2];
+    if (interior) {
+      const int key0 = q.base[0] | (q.base[1] << 10) | (q.base[2] << 20);
+      const int slot0 = (q.base[0] - win.ox) | ((q.base[1] - win.oy) << 3) | ((q.base[2] - win.oz) << 6);
+      float wz[3], az[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        wz[k] = q.w[k * 3 + 2];
+        const float dp2 = ((float)k - q.fx[2]) * c.dx;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) az[r * 3 + k] = q.affine[r * 3 + 2] * dp2;
+      }
+      const int rot9 = (p * LANES) % 9;
+#pragma unroll 1
+      for (int it = qi; it < 9; it += LANES) {
+        const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
+        const int i = col / 3, j = col - 3 * i;
+        const float wij = sel3(q.w, 0, i) * sel3(q.w, 1, j);
+        const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx;
+        float br[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) br[r] = c.p_mass * v[r] + q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1;
+        const int sl = slot0 + i + 8 * j, key = key0 + i + (j << 10);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float wgt = wij * wz[k];
+          bt.key[sl + 64 * k] = key + (k << 20);
+          __hip_atomic_fetch_add(&bt.val[sl + 64 * k], (double)(wgt * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl + 64 * k], (double)(wgt * (br[r] + az[r * 3 + k])), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    } else {
     const int rot = (p * LANES) % 27;
 #pragma unroll 1
     for (int it = qi; it < ((UD_MPM_ABLATE & 64) ? 1 : 27); it += LANES) {
@@ -289,7 +382,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
       const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
       if (sc >= 0) {
         const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
-        const int sl = (UD_MPM_ABLATE & 512) ? (int)lg_hash<TLOG>(sc) : bt_slot<TH, TLOG>(bt, sc);   // 512: timing only, no probing
+        const int sl = (UD_MPM_ABLATE & 512) ? (int)lg_hash<TLOG>(sc) : bt_find<TH, TLOG>(bt, win, sc);   // 512: timing only, no lookup
         float contrib[4];
         contrib[0] = weight * c.p_mass;
 #pragma unroll
@@ -310,6 +403,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
         }
       }
       if (gc != sc) touch(a, b, gc, cell_lin(c, gc));   // Q5: a clamped gather cell takes part with m = 0
+    }
     }
   }
   // flush: one global atomic per distinct cell and component.  Cells this substep sees for the first time (epoch stamp)
@@ -648,25 +742,29 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   bt_clear<TH>(bt);
-  __syncthreads();
   float4* gacc = a.w.gacc + (long)b * a.G;
-  if (p < c.N) {
+  const bool live = p < c.N;
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
-  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
-  float x[3], gx[3], gv[3], gC[9];
+  int base[3] = {0, 0, 0};
+  float fx[3], w[9];
+  if (live) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) { x[d] = hi[d * c.Np + p]; gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+    for (int d = 0; d < 3; ++d) {
+      const float xd = hi[d * c.Np + p];
+      base[d] = (int)(xd * c.inv_dx - 0.5f);
+      const float f = xd * c.inv_dx - (float)base[d];
+      fx[d] = f;
+      w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+    }
+  }
+  const BlockWin win = bt_window(c, live, base);
+  if (live) {
+  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gx[3], gv[3], gC[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
-  int base[3];
-  float fx[3], w[9];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    base[d] = (int)(x[d] * c.inv_dx - 0.5f);
-    const float f = x[d] * c.inv_dx - (float)base[d];
-    fx[d] = f;
-    w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
-  }
   float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
@@ -686,10 +784,13 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     const float4 v4 = vel[lin];
     const float vv[3] = {v4.x, v4.y, v4.z};
     float gwt = 0.f;
+    const int sl = bt_find<TH, TLOG>(bt, win, gkey);      // one lookup per cell (bt_add per component repeated it three times)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-      bt_add<TH, TLOG>(bt, (float*)(gacc + lin), gkey, r, weight * gnv[r] + 4.f * c.inv_dx * weight * gCd);
+      const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+      if (sl >= 0) __hip_atomic_fetch_add(&bt.val[r * TH + sl], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else atomicAdd((float*)(gacc + lin) + r, gcell);
       gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
