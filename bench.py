@@ -159,6 +159,8 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if name == "whip_rope" and B == 32 and os.path.exists(tj):
             traffic = json.load(open(tj)).get("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", {}).get("hbm_bytes_per_launch")
+        elif B == 32 and os.path.exists(tj):      # many-workgroup path: all kernels of one step call (tools/pmc_large.sh)
+            traffic = json.load(open(tj)).get(f"large_path:{name}:{dom}", {}).get("hbm_bytes_per_launch")
         print(json.dumps({
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,

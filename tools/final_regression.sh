@@ -1,0 +1,23 @@
+#!/bin/bash
+# end-of-round regression on the GPU box: the GPU test suite, then every bench line of profiles/README.md.  usage: TAG=r01i bash tools/final_regression.sh
+cd $GRAFT_REPO_ROOT
+TAG=${TAG:-r01i}; O=gpurun_out/final; rm -rf $O; mkdir -p $O
+timeout -k 10 900 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/${TAG}_gpu_tests.log; tail -2 $O/${TAG}_gpu_tests.log
+run() { name=$1; shift; timeout -k 10 300 python bench.py "$@" 2>$O/$name.err | tail -n 1 > $O/${TAG}_bench_line_$name.json
+  python - <<PY
+import json
+d = json.load(open("$O/${TAG}_bench_line_$name.json"))
+print("$name", round(d["value"]), "%.2f ms" % d["ms_per_step"], "frac %.4f" % d["roofline"]["frac"], d["roofline"].get("kernel_ms"), "traffic", d["roofline"].get("traffic"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+PY
+}
+run fold_cloth1
+run fold_cloth1_para_32envs --workload fold_cloth1_para --no-cpu-baseline
+run fold_tshirt --workload fold_tshirt --no-cpu-baseline
+run whip_rope --workload whip_rope
+run whip_rope_ngrid128 --workload whip_rope --n-grid 128 --no-cpu-baseline
+run whip_rope_ngrid256 --workload whip_rope --n-grid 256 --no-cpu-baseline
+run shape_rope --workload shape_rope
+run pour_water --workload pour_water
+run pour_soup --workload pour_soup
+run torus_ngrid64 --workload torus --n-grid 64
+run torus_ngrid128 --workload torus --n-grid 128
