@@ -242,15 +242,27 @@ __device__ __forceinline__ int bt_find(const BlockTable& t, const BlockWin& w, i
 }
 
 // ---- forward kernels ---------------------------------------------------------------------------------
+// The kernels over an env's active-cell list are launched for `cap` cells (the host does not know the count).  One 256-cell tile
+// per block meant ~51 k blocks per launch on pour_soup (cap = 54 N = 412 k cells per env, ~2-5 k of them active): lg_clear_fk and
+// lg_restore, a few stores per cell, took 15 and 21 us -- block dispatch.  The grid is LG_TILES times smaller now and block x walks
+// tiles x, x + gridDim.x, ... until one lies past the list: the active tiles (8-20 per env) still go to different blocks --
+// giving each block LG_TILES consecutive tiles put them all on one or two blocks per env and made lg_grid_adj 4x slower.
+constexpr int LG_TILES = 8;
+__host__ __device__ constexpr int lg_cell_blocks(int cap) { return (cap + 256 * LG_TILES - 1) / (256 * LG_TILES); }
+
 // clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
 __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
-  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y + a.b0;
   const int prev = (a.f + 1) & 1, cur = a.f & 1;   // works for f ascending (forward) and descending (backward)
   const int n = min(a.w.count[prev * a.B + b], a.cap);
-  if (t < n) {
-    const long lin = cell_lin(a.c, a.w.list[((long)prev * a.B + b) * a.cap + t]);
-    a.w.val[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (clear_bwd) a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < LG_TILES; ++u) {
+    const int t = (u * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (t - (int)threadIdx.x >= n) break;
+    if (t < n) {
+      const long lin = cell_lin(a.c, a.w.list[((long)prev * a.B + b) * a.cap + t]);
+      a.w.val[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (clear_bwd) a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   if (blockIdx.x == 0) {
     const int S = a.c.steps, f = a.f, tid = threadIdx.x;
@@ -442,8 +454,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
 }
 
 // grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
-__global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
-  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, int to_vel) {
   const int cur = a.f & 1;
   if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
@@ -485,6 +496,14 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
     } else if (a.status) {
       a.status[b] = 1;   // pool exhausted: the backward of this env is invalid (UD_ERR_OVERFLOW, reported like the LDS table's)
     }
+  }
+}
+__global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
+  const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+  for (int u = 0; u < LG_TILES; ++u) {
+    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    if (base >= n) break;
+    lg_grid_cell(a, b, base + threadIdx.x, to_vel);
   }
 }
 
@@ -828,8 +847,8 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 // It also zeroes the cotangent cells of substep f + 1 (just consumed by its p2g adjoint), and a last call with f = -1 does
 // only that for substep 0: the handle's gacc grid is all-zero again afterwards, which the recomputing backward relies on
 // (a handle may serve both modes: a step whose pool overflowed falls back to recomputing).
-__global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
-  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x, S = a.c.steps;
+__device__ __forceinline__ void lg_restore_tile(const LargeArgs& a, int b, int t) {
+  const int S = a.c.steps;
   const int* idx = gck_idx(a, b);
   if (a.f + 1 < S) {                                  // cells of substep f + 1: done with
     const int first = idx[a.f + 1], n = min(min(idx[a.f + 2], a.gck_budget) - first, a.cap);
@@ -841,7 +860,7 @@ __global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
   if (a.f < 0) return;
   const int cur = a.f & 1;
   const int first = idx[a.f], n = min(min(idx[a.f + 1], a.gck_budget) - first, a.cap);
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = max(n, 0);
+  if (t == 0) a.w.count[cur * a.B + b] = max(n, 0);
   if (t >= n) return;
   const float4* r = gck_pool(a, b) + (long)(first + t) * 2;
   const float4 r0 = r[0], r1 = r[1];
@@ -850,6 +869,19 @@ __global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
   a.w.list[((long)cur * a.B + b) * a.cap + t] = key;
   a.w.vel[(long)b * a.G + lin] = make_float4(r1.y, r1.z, r1.w, 0.f);
   a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
+  const int b = blockIdx.y + a.b0, S = a.c.steps;
+  const int* idx = gck_idx(a, b);                   // the longer of the two lists this launch walks (records of f + 1 and of f)
+  int n = 1;                                        // tile 0 always runs: it publishes the count
+  if (a.f + 1 < S) n = max(n, min(idx[a.f + 2], a.gck_budget) - idx[a.f + 1]);
+  if (a.f >= 0) n = max(n, min(idx[a.f + 1], a.gck_budget) - idx[a.f]);
+  n = min(n, a.cap);
+  for (int u = 0; u < LG_TILES; ++u) {
+    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    if (base >= n) break;
+    lg_restore_tile(a, b, base + threadIdx.x);
+  }
 }
 
 // (m, mv) of active cell t of substep f: from the grid checkpoint when there is one, else from the recomputed dense grid
@@ -863,9 +895,8 @@ __device__ __forceinline__ float4 cell_mass_momentum(const LargeArgs& a, int b, 
 }
 
 // grid-op adjoint over the active cells
-__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
-  __shared__ float red[4][UD_PRIMC_NGRAD];
-  const int b = blockIdx.y + a.b0, t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int tile_base, float (*red)[UD_PRIMC_NGRAD]) {
+  const int t = tile_base + threadIdx.x;
   const int cur = a.f & 1;
   const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
   if (a.c.position_control) {
@@ -892,7 +923,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   // ---- soft contact: collide_batch of each primitive in turn (forward), reversed here --------------------------------
   // The grid covers `cap` cells per env, most blocks hold no active cell: leave block-uniformly (safe for the barriers
   // below) before any of the collide arithmetic.
-  if ((int)(blockIdx.x * blockDim.x) >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  if (tile_base >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
   int ci = 0, cj = 0, ck = 0;
   long lin = 0;
@@ -968,6 +999,15 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
     float gmm;
     grid_head_adjoint(mv.x, mvv, g, gmm);
     a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+  }
+}
+__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
+  __shared__ float red[4][UD_PRIMC_NGRAD];
+  const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+  for (int u = 0; u < LG_TILES; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
+    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    if (base >= n) break;
+    lg_grid_adj_tile(a, b, base, red);
   }
 }
 
@@ -1355,7 +1395,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
       const int Bg = grp[g].Bg;
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
-      const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
+      const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
       if (f == S) { hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 0); continue; }   // restore the all-zero grid invariant
       hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 1, 0);
       if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
@@ -1415,7 +1455,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       const int Bg = grp[g].Bg;
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
-      const dim3 gc((L->cap + 255) / 256, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
+      const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
       if (gck) {          // the dense val grid is never touched: nothing to recompute; gacc is handed back all-zero
         hipLaunchKernelGGL(lg_restore, gc, blk, 0, s, a);
         if (f < 0) continue;
