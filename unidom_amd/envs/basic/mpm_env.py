@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 import weakref
 
 import numpy as np
@@ -81,7 +82,7 @@ class MPMEnv:
         self.step_diff = self.build_step_diff()
         self.step_diff_unfused = self.build_step_diff(fused=False)
         if not os.path.exists(conf.goal_path):
-            print("**************** Warning: goal file does not exist!")
+            print("**************** Warning: goal file does not exist!", file=sys.stderr)   # the reference prints it to stdout
             self.goal = torch.zeros((1, 3), device=self.device)
         else:
             self.goal = torch.tensor(np.load(conf.goal_path), dtype=torch.float32, device=self.device)
