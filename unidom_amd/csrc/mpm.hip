@@ -120,11 +120,16 @@ __device__ __forceinline__ bool cell_of(int q, int t, int& i, int& j, int& k) {
 }
 
 // LDS layout helpers
-// Cell slot s owns 32 bytes at acc[4s]: while p2g scatters they are four doubles (m, mv[3]); the grid op reads them and
-// rewrites the same bytes as floats {m, mv[3], vel[3], -} (accf = float view, 8 per slot).  In the adjoint gacc[3s..3s+2]
+// Cell slot s owns four doubles acc[a][s]: while p2g scatters they are (m, mv[3]); the grid op reads them and
+// rewrites the same bytes as floats {m, mv[3], vel[3], -} (accf = float view, 8 per slot).  In the adjoint gacc[0..2][s]
 // are doubles while the g2p adjoint scatters; the grid-op adjoint rewrites them as floats {g_mv[3], g_m, -, -} (6 per slot).
+// Component-major inside the table (acc[4][H], gacc[3][H]): with slot-major rows of 32 bytes the lanes of one ds_add_f64 (all
+// on the same component) land on 8 of the 64 banks.  Measured on whip_rope: 1 % (0.691 + 1.186 -> 0.684 + 1.175 ms per step) --
+// kept for consistency with mpm_large.hip, not because it matters.  The float overlay of double (a, s) is floats 2 (a H + s) + {0, 1}.
+#define ACC_D(H, s, a) ((a) * (H) + (s))
+#define ACC_F(H, s, k) ((((k) >> 1) * (H) + (s)) * 2 + ((k) & 1))
 struct Lds {
-  int* key; double* acc;             // [H], [4H]
+  int* key; double* acc;             // [H], [4][H]
   double* gacc;                      // bwd only: [3H]
   float* ppos; float* prot;          // [S*3], [S*4]
   float* ppin; float* gppos; double* gpv;  // bwd only: [S*3] each (gpv accumulates atomically -> double)
@@ -204,7 +209,7 @@ __device__ __forceinline__ bool p2g_lane(const MpmConst& c, const Lds& L, const 
       }
       if (quadrun_reduce<4>(ss, contrib)) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) lds_add(&L.acc[ss * 4 + a], contrib[a]);
+        for (int a = 0; a < 4; ++a) lds_add(&L.acc[ACC_D(c.H, ss, a)], contrib[a]);
       }
     }
   }
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
   const float hard = a.hard[cp];
   for (int e = tid; e < S * 3; e += nt) L.ppos[e] = a.ppos[(size_t)b * S * 3 + e];
   for (int e = tid; e < S * 4; e += nt) L.prot[e] = a.prot[(size_t)b * S * 4 + e];
-  for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0; }
+  for (int s = tid; s < H; s += nt) { L.key[s] = -1; L.acc[ACC_D(c.H, s, 0)] = 0.0; L.acc[ACC_D(c.H, s, 1)] = 0.0; L.acc[ACC_D(c.H, s, 2)] = 0.0; L.acc[ACC_D(c.H, s, 3)] = 0.0; }
   if (tid == 0) *L.count = 0;
   float pv[3], pw[3], psize[3];
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
     // ---- A: clear the cell table; compact lanes: land the previous g2p, checkpoint, particle pre-pass -> stage ----
     for (int e = tid, n = *L.count; e < n; e += nt) {   // clear the values of the slots seen so far
       const int s = L.list[e];
-      L.acc[s * 4] = 0.0; L.acc[s * 4 + 1] = 0.0; L.acc[s * 4 + 2] = 0.0; L.acc[s * 4 + 3] = 0.0;
+      L.acc[ACC_D(c.H, s, 0)] = 0.0; L.acc[ACC_D(c.H, s, 1)] = 0.0; L.acc[ACC_D(c.H, s, 2)] = 0.0; L.acc[ACC_D(c.H, s, 3)] = 0.0;
     }
     if (cwave) {
       if (f > 0) {
@@ -383,10 +388,10 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
         const int s = L.list[e];
         int ci, cj, ckk;
         decode_cell(c, L.key[s], ci, cj, ckk);
-        const float mm = (float)L.acc[s * 4];
-        float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+        const float mm = (float)L.acc[ACC_D(c.H, s, 0)];
+        float mvv[3] = {(float)L.acc[ACC_D(c.H, s, 1)], (float)L.acc[ACC_D(c.H, s, 2)], (float)L.acc[ACC_D(c.H, s, 3)]}, vo[3];
         grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
-        accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];   // same thread read the doubles above
+        accf[ACC_F(c.H, s, 4)] = vo[0]; accf[ACC_F(c.H, s, 5)] = vo[1]; accf[ACC_F(c.H, s, 6)] = vo[2];   // same thread read the doubles above
       }
     }
     __syncthreads();
@@ -400,7 +405,7 @@ __global__ void __launch_bounds__(512) mpm_step_fwd_kernel(MpmFwdArgs a) {
         const int gs = slots[t] & 0xffff;
         const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
         const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
-        const float g[3] = {accf[gs * 8 + 4], accf[gs * 8 + 5], accf[gs * 8 + 6]};
+        const float g[3] = {accf[ACC_F(c.H, gs, 4)], accf[ACC_F(c.H, gs, 5)], accf[ACC_F(c.H, gs, 6)]};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           nv[r] += weight * g[r];
@@ -517,8 +522,8 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.0; }
     for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
     for (int s = tid; s < H; s += nt) {
-      L.key[s] = -1; L.acc[s * 4] = 0.0;
-      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+      L.key[s] = -1; L.acc[ACC_D(c.H, s, 0)] = 0.0;
+      for (int d = 0; d < 3; ++d) { L.acc[ACC_D(c.H, s, 1 + d)] = 0.0; L.gacc[ACC_D(c.H, s, d)] = 0.0; }
     }
     if (tid == 0) *L.count = 0;
     // copy_frame adjoint: position[0] <- position[steps-1]
@@ -563,9 +568,9 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
     // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
     for (int e = tid, n = *L.count; e < n; e += nt) {
       const int s = L.list[e];
-      L.acc[s * 4] = 0.0;
+      L.acc[ACC_D(c.H, s, 0)] = 0.0;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+      for (int d = 0; d < 3; ++d) { L.acc[ACC_D(c.H, s, 1 + d)] = 0.0; L.gacc[ACC_D(c.H, s, d)] = 0.0; }
     }
     if (pend && tid < S * 3) { L.gppos[tid] = pend_val; L.gpv[tid] += (double)pend_pv; }
     __syncthreads();
@@ -593,11 +598,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       const int s = L.list[e];
       int ci, cj, ckk;
       decode_cell(c, L.key[s], ci, cj, ckk);
-      const float mm = (float)L.acc[s * 4];
-      float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+      const float mm = (float)L.acc[ACC_D(c.H, s, 0)];
+      float mvv[3] = {(float)L.acc[ACC_D(c.H, s, 1)], (float)L.acc[ACC_D(c.H, s, 2)], (float)L.acc[ACC_D(c.H, s, 3)]}, vo[3];
       grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
-      accf[s * 8] = mm; accf[s * 8 + 1] = mvv[0]; accf[s * 8 + 2] = mvv[1]; accf[s * 8 + 3] = mvv[2];   // raw values for the adjoint
-      accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];
+      accf[ACC_F(c.H, s, 0)] = mm; accf[ACC_F(c.H, s, 1)] = mvv[0]; accf[ACC_F(c.H, s, 2)] = mvv[1]; accf[ACC_F(c.H, s, 3)] = mvv[2];   // raw values for the adjoint
+      accf[ACC_F(c.H, s, 4)] = vo[0]; accf[ACC_F(c.H, s, 5)] = vo[1]; accf[ACC_F(c.H, s, 6)] = vo[2];
     }
     __syncthreads();
     // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
@@ -619,7 +624,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-          const float vel = accf[gs * 8 + 4 + r];
+          const float vel = accf[ACC_F(c.H, gs, 4 + r)];
           gsc[r] = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
           gwt += vel * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
@@ -627,7 +632,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
         }
         if (quadrun_reduce<3>(gs, gsc)) {
 #pragma unroll
-          for (int r = 0; r < 3; ++r) lds_add(&L.gacc[gs * 3 + r], gsc[r]);
+          for (int r = 0; r < 3; ++r) lds_add(&L.gacc[ACC_D(c.H, gs, r)], gsc[r]);
         }
         // gw[k*3+d]: select-accumulate (i, j, k are compile-time after unrolling only through cidx = q + 4t)
 #pragma unroll
@@ -644,16 +649,16 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
       const int s = L.list[e];
       int ci, cj, ckk;
       decode_cell(c, L.key[s], ci, cj, ckk);
-      const float m = accf[s * 8];
-      float mvv[3] = {accf[s * 8 + 1], accf[s * 8 + 2], accf[s * 8 + 3]};
-      float g[3] = {(float)L.gacc[s * 3], (float)L.gacc[s * 3 + 1], (float)L.gacc[s * 3 + 2]}, gmm, dfric, dpv[3];
+      const float m = accf[ACC_F(c.H, s, 0)];
+      float mvv[3] = {accf[ACC_F(c.H, s, 1)], accf[ACC_F(c.H, s, 2)], accf[ACC_F(c.H, s, 3)]};
+      float g[3] = {(float)L.gacc[ACC_D(c.H, s, 0)], (float)L.gacc[ACC_D(c.H, s, 1)], (float)L.gacc[ACC_D(c.H, s, 2)]}, gmm, dfric, dpv[3];
       const bool ctrl = grid_op_adjoint(c, pf, ci, cj, ckk, m, mvv, g, gmm, dfric, dpv);
       acc_fric += dfric;
       if (ctrl) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) lds_add(&L.gpv[f * 3 + d], dpv[d]);
       }
-      gaccf[s * 6] = g[0]; gaccf[s * 6 + 1] = g[1]; gaccf[s * 6 + 2] = g[2]; gaccf[s * 6 + 3] = gmm;   // same thread read the doubles
+      gaccf[ACC_F(c.H, s, 0)] = g[0]; gaccf[ACC_F(c.H, s, 1)] = g[1]; gaccf[ACC_F(c.H, s, 2)] = g[2]; gaccf[ACC_F(c.H, s, 3)] = gmm;   // same thread read the doubles
     }
     __syncthreads();
     // ---- F: p2g adjoint (gather) + particle pre-pass adjoint + FK adjoint ----
@@ -670,10 +675,10 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_kernel(MpmBwdArgs a) {
         const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
         const float weight = wi * wj * wk;
         const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
-        float gwt = c.p_mass * gaccf[ss * 6 + 3];
+        float gwt = c.p_mass * gaccf[ACC_F(c.H, ss, 3)];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-          const float gc = gaccf[ss * 6 + r];
+          const float gc = gaccf[ACC_F(c.H, ss, r)];
           const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
           gwt += gc * (c.p_mass * v[r] + ad);
           gvp[r] += weight * c.p_mass * gc;
@@ -853,8 +858,8 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
     for (int e = tid; e < S * 3; e += nt) { L.ppos[e] = tail[e]; L.ppin[e] = tail[S * 7 + e]; L.gpv[e] = 0.0; }
     for (int e = tid; e < S * 4; e += nt) L.prot[e] = tail[S * 3 + e];
     for (int s = tid; s < H; s += nt) {
-      L.key[s] = -1; L.acc[s * 4] = 0.0;
-      for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+      L.key[s] = -1; L.acc[ACC_D(c.H, s, 0)] = 0.0;
+      for (int d = 0; d < 3; ++d) { L.acc[ACC_D(c.H, s, 1 + d)] = 0.0; L.gacc[ACC_D(c.H, s, d)] = 0.0; }
     }
     if (tid == 0) *L.count = 0;
     for (int e = tid; e < S * 3; e += nt) {           // copy_frame adjoint: position[0] <- position[steps-1]
@@ -980,9 +985,9 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
       // ---- A: clear the table; land the FK-adjoint writes of the previous iteration ----
       for (int e = ft, n = *L.count; e < n; e += nS) {
         const int s = L.list[e];
-        L.acc[s * 4] = 0.0;
+        L.acc[ACC_D(c.H, s, 0)] = 0.0;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { L.acc[s * 4 + 1 + d] = 0.0; L.gacc[s * 3 + d] = 0.0; }
+        for (int d = 0; d < 3; ++d) { L.acc[ACC_D(c.H, s, 1 + d)] = 0.0; L.gacc[ACC_D(c.H, s, d)] = 0.0; }
       }
       if (pend && fkl) { L.gppos[ft] = pend_val; L.gpv[ft] += (double)pend_pv; }
       __syncthreads();   // b1
@@ -1008,11 +1013,11 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
         const int s = L.list[e];
         int ci, cj, ckk;
         decode_cell(c, L.key[s], ci, cj, ckk);
-        const float mm = (float)L.acc[s * 4];
-        float mvv[3] = {(float)L.acc[s * 4 + 1], (float)L.acc[s * 4 + 2], (float)L.acc[s * 4 + 3]}, vo[3];
+        const float mm = (float)L.acc[ACC_D(c.H, s, 0)];
+        float mvv[3] = {(float)L.acc[ACC_D(c.H, s, 1)], (float)L.acc[ACC_D(c.H, s, 2)], (float)L.acc[ACC_D(c.H, s, 3)]}, vo[3];
         grid_op<false>(c, pf, ci, cj, ckk, mm, mvv, vo, nullptr);
-        accf[s * 8] = mm; accf[s * 8 + 1] = mvv[0]; accf[s * 8 + 2] = mvv[1]; accf[s * 8 + 3] = mvv[2];   // raw values for the adjoint
-        accf[s * 8 + 4] = vo[0]; accf[s * 8 + 5] = vo[1]; accf[s * 8 + 6] = vo[2];
+        accf[ACC_F(c.H, s, 0)] = mm; accf[ACC_F(c.H, s, 1)] = mvv[0]; accf[ACC_F(c.H, s, 2)] = mvv[1]; accf[ACC_F(c.H, s, 3)] = mvv[2];   // raw values for the adjoint
+        accf[ACC_F(c.H, s, 4)] = vo[0]; accf[ACC_F(c.H, s, 5)] = vo[1]; accf[ACC_F(c.H, s, 6)] = vo[2];
       }
       __syncthreads();   // b3
       // ---- D: g2p adjoint (scatter g onto grid velocities; weight / fx cotangents) ----
@@ -1035,7 +1040,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
             const float gCd = gCq[r * 3] * dp[0] + gCq[r * 3 + 1] * dp[1] + gCq[r * 3 + 2] * dp[2];
-            const float vel = accf[gs * 8 + 4 + r];
+            const float vel = accf[ACC_F(c.H, gs, 4 + r)];
             gsc[r] = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
             gwt += vel * (gnv[r] + 4.f * c.inv_dx * gCd);
 #pragma unroll
@@ -1043,7 +1048,7 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
           }
           if (quadrun_reduce<3>(gs, gsc)) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) lds_add(&L.gacc[gs * 3 + r], gsc[r]);
+            for (int r = 0; r < 3; ++r) lds_add(&L.gacc[ACC_D(c.H, gs, r)], gsc[r]);
           }
 #pragma unroll
           for (int kk = 0; kk < 3; ++kk) {
@@ -1059,16 +1064,16 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
         const int s = L.list[e];
         int ci, cj, ckk;
         decode_cell(c, L.key[s], ci, cj, ckk);
-        const float m = accf[s * 8];
-        float mvv[3] = {accf[s * 8 + 1], accf[s * 8 + 2], accf[s * 8 + 3]};
-        float g[3] = {(float)L.gacc[s * 3], (float)L.gacc[s * 3 + 1], (float)L.gacc[s * 3 + 2]}, gmm, dfric, dpv[3];
+        const float m = accf[ACC_F(c.H, s, 0)];
+        float mvv[3] = {accf[ACC_F(c.H, s, 1)], accf[ACC_F(c.H, s, 2)], accf[ACC_F(c.H, s, 3)]};
+        float g[3] = {(float)L.gacc[ACC_D(c.H, s, 0)], (float)L.gacc[ACC_D(c.H, s, 1)], (float)L.gacc[ACC_D(c.H, s, 2)]}, gmm, dfric, dpv[3];
         const bool ctrl = grid_op_adjoint(c, pf, ci, cj, ckk, m, mvv, g, gmm, dfric, dpv);
         acc_fric += dfric;
         if (ctrl) {
 #pragma unroll
           for (int d = 0; d < 3; ++d) lds_add(&L.gpv[f * 3 + d], dpv[d]);
         }
-        gaccf[s * 6] = g[0]; gaccf[s * 6 + 1] = g[1]; gaccf[s * 6 + 2] = g[2]; gaccf[s * 6 + 3] = gmm;   // same thread read the doubles
+        gaccf[ACC_F(c.H, s, 0)] = g[0]; gaccf[ACC_F(c.H, s, 1)] = g[1]; gaccf[ACC_F(c.H, s, 2)] = g[2]; gaccf[ACC_F(c.H, s, 3)] = gmm;   // same thread read the doubles
       }
       __syncthreads();   // b5
       // ---- F: p2g adjoint (gather) -> ret; FK adjoint ----
@@ -1085,10 +1090,10 @@ __global__ void __launch_bounds__(512) mpm_step_bwd_ws_kernel(MpmBwdArgs a) {
           const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
           const float weight = wi * wj * wk;
           const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
-          float gwt = c.p_mass * gaccf[ss * 6 + 3];
+          float gwt = c.p_mass * gaccf[ACC_F(c.H, ss, 3)];
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
-            const float gc = gaccf[ss * 6 + r];
+            const float gc = gaccf[ACC_F(c.H, ss, r)];
             const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
             gwt += gc * (c.p_mass * vq[r] + ad);
             gvp[r] += weight * c.p_mass * gc;
