@@ -138,11 +138,17 @@ __global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* ac
   a.w.count[1 * a.B + b] = 0;
 }
 
+// The grid values are double-buffered, buffer k belongs to active list k (substep f uses k = f & 1): the cells of substep f - 1
+// can then be zeroed while substep f runs -- plb_grid(f) does it next to its own work -- instead of in a launch of their own
+// between g2p(f - 1) and p2g(f).  One launch less per substep (4 -> 3) on a path whose kernels sit near the launch floor.
+__device__ __forceinline__ double* plb_buf(const PlbArgs& a, int k, int b) { return a.w.val + (((long)k * a.B + b) * a.G) * 4; }
+
+// end of a step only: zero the cells of the last substep (list / buffer `prev`), back to the all-zero grid invariant
 __global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const int prev = (a.f + 1) & 1, cur = a.f & 1;
   if (t < min(a.w.count[prev * a.B + b], a.cap)) {
-    double* cell = a.w.val + ((long)b * a.G + a.w.list[((long)prev * a.B + b) * a.cap + t]) * 4;
+    double* cell = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
     cell[0] = 0.0; cell[1] = 0.0; cell[2] = 0.0; cell[3] = 0.0;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = 0;
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   const PlbConst& c = a.c;
   for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
   __syncthreads();
-  double* val = a.w.val + (long)b * a.G * 4;
+  double* val = plb_buf(a, a.f & 1, b);
   if (p < c.N) {
     const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
     double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
@@ -311,10 +317,14 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
 __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
-  const int cur = a.f & 1;
+  const int cur = a.f & 1, prev = cur ^ 1;
+  if (t < min(a.w.count[prev * a.B + b], a.cap)) {          // the previous substep's cells, in the other buffer: done with
+    double* old = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
+    old[0] = 0.0; old[1] = 0.0; old[2] = 0.0; old[3] = 0.0;
+  }
   if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
-  double* cell = a.w.val + ((long)b * a.G + lin) * 4;
+  double* cell = plb_buf(a, cur, b) + lin * 4;
   const double m = cell[0];
   double vv[3] = {0.0, 0.0, 0.0};
   if (m > 1e-12) {
@@ -358,6 +368,7 @@ template <int LANES>
 __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
+  if (gid == 0) a.w.count[((a.f + 1) & 1) * a.B + b] = 0;   // the other list: plb_grid has just retired it, p2g of the next substep refills it
   if (p >= c.N) return;   // whole quads leave together
   const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
   double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
@@ -373,7 +384,7 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
     fx[d] = f;
     w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
   }
-  const double* val = a.w.val + (long)b * a.G * 4;
+  const double* val = plb_buf(a, a.f & 1, b);
   double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
   for (int cidx = qi; cidx < 27; cidx += LANES) {
@@ -496,7 +507,7 @@ static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
   const ud::PlbConst& c = h->c;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_val = take((size_t)B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
+  const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
   const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
   const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&h->arena, off);
@@ -569,7 +580,6 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted);
   for (int f = 0; f < h->c.S; ++f) {
     a.f = f; a.epoch = h->epoch++;
-    hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
     hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
