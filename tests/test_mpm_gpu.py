@@ -235,6 +235,28 @@ def _scaled_case(S, seed, B=1, grid_ckpt_cells=0):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
+@pytest.fixture
+def one_lane_per_particle(monkeypatch):
+    """The many-workgroup kernels come in two lane mappings: 4 lanes per particle below 100 k particles per launch, 1 beyond --
+    sizes the CPU oracle cannot follow.  UD_LG_LANES (read at every step call) forces the mapping, so the one-lane kernels
+    (the ones bench.py's n_grid-256 and pour_soup workloads run) meet the oracle at test sizes."""
+    monkeypatch.setenv("UD_LG_LANES", "1")
+
+
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
+def test_large_path_one_lane_kernels_match_oracle_n798(grid_ckpt_cells, one_lane_per_particle):
+    test_large_path_matches_oracle_n798(grid_ckpt_cells)
+
+
+def test_collide_shape_rope_geometry_one_lane_kernels(one_lane_per_particle):
+    test_collide_shape_rope_geometry_fwd_bwd()
+
+
+@pytest.mark.parametrize("case", ["body_at_the_domain_corner", "across_the_upper_grid_edge", "negative_weights", "four_box_primitives"])
+def test_mpm_step_edge_cases_one_lane_kernels(demo, case, one_lane_per_particle):
+    test_mpm_step_edge_cases(demo, case)
+
+
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
 def test_large_path_matches_oracle_n798(grid_ckpt_cells):
     """grid_ckpt_cells = 0: the backward recomputes p2g + grid op; 6: it restores the grid from the forward's checkpoint."""

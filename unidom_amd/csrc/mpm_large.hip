@@ -1346,6 +1346,15 @@ static void lg_join(MpmLarge* L, int G, hipStream_t st, const LgGroup* grp) {
   }
 }
 
+// lanes per particle: 4 while the launch is too small to fill the chip, 1 beyond (see LgTable).  UD_LG_LANES=1|4 overrides it --
+// a diagnostic, and how the tests reach the one-lane kernels at sizes their CPU oracle can follow.
+static int lg_lanes(int B, int N) {
+  const char* e = getenv("UD_LG_LANES");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 1 || forced == 4) return forced;
+  return ((long)B * N < 100000) ? 4 : 1;
+}
+
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,
@@ -1355,7 +1364,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N;
   const dim3 blk(256), blks(LG_SCATTER_T);
-  const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
+  const int lanes = lg_lanes(B, N);                      // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
@@ -1426,7 +1435,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 blk(256), blks(LG_SCATTER_T);
-  const int lanes = ((long)B * N < 100000) ? 4 : 1;   // lanes per particle in the four particle kernels
+  const int lanes = lg_lanes(B, N);                      // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   const CkLayout ck = ck_layout(c);
   const long rec = ck.rec;
