@@ -133,3 +133,11 @@ def test_hip_matches_restatement_quality_2():
         cur = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act, E, nu, ys, nthreads=2)
     for key, t in (("x", s.x), ("v", s.v), ("C", s.C), ("F", s.F)):
         assert _rel(t.cpu().numpy(), cur[key]) < 1e-9, (key, _rel(t.cpu().numpy(), cur[key]))
+
+
+@pytest.mark.gpu
+def test_hip_one_lane_kernels_match_restatement(monkeypatch):
+    """plb_p2g / plb_g2p come in two lane mappings (4 lanes per particle below 100 k particles per launch, 1 beyond); UD_PLB_LANES,
+    read at every step call, forces one lane per particle so that mapping meets the restatement too."""
+    monkeypatch.setenv("UD_PLB_LANES", "1")
+    test_hip_matches_restatement_full_torus_state()

@@ -566,8 +566,9 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
-  static const int force_lanes = [] { const char* e = getenv("UD_PLB_LANES"); return e ? atoi(e) : 0; }();   // diagnostic override
-  const int lanes = force_lanes ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);   // lanes per particle in p2g / g2p
+  const char* lanes_env = getenv("UD_PLB_LANES");          // diagnostic override, read per call (the tests reach both mappings with it)
+  const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
+  const int lanes = (force_lanes == 1 || force_lanes == 4) ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);   // lanes per particle in p2g / g2p
   const dim3 gq((4 * h->c.N + 255) / 256, B);
   hipLaunchKernelGGL(ud::plb_prologue, dim3((B + 63) / 64), dim3(64), 0, st, a, prim_pos, action);
   static const int no_sort = [] { const char* e = getenv("UD_PLB_NO_SORT"); return e ? atoi(e) : 0; }();   // diagnostic override
