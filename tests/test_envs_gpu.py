@@ -652,3 +652,12 @@ def test_pour_soup_reset_step_matches_oracle_and_grad():
         np.testing.assert_allclose(npy(s1.primitives[i].position[:, 0]) + shift, o32["ppos"][:, i, 0], atol=2e-7)
     reward.sum().backward()
     assert torch.isfinite(a.grad).all() and a.grad[:, [0, 2]].abs().min() > 0 and (a.grad[:, 1] == 0).all()
+
+
+@pytest.mark.gpu
+def test_pour_soup_step_matches_oracle_with_one_lane_kernels(monkeypatch):
+    """bench.py's pour_soup workload (32 envs x 7631 particles) runs the one-lane-per-particle kernels of the many-workgroup path;
+    at the two envs the oracle can follow the four-lane ones would run.  UD_LG_LANES=1 (read per step call) puts the same env.step
+    through the one-lane kernels: internal spatial order, block window / hash staging, soft contact, mixed materials."""
+    monkeypatch.setenv("UD_LG_LANES", "1")
+    test_pour_soup_reset_step_matches_oracle_and_grad()
