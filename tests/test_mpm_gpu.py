@@ -257,6 +257,26 @@ def test_mpm_step_edge_cases_one_lane_kernels(demo, case, one_lane_per_particle)
     test_mpm_step_edge_cases(demo, case)
 
 
+def test_full_batch_launch_agrees_with_the_oracle_checked_small_one():
+    """Size-independent property at bench size: envs are independent, so env b of a 128-env launch (102 k particles -- past the
+    100 k threshold, i.e. the one-lane kernels and a single env group, what bench.py's large workloads run) must equal the same env
+    stepped in a 2-env launch (four-lane kernels, two env groups -- the configuration test_large_path_matches_oracle_n798 pins to
+    the oracle).  Forward and adjoint, grid checkpoint on."""
+    S = 5
+    simL, stL, gL, N = _scaled_case(S, 3, B=128, grid_ckpt_cells=6)
+    assert 128 * N >= 100000
+    pick = [0, 77]
+    simS, _, _, _ = _scaled_case(S, 3, B=2, grid_ckpt_cells=6)
+    stS = {k: np.ascontiguousarray(v[pick]) for k, v in stL.items()}
+    gS = {k: np.ascontiguousarray(v[pick]) for k, v in gL.items()}
+    big, small = run_hip(simL, stL, g=gL, clip=True), run_hip(simS, stS, g=gS, clip=True)
+    for key in ("x", "v", "C", "F"):
+        assert _rel(big[key][pick], small[key]) < 2e-5, (key, _rel(big[key][pick], small[key]))
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(big[key]).all(), key
+        assert _rel(big[key][pick], small[key]) < 2e-3, (key, _rel(big[key][pick], small[key]))
+
+
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
 def test_large_path_matches_oracle_n798(grid_ckpt_cells):
     """grid_ckpt_cells = 0: the backward recomputes p2g + grid op; 6: it restores the grid from the forward's checkpoint."""
