@@ -13,7 +13,12 @@
  *   - purely functional like the reference (NamedTuple._replace): inputs are never written, the caller owns
  *     every state / gradient / checkpoint buffer; a handle owns constant tables and, for the many-workgroup MPM and
  *     PLB paths, a scratch arena (HBM grid + active-cell lists) that is (re)allocated when a larger batch arrives.
- *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside.
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside, with ONE
+ *     exception: handle-owned scratch is sized for the largest batch seen so far.  The first call with a given handle,
+ *     and any later call whose B exceeds every earlier one, allocates it with hipMalloc (itself a device-wide
+ *     synchronising runtime call) after hipStreamSynchronize(stream) + hipFree of the smaller arena.  That concerns
+ *     ud_cloth_rollout_bwd for bodies above 1024 particles (cotangent parking arena), ud_mpm_step_fwd/bwd on the
+ *     many-workgroup path (grid + active lists) and ud_plb_step.  In steady state (same or smaller B) nothing syncs.
  *   - return value: 0 = ok, negative = ud_status; ud_last_error() gives the text (thread-local).
  *   - a handle is bound to the device current at create time; not thread-safe per handle.
  */
@@ -55,16 +60,22 @@ typedef struct {
   float max_v;     /* 2.0                                  :23 */
   float small_num; /* 1e-8                                 :24 */
   int substeps;    /* 50 = fori_loop bound                 cloth_simulator.py:176 */
-  int mode;        /* 0 (default): forward in the reference's f32 operation order (bit-identical to the CPU
-                    *    restatement) + restructured adjoint kernel (one reduction round per substep);
-                    * 1: reference-order forward AND reference-order adjoint (six reductions per substep);
-                    * 2: restructured fast-math forward + restructured adjoint (f32 round-off differences,
-                    *    which this stiff system amplifies over long rollouts -- see DESIGN.md) */
+  int mode;        /* 0 (default): forward in operation order "v2" -- the reference's formulas re-associated into fewer
+                    *    IEEE operations, no FMA contraction; bit-identical to the CPU restatement compiled in the SAME
+                    *    order (oracle cloth_substep_fwd_v2), and 1.5e-5 (v, one substep) / 9e-3 (50 substeps) away from
+                    *    the reference-order restatement in f32, 1e-9 in f64 -- + restructured adjoint
+                    *    kernel (one reduction round per substep);
+                    * 1: forward in the reference's literal f32 operation order (bit-identical to the CPU restatement
+                    *    of that order) AND reference-order adjoint (six reductions per substep);
+                    * 2: v2 structure with fast-math (v_rsq, FMA) forward + restructured adjoint (f32 round-off
+                    *    differences, which this stiff system amplifies over long rollouts -- see DESIGN.md).
+                    * Bodies above 1024 particles always run the reference-order forward. */
 } ud_cloth_conf;
 
 /* mask: host pointer, N*N bytes, row-major, non-zero = cloth particle (create_cloth_mask,
  * fold_cloth1_env.py:48-53).  Particle order = row-major nonzero(mask) (cloth_simulator.py:52).
- * Limits: 1 <= P <= 1024; the mask must not touch the lattice border (UD_ERR_UNSUPPORTED otherwise). */
+ * Limits: 1 <= P <= 4096 (P <= 1024: one particle per lane; above: up to four particles per lane, one workgroup
+ * per env); the mask must not touch the lattice border (UD_ERR_UNSUPPORTED otherwise). */
 int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** out);
 void ud_cloth_destroy(ud_cloth* h);
 int ud_cloth_num_particles(const ud_cloth* h);

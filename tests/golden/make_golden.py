@@ -155,7 +155,7 @@ def main():
     print("pour_soup veg cloud", veg.shape, veg.min(0), veg.max(0))
 
     # goals of the sibling envs on the same kernels (data files: inputs of their reward)
-    for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "shape_rope", "pour_water"):
+    for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "fold_tshirt", "shape_rope", "pour_water"):
         src = f"{REF}/core/envs/goals/{task}/goal.npy"
         dst = f"{REPO}/unidom_amd/envs/goals/{task}"
         os.makedirs(dst, exist_ok=True)

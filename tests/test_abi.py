@@ -73,3 +73,25 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
         assert int(got[name]) == C.sizeof(st), (name, got[name], C.sizeof(st))
         for field, _ in st._fields_:
             assert int(got[f"{name}.{field}"]) == getattr(st, field).offset, (name, field)
+
+
+def test_integration_stub_and_lib_structs_are_the_header(tmp_path):
+    """INTEGRATION.md shows the reference-side ctypes binding; its struct block is generated from include/unidom_hip.h
+    (tools/gen_binding_stub.py) and must be current, and unidom_amd/_lib.py's hand-written structs must list the same
+    fields with the same ctypes."""
+    import ctypes as C
+    import importlib.util
+
+    from unidom_amd import _lib
+    spec = importlib.util.spec_from_file_location("gen_binding_stub", os.path.join(ROOT, "tools", "gen_binding_stub.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.current_block() == gen.render(), "run `python tools/gen_binding_stub.py --write`"
+    parsed = dict(gen.parse_structs())
+    assert set(parsed) == {"ud_cloth_conf", "ud_mpm_conf", "ud_plb_conf"}
+    for name, fields in parsed.items():
+        mine = [(f, t) for f, t in getattr(_lib, name)._fields_]
+        theirs = [(f, eval(ct, {"C": C})) for f, ct, _ in fields]
+        assert [f for f, _ in mine] == [f for f, _ in theirs], name
+        for (f, a), (_, b) in zip(mine, theirs):
+            assert C.sizeof(a) == C.sizeof(b) and a._type_ == b._type_ if hasattr(a, "_type_") else a is b, (name, f)

@@ -15,10 +15,9 @@ import time
 import numpy as np
 import torch
 
-from ...envs.basic.cloth_env import ClothEnv
 from ...envs.registration import env_functions
 from ...utils import prng
-from .core import APG, init_distributed, shard_envs
+from .core import APG, init_distributed, shard_envs, squashes_actions
 
 
 def build_parser(para: bool):
@@ -58,6 +57,8 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
     # seeds (apg.py:75-80)
     key = prng.PRNGKey(args.seed)
     key, key_models, key_env = prng.split(key, 3)
+    key_env = prng.split(key_env, 1)[0]                           # [process_id] of process_count = 1: the reference is one
+    key = prng.split(key, 1)[0]                                   # process driving `gpus` devices; a rank here = a device there
     key_eval = prng.PRNGKey(args.seed + 666)
 
     env_kwargs = dict(batch_size=shard_envs(args.num_envs, world), seed=args.seed, aux_reward=True, device=device)
@@ -69,14 +70,17 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
     environment_fn = env_functions[args.env]
     core_env = environment_fn(**env_kwargs)
     eval_env = environment_fn(**eval_kwargs) if rank == 0 else None
-    is_cloth = isinstance(core_env, ClothEnv)
+    fixed_reset = squashes_actions(core_env)                      # apg.py:297: cloth envs and shape_rope / push_rope (_hard)
 
-    learner = APG(core_env, args.ep_len, learning_rate=args.lr, max_gradient_norm=args.max_grad_norm, seed=args.seed)
+    # policy_model.init(key_models) (apg.py:107); the noise key travels in the (replicated) TrainingState (apg.py:276-284)
+    learner = APG(core_env, args.ep_len, learning_rate=args.lr, max_gradient_norm=args.max_grad_norm, seed=args.seed,
+                  key=key, key_models=key_models)
     evaluator = None
     if rank == 0:
-        evaluator = APG(eval_env, args.ep_len, seed=args.seed + 666)
+        evaluator = APG(eval_env, args.ep_len, seed=args.seed + 666, key=key_eval, key_models=key_models)
         evaluator.policy = learner.policy
 
+    key_debug, key_eval = prng.split(key_eval)                    # apg.py:286
     _, first_state = core_env.reset(key_env)
     _, eval_first_state = eval_env.reset(key_eval) if rank == 0 else (None, None)
 
@@ -85,8 +89,9 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
         if randomize_stiffness:                                   # apg_para.py:324-329
             np.random.seed(it)
             stiff = np.random.uniform(args.train_min_stiff, args.train_max_stiff)
-        if is_cloth:
-            # key_env is never advanced on the cloth branch (apg.py:297-300): same initial state every iteration;
+        if fixed_reset:
+            key_debug, key_eval = prng.split(key_eval)            # apg.py:298 (this branch only)
+            # key_env is never advanced on this branch (apg.py:297-300): same initial state every iteration;
             # every device draws its own shift from split(key_env, devices)[rank]
             key_envs = prng.split(key_env, world)
             _, train_first_state = core_env.reset(key_envs[rank])
@@ -109,11 +114,11 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
                 for test_step in range(10):
                     np.random.seed((it * test_step) + test_step)
                     es = np.random.uniform(args.eval_min_stiff, args.eval_max_stiff)
-                    r = evaluator.evaluate(_with_stiffness(eval_first_state, es), eval_env.max_steps)
+                    r = evaluator.evaluate(_with_stiffness(eval_first_state, es), eval_env.max_steps, key_debug)
                     test[f"eval_env_stiffness_{test_step}"] = float(es)
                     test[f"test_reward_{test_step}"] = float(r.sum(0).mean())
             else:
-                r = evaluator.evaluate(eval_first_state, eval_env.max_steps)
+                r = evaluator.evaluate(eval_first_state, eval_env.max_steps, key_debug)
                 test["test_reward"] = float(r.sum(0).mean())
                 test["last_reward"] = float(r[-1].mean())
             print(f"[it {it}] Test reward {test}")
@@ -122,6 +127,8 @@ def train(args, para_obs: bool = False, randomize_stiffness: bool = False, num_e
         t = time.time()
         metrics = learner.minimize(train_first_state)
         train_reward = float(metrics["reward"].sum(0).mean())     # host sync, like block_until_ready (apg.py:337)
+        if hasattr(core_env.simulator, "check_status"):           # device-side capacity flags of this update (already synced)
+            core_env.simulator.check_status()
         dt_it = time.time() - t
         if rank == 0:
             rec = {"iter": it, "train_reward": train_reward, "grad_norm": float(metrics["grad_norm"]),

@@ -12,27 +12,48 @@ brax / flax / optax are third-party and absent; their semantics are restated fro
 """
 from __future__ import annotations
 
-import math
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn.functional as Fn
 
 from ...envs.basic.cloth_env import ClothEnv
+from ...envs.basic.mpm_env import MPMEnv
+from ...envs.shape_rope_env import ShapeRopeEnv
+from ...utils import prng
+
+
+def squashes_actions(env) -> bool:
+    """The reference's predicate `not isinstance(core_env, MPMEnv) or isinstance(core_env, ShapeRopeEnv)`
+    (apg.py:185, :297): these envs take sigmoid(actions) in [0,1] (pick / place points, pusher start / end points) and are
+    reset from `split(key_env, devices)` every iteration; the others (whip_rope, pour_water, pour_soup) take the raw tanh
+    sample and go through auto_reset (apg.py:90-91, :302-307)."""
+    is_a = issubclass if isinstance(env, type) else isinstance         # an env class (registry entry) or an instance
+    return (not is_a(env, MPMEnv)) or is_a(env, ShapeRopeEnv)
 
 
 class Policy(torch.nn.Module):
-    def __init__(self, obs_size, action_size, hidden=(512, 256), seed=0):
+    """brax 0.0.13 `networks.make_model([512, 256, 2*act], obs_size, activation=swish)` (apg.py:353-358): a flax MLP of
+    Dense layers named hidden_0.. with lecun_uniform kernels and zero biases, initialised by `module.init(key_models, zeros)`
+    (apg.py:107).  The kernels are drawn exactly as flax / jax draw them from `key` (utils/prng.py: the parameter key is
+    fold_in(key, sha1("hidden_i")), the kernel [in, out] = uniform(k, (in, out), -1, 1) * sqrt(3 / fan_in) in f32) and
+    stored transposed in torch's [out, in] layout.  No torch generator is involved."""
+
+    def __init__(self, obs_size, action_size, hidden=(512, 256), seed=0, key=None):
         super().__init__()
         sizes = [obs_size, *hidden, 2 * action_size]
-        g = torch.Generator().manual_seed(seed)
+        key = prng.PRNGKey(seed) if key is None else np.asarray(key, np.uint32)
         self.layers = torch.nn.ModuleList()
         for i in range(len(sizes) - 1):
-            lin = torch.nn.Linear(sizes[i], sizes[i + 1])
-            bound = math.sqrt(3.0 / sizes[i])               # lecun_uniform: U(-sqrt(3/fan_in), +)
+            fan_in, fan_out = sizes[i], sizes[i + 1]
+            lin = torch.nn.Linear(fan_in, fan_out)
+            k = prng.flax_param_key(key, (f"hidden_{i}",), 0)          # Dense's first make_rng('params') is the kernel's
+            scale = np.sqrt(np.float32(3.0 / fan_in)).astype(np.float32)   # variance_scaling(1, "fan_in", "uniform")
+            kernel = prng.uniform(k, fan_in * fan_out, -1.0, 1.0).reshape(fan_in, fan_out) * scale
             with torch.no_grad():
-                lin.weight.copy_((torch.rand(lin.weight.shape, generator=g) * 2 - 1) * bound)
+                lin.weight.copy_(torch.from_numpy(np.ascontiguousarray(kernel.T)))
                 lin.bias.zero_()
             self.layers.append(lin)
 
@@ -46,6 +67,8 @@ class Policy(torch.nn.Module):
 
 
 def sample_action(logits, eps, min_std=0.001):
+    """brax NormalTanhDistribution(event_size).sample (apg.py:98-100, :184): loc, raw = split(logits, 2);
+    tanh(loc + (softplus(raw) + min_std) * eps), eps = jax.random.normal(key_sample, loc.shape)."""
     loc, raw = torch.chunk(logits, 2, dim=-1)
     return torch.tanh(loc + (Fn.softplus(raw) + min_std) * eps)
 
@@ -103,37 +126,61 @@ def shard_envs(num_envs: int, world: int) -> int:
 
 
 class APG:
-    def __init__(self, env, episode_length, learning_rate=1e-4, max_gradient_norm=1e9, seed=0, truncation_length=None):
+    def __init__(self, env, episode_length, learning_rate=1e-4, max_gradient_norm=1e9, seed=0, truncation_length=None,
+                 key=None, key_models=None):
+        """`key` / `key_models`: the noise key carried in TrainingState and the model-init key (apg.py:76-80, :107, :276).
+        Given only `seed` they are derived as the reference's train() derives them: key, key_models, _ = split(PRNGKey(seed), 3);
+        key = split(key, process_count=1)[0].  Every device holds the SAME noise key (the reference replicates the
+        TrainingState, apg.py:282-284), so every rank draws the same eps for its own environments."""
         self.env = env
         self.episode_length = episode_length
         self.max_gradient_norm = max_gradient_norm
         self.truncation_length = truncation_length
         self.device = env.device
-        self.is_cloth = isinstance(env, ClothEnv)            # sigmoid on actions for non-MPM envs (apg.py:185)
+        self.is_cloth = isinstance(env, ClothEnv)            # ClothEnv.step_diff takes want_lists
+        self.squash = squashes_actions(env)                  # apg.py:185
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.policy = Policy(env.observation_size, env.action_size, seed=seed).to(self.device)
+        if key is None or key_models is None:
+            k, km, _ = prng.split(prng.PRNGKey(seed), 3)
+            key = prng.split(k, 1)[0] if key is None else key
+            key_models = km if key_models is None else key_models
+        self.key = np.asarray(key, np.uint32)
+        self.policy = Policy(env.observation_size, env.action_size, key=key_models).to(self.device)
         self.sync = GradSync(self.policy, learning_rate, max_gradient_norm)
         self.params, self.n_params, self.flat_grad, self.optimizer = (
             self.sync.params, self.sync.n_params, self.sync.flat_grad, self.sync.optimizer)
-        self.gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + self.rank)
         self.want_lists = False   # the loss never reads obs_list/state_list (XLA dead-code-eliminates them)
 
     # ------------------------------------------------------------------------------------------------
     def get_obs(self, state):
         return self.env.get_obs(state)
 
-    def rollout(self, state, deterministic_noise=None):
+    def draw_noise(self, key, steps):
+        """The noise of `steps` scanned do_one_step calls (apg.py:177-184): per step `key, key_sample = split(key)` and
+        eps = jax.random.normal(key_sample, loc.shape = [B, action_size]).  The keys do not depend on the device state, so
+        the whole episode's noise is drawn on the host up front and uploaded once.  Returns (key after the scan, eps [T,B,A])."""
+        B, A = self.env.batch_size, self.env.action_size
+        eps = np.empty((steps, B, A), np.float32)
+        for t in range(steps):
+            key, key_sample = prng.split(key)
+            eps[t] = prng.normal(key_sample, B * A).reshape(B, A)
+        host = torch.from_numpy(eps)
+        if torch.device(self.device).type == "cuda":
+            host = host.pin_memory()
+        return key, host.to(self.device, non_blocking=True)
+
+    def _act(self, state, eps):
+        actions = sample_action(self.policy(self.get_obs(state)), eps)
+        return torch.sigmoid(actions) if self.squash else actions              # apg.py:185-186
+
+    def rollout(self, state, key=None, deterministic_noise=None):
         """do_one_step scanned episode_length times (apg.py:177-215). Returns (rewards[T,B], states, actions)."""
+        if deterministic_noise is None:
+            _, deterministic_noise = self.draw_noise(self.key if key is None else key, self.episode_length)
         rewards, actions_l, states = [], [], []
         for t in range(self.episode_length):
-            obs = self.get_obs(state)
-            logits = self.policy(obs)
-            eps = (torch.randn(logits.shape[0], logits.shape[1] // 2, device=self.device, generator=self.gen)
-                   if deterministic_noise is None else deterministic_noise[t])
-            actions = sample_action(logits, eps)
-            if self.is_cloth:
-                actions = torch.sigmoid(actions)
+            actions = self._act(state, deterministic_noise[t])
             if self.is_cloth:
                 _, reward, done, info = self.env.step_diff(actions, state, want_lists=self.want_lists)
             else:
@@ -146,27 +193,28 @@ class APG:
             states.append(state)
         return torch.stack(rewards), states, actions_l
 
-    def loss(self, state, deterministic_noise=None):
-        rewards, states, actions = self.rollout(state, deterministic_noise)
+    def loss(self, state, key=None, deterministic_noise=None):
+        rewards, states, actions = self.rollout(state, key, deterministic_noise)
         return -rewards.mean(), (rewards, states, actions)
 
     def minimize(self, state, deterministic_noise=None):
-        """One APG update (apg.py:217-258). Returns metrics dict (tensors; no host sync here)."""
+        """One APG update (apg.py:217-258): key, key_grad = split(training_state.key); grad of loss(.., key_grad);
+        nan_to_num, clip, mean over devices, Adam.  Returns metrics dict (tensors; no host sync here)."""
+        self.key, key_grad = prng.split(self.key)
         self.sync.zero_grad()
-        loss, (rewards, _, _) = self.loss(state, deterministic_noise)
+        loss, (rewards, _, _) = self.loss(state, key_grad, deterministic_noise)
         loss.backward()
         raw_norm = self.sync.step()
         return {"grad_norm": raw_norm, "reward": rewards.detach(), "loss": loss.detach()}
 
     @torch.no_grad()
-    def evaluate(self, state, steps):
+    def evaluate(self, state, steps, key=None):
+        """run_eval (apg.py:127-149): `steps` scanned do_one_step_eval calls drawing their noise from `key` (key_debug)."""
+        _, noise = self.draw_noise(self.key if key is None else key, steps)
         rewards = []
-        for _ in range(steps):
-            obs = self.get_obs(state)
-            eps = torch.randn(obs.shape[0], self.env.action_size, device=self.device, generator=self.gen)
-            actions = sample_action(self.policy(obs), eps)
+        for t in range(steps):
+            actions = self._act(state, noise[t])
             if self.is_cloth:
-                actions = torch.sigmoid(actions)
                 _, reward, _, info = self.env.step_diff(actions, state, want_lists=False)
             else:
                 _, reward, _, info = self.env.step_diff(actions, state)

@@ -20,6 +20,16 @@ __device__ __forceinline__ float mean_sq3(float ax, float ay, float az, float bx
   return (dx * dx + dy * dy + dz * dz) / 3.0f;   // ((a - b) ** 2).mean(-1)
 }
 
+// (value, index) minimum as jnp.min / torch.min take it: a NaN candidate wins over any number (the reduction propagates
+// NaN), equal values keep the smaller index.  The index starts at 0, so it is in range whatever the values are: with
+// every distance +inf or NaN the backward kernels still address element 0 and the non-finite value flows through sqrt
+// exactly as it does in the reference's expression (no sentinel index can reach an address computation).
+__device__ __forceinline__ bool min_takes(float ov, int oi, float best, int bi) {
+  const bool on = ov != ov, bn = best != best;
+  if (on || bn) return on && (!bn || oi < bi);
+  return ov < best || (ov == best && oi < bi);
+}
+
 // block-wide sum of one float per thread (GLUE_T threads); result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* scratch) {
   v = wave_sum(v);
@@ -56,16 +66,16 @@ __global__ void __launch_bounds__(GLUE_T) chamfer_fwd_kernel(int P, int Q, const
   const bool live = r < nr;
   const int rr = live ? r : nr - 1;
   const float ax = rows[rr * 3], ay = rows[rr * 3 + 1], az = rows[rr * 3 + 2];
-  float best = INFINITY; int bi = 0x7fffffff;
+  float best = INFINITY; int bi = 0;
   for (int c = c0; c < nc; c += 4) {
     const float m = dir == 0 ? mean_sq3(ax, ay, az, cs[c], cs[nc + c], cs[2 * nc + c])
                              : mean_sq3(cs[c], cs[nc + c], cs[2 * nc + c], ax, ay, az);   // (x - y) in both directions
-    if (m < best) { best = m; bi = c; }
+    if (m < best || (m != m && best == best)) { best = m; bi = c; }   // first minimum; the first NaN sticks
   }
 #pragma unroll
   for (int off = 1; off <= 2; off <<= 1) {   // the four lanes of a row: smallest value, then smallest index
     const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
-    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    if (min_takes(ov, oi, best, bi)) { best = ov; bi = oi; }
   }
   float s = 0.f;
   if (live && c0 == 0) {
@@ -117,21 +127,21 @@ __global__ void __launch_bounds__(GLUE_T) pnp_fwd_kernel(int B, int P, const flo
   const float* a = actions + b * 6;
   const float* xb = x + (size_t)b * P * 3;
   const float px = a[0], py = a[1], pz = a[2];
-  float best = INFINITY; int bi = 0x7fffffff;
+  float best = INFINITY; int bi = 0;
   for (int p = tid; p < P; p += GLUE_T) {   // contact_distance = min_p |pick - x_p|  (:206-209)
     const float dx = px - xb[p * 3], dy = py - xb[p * 3 + 1], dz = pz - xb[p * 3 + 2];
     const float s = dx * dx + dy * dy + dz * dz;
-    if (s < best) { best = s; bi = p; }
+    if (s < best || (s != s && best == best)) { best = s; bi = p; }
   }
   for (int off = 32; off >= 1; off >>= 1) {   // (value, first index) minimum over the wave
     const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
-    if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    if (min_takes(ov, oi, best, bi)) { best = ov; bi = oi; }
   }
   if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
   __syncthreads();
   if (tid == 0) {
     for (int q = 1; q < GLUE_T / 64; ++q)
-      if (sv[q] < best || (sv[q] == best && si[q] < bi)) { best = sv[q]; bi = si[q]; }
+      if (min_takes(sv[q], si[q], best, bi)) { best = sv[q]; bi = si[q]; }
     contact[b] = sqrtf(best);
     contact_idx[b] = bi;
   }

@@ -126,8 +126,9 @@ class ClothSimulator:
         self.normalize_grad = True           # live norm_grad, :182-196
         self.record_grasp = False            # tests: capture the gripper masks (Q3)
         self.last_grasp = None
-        # kernel family (include/unidom_hip.h ud_cloth_conf.mode): 0 reference-order forward + restructured adjoint
-        # (default), 1 reference-order forward and adjoint, 2 fast-math forward + restructured adjoint
+        # kernel family (include/unidom_hip.h ud_cloth_conf.mode): 0 (default) forward in operation order "v2" (the reference's
+        # formulas re-associated; bit-identical to the CPU restatement of the same order) + restructured adjoint, 1 forward
+        # and adjoint in the reference's literal operation order, 2 fast-math v2 forward + restructured adjoint
         self.mode = int(getattr(conf, "kernel_mode", 0) if mode is None else mode)
         self.profile = None                  # bench.py: {"fwd": [...], "bwd": [...]} lists of (start, end) events
         self._suction_col = torch.tensor([[False, False, False, True] * 2], device=self.device)   # columns robot_step leaves unscaled

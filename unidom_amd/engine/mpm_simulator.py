@@ -140,6 +140,7 @@ class SimpleMPMSimulator:
         self.sort_particles = int(getattr(conf, "sort_particles", 0))     # include/unidom_hip.h: internal spatial order (liquids)
         self.profile = None
         self.status_log = []
+        self._status_acc = None          # flags folded out of status_log (device scalar), read by check_status()
         self._h = None
         self._h_large = False            # the handle runs the many-workgroup path (N > 128 or soft contact)
         self._flag_stream = None
@@ -273,12 +274,22 @@ class SimpleMPMSimulator:
 
     def check_status(self):
         """Host sync: raise if any launch since the last check overflowed its LDS cell table."""
-        if self.status_log:
-            bad = torch.stack(self.status_log).sum().item()
-            self.status_log = []
+        if self.status_log or self._status_acc is not None:
+            self._fold_status(0)
+            bad = self._status_acc.item()
+            self._status_acc = None
             if bad:
                 raise _lib.UnidomError("MPM device-side capacity exceeded (UD_ERR_OVERFLOW): LDS cell table (one-workgroup path) or "
                                        "grid-checkpoint pool (conf.grid_ckpt_cells too small) -- particle cloud too spread out")
+
+    def _fold_status(self, keep):
+        """Fold all but the newest `keep` per-launch flag tensors into one persistent device counter (no host sync), so a
+        long run that never calls check_status() cannot lose a flag by list truncation."""
+        old = self.status_log[:len(self.status_log) - keep] if keep else self.status_log
+        if old:
+            s = torch.stack([t.ne(0).sum() for t in old]).sum()
+            self._status_acc = s if self._status_acc is None else self._status_acc + s
+        self.status_log = self.status_log[len(self.status_log) - keep:] if keep else []
 
     # -- the hot path --------------------------------------------------------------------------------------
     def step_jax(self, state: MPMState, action):
@@ -289,7 +300,7 @@ class SimpleMPMSimulator:
         if len(state.primitives) != P:
             raise _lib.UnidomError(f"state has {len(state.primitives)} primitives, the kernel handle was built for {P}")
         if len(self.status_log) > 256:
-            self.status_log = self.status_log[-8:]
+            self._fold_status(8)
         prims = state.primitives
         if P == 1:
             pos, rot, size = prims[0].position, prims[0].rotation, prims[0].size

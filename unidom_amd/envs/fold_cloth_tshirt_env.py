@@ -4,8 +4,9 @@ dt 0.5e-3, five pick-and-place steps per episode, observation = every tenth part
 
 The reference reads the mask from others/t-shirt.jpg with cv2 (resize, rotate, threshold); here it is the data file
 others/tshirt_mask.npy, recovered from the recorded reset state of the reference's expert_demo/fold_tshirt/demo_0.pkl
-(tests/golden/make_golden.py).  The reference ships no goal for this task (goals/fold_tshirt/ is empty: it warns and uses
-zeros), and neither does this repo.  Bodies above 1024 particles run the several-particles-per-lane kernels of csrc/cloth.hip."""
+(tests/golden/make_golden.py).  The goal cloud is the reference's goals/fold_tshirt/goal.npy ((3573, 3) f32, conf.goal_path
+:36-37), re-packed by the same script into envs/goals/fold_tshirt/.  Bodies above 1024 particles run the
+several-particles-per-lane kernels of csrc/cloth.hip."""
 import numpy as np
 import torch
 

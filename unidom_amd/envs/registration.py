@@ -19,16 +19,14 @@ env_functions = {
     "fold_tshirt": FoldTshirtEnv,
 }
 
-try:  # MPM envs (whip_rope) register themselves once the MPM kernels are built
-    from .whip_rope_env import WhipRopeEnv
-    from .shape_rope_env import ShapeRopeEnv
-    from .shape_rope_hard_env import ShapeRopeHardEnv
-    from .pour_water_env import PourWaterEnv
-    from .pour_soup_env import PourSoupEnv
-    env_functions["whip_rope"] = WhipRopeEnv
-    env_functions["shape_rope"] = env_functions["push_rope"] = ShapeRopeEnv                  # both names, registration.py:18-21
-    env_functions["shape_rope_hard"] = env_functions["push_rope_hard"] = ShapeRopeHardEnv
-    env_functions["pour_water"] = PourWaterEnv
-    env_functions["pour_soup"] = PourSoupEnv
-except ImportError:  # pragma: no cover
-    pass
+from .whip_rope_env import WhipRopeEnv
+from .shape_rope_env import ShapeRopeEnv
+from .shape_rope_hard_env import ShapeRopeHardEnv
+from .pour_water_env import PourWaterEnv
+from .pour_soup_env import PourSoupEnv
+
+env_functions["whip_rope"] = WhipRopeEnv
+env_functions["shape_rope"] = env_functions["push_rope"] = ShapeRopeEnv                  # both names, registration.py:18-21
+env_functions["shape_rope_hard"] = env_functions["push_rope_hard"] = ShapeRopeHardEnv
+env_functions["pour_water"] = PourWaterEnv
+env_functions["pour_soup"] = PourSoupEnv
