@@ -11,6 +11,7 @@ nan_to_num + clip, the RCCL all-reduce of the flat policy gradient when N > 1, a
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no RANK in the environment: bench.py starts that torch.distributed.run itself
 
 Weak scaling: every rank owns 4 envs; `value` is the whole-job aggregate.  Rank 0 prints ONE JSON line.
 """
@@ -38,31 +39,142 @@ BYTES_BWD = 72 * P     # read saved x,v + read g_x,g_v + write g_x,g_v
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def self_launch(argv):
+    """`--gpus N` (N > 1) without RANK in the environment: start the N ranks ourselves -- one child
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same flags>` -- BEFORE this process makes any GPU call,
+    relay rank 0's single JSON line, and exit non-zero if the launcher or any rank does (the reference: one process driving
+    `--gpus` devices through jax.pmap, apg.py:83-85, :269-271)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = int(argv[argv.index("--gpus") + 1]) if "--gpus" in argv else int([a for a in argv if a.startswith("--gpus=")][0].split("=")[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        print(f"bench.py: the {n}-rank launch failed (exit code {r.returncode}, {len(lines)} result lines)", file=sys.stderr)
+        raise SystemExit(r.returncode or 1)
+    print(lines[0], flush=True)
+    raise SystemExit(0)
+
+
+def bench_selftest(args, rank, world, device):
+    """The N-rank plumbing of this file without a simulator: init_distributed, the barrier-bracketed timed region, the
+    max-over-ranks timing, the per-update gradient all-reduce of GradSync, rank 0's single JSON line.  Used by the CPU test
+    (gloo, 2 ranks, UNIDOM_DIST_BACKEND=gloo); it measures nothing about the hot path."""
+    from unidom_amd.algorithms.apg.core import GradSync, Policy
+    pol = Policy(32, 6, hidden=(64, 32), seed=0).to(device)
+    sync = GradSync(pol, 1e-3, 0.3)
+    x = torch.linspace(-1, 1, 4 * 32, device=device).reshape(4, 32) * (1 + rank)
+
+    def one():
+        sync.zero_grad()
+        (pol(x) ** 2).sum().backward()
+        sync.step()
+
+    def barrier():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    barrier()
+    tm = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    same = torch.ones((), device=device)
+    if world > 1:
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = (lo == hi).all().float()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest_updates_per_sec", "value": world * args.steps / float(tm[0]), "unit": "updates/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tm[0]) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "selftest (no simulator): policy gradient all-reduce + Adam"},
+                          "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                          "allreduce_bytes_per_update": sync.n_params * 4 if world > 1 else 0,
+                          "replicas_identical": bool(same.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dist_info(world, allreduce_params=0):
+    """What the line says about the N-rank run: the world size torch.distributed reports (not the flag), and the bytes of the
+    one collective per update (the policy-gradient mean, apg.py:235); 0 for simulator-only workloads (replicas, no collective)."""
+    return {"n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "allreduce_bytes_per_update": allreduce_params * 4 if world > 1 else 0}
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch from the committed counter passes (profiles/pmc_traffic.json), or None when there is no
+    entry or the kernel sources have changed since the passes were taken (the entry carries their hash)."""
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tj):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import src_hash
+    e = json.load(open(tj)).get(key)
+    if not e or e.get("src_sha16") != src_hash.sha16(key):
+        return None
+    return e.get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
-    """Oracle (CPU restatement, NOT JAX-CPU) timed on the host cores: fwd + adjoint of the same workload.
-    The oracle is only the thing timed/compared here, never the product path."""
-    from oracle.pyoracle import ClothOracle
+    """Oracle (CPU restatement, NOT JAX-CPU), rebuilt here with -O3 -march=native, timed on the host cores: forward + adjoint
+    of the headline workload (4 envs x ep_len step_diffs) on min(4, nproc) threads (`value`), the same on ONE thread, and
+    nproc envs on nproc threads (all cores busy).  The oracle is only the thing timed here, never the product path."""
+    from oracle import pyoracle
     from tests.conftest import fold_cloth1_mask, make_cloth_case
-    orc = ClothOracle(fold_cloth1_mask())
-    rng = np.random.default_rng(0)
-    x, v, prim, k, mu, actions = make_cloth_case(rng, sample_envs, MACRO, deform=0.0005, v_scale=0.01)
-    actions *= 0.2
-    g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
-    threads = min(sample_envs, os.cpu_count() or 1)
-    t0 = time.time()
-    for _ in range(ep_len):
-        orc.rollout_fwd(x, v, prim, k, mu, actions, nthreads=threads)
-    t_f = time.time() - t0
-    t0 = time.time()
-    for _ in range(ep_len):
-        orc.rollout_bwd(x, v, prim, k, mu, actions, g[0], g[1], g[2], normalize=True, nthreads=threads)
-    t_b = time.time() - t0
-    n = sample_envs * ep_len * MACRO * SUBSTEPS
+    pyoracle.use_native()
+    orc = pyoracle.ClothOracle(fold_cloth1_mask())
+    nproc = os.cpu_count() or 1
+
+    def run(envs, threads, reps):
+        rng = np.random.default_rng(0)
+        x, v, prim, k, mu, actions = make_cloth_case(rng, envs, MACRO, deform=0.0005, v_scale=0.01)
+        actions *= 0.2
+        g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
+        t0 = time.time()
+        for _ in range(reps):
+            orc.rollout_fwd(x, v, prim, k, mu, actions, nthreads=threads)
+        t_f = time.time() - t0
+        t0 = time.time()
+        for _ in range(reps):
+            orc.rollout_bwd(x, v, prim, k, mu, actions, g[0], g[1], g[2], normalize=True, nthreads=threads)
+        t_b = time.time() - t0
+        return envs * reps * MACRO * SUBSTEPS, t_f, t_b
+
+    threads = min(sample_envs, nproc)
+    n, t_f, t_b = run(sample_envs, threads, ep_len)
+    n1, t_f1, t_b1 = run(1, 1, ep_len)
+    nn, t_fn, t_bn = run(nproc, nproc, ep_len)
     return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
-            "sample": f"CPU restatement (C++ -O2, f32, reference op order; not JAX-CPU): {sample_envs} envs x "
-                      f"{ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint (with its "
-                      f"own state recompute) {t_b:.2f}s, OpenMP over envs ({threads} threads; substeps are sequential)",
-            "fwd_only_value": n / t_f}
+            "sample": f"CPU restatement (C++ -O3 -march=native built on this host, f32, reference op order, no FMA contraction; not "
+                      f"JAX-CPU): {sample_envs} envs x {ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint "
+                      f"{t_b:.2f}s; the adjoint call recomputes the forward states itself (it keeps no checkpoint), so its time "
+                      f"includes one more forward; OpenMP over envs ({threads} threads; substeps are sequential)",
+            "fwd_only_value": n / t_f,
+            "one_thread": {"value": n1 / (t_f1 + t_b1), "fwd_only_value": n1 / t_f1, "cores": 1, "sample": f"1 env x {ep_len} step_diff"},
+            "all_cores": {"value": nn / (t_fn + t_bn), "fwd_only_value": nn / t_fn, "cores": nproc,
+                          "sample": f"{nproc} envs x {ep_len} step_diff on {nproc} threads (more envs than the headline workload has)"}}
 
 
 def saturation_probe(env, device, num_envs=1024, reps=3):
@@ -155,16 +267,15 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
         per_sub = (192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act)
         per_launch = B * S * per_sub
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
-        traffic = None          # PMC passes exist for the default whip_rope shape only (32 envs, one workgroup per env)
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if name == "whip_rope" and B == 32 and os.path.exists(tj):
-            traffic = json.load(open(tj)).get("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", {}).get("hbm_bytes_per_launch")
-        elif B == 32 and os.path.exists(tj):      # many-workgroup path: all kernels of one step call (tools/pmc_large.sh)
-            traffic = json.load(open(tj)).get(f"large_path:{name}:{dom}", {}).get("hbm_bytes_per_launch")
+        traffic = None          # PMC passes exist for the default shapes only (32 envs per launch)
+        if name == "whip_rope" and B == 32:
+            traffic = pmc_traffic("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel")
+        elif B == 32:                             # many-workgroup path: all kernels of one step call (tools/pmc_large.sh)
+            traffic = pmc_traffic(f"large_path:{name}:{dom}")
         print(json.dumps({
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world, learner.n_params),
             "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)" if env.simulator.n_primitive > 1 or N > 128 else
@@ -222,7 +333,7 @@ def bench_torus(args, rank, world, device):
         print(json.dumps({
             "metric": "plb_substeps_per_sec_fwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"PlasticineLab Torus (f64 von-Mises MPM, N={sim.n_particles}, n_grid={sim.n_grid}, "
                                    f"{sim.substeps} substeps/env.step), forward rollout, {B} envs per GPU, step = {inner} env.steps",
                        "touched_cells": g_act, "parity": "unpinned (taichi absent)"},
@@ -301,7 +412,7 @@ def bench_mpm_scaled(args, rank, world, device):
         print(json.dumps({
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"whip_rope rope seeded at n_grid={ng} (N={N}, res {ng // 2}^3, {S} substeps/step), "
                                    f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
@@ -315,7 +426,9 @@ def bench_mpm_scaled(args, rank, world, device):
 def cpu_baseline_shape_rope(env, st, act, sample_envs=8, steps=6):   # ~11 s of host work
     """Oracle (CPU restatement, dense 64x6x64 grid, NOT JAX-CPU) on the host cores: `steps` scanned simulator.steps
     (133 substeps each) forward + adjoint for `sample_envs` of the bench's envs.  Checker only, never the product path."""
-    from oracle.pyoracle import MpmOracle
+    from oracle import pyoracle
+    pyoracle.use_native()
+    MpmOracle = pyoracle.MpmOracle
     conf = env.conf
     N, S = st.x.shape[1], conf.steps
     npy = lambda t: t.detach().cpu().numpy()[:sample_envs]
@@ -351,7 +464,7 @@ def cpu_baseline_shape_rope(env, st, act, sample_envs=8, steps=6):   # ~11 s of 
         ost.update(x=o["x"], v=o["v"], C=o["C"], F=o["F"], J=o["J"], ppos=o["ppos"], prot=o["prot"])
     n = sample_envs * steps * S
     return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
-            "sample": f"CPU restatement (C++ -O2, f32, dense res grid like the reference; not JAX-CPU): {sample_envs} envs x {steps} "
+            "sample": f"CPU restatement (C++ -O3 -march=native, f32, dense res grid like the reference; not JAX-CPU): {sample_envs} envs x {steps} "
                       f"simulator.steps x {S} substeps, forward {t_f:.2f}s + adjoint (with its own state recompute) {t_b:.2f}s, "
                       f"OpenMP over envs ({threads} threads)"}
 
@@ -406,7 +519,7 @@ def bench_fold_tshirt(args, rank, world, device):
         print(json.dumps({
             "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"fold_tshirt (mass-spring cloth, P={P} on a 180x180 lattice) step_diff + backward to the action, {B} envs per GPU"},
             "roofline": {"bound": "hbm", "kernel": "cloth_big_bwd_kernel" if dom == "bwd" else "cloth_big_fwd_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
@@ -474,7 +587,7 @@ def bench_shape_rope(args, rank, world, device):
         print(json.dumps({
             "metric": "mpm_substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"shape_rope (MLS-MPM plastic rope N={N}, res 64x6x64, soft contact, {T} x {S} substeps/env.step) "
                                    f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act},
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
@@ -494,7 +607,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
-    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water", "pour_soup"],
+    ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water", "pour_soup", "selftest"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
     ap.add_argument("--cloth-envs", type=int, default=None, help="cloth workloads: envs per GPU (default 4; 32 for fold_cloth1_para)")
@@ -506,6 +619,8 @@ def main():
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(sys.argv[1:])              # never returns; nothing above has touched a GPU
 
     from unidom_amd.algorithms.apg.core import APG, init_distributed
     from unidom_amd.envs.registration import env_functions
@@ -513,6 +628,8 @@ def main():
 
     rank, world, device = init_distributed(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.workload == "selftest":
+        return bench_selftest(args, rank, world, device)
     if args.workload == "torus":
         return bench_torus(args, rank, world, device)
     if args.workload == "shape_rope":
@@ -582,18 +699,21 @@ def main():
                  "bwd": "cloth_rollout_bwd_kernel" if args.kernel_mode == 1 else "cloth_rollout_bwd_fast_kernel"}[dom]
         per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and NUM_ENVS_PER_GPU == 4:   # the PMC passes were taken on the headline shape (4 envs per launch)
-            traffic = json.load(open(tj)).get(kname, {}).get("hbm_bytes_per_launch")
+        # the PMC passes were taken on the headline shape (4 envs per launch); null once the kernel sources have changed
+        traffic = pmc_traffic(kname) if NUM_ENVS_PER_GPU == 4 else None
         out = {
             "metric": "substeps_per_sec_fwd_bwd", "value": units / dt, "unit": "substeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload} (mass-spring cloth, P=512) APG loss+grad+update: num_envs={NUM_ENVS_PER_GPU} per GPU, "
                                    "ep_len=3, 40 macro x 50 substeps per step_diff",
-                       "kernel_mode": args.kernel_mode, "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
+                       "kernel_mode": args.kernel_mode,
+                       "order": {0: "v2 (the reference's formulas re-associated; bit-exact vs the CPU restatement of the same order)",
+                                 1: "reference (literal operation order)", 2: "v2 fast-math"}[args.kernel_mode],
+                       "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
                        "parallelism": f"env-sharded dp{world}, 1 RCCL all-reduce of {learner.n_params} f32 per update"},
+            "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+            "allreduce_bytes_per_update": learner.n_params * 4 if world > 1 else 0,
             "fwd_only_substeps_per_sec": units / dt_fwd,
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -24,10 +24,19 @@ def build(force: bool = False) -> str:
     return so
 
 
-def lib():
+def use_native():
+    """bench.py's cpu_baseline leg only: (re)build the restatement with -O3 -march=native ON THIS MACHINE and
+    bind this process to it.  Same sources, same -ffp-contract=off / no fast-math; only the instruction set differs."""
+    global _LIB
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native"])
+    _LIB = None
+    lib(os.path.join(_HERE, "_native", "liboracle.so"))
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(path or build())
         _LIB.oc_cloth_create.restype = C.c_void_p
         if hasattr(_LIB, "oc_mpm_create"):
             _LIB.oc_mpm_create.restype = C.c_void_p

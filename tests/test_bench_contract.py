@@ -31,3 +31,31 @@ def test_committed_headline_line_has_the_contract_keys():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     assert line["value"] > cpu["value"]          # not a target, but a GPU line slower than the CPU port would be a regression
+
+
+def test_bench_gpus_2_launches_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` with no RANK in the environment starts the two ranks itself (torch.distributed.run,
+    127.0.0.1), rank 0 prints ONE JSON line, and the parent relays it.  Driven here with gloo on the CPU
+    (UNIDOM_DIST_BACKEND=gloo) on the simulator-free selftest workload: the launcher, init_distributed, the barrier-bracketed
+    timed region, the max-over-ranks timing and the gradient all-reduce are the ones every workload uses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["UNIDOM_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--workload", "selftest"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["allreduce_bytes_per_update"] == 4 * (32 * 64 + 64 + 64 * 32 + 32 + 32 * 12 + 12)
+    assert line["replicas_identical"] is True and line["value"] > 0
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["UNIDOM_DIST_BACKEND"] = "gloo"
+    # the cloth workload cannot run without a GPU: every rank raises, the parent must exit non-zero and print no result line
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-saturation"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

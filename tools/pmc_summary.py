@@ -4,8 +4,11 @@ usage: python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SI
 FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) gfx950 tallies 128-B read
 requests at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is.  Each counter comes from its own pass.
 """
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import src_hash
 
 
 def load(path, counter):
@@ -24,6 +27,7 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"FETCH_SIZE": {"n": len(f), "mean_kb": sum(f) / len(f), "min_kb": min(f), "max_kb": max(f)},
               "WRITE_SIZE": {"n": len(w), "mean_kb": sum(w) / len(w), "min_kb": min(w), "max_kb": max(w)},
               "hbm_bytes_per_launch": (2 * max(f) + max(w)) * 1024,
+              "src_sha16": src_hash.sha16(k),   # bench.py reports traffic only while the kernel sources still hash to this
               "note": "2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KB x 1024, separate --pmc passes; "
                       "max over launches (forward launches under no_grad write no checkpoints)"}
 json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json", "w"), indent=1)

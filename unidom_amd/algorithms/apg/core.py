@@ -224,9 +224,16 @@ class APG:
 
 
 def init_distributed(gpus: int):
-    """One process per GPU. Under torchrun (RANK/WORLD_SIZE set) join the RCCL group; otherwise single GPU."""
+    """One process per GPU. Under torchrun (RANK/WORLD_SIZE set) join the RCCL group; otherwise single GPU.
+    UNIDOM_DIST_BACKEND=gloo (tests; rehearsals without GPUs) joins a gloo group on the CPU instead -- only host-side code
+    (the launcher, the collective, the update rule) can run there, the simulators have no CPU path."""
     import os
+    backend = os.environ.get("UNIDOM_DIST_BACKEND", "nccl")
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if backend == "gloo":
+            if not dist.is_initialized():
+                dist.init_process_group(backend="gloo")
+            return dist.get_rank(), dist.get_world_size(), torch.device("cpu")
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         if not dist.is_initialized():
@@ -235,7 +242,7 @@ def init_distributed(gpus: int):
     if gpus > 1:
         raise SystemExit(f"--gpus {gpus}: launch one process per GPU, e.g. "
                          f"python -m torch.distributed.run --nproc-per-node {gpus} --master-addr 127.0.0.1 -m <module> ...")
-    return 0, 1, torch.device("cuda", 0)
+    return 0, 1, (torch.device("cpu") if backend == "gloo" else torch.device("cuda", 0))
 
 
 class Timer:
