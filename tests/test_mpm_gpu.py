@@ -164,7 +164,9 @@ def test_batched_envs_with_different_parameters(demo):
     orc = MpmOracle(67, steps=S)
     for n, st in enumerate(cases):
         of = orc.step_fwd(st)
-        assert _rel(oh["x"][n], of["x"][0]) < 1e-5 and _rel(oh["v"][n], of["v"][0]) < 1e-4   # north_star: 1e-4 relative
+        # x: 1e-5, not the 5e-6 of the other forward tests -- measured 1.75e-6 here (round 1, gpurun_out/t12.log), run-to-run
+        # variation from the order of the LDS atomics over 50 substeps with per-env parameters; v: north_star's 1e-4 relative
+        assert _rel(oh["x"][n], of["x"][0]) < 1e-5 and _rel(oh["v"][n], of["v"][0]) < 1e-4
         assert _rel(oh["C"][n], of["C"][0]) < 1e-3 and _rel(oh["F"][n], of["F"][0]) < 5e-5
 
 
@@ -206,9 +208,19 @@ class ScaledConf(LegacyConf):
     E, nu = 100, 0.1
 
 
-def _scaled_case(S, seed, B=1, grid_ckpt_cells=0):
+class ScaledConf256(LegacyConf):
+    """BASELINE config 4's stated size: "128^3 grid" = res 128^3 at n_grid 256 -> N = 6675."""
+    n_grid = 256
+    res = (128, 128, 128)
+    dx, inv_dx = 1 / 256, 256.0
+    p_vol = (dx * 0.5) ** 2
+    p_mass = p_vol * 1
+    E, nu = 100, 0.1
+
+
+def _scaled_case(S, seed, B=1, grid_ckpt_cells=0, conf_cls=ScaledConf):
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
-    conf = ScaledConf()
+    conf = conf_cls()
     conf.steps = S
     sim = SimpleMPMSimulator(conf, B, use_position_control=True)
     sim.grid_ckpt_cells = grid_ckpt_cells
@@ -275,6 +287,39 @@ def test_full_batch_launch_agrees_with_the_oracle_checked_small_one():
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
         assert np.isfinite(big[key]).all(), key
         assert _rel(big[key][pick], small[key]) < 2e-3, (key, _rel(big[key][pick], small[key]))
+
+
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 2])
+def test_baseline_config4_size_n_grid_256_matches_oracle(grid_ckpt_cells):
+    """BASELINE config 4 at its stated size (whip_rope, "128^3 grid": n_grid 256, res 128^3, N = 6675).  A
+    16-env launch = 106 800 particles, past the 100 k threshold, so the one-lane-per-particle kernels and a single env group
+    run -- the regime bench.py --n-grid 256 measures, no lane override.  Two of its envs are followed by the CPU oracle on the
+    dense 2 M-cell grid over 3 substeps (dt = 1e-4 at dx = 1/256 is 4x the default CFL number: a short window), forward in
+    f32 and adjoint in f64, with the backward both recomputing the grid (0) and restoring it from the checkpoint (2, the
+    bench's setting)."""
+    from oracle.pyoracle import MpmOracle
+    S, B, pick = 3, 16, [0, 9]
+    sim, st, g, N = _scaled_case(S, 11, B=B, grid_ckpt_cells=grid_ckpt_cells, conf_cls=ScaledConf256)
+    assert N == 6675 and B * N >= 100000 and "UD_LG_LANES" not in os.environ
+    st["action"][9] = np.float32([-0.3, 0.2, 0.1, 0, 0, 0]) / 50
+    sub = lambda d: {k: np.ascontiguousarray(v[pick]) for k, v in d.items()}
+    orc = MpmOracle(N, n_grid=256, res=(128, 128, 128), steps=S)
+    of = orc.step_fwd(sub(st), nthreads=2)
+    assert all(np.isfinite(of[k]).all() for k in ("x", "v", "C", "F"))
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in sub(st).items()},
+                      {k: v.astype(np.float64) for k, v in sub(g).items()}, clip=True, nthreads=2)
+    oh = run_hip(sim, st, g=g, clip=True)
+    sim.check_status()
+    assert _rel(oh["x"][pick], of["x"]) < 5e-6 and _rel(oh["v"][pick], of["v"]) < 1e-4     # north_star: 1e-4 relative
+    assert _rel(oh["C"][pick], of["C"]) < 1e-3 and _rel(oh["F"][pick], of["F"]) < 5e-5
+    np.testing.assert_allclose(oh["J"][pick], of["J"], rtol=1e-5)
+    for key in ("ppos", "prot", "pv", "pw"):
+        np.testing.assert_allclose(oh[key][pick], of[key], rtol=0, atol=1e-7)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key][pick], ob[key]) < 5e-3, (key, _rel(oh[key][pick], ob[key]))
+    for key in ("gfriction", "gmu", "glamda"):
+        assert _rel(oh[key].reshape(-1)[pick], ob[key]) < 2e-2, (key, oh[key].reshape(-1)[pick], ob[key])
 
 
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
