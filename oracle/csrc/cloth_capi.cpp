@@ -26,7 +26,7 @@ template <> const ClothParams<double>& pars<double>(const OcCloth* h) { return h
 template <class T>
 static void macro_action(const T* a8, T* act /*[2][4]*/) {  // :168-169
   for (int g = 0; g < 2; ++g) {
-    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], T(-2), T(2)) / T(50);
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], T(-2), T(2)) * (T(1) / T(50));   // x / 50. as XLA executes it under jit: A / Const => A * (1 / Const) (AlgebraicSimplifier); the recorded demos discriminate
     act[g * 4 + 3] = a8[g * 4 + 3];
   }
 }
@@ -114,7 +114,7 @@ static void rollout_bwd(const OcCloth* h, int B, int TT, const T* x0, const T* v
       }
       T* ga = gactions + ((size_t)t * B + b) * 8;
       for (int g = 0; g < 2; ++g) {
-        for (int c3 = 0; c3 < 3; ++c3) ga[g * 4 + c3] = gact[g * 4 + c3] / T(50) * clip_grad(a8[g * 4 + c3], T(-2), T(2));
+        for (int c3 = 0; c3 < 3; ++c3) ga[g * 4 + c3] = gact[g * 4 + c3] * (T(1) / T(50)) * clip_grad(a8[g * 4 + c3], T(-2), T(2));
         ga[g * 4 + 3] = gact[g * 4 + 3];
       }
     }

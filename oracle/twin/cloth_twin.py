@@ -63,6 +63,14 @@ def fold_cloth1_mask(conf: ClothConf) -> np.ndarray:   # fold_cloth1_env.py:48-5
     return m
 
 
+def _recip(c, like):
+    """x / c with a compile-time constant c, as XLA's AlgebraicSimplifier rewrites it under jit: x * (1 / c), the reciprocal
+    rounded once in the array's dtype.  The reference's recorded primitive trajectories discriminate the two forms for / 3
+    (get_pnp_actions) and / 50 (robot_step): tests/test_oracle_cloth.py::test_sibling_demo_*."""
+    one = torch.ones((), dtype=like.dtype)
+    return one / torch.tensor(float(c), dtype=like.dtype)
+
+
 def _clip(x, lo, hi):
     """jnp.clip: minimum(hi, maximum(lo, x)); tie gradients split evenly."""
     lo_t = torch.as_tensor(lo, dtype=x.dtype)
@@ -200,8 +208,8 @@ class ClothTwin:
         return (out, m0, m1) if want_mask else out
 
     def robot_step(self, st: ClothState, action, record=None):                                     # :163-180
-        a0 = torch.cat([_clip(action[:3], -2, 2) / 50.0, action[3:4]])                             # :168
-        a1 = torch.cat([_clip(action[4:7], -2, 2) / 50.0, action[7:8]])                            # :169
+        a0 = torch.cat([_clip(action[:3], -2, 2) * _recip(50, action), action[3:4]])                             # :168
+        a1 = torch.cat([_clip(action[4:7], -2, 2) * _recip(50, action), action[7:8]])                            # :169
         st = st._replace(action0=a0, action1=a1)
         for _ in range(self.conf.substeps):                                                        # :176
             if record is not None:

@@ -154,6 +154,32 @@ def main():
     np.save(f"{REPO}/unidom_amd/envs/others/veg_points.npy", veg)
     print("pour_soup veg cloud", veg.shape, veg.min(0), veg.max(0))
 
+    # ---- sibling cloth demos (fold_cloth3, unfold_cloth1/3, fold_tshirt): what they pin exactly, like fold_cloth1's, is the
+    # primitive kinematics (get_pnp_actions + robot_step's action scaling + the primitive update), the 40-split key chain per
+    # step_diff and cur_step -- none of which reads the cloth's x/v (which these legacy recordings do not pin), so
+    # only those small fields are kept (fold_tshirt's x alone would be 43 KB per state).  The fold_tshirt pickles predate
+    # ClothState.stiffness / .mu (8 fields).
+    recs = collections.defaultdict(list)
+    for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "fold_tshirt"):
+        for p in sorted(glob.glob(f"{REF}/algorithms/expert_demo/{task}/demo_*.pkl")):
+            with open(p, "rb") as f:
+                d = _Legacy(f).load()
+            demo_id = int(os.path.basename(p).split("_")[1].split(".")[0])
+            for k in range(len(d["state"]) - 1):
+                s0, s1 = d["state"][k], d["state"][k + 1]
+                recs["task"].append(task)
+                recs["demo"].append(demo_id)
+                recs["k"].append(k)
+                recs["action"].append(np.asarray(d["action"][k])[0])
+                for nm, st in (("s0", s0), ("s1", s1)):
+                    recs[nm + "_primitive0"].append(np.asarray(st[2])[0])
+                    recs[nm + "_primitive1"].append(np.asarray(st[3])[0])
+                    recs[nm + "_key"].append(np.asarray(st[6])[0])
+                    recs[nm + "_cur_step"].append(np.asarray(st[7])[0])
+    recs = {k: np.stack(v) for k, v in recs.items()}
+    np.savez_compressed(f"{HERE}/cloth_sibling_demos.npz", **recs)
+    print("sibling cloth demos:", {t: int((recs["task"] == t).sum()) for t in np.unique(recs["task"])})
+
     # goals of the sibling envs on the same kernels (data files: inputs of their reward)
     for task in ("fold_cloth3", "unfold_cloth1", "unfold_cloth3", "fold_tshirt", "shape_rope", "pour_water"):
         src = f"{REF}/core/envs/goals/{task}/goal.npy"

@@ -31,7 +31,7 @@ __device__ __forceinline__ void macro_action(const float* a8, float* act) {  // 
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) * (1.0f / 50.0f);   // "/ 50." under jit = * (1 / 50) (pinned by the demos)
     act[g * 4 + 3] = a8[g * 4 + 3];
   }
 }
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(MAXT) cloth_rollout_bwd_kernel(ClothBwdArgs a)
         float tot = 0.f;
         for (int q = 0; q < nw; ++q) tot += rd[q * 8 + i];
         const int d = i & 3;
-        float out = (d < 3) ? tot / 50.0f * clip_grad(a8[i], -2.0f, 2.0f) : tot;
+        float out = (d < 3) ? tot * (1.0f / 50.0f) * clip_grad(a8[i], -2.0f, 2.0f) : tot;
         a.g_actions[((size_t)t * B + b) * 8 + i] = out;
       }
       __syncthreads();
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
         float tot = 0.f;
         for (int qq = 0; qq < nw; ++qq) tot += rd[qq * 8 + tid];
         const int d = tid & 3;
-        a.g_actions[((size_t)t * B + b) * 8 + tid] = (d < 3) ? tot / 50.0f * clip_grad(a8[tid], -2.0f, 2.0f) : tot;
+        a.g_actions[((size_t)t * B + b) * 8 + tid] = (d < 3) ? tot * (1.0f / 50.0f) * clip_grad(a8[tid], -2.0f, 2.0f) : tot;
       }
       __syncthreads();
     }

@@ -27,7 +27,7 @@ __device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  /
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) * (1.0f / 50.0f);   // "/ 50." under jit = * (1 / 50) (pinned by the demos)
     act[g * 4 + 3] = a8[g * 4 + 3];
   }
 }
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
     macro_action_f(a8, act);
 #pragma unroll
     for (int d = 0; d < 8; ++d) ga[d] = 0.f;
-    const float addl = pm3 ? clipf(a8[i & 7], -2.0f, 2.0f) / 50.0f : 0.f;   // this lane's component of the primitive move
+    const float addl = pm3 ? clipf(a8[i & 7], -2.0f, 2.0f) * (1.0f / 50.0f) : 0.f;   // this lane's component of the primitive move
     float gaP = 0.f;
     for (int s = S - 1; s >= 0; --s, ++step) {
       float x[3], v[3];
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(512) cloth_rollout_bwd_fast_kernel(ClothBwdArg
         for (int q = 0; q < nw; ++q) tot += mac[q * 8 + i];
         tot += gaP;
         const int d = i & 3;
-        a.g_actions[((size_t)t * B + b) * 8 + i] = (d < 3) ? tot / 50.0f * clip_grad(a8[i], -2.0f, 2.0f) : tot;
+        a.g_actions[((size_t)t * B + b) * 8 + i] = (d < 3) ? tot * (1.0f / 50.0f) * clip_grad(a8[i], -2.0f, 2.0f) : tot;
       }
     }
   }

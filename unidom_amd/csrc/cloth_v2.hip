@@ -14,7 +14,7 @@ __device__ __forceinline__ void macro_action_f(const float* a8, float* act) {  /
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) / 50.0f;
+    for (int c = 0; c < 3; ++c) act[g * 4 + c] = clipf(a8[g * 4 + c], -2.0f, 2.0f) * (1.0f / 50.0f);   // "/ 50." under jit = * (1 / 50) (pinned by the demos)
     act[g * 4 + 3] = a8[g * 4 + 3];
   }
 }

@@ -116,6 +116,10 @@ __global__ void __launch_bounds__(GLUE_T) chamfer_bwd_kernel(int P, int Q, const
 }
 
 // ---- pick-and-place expansion + contact distance -------------------------------------------------
+// Divisions by the literals 3 and 20 are multiplications by the f32 reciprocal, as XLA's AlgebraicSimplifier rewrites them under
+// jit (A / Const => A * (1 / Const)): the reference's recorded primitive trajectories tell the two forms apart for / 3 (and
+// for robot_step's / 50); 0.06 / 10 is constant / constant and is folded as a true division.
+constexpr float R3 = 1.0f / 3.0f, R20 = 1.0f / 20.0f;
 // macro rows (cloth_env.py:148-171): 3 x down ((pick_xz - primitive0.xyz)/3, 1) | 10 x up (0, 0.06/10, 0, 0) |
 // 20 x move ((place_xz - pick_xz)/20, 0) | 7 x release (0,0,0,1); columns 4-7 (second gripper) are zero.
 __global__ void __launch_bounds__(GLUE_T) pnp_fwd_kernel(int B, int P, const float* __restrict__ actions, const float* __restrict__ prim0,
@@ -149,11 +153,11 @@ __global__ void __launch_bounds__(GLUE_T) pnp_fwd_kernel(int B, int P, const flo
     const int t = tid;
     float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
     if (t < 3) {
-      r0 = (px - prim0[b * 4]) / 3.0f; r1 = (0.f - prim0[b * 4 + 1]) / 3.0f; r2 = (pz - prim0[b * 4 + 2]) / 3.0f; r3 = 1.f;
+      r0 = (px - prim0[b * 4]) * R3; r1 = (0.f - prim0[b * 4 + 1]) * R3; r2 = (pz - prim0[b * 4 + 2]) * R3; r3 = 1.f;
     } else if (t < 13) {
       r0 = 0.f / 10.0f; r1 = 0.06f / 10.0f; r2 = 0.f / 10.0f;
     } else if (t < 33) {
-      r0 = (a[3] - px) / 20.0f; r1 = 0.f / 20.0f; r2 = (a[5] - pz) / 20.0f;
+      r0 = (a[3] - px) * R20; r1 = 0.f * R20; r2 = (a[5] - pz) * R20;
     } else {
       r3 = 1.f;
     }
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(GLUE_T) pnp_bwd_kernel(int B, int P, const flo
       for (int d = 0; d < 3; ++d) down[d] += g_macro[((size_t)t * B + b) * 8 + d];
     for (int t = 13; t < 33; ++t)
       for (int d = 0; d < 3; ++d) move[d] += g_macro[((size_t)t * B + b) * 8 + d];
-    for (int d = 0; d < 3; ++d) { down[d] /= 3.0f; move[d] /= 20.0f; }
+    for (int d = 0; d < 3; ++d) { down[d] *= R3; move[d] *= R20; }
     // contact = |pick - x_p*|: d/dpick = (pick - x_p*) / contact, d/dx_p* = -(...)
     const int p = contact_idx[b];
     const float gc = g_contact ? g_contact[b] : 0.f;

@@ -25,6 +25,11 @@ from .. import _lib
 from ..utils import prng
 
 
+# `x / 50.` (cloth_simulator.py:168-169) as the reference executes it: under jit XLA rewrites a division by a compile-time
+# constant into a multiplication by its f32 reciprocal, and the recorded demos tell the two apart
+_R50 = float(np.float32(1.0) / np.float32(50.0))
+
+
 class ClothState(NamedTuple):  # cloth_simulator.py:13-23
     x: torch.Tensor            # [B,P,3]
     v: torch.Tensor            # [B,P,3]
@@ -217,15 +222,15 @@ class ClothSimulator:
         out = _Rollout.apply(self, state.x, state.v, prim, k, state.mu, actions, want_lists)
         xo, vo, po = out[:3]
         a_last = actions[-1].detach()                                                # bookkeeping fields, never differentiated
-        both = torch.where(self._suction_col, a_last, a_last.clamp(-2, 2) / 50.0)    # :168-169 for both grippers at once
+        both = torch.where(self._suction_col, a_last, a_last.clamp(-2, 2) * _R50)    # :168-169 for both grippers at once
         act0, act1 = both[:, :4], both[:, 4:]
         key = prng.split_first(state.key, T)                                         # :172, once per robot_step
         new = state._replace(x=xo, v=vo, primitive0=po[:, 0], primitive1=po[:, 1], action0=act0, action1=act1, key=key)
         if not want_lists:
             return new, None
         xl, vl, pl = out[3:]
-        a0l = torch.cat([actions[..., :3].clamp(-2, 2) / 50.0, actions[..., 3:4]], -1)
-        a1l = torch.cat([actions[..., 4:7].clamp(-2, 2) / 50.0, actions[..., 7:8]], -1)
+        a0l = torch.cat([actions[..., :3].clamp(-2, 2) * _R50, actions[..., 3:4]], -1)
+        a1l = torch.cat([actions[..., 4:7].clamp(-2, 2) * _R50, actions[..., 7:8]], -1)
         keys, kk = [], state.key
         for _ in range(T):
             kk = prng.split_first(kk, 1)

@@ -22,6 +22,11 @@ from . import _fused
 from .step_info import _StepInfo
 
 
+# `/ 3` and `/ 20` of get_pnp_actions as the reference executes them under jit: multiplications by the f32 reciprocal (XLA's
+# A / Const => A * (1 / Const)); the recorded demos discriminate (csrc/env_glue.hip)
+_R3, _R20 = float(np.float32(1) / np.float32(3)), float(np.float32(1) / np.float32(20))
+
+
 class ClothEnv:
     PARTICLE = "PARTICLE"
     DEPTH = "DEPTH"
@@ -85,12 +90,12 @@ class ClothEnv:
         pick = torch.cat([actions[:, 0:1], zero, actions[:, 2:3]], -1)       # :145
         place = torch.cat([actions[:, 3:4], zero, actions[:, 5:6]], -1)      # :146
         one = torch.ones_like(zero)
-        act_down = torch.cat([(pick - state.primitive0[:, :3]) / 3, one], -1)                       # :148-151
+        act_down = torch.cat([(pick - state.primitive0[:, :3]) * _R3, one], -1)                       # :148-151
         act_up = torch.tensor([0, 0.06, 0, 0], device=dev).repeat(B, 1)
         act_up = torch.cat([act_up[:, :3] / 10, act_up[:, 3:]], -1)                                  # :154-156
         move = place - pick
         move = torch.cat([move[:, 0:1], zero, move[:, 2:3]], -1)                                     # :159-160
-        act_move = torch.cat([move / 20, zero], -1)                                                  # :161-163
+        act_move = torch.cat([move * _R20, zero], -1)                                                  # :161-163
         act_release = torch.tensor([0.0, 0, 0, 1], device=dev).repeat(B, 1)                          # :166
         sub = torch.cat([act_down[None].expand(3, B, 4), act_up[None].expand(10, B, 4),
                          act_move[None].expand(20, B, 4), act_release[None].expand(7, B, 4)], 0)
