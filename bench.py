@@ -511,6 +511,8 @@ def bench_fold_tshirt(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         P = st.x.shape[1]
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        cluster = os.environ.get("UD_CLOTH_CLUSTER", "1") != "0" and B * -(-P // 512) <= n_cu     # csrc/cloth.hip::cloth_use_cluster
         units = world * B * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
@@ -521,10 +523,14 @@ def bench_fold_tshirt(args, rank, world, device):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"fold_tshirt (mass-spring cloth, P={P} on a 180x180 lattice) step_diff + backward to the action, {B} envs per GPU"},
-            "roofline": {"bound": "hbm", "kernel": "cloth_big_bwd_kernel" if dom == "bwd" else "cloth_big_fwd_kernel", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": per_launch,
-                         "note": "one workgroup of 1024 lanes per env, 4 particles per lane, 2000 sequential substeps per launch"}}), flush=True)
+            "roofline": {"bound": "hbm", "kernel": ("cloth_cluster_bwd_kernel" if dom == "bwd" else "cloth_cluster_fwd_kernel") if cluster
+                         else ("cloth_big_bwd_kernel" if dom == "bwd" else "cloth_big_fwd_kernel"), "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("cloth_cluster_bwd_kernel" if dom == "bwd" else "cloth_cluster_fwd_kernel") if cluster and B == 4 else None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
+                         "note": (f"{-(-P // 512)} workgroups of 512 lanes per env (one particle per lane), halo positions / force cotangents / "
+                                  "block sums exchanged through HBM every substep; 2000 sequential substeps per launch") if cluster else
+                                 "one workgroup of 1024 lanes per env, 4 particles per lane, 2000 sequential substeps per launch"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

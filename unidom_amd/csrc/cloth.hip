@@ -815,8 +815,11 @@ __global__ void __launch_bounds__(UD_BIG_T) cloth_big_bwd_kernel(ClothBwdArgs a,
 // host side: handle + C ABI
 // ------------------------------------------------------------------------------------------------
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include "cloth_cluster.h"
 
 struct ud_cloth {
   ud::ClothConst c;
@@ -826,7 +829,36 @@ struct ud_cloth {
   float* d_L0 = nullptr;
   float* d_park = nullptr;   // P > 1024 only: adjoint scratch [B][UD_BIG_PARK][Pp]
   int park_B = 0;
+  // P > 1024, several workgroups per env (cloth_cluster.h): parts per env, halo width (0 = the body does not qualify),
+  // CUs of the device, and the hand-off arena [arena_B][cl_env_granules]
+  int cl_W = 0, cl_H = 0, n_cu = 0;
+  ud::cl_granule* d_arena = nullptr;
+  int arena_B = 0;
 };
+
+// Several workgroups per env when the body qualifies (halo <= CL_HMAX), every part of every env can be resident at once
+// (one 512-lane workgroup per CU) and the caller did not ask for the reference-order kernels (mode 1).
+// UD_CLOTH_CLUSTER=0 (read at every call; diagnostics and tests) keeps the one-workgroup kernels.
+static bool cloth_use_cluster(const ud_cloth* h, int B) {
+  if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1) return false;
+  const char* e = getenv("UD_CLOTH_CLUSTER");
+  if (e && e[0] == '0') return false;
+  return (long)B * h->cl_W <= (long)h->n_cu;
+}
+
+// (re)size and zero the hand-off arena: tags start at 1, so a zeroed arena matches nothing.  Growing it is the one place
+// that synchronises (see the header: first call / larger B than ever before).
+static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::ClusterArgs* q) {
+  const size_t per = ud::cl_env_granules(h->c.Pp, h->cl_W) * sizeof(ud::cl_granule);
+  if (h->arena_B < B) {
+    if (h->d_arena) { (void)hipStreamSynchronize(stream); (void)hipFree(h->d_arena); h->d_arena = nullptr; h->arena_B = 0; }
+    if (hipMalloc((void**)&h->d_arena, per * B) != hipSuccess) { ud::set_error("ud_cloth: hand-off arena allocation failed"); return UD_ERR_HIP; }
+    h->arena_B = B;
+  }
+  UD_HIP_CHECK(hipMemsetAsync(h->d_arena, 0, per * B, stream));
+  q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena;
+  return UD_OK;
+}
 
 extern "C" {
 
@@ -870,9 +902,18 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   h->c.cell = (float)(1.0 / N);
   h->c.Ls = fmaxf((float)(1.0 / N) * sqrtf(1.0f), 1e-12f);
   h->c.Ld = fmaxf((float)(1.0 / N) * sqrtf(2.0f), 1e-12f);
+  if (Pp > 1024) {   // widest index distance of a spring -> halo of the several-workgroups-per-env kernels
+    int far = 0;
+    for (int p = 0; p < P; ++p)
+      for (int l = 0; l < 8; ++l) { const int j = nbr[(size_t)l * Pp + p]; if (j >= 0) far = std::max(far, std::abs(j - p)); }
+    const int H = (far + 63) / 64 * 64;
+    h->cl_W = (P + ud::CL_T - 1) / ud::CL_T;
+    h->cl_H = (H >= 64 && H <= ud::CL_HMAX && h->cl_W <= 8) ? H : 0;
+  }
   h->mode = conf->mode;
   if (h->mode < 0 || h->mode > 2) { ud::set_error("ud_cloth_create: mode must be 0, 1 or 2"); delete h; return UD_ERR_INVALID; }
   hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_nbr, nbr.size() * sizeof(int));
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_L0, L0.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -896,6 +937,7 @@ void ud_cloth_destroy(ud_cloth* h) {
   if (!h) return;
   (void)hipFree(h->d_nbr);
   if (h->d_park) (void)hipFree(h->d_park);
+  if (h->d_arena) (void)hipFree(h->d_arena);
   (void)hipFree(h->d_L0);
   delete h;
 }
@@ -921,7 +963,12 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   a.x_out = x_out; a.v_out = v_out; a.prim_out = prim_out; a.x_list = x_list; a.v_list = v_list;
   a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
-  if (h->c.Pp > 1024)
+  if (cloth_use_cluster(h, B)) {
+    ud::ClusterArgs q;
+    const int rc = cloth_cluster_arena(h, B, (hipStream_t)stream, &q);
+    if (rc != UD_OK) return rc;
+    ud::cloth_launch_fwd_cluster(a, q, (hipStream_t)stream);
+  } else if (h->c.Pp > 1024)
     hipLaunchKernelGGL(ud::cloth_big_fwd_kernel, dim3(B), dim3(UD_BIG_T), (size_t)9 * h->c.Pp * sizeof(float), (hipStream_t)stream, a);
   else if (h->mode == 2 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
@@ -952,7 +999,12 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
   a.g_prim_list = g_prim_list; a.normalize = normalize;
   a.g_x0 = g_x0; a.g_v0 = g_v0; a.g_prim0 = g_prim0; a.g_actions = g_actions; a.g_k = g_stiffness; a.g_mu = g_mu;
   const size_t shmem = ((size_t)6 * h->c.Pp + 192 + 128) * sizeof(float);
-  if (h->c.Pp > 1024) {
+  if (cloth_use_cluster(h, B)) {
+    ud::ClusterArgs q;
+    const int rc = cloth_cluster_arena(h, B, (hipStream_t)stream, &q);
+    if (rc != UD_OK) return rc;
+    ud::cloth_launch_bwd_cluster(a, q, (hipStream_t)stream);
+  } else if (h->c.Pp > 1024) {
     if (h->park_B < B) {   // scratch of the big-body adjoint, grown on demand
       if (h->d_park) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(h->d_park); h->d_park = nullptr; h->park_B = 0; }
       if (hipMalloc((void**)&h->d_park, (size_t)B * UD_BIG_PARK * h->c.Pp * sizeof(float)) != hipSuccess) {
