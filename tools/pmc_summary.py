@@ -21,15 +21,20 @@ def load(path, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
+dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+out = json.load(open(dst)) if os.path.exists(dst) else {}      # entries of kernels not in these passes are kept
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
+    if k.startswith("void "):
+        k = k[5:]
     out[k] = {"FETCH_SIZE": {"n": len(f), "mean_kb": sum(f) / len(f), "min_kb": min(f), "max_kb": max(f)},
               "WRITE_SIZE": {"n": len(w), "mean_kb": sum(w) / len(w), "min_kb": min(w), "max_kb": max(w)},
               "hbm_bytes_per_launch": (2 * max(f) + max(w)) * 1024,
               "src_sha16": src_hash.sha16(k),   # bench.py reports traffic only while the kernel sources still hash to this
               "note": "2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KB x 1024, separate --pmc passes; "
                       "max over launches (forward launches under no_grad write no checkpoints)"}
-json.dump(out, open(sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(out, open(dst, "w"), indent=1)
 for k, v in out.items():
+    if k not in fetch and k not in write:
+        continue
     print(k, "%.1f MB/launch" % (v["hbm_bytes_per_launch"] / 1e6), "fetch n=%d" % v["FETCH_SIZE"]["n"])
