@@ -195,8 +195,11 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
  *   GenORM/policy/pbm/plb/engine/mpm_simulator.py:438-449 (step), :256-268 (substep: clear_grid, compute_F_tmp,
  *   svd, p2g :166-195 with compute_von_mises :133-150, forward_kinematics, grid_op :200-232, g2p :234-253),
  *   engine/primitive/primitives.py:17-53 (Sphere), engine/primitive/primive_base.py:118-121,185-192.
- * Forward only this round (the Torus rollout of optimizer/solver.py:290-350 never differentiates).
- * Parity for this entry point is UNPINNED: taichi is absent and the reference ships no recording of this path.
+ * Adjoint (ud_plb_step_bwd): substep_grad :271-289 with backward_svd :107-124; the differentiable leaves are the particle
+ * state, primitive 0's action and position, and per env E, nu, yield_stress (PlasticineLab/sim2sim/plb/engine/
+ * mpm_simulator.py:27-29,485-498: get_parameter_grad) and the ground friction (optimize_ground_friction, :57-58).
+ * Losses (ud_plb_loss_*): engine/losses/loss.py:112-243 (density, SDF, soft / hard contact, weighted sum).
+ * Parity for these entry points is UNPINNED: taichi is absent and the reference ships no recording of this path.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct ud_plb ud_plb;
 
@@ -219,7 +222,33 @@ void ud_plb_destroy(ud_plb* h);
 int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
                     const double* prim_pos, const double* softness, const double* action, const double* E,
                     const double* nu, const double* yield_stress, double* x_out, double* v_out, double* C_out,
-                    double* F_out, double* prim_pos_out, void* stream);
+                    double* F_out, double* prim_pos_out, void* ckpt, void* stream);
+/* ckpt (may be NULL = no backward): ud_plb_ckpt_bytes(h, B) bytes, caller-owned, opaque: every substep's particle state,
+ * the primitive trajectory and the internal spatial order of this call, consumed by ud_plb_step_bwd. */
+size_t ud_plb_ckpt_bytes(const ud_plb* h, int B);
+
+/* Adjoint of one env.step.  g_x, g_v [B,N,3], g_C, g_F [B,N,3,3], g_prim_pos [B,n_primitives,3]: cotangents of the
+ * step's outputs (any may be NULL = zero).  Outputs: cotangents of the inputs x, v, C, F (required), of prim_pos
+ * [B,n_primitives,3], of action [B,3], and per env of E, nu, yield_stress and the ground friction [B] (each may be NULL).
+ * softness, action, E, nu, yield_stress: the forward call's inputs again. */
+int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, const double* action, const double* E,
+                    const double* nu, const double* yield_stress, const double* g_x, const double* g_v, const double* g_C,
+                    const double* g_F, const double* g_prim_pos, double* g_x0, double* g_v0, double* g_C0, double* g_F0,
+                    double* g_prim_pos0, double* g_action, double* g_E, double* g_nu, double* g_yield_stress,
+                    double* g_ground_friction, void* stream);
+
+/* Loss of a particle state (engine/losses/loss.py): x [B,N,3], prim_pos [B,n_primitives,3], target_density and target_sdf
+ * [n_grid^3] (shared by the envs), weights [3] = (contact, density, sdf) -- all device arrays.
+ *   density = sum_I |grid_mass_I - target_density_I|, sdf = sum_I target_sdf_I grid_mass_I  with grid_mass = the p2g of the
+ *   particle masses (compute_grid_m_kernel); contact = sum_primitives min_dist^2 with, soft_contact != 0: min_dist =
+ *   sum_i d_i w(d_i) / sum_i w(d_i), w(d) = 1 / (1 + 1e4 d^2), d_i = max(sdf(x_i), 0); soft_contact == 0: min_i d_i.
+ * loss [B] = weights . (contact, density, sdf); parts [B,3] (may be NULL) = the three terms.
+ * ud_plb_loss_bwd: g_loss [B] -> g_x [B,N,3], g_prim_pos [B,n_primitives,3] (may be NULL). */
+int ud_plb_loss_fwd(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density,
+                    const double* target_sdf, const double* weights, int soft_contact, double* loss, double* parts, void* stream);
+int ud_plb_loss_bwd(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density,
+                    const double* target_sdf, const double* weights, int soft_contact, const double* g_loss, double* g_x,
+                    double* g_prim_pos, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cloth-env arithmetic either side of the rollout (the reference jit-fuses it into step_diff; here one forward and

@@ -141,3 +141,215 @@ def test_hip_one_lane_kernels_match_restatement(monkeypatch):
     read at every step call, forces one lane per particle so that mapping meets the restatement too."""
     monkeypatch.setenv("UD_PLB_LANES", "1")
     test_hip_matches_restatement_full_torus_state()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# adjoint, losses, parameter gradients (SURVEY.md 8f rank 4).  The checker is torch.autograd through the torch twin, whose
+# forward is held against the literal NumPy twin and whose gradient is held against central differences here.
+# ---------------------------------------------------------------------------------------------------------------------
+def _small_case(B, N, seed, n_grid_quality=0.5, low=True):
+    """A body resting on / falling onto the floor (friction branch), sphere 0 inside it (sticky contact), sphere 1 away."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(B, N, 3)) * np.array([0.25, 0.12 if low else 0.2, 0.25]) + np.array([0.38, 0.035 if low else 0.2, 0.38])
+    v = rng.normal(size=(B, N, 3)) * 0.3 + np.array([0.0, -0.8, 0.0])
+    Cm = rng.normal(size=(B, N, 3, 3)) * 2.0
+    F = np.eye(3)[None, None] + rng.normal(size=(B, N, 3, 3)) * 0.12
+    prim = np.array([[0.5, 0.1 if low else 0.3, 0.5], [0.2, 0.7, 0.2]])[None].repeat(B, 0) + rng.normal(size=(B, 2, 3)) * 0.01
+    soft = np.array([[666.0, 666.0]]).repeat(B, 0)
+    act = rng.uniform(-0.9, 0.9, size=(B, 3)) * np.array([1.0, 0.3, 1.0])
+    E = np.array([5e3, 3e3, 4e3])[:B]
+    nu = np.array([0.35, 0.3, 0.25])[:B]
+    ys = np.array([1762.2, 30.0, 200.0])[:B]          # env 1 yields almost everywhere, env 0 hardly
+    return x, v, Cm, F, prim, soft, act, E, nu, ys
+
+
+def _twin_step(conf, case, fric, w):
+    import torch
+    from oracle.twin.plb_twin_torch import PlbTorchTwin
+    x, v, Cm, F, prim, soft, act, E, nu, ys = case
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), requires_grad=r)
+    leaves = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys), fric=T(np.full(len(E), fric)))
+    tw = PlbTorchTwin(conf)
+    out = tw.step(leaves["x"], leaves["v"], leaves["C"], leaves["F"], leaves["prim"], leaves["act"], T(soft, False), leaves["E"],
+                  leaves["nu"], leaves["ys"], leaves["fric"])
+    loss = sum((o * torch.tensor(wi)).sum() for o, wi in zip(out, w))
+    return leaves, out, loss
+
+
+def test_torch_twin_is_the_numpy_twin_and_its_autograd_is_the_derivative():
+    import torch
+    torch.set_num_threads(4)
+    conf = PlbConf(quality=0.25, n_particles=60)            # n_grid 16, 4 substeps
+    case = _small_case(1, 60, 0)
+    x, v, Cm, F, prim, soft, act, E, nu, ys = case
+    r = PlbTwin(conf).step(x[0], v[0], Cm[0], F[0], prim[0], act[0], soft[0], E=E[0], nu=nu[0], yield_stress=ys[0])
+    rng = np.random.default_rng(5)
+    w = [rng.normal(size=s) for s in ((1, 60, 3), (1, 60, 3), (1, 60, 3, 3), (1, 60, 3, 3), (1, 2, 3))]
+    leaves, out, loss = _twin_step(conf, case, conf.ground_friction, w)
+    for o, ref in zip(out, r):
+        assert _rel(o.detach().numpy()[0], ref) < 1e-11
+    loss.backward()
+
+    def f(**kw):
+        c2 = list(case)
+        names = ["x", "v", "C", "F", "prim", "soft", "act", "E", "nu", "ys"]
+        for k, val in kw.items():
+            c2[names.index(k)] = val
+        return float(_twin_step(conf, tuple(c2), kw.get("fric", conf.ground_friction), w)[2].detach())
+
+    h = 1e-6
+    for name, idx in (("x", (0, 7, 1)), ("v", (0, 3, 0)), ("C", (0, 11, 2, 1)), ("F", (0, 20, 0, 1)), ("act", (0, 0)), ("prim", (0, 0, 2))):
+        names = ["x", "v", "C", "F", "prim", "soft", "act", "E", "nu", "ys"]
+        base = case[names.index(name)]
+        up, dn = base.copy(), base.copy()
+        up[idx] += h; dn[idx] -= h
+        fd = (f(**{name: up}) - f(**{name: dn})) / (2 * h)
+        an = float(leaves[name].grad[idx])
+        assert abs(fd - an) < 1e-5 * max(1.0, abs(an)), (name, fd, an)
+    for name, val in (("E", E), ("nu", nu), ("ys", ys)):
+        hh = 1e-6 * val[0]
+        fd = (f(**{name: val + hh}) - f(**{name: val - hh})) / (2 * hh)
+        an = float(leaves[name].grad[0])
+        assert abs(fd - an) < 1e-5 * max(1e-3, abs(an)), (name, fd, an)
+
+
+def test_loss_twin_known_answers():
+    """density: a grid mass equal to the target costs 0; sdf: linear in the mass; contact (soft): one particle at distance d from
+    a sphere gives min_dist = d; hard: the nearest particle's distance."""
+    import torch
+    from oracle.twin.plb_twin_torch import PlbTorchTwin
+    conf = PlbConf(quality=0.25, n_particles=5)
+    tw = PlbTorchTwin(conf)
+    x = torch.tensor([[[0.5, 0.5, 0.5], [0.52, 0.5, 0.5], [0.6, 0.55, 0.5], [0.3, 0.3, 0.3], [0.7, 0.3, 0.4]]], dtype=torch.float64)
+    gm = tw.grid_mass(x)
+    assert abs(float(gm.sum()) - 5 * conf.p_mass) < 1e-15                      # the B-spline weights sum to 1
+    prim = torch.tensor([[[0.5, 0.5, 0.56], [0.9, 0.9, 0.9]]], dtype=torch.float64)
+    zero = torch.zeros(conf.n_grid ** 3, dtype=torch.float64)
+    total, parts = tw.loss(x, prim, gm[0].detach(), zero, (1.0, 1.0, 1.0), soft_contact=False)
+    d0 = np.sqrt(0.06 ** 2 + 1e-14) - 0.025
+    d1 = np.sqrt(0.3 ** 2 + 0.35 ** 2 + 0.4 ** 2 + 1e-14) - 0.025           # particle 2 is the nearest to sphere 1
+    assert abs(float(parts[0, 1])) < 1e-18 and abs(float(parts[0, 0]) - (d0 ** 2 + d1 ** 2)) < 1e-12
+    sdf = torch.full((conf.n_grid ** 3,), 2.0, dtype=torch.float64)
+    total, parts = tw.loss(x, prim, zero, sdf, (0.0, 0.0, 1.0))
+    assert abs(float(total) - 2.0 * 5 * conf.p_mass) < 1e-15
+    one = x[:, :1]
+    total, parts = tw.loss(one, prim[:, :1], zero, zero, (1.0, 0.0, 0.0), soft_contact=True)
+    assert abs(float(total) - d0 ** 2) < 1e-15
+
+
+def _hip_sim(N, B, quality=0.5):
+    from unidom_amd.engine.plb_simulator import PlbConf as HipConf, PlbSimulator
+    cfg = HipConf()
+    cfg.quality = quality
+    cfg.n_particles = N
+    return PlbSimulator(cfg, batch_size=B)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("low", [True, False])
+def test_hip_step_adjoint_matches_torch_twin(low):
+    """ud_plb_step_fwd (with checkpoint) + ud_plb_step_bwd against torch.autograd through the twin: three envs with different
+    E / nu / yield stress (one yields almost everywhere: the return-mapping adjoint; one hardly: the SVD adjoint alone), a body
+    on the floor (ground-friction branch and the boundary zeroing) or in the air, sphere 0 inside it (sticky contact -> action
+    and primitive-position cotangents).  n_grid 32, 9 substeps.  f64 on both sides; what differs is summation order (atomics)
+    and the SVD (Jacobi vs LAPACK), amplified by the clamped 1 / (s_j^2 - s_i^2) of backward_svd: 1e-6 relative."""
+    import torch
+    torch.set_num_threads(8)
+    B, N = 3, 300
+    sim = _hip_sim(N, B)
+    assert (sim.n_grid, sim.substeps) == (32, 9)
+    conf = PlbConf(quality=0.5, n_particles=N)
+    case = _small_case(B, N, 1, low=low)
+    x, v, Cm, F, prim, soft, act, E, nu, ys = case
+    rng = np.random.default_rng(9)
+    w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
+    leaves, out, loss = _twin_step(conf, case, conf.ground_friction, w)
+    loss.backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    st = sim.reset()
+    hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
+    s = st._replace(x=hl["x"], v=hl["v"], C=hl["C"], F=hl["F"], prim_pos=hl["prim"], softness=T(soft, False), E=hl["E"], nu=hl["nu"],
+                    yield_stress=hl["ys"])
+    s1 = sim.step(s, hl["act"])
+    for o, t, name in zip(out, (s1.x, s1.v, s1.C, s1.F, s1.prim_pos), "xvCFp"):
+        assert _rel(t.detach().cpu().numpy(), o.detach().numpy()) < 1e-9, name
+    hloss = sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w))
+    sim.ground_friction_grad = None
+    hloss.backward()
+    for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
+        got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
+        assert np.isfinite(got).all(), name
+        assert _rel(got, ref) < 1e-6, (name, _rel(got, ref))
+    gfr = sim.ground_friction_grad.cpu().numpy()
+    ref = leaves["fric"].grad.numpy()
+    assert _rel(gfr, ref) < 1e-6 or np.abs(ref).max() < 1e-12, (gfr, ref)
+    if low:
+        assert np.abs(ref).max() > 0          # the friction branch really ran
+    assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()[1]) > 0
+
+
+@pytest.mark.gpu
+def test_hip_two_steps_chain_and_forward_without_checkpoint():
+    """Two env.steps chained through autograd (the tape of solver.py:41-54) equal the twin's; a forward under no_grad (no
+    checkpoint) gives the same state as the checkpointing forward."""
+    import torch
+    torch.set_num_threads(8)
+    B, N = 2, 200
+    sim = _hip_sim(N, B)
+    conf = PlbConf(quality=0.5, n_particles=N)
+    case = _small_case(B, N, 4)
+    x, v, Cm, F, prim, soft, act, E, nu, ys = case
+    from oracle.twin.plb_twin_torch import PlbTorchTwin
+    Tc = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), requires_grad=r)
+    tl = dict(x=Tc(x), act=Tc(act), E=Tc(E))
+    tw = PlbTorchTwin(conf)
+    fr = Tc(np.full(B, conf.ground_friction), False)
+    o1 = tw.step(tl["x"], Tc(v, False), Tc(Cm, False), Tc(F, False), Tc(prim, False), tl["act"], Tc(soft, False), tl["E"], Tc(nu, False), Tc(ys, False), fr)
+    o2 = tw.step(*o1[:4], o1[4], tl["act"] * 0.5, Tc(soft, False), tl["E"], Tc(nu, False), Tc(ys, False), fr)
+    (o2[0].sum() + o2[1][..., 1].sum()).backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    hl = dict(x=T(x), act=T(act), E=T(E))
+    st = sim.reset()._replace(x=hl["x"], v=T(v, False), C=T(Cm, False), F=T(F, False), prim_pos=T(prim, False), softness=T(soft, False),
+                              E=hl["E"], nu=T(nu, False), yield_stress=T(ys, False))
+    s1 = sim.step(st, hl["act"])
+    s2 = sim.step(s1, hl["act"] * 0.5)
+    assert _rel(s2.x.detach().cpu().numpy(), o2[0].detach().numpy()) < 1e-9
+    (s2.x.sum() + s2.v[..., 1].sum()).backward()
+    for name in ("x", "act", "E"):
+        assert _rel(hl[name].grad.cpu().numpy(), tl[name].grad.numpy()) < 1e-6, name
+    with torch.no_grad():
+        n1 = sim.step(st, hl["act"])
+    assert _rel(n1.x.cpu().numpy(), s1.x.detach().cpu().numpy()) < 1e-12 and _rel(n1.F.cpu().numpy(), s1.F.detach().cpu().numpy()) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("soft_contact", [True, False])
+def test_hip_losses_match_torch_twin(soft_contact):
+    """ud_plb_loss_fwd / bwd (density, SDF, contact; engine/losses/loss.py) against the twin and its autograd, at the Torus
+    task's own size (N = 1000, n_grid 64), with a target density that is another body's grid mass and a random SDF field."""
+    import torch
+    from oracle.twin.plb_twin_torch import PlbTorchTwin
+    B, N = 2, 1000
+    sim = _hip_sim(N, B, quality=1.0)
+    conf = PlbConf(n_particles=N)
+    rng = np.random.default_rng(2)
+    x = np.stack([torus_particles(1000), torus_particles(1000) + rng.normal(size=(1000, 3)) * 0.003])
+    prim = np.array([[[0.47, 0.28, 0.5], [0.55, 0.62, 0.5]], [[0.5, 0.35, 0.52], [0.5, 0.1, 0.5]]])
+    tw = PlbTorchTwin(conf)
+    other = torch.tensor((torus_particles(1000) + np.array([0.004, -0.01, 0.0]))[None])
+    td = tw.grid_mass(other)[0]
+    ts = torch.tensor(rng.normal(size=conf.n_grid ** 3))
+    wts = (3.0, 0.7, 1.3)
+    tx, tp = torch.tensor(x, requires_grad=True), torch.tensor(prim, requires_grad=True)
+    total, parts = tw.loss(tx, tp, td, ts, wts, soft_contact=soft_contact)
+    gl = torch.tensor([1.0, -2.5], dtype=torch.float64)
+    (total * gl).sum().backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    hx, hp = T(x), T(prim)
+    st = sim.reset()._replace(x=hx, prim_pos=hp)
+    hloss, hparts = sim.compute_loss(st, td.numpy(), ts.numpy(), wts, soft_contact)
+    assert _rel(hloss.detach().cpu().numpy(), total.detach().numpy()) < 1e-11
+    assert _rel(hparts.cpu().numpy(), parts.detach().numpy()) < 1e-11
+    (hloss * T(gl.numpy(), False)).sum().backward()
+    assert _rel(hx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-9 and _rel(hp.grad.cpu().numpy(), tp.grad.numpy()) < 1e-9
+    assert np.abs(tp.grad.numpy()).max() > 0

@@ -19,7 +19,7 @@ SYMBOLS = [
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
     "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
-    "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd",
+    "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd", "ud_plb_ckpt_bytes", "ud_plb_step_bwd", "ud_plb_loss_fwd", "ud_plb_loss_bwd",
     "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
     "ud_mpm_focus_fwd", "ud_mpm_focus_bwd", "ud_mpm_finish_fwd", "ud_mpm_finish_bwd",
 ]
@@ -72,6 +72,7 @@ def lib():
         L.ud_version.restype = C.c_char_p
         L.ud_cloth_ckpt_bytes.restype = C.c_size_t
         L.ud_mpm_ckpt_bytes.restype = C.c_size_t
+        L.ud_plb_ckpt_bytes.restype = C.c_size_t
         for name in SYMBOLS:
             if not hasattr(L, name):
                 raise UnidomError(f"{SO_PATH} does not export {name}")

@@ -12,113 +12,11 @@
 // but only cells on the per-env active list are ever read, written or cleared.  No MFMA (scatter / stencil work).
 // ti.svd (third party) is replaced by a one-sided Jacobi SVD in registers.  Parity: UNPINNED (see the header).
 #include <cstdlib>
-#include "common.h"
+#include "plb_common.h"
 
 #include <vector>
 
 namespace ud {
-
-struct PlbConst {
-  int N, Np, n_grid, S, np;
-  double dt, dx, inv_dx, p_mass, p_vol, g30dt[3], fric, radius[2], lo[3], hi[3];
-};
-
-struct PlbBuf {
-  double* val;    // [B][G][4] (m, mv) -> after the grid op (m, v)
-  int* stamp;     // [B][G]
-  int* list;      // [2][B][cap]
-  int* count;     // [2][B]
-  double* pos;    // [B][S+1][np][3] primitive positions of this step
-  double* hist;   // [B][2][24][Np]
-  int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
-};
-
-struct PlbArgs {
-  PlbConst c;
-  PlbBuf w;
-  int B, f, epoch, cap;
-  long G;
-  const double *softness, *E, *nu, *ys;
-};
-
-// ---- double 3x3 helpers -----------------------------------------------------------------------------
-__device__ __forceinline__ void dm_mul(const double* A, const double* B, double* R) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
-}
-__device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, double* R) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
-}
-
-#define UD_DJROT(p, q)                                                                       \
-  {                                                                                          \
-    double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                      \
-    double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                      \
-    double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                      \
-    const bool rot = fabs(ga) > 1e-17 * sqrt(al * be);                                        \
-    double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
-    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
-    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
-    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
-      double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
-      a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
-      double vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                          \
-      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                   \
-    }                                                                                         \
-  }
-#define UD_DCSWAP(p, q)                                                              \
-  if (sv[p] < sv[q]) {                                                               \
-    double ts = sv[p]; sv[p] = sv[q]; sv[q] = ts;                                    \
-    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                  \
-      double t1 = a[i * 3 + p]; a[i * 3 + p] = a[i * 3 + q]; a[i * 3 + q] = t1;      \
-      double t2 = vv[i * 3 + p]; vv[i * 3 + p] = vv[i * 3 + q]; vv[i * 3 + q] = t2;  \
-    }                                                                                \
-  }
-
-// A = U diag(S) Vh, S descending >= 0 (one-sided Jacobi, 6 sweeps reach f64 round-off for |F - I| = O(1))
-__device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, double* Vh) {
-  double a[9], vv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) a[i] = A[i];
-#pragma unroll 1
-  for (int sweep = 0; sweep < 6; ++sweep) {
-    UD_DJROT(0, 1)
-    UD_DJROT(0, 2)
-    UD_DJROT(1, 2)
-  }
-  double sv[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) sv[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
-  UD_DCSWAP(0, 1)
-  UD_DCSWAP(1, 2)
-  UD_DCSWAP(0, 1)
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    S[j] = sv[j];
-    const double inv = sv[j] > 1e-300 ? 1.0 / sv[j] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
-  }
-}
-
-__device__ __forceinline__ double dsel3(const double* w, int d, int i) { return (i == 0) ? w[d] : ((i == 1) ? w[3 + d] : w[6 + d]); }
-
-__device__ __forceinline__ long plb_lin(const PlbConst& c, int i, int j, int k) { return ((long)i * c.n_grid + j) * c.n_grid + k; }
-
-__device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin) {
-  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
-  if (old != a.epoch) {
-    const int cur = a.f & 1;
-    const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
-    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = (int)lin;
-  }
-}
 
 // ---- kernels -------------------------------------------------------------------------------------------
 // primitive positions for the whole step: pos[s+1] = clamp(pos[s] + v), v = clip(action)*scale/substeps for primitive 0
@@ -138,15 +36,11 @@ __global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* ac
   a.w.count[1 * a.B + b] = 0;
 }
 
-// The grid values are double-buffered, buffer k belongs to active list k (substep f uses k = f & 1): the cells of substep f - 1
-// can then be zeroed while substep f runs -- plb_grid(f) does it next to its own work -- instead of in a launch of their own
-// between g2p(f - 1) and p2g(f).  One launch less per substep (4 -> 3) on a path whose kernels sit near the launch floor.
-__device__ __forceinline__ double* plb_buf(const PlbArgs& a, int k, int b) { return a.w.val + (((long)k * a.B + b) * a.G) * 4; }
 
 // end of a step only: zero the cells of the last substep (list / buffer `prev`), back to the all-zero grid invariant
 __global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int prev = (a.f + 1) & 1, cur = a.f & 1;
+  const int prev = a.lb ^ 1, cur = a.lb;
   if (t < min(a.w.count[prev * a.B + b], a.cap)) {
     double* cell = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
     cell[0] = 0.0; cell[1] = 0.0; cell[2] = 0.0; cell[3] = 0.0;
@@ -154,32 +48,10 @@ __global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = 0;
 }
 
-#define PLB_H 1024
-#define PLB_LOGH 10
-__device__ __forceinline__ unsigned plb_hash(int cell) {
-  unsigned h = (unsigned)cell;
-  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
-  return h >> (32 - PLB_LOGH);
-}
 
 // compute_F_tmp + svd + von Mises + p2g (:91-99, :133-195)
 // LANES lanes per particle (as in mpm_large.hip): 4 while the launch is too small to fill the chip -- the quad splits the 27
 // stencil cells 7/7/7/6 (every lane repeats the particle pre-pass on otherwise idle SIMDs) -- 1 once it is full.
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-template <int LANES>
-__device__ __forceinline__ double plb_quad_sum(double v) {
-  if (LANES == 4) {
-    v += dpp_d<0xB1>(v);  // quad_perm [1,0,3,2]
-    v += dpp_d<0x4E>(v);  // quad_perm [2,3,0,1]
-  }
-  return v;
-}
 
 template <int LANES>
 __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
@@ -189,10 +61,10 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   const PlbConst& c = a.c;
   for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
   __syncthreads();
-  double* val = plb_buf(a, a.f & 1, b);
+  double* val = plb_buf(a, a.lb, b);
   if (p < c.N) {
-    const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
-    double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
+    const double* hi_ = plb_hist(a, b, a.hs_in);
+    double* ho = plb_hist(a, b, a.hs_out);
     double x[3], v[3], Cm[9], F[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; v[d] = hi_[(3 + d) * c.Np + p]; }
@@ -301,7 +173,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   }
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
   __syncthreads();
-  const int cur = a.f & 1;
+  const int cur = a.lb;
   if (threadIdx.x == 0) s_base = s_new ? atomicAdd(&a.w.count[cur * a.B + b], s_new) : 0;
   __syncthreads();
   int e = s_base + mine;
@@ -317,7 +189,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
 __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
-  const int cur = a.f & 1, prev = cur ^ 1;
+  const int cur = a.lb, prev = cur ^ 1;
   if (t < min(a.w.count[prev * a.B + b], a.cap)) {          // the previous substep's cells, in the other buffer: done with
     double* old = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
     old[0] = 0.0; old[1] = 0.0; old[2] = 0.0; old[3] = 0.0;
@@ -325,41 +197,8 @@ __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
   if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
   double* cell = plb_buf(a, cur, b) + lin * 4;
-  const double m = cell[0];
-  double vv[3] = {0.0, 0.0, 0.0};
-  if (m > 1e-12) {
-    const int n = c.n_grid;
-    const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vv[k] = (1.0 / m) * cell[1 + k] + c.g30dt[k];
-    const double gp[3] = {I[0] * c.dx, I[1] * c.dx, I[2] * c.dx};
-    const double* P0 = a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
-    const double* P1 = P0 + c.np * 3;
-    for (int pi = 0; pi < c.np; ++pi) {                                    // Sphere.collide (sticky), primitives.py:46-53
-      const double d0 = gp[0] - P0[pi * 3], d1 = gp[1] - P0[pi * 3 + 1], d2 = gp[2] - P0[pi * 3 + 2];
-      const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi];
-      const double soft = a.softness[b * c.np + pi];
-      const double infl = fmin(exp(-dist * soft), 1.0);
-      if (((soft > 0 && infl > 0.1) || dist <= 0.001) && soft > 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k] = (P1[pi * 3 + k] - P0[pi * 3 + k]) / c.dt;   // collider_v, identity rotations
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      if (I[d] < 3 && vv[d] < 0) {
-        if (d != 1 || c.fric == 0) vv[d] = 0;
-        else if (c.fric < 10) {
-          const double lin_ = vv[1] + 1e-30;
-          const double vit[3] = {vv[0] - I[0] * 1e-30, vv[1] - lin_ - I[1] * 1e-30, vv[2] - I[2] * 1e-30};
-          const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
-          const double s = fmax(1.0 + c.fric * lin_ / lit, 0.0);
-          vv[0] = s * (vit[0] + I[0] * 1e-30); vv[2] = s * (vit[2] + I[2] * 1e-30); vv[1] = 0;
-        } else { vv[0] = 0; vv[1] = 0; vv[2] = 0; }
-      }
-      if (I[d] > n - 3 && vv[d] > 0) vv[d] = 0;
-    }
-  }
+  double vv[3];
+  plb_grid_cell(c, lin, cell[0], cell + 1, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, vv);
   cell[1] = vv[0]; cell[2] = vv[1]; cell[3] = vv[2];
 }
 
@@ -368,10 +207,10 @@ template <int LANES>
 __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  if (gid == 0) a.w.count[((a.f + 1) & 1) * a.B + b] = 0;   // the other list: plb_grid has just retired it, p2g of the next substep refills it
+  if (gid == 0) a.w.count[(a.lb ^ 1) * a.B + b] = 0;   // the other list: plb_grid has just retired it, p2g of the next substep refills it
   if (p >= c.N) return;   // whole quads leave together
-  const double* hi_ = a.w.hist + ((long)b * 2 + (a.f & 1)) * 24 * c.Np;
-  double* ho = a.w.hist + ((long)b * 2 + ((a.f + 1) & 1)) * 24 * c.Np;
+  const double* hi_ = plb_hist(a, b, a.hs_in);
+  double* ho = plb_hist(a, b, a.hs_out);
   double x[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) x[d] = hi_[d * c.Np + p];
@@ -384,7 +223,7 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
     fx[d] = f;
     w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
   }
-  const double* val = plb_buf(a, a.f & 1, b);
+  const double* val = plb_buf(a, a.lb, b);
   double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
   for (int cidx = qi; cidx < 27; cidx += LANES) {
@@ -464,7 +303,7 @@ __global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, cons
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
   if (p >= c.N) return;
-  double* h = a.w.hist + (long)b * 2 * 24 * c.Np;
+  double* h = plb_hist(a, b, 0);
   const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
   const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
@@ -479,7 +318,7 @@ __global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x
   if (blockIdx.x == 0 && threadIdx.x < c.np * 3)
     prim_o[(long)b * c.np * 3 + threadIdx.x] = a.w.pos[((long)b * (c.S + 1) + c.S) * c.np * 3 + threadIdx.x];   // copyframe(cur, 0)
   if (p >= c.N) return;
-  const double* h = a.w.hist + ((long)b * 2 + slot) * 24 * c.Np;
+  const double* h = plb_hist(a, b, slot);
   const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
   const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
@@ -488,21 +327,17 @@ __global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x
   for (int d = 0; d < 9; ++d) { Cm[o9 + d] = h[(6 + d) * c.Np + p]; F[o9 + d] = h[(15 + d) * c.Np + p]; }
 }
 
+void plb_launch_p2g1(const PlbArgs& a, dim3 grid, hipStream_t st) { hipLaunchKernelGGL(plb_p2g<1>, grid, dim3(256), 0, st, a); }
+
 }  // namespace ud
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct ud_plb {
-  ud::PlbConst c;
-  int B = 0, cap = 0, epoch = 1;
-  long G = 0;
-  ud::PlbBuf w{};
-  void* arena = nullptr;
-};
-
-static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
-  if (B <= h->B) return UD_OK;
+int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
+  if (B <= h->B && (!adj || h->has_adj) && (!loss || h->has_loss)) return UD_OK;
+  adj = adj || h->has_adj; loss = loss || h->has_loss;
+  B = std::max(B, h->B);
   if (h->arena) { (void)hipStreamSynchronize(st); (void)hipFree(h->arena); h->arena = nullptr; }
   const ud::PlbConst& c = h->c;
   size_t off = 0;
@@ -510,16 +345,32 @@ static int plb_reserve(ud_plb* h, int B, hipStream_t st) {
   const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
   const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
   const size_t o_perm = take((size_t)B * c.Np * 4);
+  const size_t o_gacc = adj ? take((size_t)B * h->G * 32) : 0, o_gstate = adj ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
+  const size_t o_gxs = adj ? take((size_t)B * 3 * c.Np * 8) : 0, o_gpos = adj ? take((size_t)B * (c.S + 1) * c.np * 3 * 8 + 64) : 0, o_gpar = adj ? take((size_t)B * 4 * 8) : 0;
+  const size_t o_gm = loss ? take((size_t)B * h->G * 8) : 0, o_lred = loss ? take((size_t)B * 16 * 8) : 0;
   hipError_t e = hipMalloc(&h->arena, off);
-  if (e != hipSuccess) { ud::set_error("ud_plb: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); h->B = 0; return UD_ERR_HIP; }
+  if (e != hipSuccess) { ud::set_error("ud_plb: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); h->B = 0; h->has_adj = h->has_loss = false; return UD_ERR_HIP; }
   e = hipMemsetAsync(h->arena, 0, off, st);
   if (e != hipSuccess) { ud::set_error("ud_plb: memset failed"); return UD_ERR_HIP; }
   char* base = (char*)h->arena;
   h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
   h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
   h->w.perm = (int*)(base + o_perm);
-  h->B = B; h->epoch = 1;
+  h->w.gacc = adj ? (double*)(base + o_gacc) : nullptr; h->w.gstate = adj ? (double*)(base + o_gstate) : nullptr;
+  h->w.gxs = adj ? (double*)(base + o_gxs) : nullptr; h->w.gpos = adj ? (double*)(base + o_gpos) : nullptr; h->w.gpar = adj ? (double*)(base + o_gpar) : nullptr;
+  h->gm = loss ? (double*)(base + o_gm) : nullptr; h->lred = loss ? (double*)(base + o_lred) : nullptr;
+  h->B = B; h->epoch = 1; h->has_adj = adj; h->has_loss = loss;
   return UD_OK;
+}
+
+// caller-owned checkpoint of one step call: hist[B][S+1][24][Np] | pos[B][S+1][np][3] | perm[B][Np] (int)
+void plb_ckpt_layout(const ud::PlbConst& c, int B, size_t* o_hist, size_t* o_pos, size_t* o_perm, size_t* total) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  *o_hist = take((size_t)B * (c.S + 1) * 24 * c.Np * 8);
+  *o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8);
+  *o_perm = take((size_t)B * c.Np * 4);
+  *total = off;
 }
 
 extern "C" {
@@ -550,20 +401,34 @@ void ud_plb_destroy(ud_plb* h) {
   delete h;
 }
 
+size_t ud_plb_ckpt_bytes(const ud_plb* h, int B) {
+  if (!h || B < 1) return 0;
+  size_t a, b, c, total;
+  plb_ckpt_layout(h->c, B, &a, &b, &c, &total);
+  return total;
+}
+
 int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
                     const double* prim_pos, const double* softness, const double* action, const double* E,
                     const double* nu, const double* yield_stress, double* x_out, double* v_out, double* C_out,
-                    double* F_out, double* prim_pos_out, void* stream) {
+                    double* F_out, double* prim_pos_out, void* ckpt, void* stream) {
   if (!h || !x || !v || !C || !F || !prim_pos || !softness || !action || !E || !nu || !yield_stress || !x_out || !v_out || !C_out ||
       !F_out || !prim_pos_out) {
     ud::set_error("ud_plb_step_fwd: null argument"); return UD_ERR_INVALID;
   }
   if (B < 1) { ud::set_error("ud_plb_step_fwd: B=%d", B); return UD_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  int rc = plb_reserve(h, B, st);
+  int rc = plb_reserve(h, B, st, false, false);
   if (rc) return rc;
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
+  a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0;
+  if (ckpt) {   // keep every substep's particle state, the primitive trajectory and the spatial order for ud_plb_step_bwd
+    size_t o_hist, o_pos, o_perm, total;
+    plb_ckpt_layout(h->c, B, &o_hist, &o_pos, &o_perm, &total);
+    a.w.hist = (double*)((char*)ckpt + o_hist); a.w.pos = (double*)((char*)ckpt + o_pos); a.w.perm = (int*)((char*)ckpt + o_perm);
+    a.slots = h->c.S + 1;
+  }
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
   const char* lanes_env = getenv("UD_PLB_LANES");          // diagnostic override, read per call (the tests reach both mappings with it)
@@ -581,13 +446,14 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted);
   for (int f = 0; f < h->c.S; ++f) {
     a.f = f; a.epoch = h->epoch++;
+    a.hs_in = f % a.slots; a.hs_out = (f + 1) % a.slots; a.lb = f & 1;
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
     hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
   }
-  a.f = h->c.S; a.epoch = h->epoch++;
+  a.f = h->c.S; a.epoch = h->epoch++; a.lb = h->c.S & 1;
   hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);   // back to the all-zero grid invariant
-  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S & 1, x_out, v_out, C_out, F_out, prim_pos_out, sorted);
+  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S % a.slots, x_out, v_out, C_out, F_out, prim_pos_out, sorted);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ud::set_error("ud_plb_step_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;

@@ -1,0 +1,712 @@
+// PlasticineLab-style MLS-MPM, float64: the adjoint of one env.step, the loss kernels and the parameter gradients
+// (SURVEY.md 8f rank 4).  What it replaces (reference, Taichi reverse mode):
+//   /root/reference/GenORM/policy/pbm/plb/engine/mpm_simulator.py
+//       substep_grad :271-289 = recompute (clear_grid, compute_F_tmp, svd, p2g, grid_op), then g2p.grad, grid_op.grad,
+//       forward_kinematics.grad, p2g.grad, svd_grad :101-105 with backward_svd :107-124 (clamp :152-161), compute_F_tmp.grad
+//   /root/reference/GenORM/policy/pbm/plb/engine/losses/loss.py
+//       compute_loss_kernel :190-214 and its grad :216-243: density :145-148, sdf :150-153, soft / hard contact :117-140,
+//       sum_up :158-162; compute_grid_m_kernel mpm_simulator.py:456-466
+//   /root/reference/PlasticineLab/sim2sim/plb/engine/mpm_simulator.py:27-29,485-498  E, nu, yield_stress as differentiable
+//       scalars + get_parameter_grad; optimize_ground_friction (G variant :57-58) likewise.
+// Structure: the forward call keeps every substep's particle state, the primitive trajectory and the spatial order in a
+// caller-owned checkpoint (ud_plb_ckpt_bytes); the backward walks the substeps in reverse, per substep
+//   plb_p2g (recompute, plb.hip) -> plb_grid_keep (v_out beside (m, mv)) -> plb_g2p_adj (scatter of the v_out cotangent,
+//   x cotangent through the weights) -> plb_grid_adj (cell by cell: boundary / friction / sticky sphere / normalisation)
+//   -> plb_p2g_adj (gather; stress, von Mises return mapping, SVD and F update in reverse; E / nu / yield-stress sums)
+//   -> plb_adj_clear,
+// over the touched cells only, like the forward.  One lane per particle in the adjoint kernels (the f64 pre-pass adjoint is
+// register-heavy; the forward's four-lane mapping is a later step).  Parity: UNPINNED -- taichi is absent and the reference
+// ships no gradient of this path; the checker is torch.autograd through oracle/twin/plb_twin_torch.py (tests/test_plb.py).
+#include <cstdlib>
+
+#include "plb_common.h"
+
+namespace ud {
+
+__device__ __forceinline__ void dm_mul_at(const double* A, const double* B, double* R) {   // A^T B
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
+__device__ __forceinline__ void plb_weights(const PlbConst& c, const double* x, int* base, double* fx, double* w, double* dw) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    base[d] = (int)(x[d] * c.inv_dx - 0.5);
+    const double f = x[d] * c.inv_dx - (double)base[d];
+    fx[d] = f;
+    w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
+    dw[d] = -(1.5 - f); dw[3 + d] = -2 * (f - 1); dw[6 + d] = f - 0.5;
+  }
+}
+
+// ---- grid op, kept: v_out of every touched cell into buffer 1 (buffer 0 keeps (m, mv)) ---------------------------------
+__global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (t >= min(a.w.count[a.lb * a.B + b], a.cap)) return;
+  const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
+  const double* cell = plb_buf(a, 0, b) + lin * 4;
+  double vv[3];
+  plb_grid_cell(c, lin, cell[0], cell + 1, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, vv);
+  double* out = plb_buf(a, 1, b) + lin * 4;
+  out[0] = vv[0]; out[1] = vv[1]; out[2] = vv[2];
+}
+
+// ---- g2p adjoint (:234-253 in reverse) -------------------------------------------------------------------------------
+// inputs: cotangent of state f + 1 (gstate slot `gs_in`); outputs: v_out cotangents scattered into gacc, the x cotangent
+// that flows through g2p (weights, dpos, the position clamp) into gxs, and gv1 (with the advection term) kept in gstate.
+__global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (p >= c.N) return;
+  const double* hi_ = plb_hist(a, b, a.hs_in);
+  const double* ho = plb_hist(a, b, a.hs_out);
+  const double* g1 = a.w.gstate + ((long)b * 2 + gs_in) * 24 * c.Np;
+  double x[3], gx1[3], gv1[3], gC1[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; gx1[d] = g1[d * c.Np + p]; gv1[d] = g1[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gC1[d] = g1[(6 + d) * c.Np + p];
+  double gxp[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {   // x1 = clamp(x + dt v1, 0, 1 - 3 dx): the cotangent passes where the clamp is inactive
+    const double xn = x[d] + c.dt * ho[(3 + d) * c.Np + p];
+    const double pass = (xn >= 0.0 && xn <= 1.0 - 3 * c.dx) ? 1.0 : 0.0;
+    gxp[d] = pass * gx1[d];
+    gv1[d] += c.dt * gxp[d];
+  }
+  int base[3];
+  double fx[3], w[9], dw[9];
+  plb_weights(c, x, base, fx, w, dw);
+  const double* vout = plb_buf(a, 1, b);
+  double* gacc = a.w.gacc + (long)b * a.G * 4;
+  double gfx[3] = {0, 0, 0};
+  const double k4 = 4 * c.inv_dx;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
+    const double weight = wi * wj * wk;
+    const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
+    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+    const long lin = plb_lin(c, ci, cj, ck);
+    const double g[3] = {vout[lin * 4], vout[lin * 4 + 1], vout[lin * 4 + 2]};
+    double gw = 0, gdp[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double cd = gC1[r * 3] * dp[0] + gC1[r * 3 + 1] * dp[1] + gC1[r * 3 + 2] * dp[2];
+      atomicAdd(gacc + lin * 4 + r, weight * (gv1[r] + k4 * cd));
+      gw += g[r] * (gv1[r] + k4 * cd);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) gdp[s] += k4 * weight * gC1[r * 3 + s] * g[r];
+    }
+    gfx[0] += gw * dsel3(dw, 0, i) * wj * wk - gdp[0];
+    gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - gdp[1];
+    gfx[2] += gw * wi * wj * dsel3(dw, 2, k) - gdp[2];
+  }
+  double* gxs = a.w.gxs + (long)b * 3 * c.Np;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gxs[d * c.Np + p] = gxp[d] + c.inv_dx * gfx[d];
+}
+
+// ---- grid op adjoint (:200-232 in reverse), one touched cell per lane -------------------------------------------------
+__global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (t >= min(a.w.count[a.lb * a.B + b], a.cap)) return;
+  const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
+  const double* cell = plb_buf(a, 0, b) + lin * 4;
+  double* ga = a.w.gacc + ((long)b * a.G + lin) * 4;
+  double g[3] = {ga[0], ga[1], ga[2]};
+  const double m = cell[0];
+  if (!(m > 1e-12)) { ga[0] = 0; ga[1] = 0; ga[2] = 0; ga[3] = 0; return; }
+  const int n = c.n_grid;
+  const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
+  const double* P0 = a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
+  const double* P1 = P0 + c.np * 3;
+  // forward, keeping the velocity that entered each boundary stage
+  double vv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vv[k] = (1.0 / m) * cell[1 + k] + c.g30dt[k];
+  bool stick[2] = {false, false};
+  const double gp[3] = {I[0] * c.dx, I[1] * c.dx, I[2] * c.dx};
+  for (int pi = 0; pi < c.np; ++pi) {
+    const double d0 = gp[0] - P0[pi * 3], d1 = gp[1] - P0[pi * 3 + 1], d2 = gp[2] - P0[pi * 3 + 2];
+    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi];
+    const double sf = a.softness[b * c.np + pi];
+    const double infl = fmin(exp(-dist * sf), 1.0);
+    if (((sf > 0 && infl > 0.1) || dist <= 0.001) && sf > 0) {
+      stick[pi] = true;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vv[k] = (P1[pi * 3 + k] - P0[pi * 3 + k]) / c.dt;
+    }
+  }
+  double vin[3][3];        // velocity entering stage d
+  int kind[3];             // 0 nothing, 1 component zeroed, 2 friction, 3 all zeroed
+  bool hiz[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vin[d][k] = vv[k];
+    kind[d] = 0;
+    if (I[d] < 3 && vv[d] < 0) {
+      if (d != 1 || c.fric == 0) { vv[d] = 0; kind[d] = 1; }
+      else if (c.fric < 10) {
+        const double lin_ = vv[1] + 1e-30;
+        const double vit[3] = {vv[0] - I[0] * 1e-30, vv[1] - lin_ - I[1] * 1e-30, vv[2] - I[2] * 1e-30};
+        const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
+        const double s = fmax(1.0 + c.fric * lin_ / lit, 0.0);
+        vv[0] = s * (vit[0] + I[0] * 1e-30); vv[2] = s * (vit[2] + I[2] * 1e-30); vv[1] = 0;
+        kind[d] = 2;
+      } else { vv[0] = 0; vv[1] = 0; vv[2] = 0; kind[d] = 3; }
+    }
+    hiz[d] = (I[d] > n - 3 && vv[d] > 0);
+    if (hiz[d]) vv[d] = 0;
+  }
+  // reverse
+  double gfric = 0;
+#pragma unroll
+  for (int d = 2; d >= 0; --d) {
+    if (hiz[d]) g[d] = 0;
+    if (kind[d] == 1) g[d] = 0;
+    else if (kind[d] == 3) { g[0] = 0; g[1] = 0; g[2] = 0; }
+    else if (kind[d] == 2) {
+      const double* u = vin[d];
+      const double lin_ = u[1] + 1e-30;
+      const double vit[3] = {u[0] - I[0] * 1e-30, u[1] - lin_ - I[1] * 1e-30, u[2] - I[2] * 1e-30};
+      const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
+      const double arg = 1.0 + c.fric * lin_ / lit;
+      const double s = fmax(arg, 0.0);
+      const double gs = g[0] * (vit[0] + I[0] * 1e-30) + g[2] * (vit[2] + I[2] * 1e-30);
+      double gvit[3] = {g[0] * s, 0.0, g[2] * s};
+      double glin = 0, glit = 0;
+      if (arg > 0) { glin = gs * c.fric / lit; glit = -gs * c.fric * lin_ / (lit * lit); gfric += gs * lin_ / lit; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gvit[k] += glit * vit[k] / lit;
+      glin -= gvit[1];                       // vit_y = v_y - lin - I_y 1e-30
+      g[0] = gvit[0]; g[2] = gvit[2]; g[1] = gvit[1] + glin;
+    }
+  }
+  double* gpos = a.w.gpos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
+  for (int pi = c.np - 1; pi >= 0; --pi) {
+    if (stick[pi]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double q = g[k] / c.dt;
+        if (q != 0.0) { atomicAdd(gpos + c.np * 3 + pi * 3 + k, q); atomicAdd(gpos + pi * 3 + k, -q); }
+        g[k] = 0;
+      }
+    }
+  }
+  if (gfric != 0.0) atomicAdd(a.w.gpar + b * 4 + 3, gfric);
+  const double im = 1.0 / m;
+  ga[0] = g[0] * im; ga[1] = g[1] * im; ga[2] = g[2] * im;
+  ga[3] = -(g[0] * cell[1] + g[1] * cell[2] + g[2] * cell[3]) * im * im;
+}
+
+// ---- p2g adjoint + particle pre-pass adjoint (:91-99, :133-195 in reverse) --------------------------------------------
+__global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
+  __shared__ double s_red[3][2];
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  double accE = 0, accNu = 0, accYs = 0;
+  if (p < c.N) {
+    const double* hi_ = plb_hist(a, b, a.hs_in);
+    const double* g1 = a.w.gstate + ((long)b * 2 + gs_in) * 24 * c.Np;
+    double* g0 = a.w.gstate + ((long)b * 2 + (gs_in ^ 1)) * 24 * c.Np;
+    double x[3], v[3], Cm[9], F[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; v[d] = hi_[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = hi_[(6 + d) * c.Np + p]; F[d] = hi_[(15 + d) * c.Np + p]; }
+    const double E = a.E[b], nu = a.nu[b], ys = a.ys[b];
+    const double mu = E / (2 * (1 + nu)), lam = E * nu / ((1 + nu) * (1 - 2 * nu));
+    int base[3];
+    double fx[3], w[9], dw[9];
+    plb_weights(c, x, base, fx, w, dw);
+    // ---- forward pre-pass, as plb_p2g
+    double IC[9], Ft[9], U[9], Vh[9], sig[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
+    dm_mul(IC, F, Ft);
+    dsvd3(Ft, U, sig, Vh);
+    double eps[3], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
+    double eh[3], nn = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { eh[i] = eps[i] - sum / 3; nn += eh[i] * eh[i]; }
+    const double ehn = sqrt(nn + 1e-8);
+    const double dg = ehn - ys / (2 * mu);
+    const bool yields = dg > 0;
+    double nF[9], ex[3] = {1, 1, 1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nF[i] = Ft[i];
+    if (yields) {
+      double US[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ex[i] = exp(eps[i] - (dg / ehn) * eh[i]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) US[r * 3 + i] = U[r * 3 + i] * ex[i];
+      }
+      dm_mul(US, Vh, nF);
+    }
+    const double J = nF[0] * (nF[4] * nF[8] - nF[5] * nF[7]) - nF[1] * (nF[3] * nF[8] - nF[5] * nF[6]) + nF[2] * (nF[3] * nF[7] - nF[4] * nF[6]);
+    double R[9], A[9], St[9], aff[9];
+    dm_mul(U, Vh, R);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) A[i] = nF[i] - R[i];
+    dm_mul_bt(A, nF, St);
+    const double sc = -c.dt * c.p_vol * 4 * c.inv_dx * c.inv_dx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
+    // ---- gather the cell cotangents (p2g in reverse)
+    const double* gacc = a.w.gacc + (long)b * a.G * 4;
+    double gv[3] = {0, 0, 0}, gaff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gfx[3] = {0, 0, 0};
+#pragma unroll 1
+    for (int cidx = 0; cidx < 27; ++cidx) {
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
+      const double weight = wi * wj * wk;
+      const double dp[3] = {((double)i - fx[0]) * c.dx, ((double)j - fx[1]) * c.dx, ((double)k - fx[2]) * c.dx};
+      const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+      const double* gc = gacc + plb_lin(c, ci, cj, ck) * 4;
+      const double gmv[3] = {gc[0], gc[1], gc[2]}, gm = gc[3];
+      double gw = c.p_mass * gm, gdp[3] = {0, 0, 0};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        gw += gmv[r] * (c.p_mass * v[r] + aff[r * 3] * dp[0] + aff[r * 3 + 1] * dp[1] + aff[r * 3 + 2] * dp[2]);
+        gv[r] += weight * c.p_mass * gmv[r];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { gaff[r * 3 + s] += weight * gmv[r] * dp[s]; gdp[s] += weight * gmv[r] * aff[r * 3 + s]; }
+      }
+      gfx[0] += gw * dsel3(dw, 0, i) * wj * wk - c.dx * gdp[0];
+      gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - c.dx * gdp[1];
+      gfx[2] += gw * wi * wj * dsel3(dw, 2, k) - c.dx * gdp[2];
+    }
+    const double* gxs = a.w.gxs + (long)b * 3 * c.Np;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { g0[d * c.Np + p] = gxs[d * c.Np + p] + c.inv_dx * gfx[d]; g0[(3 + d) * c.Np + p] = gv[d]; }
+    // ---- affine = sc * stress + p_mass * C ; stress = 2 mu (nF - R) nF^T + lam J (J - 1) I
+    double gC[9], Gs[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { gC[i] = c.p_mass * gaff[i]; Gs[i] = sc * gaff[i]; }
+    const double trG = Gs[0] + Gs[4] + Gs[8];
+    double gmu = 0, glam = J * (J - 1) * trG;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gmu += 2 * Gs[i] * St[i];
+    const double gJ = lam * (2 * J - 1) * trG;
+    double gM[9], gA[9], gnF[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gM[i] = 2 * mu * Gs[i];
+    dm_mul(gM, nF, gA);            // M = A nF^T: gA = gM nF
+    dm_mul_at(gM, A, gnF);         // g(nF) = gM^T A
+    const double cof[9] = {nF[4] * nF[8] - nF[5] * nF[7], nF[5] * nF[6] - nF[3] * nF[8], nF[3] * nF[7] - nF[4] * nF[6],
+                           nF[2] * nF[7] - nF[1] * nF[8], nF[0] * nF[8] - nF[2] * nF[6], nF[1] * nF[6] - nF[0] * nF[7],
+                           nF[1] * nF[5] - nF[2] * nF[4], nF[2] * nF[3] - nF[0] * nF[5], nF[0] * nF[4] - nF[1] * nF[3]};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gnF[i] += gA[i] + gJ * cof[i] + g1[(15 + i) * c.Np + p];   // + the cotangent of F[f + 1]
+    // R = U V^T (Vh = V^T):  gU = gR V = gR Vh^T,  gV = gR^T U  with gR = -gA
+    double gU[9], gV[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) V[i * 3 + j] = Vh[j * 3 + i];
+    double ngA[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ngA[i] = -gA[i];
+    dm_mul(ngA, V, gU);
+    dm_mul_at(ngA, U, gV);
+    double gsig[3] = {0, 0, 0}, gFt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double gys = 0;
+    if (yields) {   // nF = U diag(ex) V^T
+      double T1[9], T2[9];
+      dm_mul(gnF, V, T1);          // gnF V
+      dm_mul_at(gnF, U, T2);       // gnF^T U
+      double ge[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ge[i] = U[i] * T1[i] + U[3 + i] * T1[3 + i] + U[6 + i] * T1[6 + i];   // (U^T gnF V)_ii
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { gU[r * 3 + i] += T1[r * 3 + i] * ex[i]; gV[r * 3 + i] += T2[r * 3 + i] * ex[i]; }
+      }
+      double gey[3], geps[3], geh[3];
+      const double q = dg / ehn;
+      double gq = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { gey[i] = ge[i] * ex[i]; geps[i] = gey[i]; gq -= gey[i] * eh[i]; geh[i] = -q * gey[i]; }
+      // q = 1 - ys / (2 mu ehn)
+      gys = -gq / (2 * mu * ehn);
+      gmu += gq * ys / (2 * mu * mu * ehn);
+      const double gehn = gq * ys / (2 * mu * ehn * ehn);
+      double gsum = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { geh[i] += gehn * eh[i] / ehn; gsum += geh[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { geps[i] += geh[i] - gsum / 3; gsig[i] = (sig[i] > 0.05) ? geps[i] / sig[i] : 0.0; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gFt[i] = gnF[i];
+    }
+    // ---- backward_svd (:107-124): gFt += U ((Fm * (U^T gU - gU^T U)) sig) V^T + U (sig ((Fm * (V^T gV - gV^T V)) V^T)) + U gsig V^T
+    {
+      double UtgU[9], VtgV[9];
+      dm_mul_at(U, gU, UtgU);
+      dm_mul_at(V, gV, VtgV);
+      const double s2[3] = {sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2]};
+      double Mm[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          double val = 0.0;
+          if (i != j) {
+            double df = s2[j] - s2[i];
+            df = (df >= 0) ? fmax(df, 1e-6) : fmin(df, -1e-6);   // clamp :152-161
+            const double Fm = 1.0 / df;
+            val = Fm * (UtgU[i * 3 + j] - UtgU[j * 3 + i]) * sig[j] + sig[i] * Fm * (VtgV[i * 3 + j] - VtgV[j * 3 + i]);
+          } else {
+            val = gsig[i];
+          }
+          Mm[i * 3 + j] = val;
+        }
+      double UM[9], add[9];
+      dm_mul(U, Mm, UM);
+      dm_mul(UM, Vh, add);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) gFt[i] += add[i];
+    }
+    // ---- F_tmp = (I + dt C) F
+    double gCF[9], gF0[9];
+    dm_mul_bt(gFt, F, gCF);        // gFt F^T
+    dm_mul_at(IC, gFt, gF0);       // (I + dt C)^T gFt
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { g0[(6 + i) * c.Np + p] = gC[i] + c.dt * gCF[i]; g0[(15 + i) * c.Np + p] = gF0[i]; }
+    // ---- mu, lam -> E, nu
+    const double a1 = 1 + nu, a2 = 1 - 2 * nu;
+    accE = gmu / (2 * a1) + glam * nu / (a1 * a2);
+    accNu = gmu * (-E / (2 * a1 * a1)) + glam * E * (1 + 2 * nu * nu) / (a1 * a1 * a2 * a2);
+    accYs = gys;
+  }
+  // block sums -> one atomic per block and parameter
+  double vals[3] = {accE, accNu, accYs};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double v = vals[q];
+    v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+    const int lane = threadIdx.x & 63;
+    double tot = 0;
+    for (int r = 0; r < 4; ++r) tot += __shfl(v, r * 16);
+    if (lane == 0) s_red[q][threadIdx.x >> 6] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(a.w.gpar + b * 4 + threadIdx.x, s_red[threadIdx.x][0] + s_red[threadIdx.x][1]);
+}
+
+// zero everything the substep touched: (m, mv), v_out, cotangents; reset the list
+__global__ void __launch_bounds__(256) plb_adj_clear(PlbArgs a) {
+  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = min(a.w.count[a.lb * a.B + b], a.cap);
+  if (t < n) {
+    const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
+    double* c0 = plb_buf(a, 0, b) + lin * 4;
+    double* c1 = plb_buf(a, 1, b) + lin * 4;
+    double* g = a.w.gacc + ((long)b * a.G + lin) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c0[k] = 0.0; c1[k] = 0.0; g[k] = 0.0; }
+  }
+}
+__global__ void plb_adj_reset_counts(PlbArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < a.B) { a.w.count[b] = 0; a.w.count[a.B + b] = 0; }
+}
+
+// cotangent of the step outputs -> gstate slot (in the spatial order of the checkpoint); zero the accumulators
+__global__ void __launch_bounds__(256) plb_adj_pack(PlbArgs a, int slot, const double* gx, const double* gv, const double* gC, const double* gF, const double* gpp) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (blockIdx.x == 0) {
+    for (int e = threadIdx.x; e < (c.S + 1) * c.np * 3; e += blockDim.x)
+      a.w.gpos[(long)b * (c.S + 1) * c.np * 3 + e] = (gpp && e >= c.S * c.np * 3) ? gpp[(long)b * c.np * 3 + e - c.S * c.np * 3] : 0.0;
+    if (threadIdx.x < 4) a.w.gpar[b * 4 + threadIdx.x] = 0.0;
+  }
+  if (p >= c.N) return;
+  double* g = a.w.gstate + ((long)b * 2 + slot) * 24 * c.Np;
+  const int up = a.w.perm[(long)b * c.Np + p];
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { g[d * c.Np + p] = gx ? gx[o3 + d] : 0.0; g[(3 + d) * c.Np + p] = gv ? gv[o3 + d] : 0.0; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { g[(6 + d) * c.Np + p] = gC ? gC[o9 + d] : 0.0; g[(15 + d) * c.Np + p] = gF ? gF[o9 + d] : 0.0; }
+}
+
+__global__ void __launch_bounds__(256) plb_adj_unpack(PlbArgs a, int slot, double* gx, double* gv, double* gC, double* gF) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const PlbConst& c = a.c;
+  if (p >= c.N) return;
+  const double* g = a.w.gstate + ((long)b * 2 + slot) * 24 * c.Np;
+  const int up = a.w.perm[(long)b * c.Np + p];
+  const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { gx[o3 + d] = g[d * c.Np + p]; gv[o3 + d] = g[(3 + d) * c.Np + p]; }
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[o9 + d] = g[(6 + d) * c.Np + p]; gF[o9 + d] = g[(15 + d) * c.Np + p]; }
+}
+
+// forward_kinematics.grad + set_action in reverse: pos[s+1] = clamp(pos[s] + pv), pv = clip(action, -1, 1) / S for primitive 0
+__global__ void plb_adj_epilogue(PlbArgs a, const double* action, double* g_prim_pos0, double* g_action, double* g_E, double* g_nu, double* g_ys, double* g_fric) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const PlbConst& c = a.c;
+  const double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
+  double* G = a.w.gpos + (long)b * (c.S + 1) * c.np * 3;
+  for (int pi = 0; pi < c.np; ++pi)
+    for (int d = 0; d < 3; ++d) {
+      const double raw = (pi == 0) ? action[b * 3 + d] : 0.0;
+      const double pv = (pi == 0) ? fmin(fmax(raw, -1.0), 1.0) / (double)c.S : 0.0;
+      double gpv = 0.0;
+      for (int s = c.S - 1; s >= 0; --s) {
+        const double un = P[(s * c.np + pi) * 3 + d] + pv;
+        const double pass = (un >= c.lo[d] && un <= c.hi[d]) ? 1.0 : 0.0;
+        const double g = pass * G[((s + 1) * c.np + pi) * 3 + d];
+        G[(s * c.np + pi) * 3 + d] += g;
+        gpv += g;
+      }
+      if (g_prim_pos0) g_prim_pos0[((long)b * c.np + pi) * 3 + d] = G[pi * 3 + d];
+      if (pi == 0 && g_action) g_action[b * 3 + d] = (raw >= -1.0 && raw <= 1.0) ? gpv / (double)c.S : 0.0;
+    }
+  if (g_E) g_E[b] = a.w.gpar[b * 4];
+  if (g_nu) g_nu[b] = a.w.gpar[b * 4 + 1];
+  if (g_ys) g_ys[b] = a.w.gpar[b * 4 + 2];
+  if (g_fric) g_fric[b] = a.w.gpar[b * 4 + 3];
+}
+
+// ---- losses (engine/losses/loss.py) -----------------------------------------------------------------------------------
+// grid mass of the particles (compute_grid_m_kernel): dense [B][G], zeroed by the caller
+__global__ void __launch_bounds__(256) plb_loss_mass(PlbConst c, long G, const double* x, double* gm) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.N) return;
+  const double xp[3] = {x[((long)b * c.N + p) * 3], x[((long)b * c.N + p) * 3 + 1], x[((long)b * c.N + p) * 3 + 2]};
+  int base[3];
+  double fx[3], w[9], dw[9];
+  plb_weights(c, xp, base, fx, w, dw);
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+    atomicAdd(gm + (long)b * G + plb_lin(c, ci, cj, ck), dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k) * c.p_mass);
+  }
+}
+
+__device__ __forceinline__ double plb_block_sum(double v, double* sh) {   // 256 threads; result in thread 0
+  v += dpp_d<0xB1>(v); v += dpp_d<0x4E>(v); v += dpp_d<0x141>(v); v += dpp_d<0x140>(v);
+  double tot = 0;
+  for (int r = 0; r < 4; ++r) tot += __shfl(v, r * 16);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// density :145-148 and sdf :150-153 terms: lred[b][0] += sum |gm - td|, lred[b][1] += sum tsdf * gm
+__global__ void __launch_bounds__(256) plb_loss_grid(long G, const double* gm, const double* td, const double* tsdf, double* lred) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y;
+  double d = 0, s = 0;
+  for (long I = (long)blockIdx.x * blockDim.x + threadIdx.x; I < G; I += (long)gridDim.x * blockDim.x) {
+    const double m = gm[(long)b * G + I];
+    d += fabs(m - td[I]);
+    s += tsdf[I] * m;
+  }
+  d = plb_block_sum(d, sh);
+  s = plb_block_sum(s, sh);
+  if (threadIdx.x == 0) { atomicAdd(lred + b * 16, d); atomicAdd(lred + b * 16 + 1, s); }
+}
+
+// contact sums per primitive pi: soft :117-135 lred[b][4 + 2 pi] += sum w(d), lred[b][5 + 2 pi] += sum d w(d);
+// hard :120-124: a minimum, taken through the ordered-integer view of the non-negative double (lred[b][8 + pi], preset to +inf)
+__global__ void __launch_bounds__(256) plb_loss_contact(PlbConst c, const double* x, const double* prim_pos, int soft, double* lred) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int pi = 0; pi < c.np; ++pi) {
+    double dij = 0, sw = 0;
+    if (p < c.N) {
+      const double* xp = x + ((long)b * c.N + p) * 3;
+      const double* pp = prim_pos + ((long)b * c.np + pi) * 3;
+      const double d0 = xp[0] - pp[0], d1 = xp[1] - pp[1], d2 = xp[2] - pp[2];
+      dij = fmax(sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi], 0.0);
+      sw = 1.0 / (1.0 + dij * dij * 10000.0);
+    }
+    if (soft) {
+      const double s0 = plb_block_sum(p < c.N ? sw : 0.0, sh), s1 = plb_block_sum(p < c.N ? dij * sw : 0.0, sh);
+      if (threadIdx.x == 0) { atomicAdd(lred + b * 16 + 4 + 2 * pi, s0); atomicAdd(lred + b * 16 + 5 + 2 * pi, s1); }
+    } else if (p < c.N) {
+      atomicMin((unsigned long long*)(lred + b * 16 + 8 + pi), (unsigned long long)__double_as_longlong(dij));
+    }
+  }
+}
+
+__global__ void plb_loss_init(int B, double* lred) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B * 16) lred[t] = ((t & 15) == 8 || (t & 15) == 9) ? INFINITY : 0.0;
+}
+
+__global__ void plb_loss_finish(PlbConst c, int B, int soft, const double* wts, const double* lred, double* loss, double* parts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double* r = lred + b * 16;
+  double contact = 0;
+  for (int pi = 0; pi < c.np; ++pi) {
+    const double md = soft ? r[5 + 2 * pi] / r[4 + 2 * pi] : r[8 + pi];
+    contact += md * md;
+  }
+  loss[b] = contact * wts[0] + r[0] * wts[1] + r[1] * wts[2];
+  if (parts) { parts[b * 3] = contact; parts[b * 3 + 1] = r[0]; parts[b * 3 + 2] = r[1]; }
+}
+
+// loss adjoint: g_x and g_prim_pos.  Needs gm (grid mass) and lred (the forward's sums) of the same inputs.
+__global__ void __launch_bounds__(256) plb_loss_bwd_kernel(PlbConst c, long G, int soft, const double* wts, const double* x, const double* prim_pos,
+                                                          const double* td, const double* tsdf, const double* gm, const double* lred,
+                                                          const double* g_loss, double* g_x, double* g_pp) {
+  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= c.N) return;
+  const double gl = g_loss[b];
+  const double* xp = x + ((long)b * c.N + p) * 3;
+  int base[3];
+  double fx[3], w[9], dw[9];
+  plb_weights(c, xp, base, fx, w, dw);
+  double gfx[3] = {0, 0, 0};
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+    const long I = plb_lin(c, ci, cj, ck);
+    const double m = gm[(long)b * G + I], df = m - td[I];
+    const double gmI = gl * (wts[1] * ((df > 0) ? 1.0 : ((df < 0) ? -1.0 : 0.0)) + wts[2] * tsdf[I]) * c.p_mass;
+    const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
+    gfx[0] += gmI * dsel3(dw, 0, i) * wj * wk;
+    gfx[1] += gmI * wi * dsel3(dw, 1, j) * wk;
+    gfx[2] += gmI * wi * wj * dsel3(dw, 2, k);
+  }
+  double gx[3] = {c.inv_dx * gfx[0], c.inv_dx * gfx[1], c.inv_dx * gfx[2]};
+  const double* r = lred + b * 16;
+  for (int pi = 0; pi < c.np; ++pi) {
+    const double* pp = prim_pos + ((long)b * c.np + pi) * 3;
+    const double d0 = xp[0] - pp[0], d1 = xp[1] - pp[1], d2 = xp[2] - pp[2];
+    const double len = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14);
+    const double raw = len - c.radius[pi];
+    const double dij = fmax(raw, 0.0);
+    double gd = 0;   // d loss / d dij for this particle
+    if (soft) {
+      const double nrm = r[4 + 2 * pi], md = r[5 + 2 * pi] / nrm;
+      const double sw = 1.0 / (1.0 + dij * dij * 10000.0);
+      const double dsw = -20000.0 * dij * sw * sw;
+      // md = sum(d w) / sum(w):  d md / d d_i = (w + d w') / nrm - md w' / nrm
+      gd = gl * wts[0] * 2 * md * ((sw + dij * dsw) / nrm - md * dsw / nrm);
+    } else {
+      const double md = r[8 + pi];
+      gd = (dij == md) ? gl * wts[0] * 2 * md : 0.0;   // the minimum passes its cotangent to the argmin (ties: every one of them)
+    }
+    if (raw > 0.0 && gd != 0.0) {
+      const double q[3] = {gd * d0 / len, gd * d1 / len, gd * d2 / len};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { gx[k] += q[k]; if (g_pp) atomicAdd(g_pp + ((long)b * c.np + pi) * 3 + k, -q[k]); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g_x[((long)b * c.N + p) * 3 + k] = gx[k];
+}
+
+}  // namespace ud
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, const double* action, const double* E, const double* nu,
+                    const double* yield_stress, const double* g_x, const double* g_v, const double* g_C, const double* g_F,
+                    const double* g_prim_pos, double* g_x0, double* g_v0, double* g_C0, double* g_F0, double* g_prim_pos0,
+                    double* g_action, double* g_E, double* g_nu, double* g_yield_stress, double* g_ground_friction, void* stream) {
+  if (!h || !ckpt || !softness || !action || !E || !nu || !yield_stress || !g_x0 || !g_v0 || !g_C0 || !g_F0) {
+    ud::set_error("ud_plb_step_bwd: null argument"); return UD_ERR_INVALID;
+  }
+  if (B < 1) { ud::set_error("ud_plb_step_bwd: B=%d", B); return UD_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = plb_reserve(h, B, st, true, false);
+  if (rc) return rc;
+  ud::PlbArgs a;
+  a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
+  a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
+  size_t o_hist, o_pos, o_perm, total;
+  plb_ckpt_layout(h->c, B, &o_hist, &o_pos, &o_perm, &total);
+  a.w.hist = (double*)((char*)ckpt + o_hist); a.w.pos = (double*)((char*)ckpt + o_pos); a.w.perm = (int*)((char*)ckpt + o_perm);
+  a.slots = h->c.S + 1; a.lb = 0;
+  const int S = h->c.S;
+  const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B), gpa((h->c.N + 127) / 128, B);
+  hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(ud::plb_adj_pack, gp, blk, 0, st, a, S & 1, g_x, g_v, g_C, g_F, g_prim_pos);
+  for (int f = S - 1; f >= 0; --f) {
+    a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1;
+    ud::plb_launch_p2g1(a, gp, st);                                      // recompute (m, mv) into buffer 0 (rewrites F[f + 1] with the same values)
+    hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_g2p_adj, gp, blk, 0, st, a, (f + 1) & 1);
+    hipLaunchKernelGGL(ud::plb_grid_adj, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_p2g_adj, gpa, dim3(128), 0, st, a, (f + 1) & 1);
+    hipLaunchKernelGGL(ud::plb_adj_clear, gc, blk, 0, st, a);
+    hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
+  }
+  hipLaunchKernelGGL(ud::plb_adj_unpack, gp, blk, 0, st, a, 0, g_x0, g_v0, g_C0, g_F0);
+  hipLaunchKernelGGL(ud::plb_adj_epilogue, dim3((B + 63) / 64), dim3(64), 0, st, a, action, g_prim_pos0, g_action, g_E, g_nu, g_yield_stress, g_ground_friction);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { ud::set_error("ud_plb_step_bwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+static int plb_loss_common(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density, const double* target_sdf,
+                           const double* weights, int soft_contact, hipStream_t st) {
+  int rc = plb_reserve(h, B, st, false, true);
+  if (rc) return rc;
+  const ud::PlbConst& c = h->c;
+  hipError_t e = hipMemsetAsync(h->gm, 0, (size_t)B * h->G * 8, st);
+  if (e != hipSuccess) { ud::set_error("ud_plb_loss: memset failed"); return UD_ERR_HIP; }
+  const dim3 blk(256), gp((c.N + 255) / 256, B);
+  hipLaunchKernelGGL(ud::plb_loss_init, dim3((B * 16 + 255) / 256), blk, 0, st, B, h->lred);
+  hipLaunchKernelGGL(ud::plb_loss_mass, gp, blk, 0, st, c, h->G, x, h->gm);
+  const int gb = (int)std::min<long>((h->G + 255) / 256, 1024);
+  hipLaunchKernelGGL(ud::plb_loss_grid, dim3(gb, B), blk, 0, st, h->G, (const double*)h->gm, target_density, target_sdf, h->lred);
+  if (c.np > 0) hipLaunchKernelGGL(ud::plb_loss_contact, gp, blk, 0, st, c, x, prim_pos, soft_contact, h->lred);
+  return UD_OK;
+}
+
+int ud_plb_loss_fwd(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density, const double* target_sdf,
+                    const double* weights, int soft_contact, double* loss, double* parts, void* stream) {
+  if (!h || !x || !prim_pos || !target_density || !target_sdf || !weights || !loss) { ud::set_error("ud_plb_loss_fwd: null argument"); return UD_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = plb_loss_common(h, B, x, prim_pos, target_density, target_sdf, weights, soft_contact, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ud::plb_loss_finish, dim3((B + 63) / 64), dim3(64), 0, st, h->c, B, soft_contact, weights, (const double*)h->lred, loss, parts);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { ud::set_error("ud_plb_loss_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+int ud_plb_loss_bwd(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density, const double* target_sdf,
+                    const double* weights, int soft_contact, const double* g_loss, double* g_x, double* g_prim_pos, void* stream) {
+  if (!h || !x || !prim_pos || !target_density || !target_sdf || !weights || !g_loss || !g_x) { ud::set_error("ud_plb_loss_bwd: null argument"); return UD_ERR_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = plb_loss_common(h, B, x, prim_pos, target_density, target_sdf, weights, soft_contact, st);   // recompute the grid mass and the sums
+  if (rc) return rc;
+  if (g_prim_pos) { if (hipMemsetAsync(g_prim_pos, 0, (size_t)B * h->c.np * 3 * 8, st) != hipSuccess) { ud::set_error("ud_plb_loss_bwd: memset failed"); return UD_ERR_HIP; } }
+  const dim3 blk(256), gp((h->c.N + 255) / 256, B);
+  hipLaunchKernelGGL(ud::plb_loss_bwd_kernel, gp, blk, 0, st, h->c, h->G, soft_contact, weights, x, prim_pos, target_density, target_sdf,
+                     (const double*)h->gm, (const double*)h->lred, g_loss, g_x, g_prim_pos);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { ud::set_error("ud_plb_loss_bwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// Shared pieces of the PlasticineLab-style f64 MLS-MPM kernels: forward (plb.hip), adjoint and losses (plb_adj.hip).
+#pragma once
+#include "common.h"
+
+namespace ud {
+
+
+struct PlbConst {
+  int N, Np, n_grid, S, np;
+  double dt, dx, inv_dx, p_mass, p_vol, g30dt[3], fric, radius[2], lo[3], hi[3];
+};
+
+struct PlbBuf {
+  double* val;    // [2][B][G][4] (m, mv) -> after the grid op (m, v)
+  int* stamp;     // [B][G]
+  int* list;      // [2][B][cap]
+  int* count;     // [2][B]
+  double* pos;    // [B][S+1][np][3] primitive positions of this step (handle arena, or the caller's checkpoint)
+  double* hist;   // [B][slots][24][Np] particle state per substep: slots = 2 (ping-pong) or S + 1 (checkpoint: all of them)
+  int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
+  // adjoint only (plb_adj.hip)
+  double* gacc;   // [B][G][4] cotangent of the cell's v_out (xyz), then of (mv xyz, m)
+  double* gstate; // [B][2][24][Np] cotangent of the particle state, ping-pong over substeps
+  double* gxs;    // [B][3][Np] the part of x's cotangent that g2p's adjoint produces, handed to p2g's adjoint
+  double* gpos;   // [B][S+1][np][3] cotangent of the primitive positions
+  double* gpar;   // [B][4] cotangents of E, nu, yield_stress, ground friction
+};
+
+struct PlbArgs {
+  PlbConst c;
+  PlbBuf w;
+  int B, f, epoch, cap;
+  int slots, hs_in, hs_out;   // hist slots per env; slot of this substep's input state / output state
+  int lb;                     // active list and grid buffer of this substep (forward: f & 1, the other one is being retired)
+  long G;
+  const double *softness, *E, *nu, *ys;
+};
+
+__device__ __forceinline__ double* plb_hist(const PlbArgs& a, int b, int slot) { return a.w.hist + ((long)b * a.slots + slot) * 24 * a.c.Np; }
+
+// ---- double 3x3 helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ void dm_mul(const double* A, const double* B, double* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, double* R) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+}
+
+#define UD_DJROT(p, q)                                                                       \
+  {                                                                                          \
+    double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                      \
+    double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                      \
+    double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                      \
+    const bool rot = fabs(ga) > 1e-17 * sqrt(al * be);                                        \
+    double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
+    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
+    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
+    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
+      double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
+      a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
+      double vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                          \
+      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                   \
+    }                                                                                         \
+  }
+#define UD_DCSWAP(p, q)                                                              \
+  if (sv[p] < sv[q]) {                                                               \
+    double ts = sv[p]; sv[p] = sv[q]; sv[q] = ts;                                    \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                  \
+      double t1 = a[i * 3 + p]; a[i * 3 + p] = a[i * 3 + q]; a[i * 3 + q] = t1;      \
+      double t2 = vv[i * 3 + p]; vv[i * 3 + p] = vv[i * 3 + q]; vv[i * 3 + q] = t2;  \
+    }                                                                                \
+  }
+
+// A = U diag(S) Vh, S descending >= 0 (one-sided Jacobi, 6 sweeps reach f64 round-off for |F - I| = O(1))
+__device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, double* Vh) {
+  double a[9], vv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = A[i];
+#pragma unroll 1
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    UD_DJROT(0, 1)
+    UD_DJROT(0, 2)
+    UD_DJROT(1, 2)
+  }
+  double sv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
+  UD_DCSWAP(0, 1)
+  UD_DCSWAP(1, 2)
+  UD_DCSWAP(0, 1)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    S[j] = sv[j];
+    const double inv = sv[j] > 1e-300 ? 1.0 / sv[j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
+  }
+}
+
+__device__ __forceinline__ double dsel3(const double* w, int d, int i) { return (i == 0) ? w[d] : ((i == 1) ? w[3 + d] : w[6 + d]); }
+
+__device__ __forceinline__ long plb_lin(const PlbConst& c, int i, int j, int k) { return ((long)i * c.n_grid + j) * c.n_grid + k; }
+
+__device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin) {
+  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
+  if (old != a.epoch) {
+    const int cur = a.lb;
+    const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
+    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = (int)lin;
+  }
+}
+
+// The grid values are double-buffered, buffer k belongs to active list k (substep f uses k = f & 1): the cells of substep f - 1
+// can then be zeroed while substep f runs -- plb_grid(f) does it next to its own work -- instead of in a launch of their own
+// between g2p(f - 1) and p2g(f).  One launch less per substep (4 -> 3) on a path whose kernels sit near the launch floor.
+__device__ __forceinline__ double* plb_buf(const PlbArgs& a, int k, int b) { return a.w.val + (((long)k * a.B + b) * a.G) * 4; }
+
+#define PLB_H 1024
+#define PLB_LOGH 10
+__device__ __forceinline__ unsigned plb_hash(int cell) {
+  unsigned h = (unsigned)cell;
+  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
+  return h >> (32 - PLB_LOGH);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int LANES>
+__device__ __forceinline__ double plb_quad_sum(double v) {
+  if (LANES == 4) {
+    v += dpp_d<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);  // quad_perm [2,3,0,1]
+  }
+  return v;
+}
+
+// grid_op for one touched cell (:200-232): (m, mv) -> v_out.  P0 / P0 + np*3: primitive positions at substeps f and f + 1.
+__device__ __forceinline__ void plb_grid_cell(const PlbConst& c, long lin, double m, const double* mv, const double* P0, const double* soft, double* vv) {
+  vv[0] = 0.0; vv[1] = 0.0; vv[2] = 0.0;
+  if (!(m > 1e-12)) return;
+  const int n = c.n_grid;
+  const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) vv[k] = (1.0 / m) * mv[k] + c.g30dt[k];
+  const double gp[3] = {I[0] * c.dx, I[1] * c.dx, I[2] * c.dx};
+  const double* P1 = P0 + c.np * 3;
+  for (int pi = 0; pi < c.np; ++pi) {                                    // Sphere.collide (sticky), primitives.py:46-53
+    const double d0 = gp[0] - P0[pi * 3], d1 = gp[1] - P0[pi * 3 + 1], d2 = gp[2] - P0[pi * 3 + 2];
+    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi];
+    const double sf = soft[pi];
+    const double infl = fmin(exp(-dist * sf), 1.0);
+    if (((sf > 0 && infl > 0.1) || dist <= 0.001) && sf > 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vv[k] = (P1[pi * 3 + k] - P0[pi * 3 + k]) / c.dt;   // collider_v, identity rotations
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (I[d] < 3 && vv[d] < 0) {
+      if (d != 1 || c.fric == 0) vv[d] = 0;
+      else if (c.fric < 10) {
+        const double lin_ = vv[1] + 1e-30;
+        const double vit[3] = {vv[0] - I[0] * 1e-30, vv[1] - lin_ - I[1] * 1e-30, vv[2] - I[2] * 1e-30};
+        const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
+        const double s = fmax(1.0 + c.fric * lin_ / lit, 0.0);
+        vv[0] = s * (vit[0] + I[0] * 1e-30); vv[2] = s * (vit[2] + I[2] * 1e-30); vv[1] = 0;
+      } else { vv[0] = 0; vv[1] = 0; vv[2] = 0; }
+    }
+    if (I[d] > n - 3 && vv[d] > 0) vv[d] = 0;
+  }
+}
+
+void plb_launch_p2g1(const PlbArgs& a, dim3 grid, hipStream_t st);   // plb_p2g<1> (plb.hip), for the adjoint's recompute
+
+}  // namespace ud
+
+// ---- host side, shared by plb.hip and plb_adj.hip -----------------------------------------------------------
+struct ud_plb {
+  ud::PlbConst c;
+  int B = 0, cap = 0, epoch = 1;
+  long G = 0;
+  ud::PlbBuf w{};
+  double* gm = nullptr;     // [B][G] grid mass of the loss kernels
+  double* lred = nullptr;   // [B][16] loss partial sums
+  bool has_adj = false, has_loss = false;
+  void* arena = nullptr;
+};
+// (re)size the handle's arena: forward buffers always, adjoint / loss buffers on first use (hipStreamSynchronize + hipFree +
+// hipMalloc when it has to grow: see the header's note on host synchronisation)
+int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss);
+void plb_ckpt_layout(const ud::PlbConst& c, int B, size_t* o_hist, size_t* o_pos, size_t* o_perm, size_t* total);

@@ -1,8 +1,13 @@
-"""PlbSimulator -- host mirror of GenORM's Taichi MPMSimulator + Primitives for the Torus task (float64, forward).
+"""PlbSimulator -- host mirror of GenORM's Taichi MPMSimulator + Primitives + Loss for the Torus task (float64).
 
 Mirrors /root/reference/GenORM/policy/pbm/plb/engine/mpm_simulator.py (constants :14-32, step :438-449 in copy
-mode) and the two Sphere primitives of envs/torus.yml; the physics runs in libunidom_hip.so (csrc/plb.hip).
-The reference holds one env per process in Taichi fields; here B independent envs are batched in one call.
+mode, substep_grad :271-289), the two Sphere primitives of envs/torus.yml and engine/losses/loss.py:112-243; the
+physics runs in libunidom_hip.so (csrc/plb.hip forward, csrc/plb_adj.hip adjoint + losses).  The reference holds one
+env per process in Taichi fields and differentiates with ti.Tape; here B independent envs are batched in one call and
+`step` / `compute_loss` are torch.autograd Functions over the forward / adjoint kernel pairs, so
+`loss.backward()` plays the role of the tape: gradients reach the particle state, the action, the primitive position and
+the parameter leaves E, nu, yield_stress (PlasticineLab/sim2sim/plb/engine/mpm_simulator.py:27-29,485-498,
+get_parameter_grad) and the ground friction (optimize_ground_friction, :57-58; `PlbSimulator.ground_friction_grad`).
 """
 from __future__ import annotations
 
@@ -47,6 +52,80 @@ class PlbConf:
     upper_bound = (1.0, 1.0, 1.0)
 
 
+def _p(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _c(t):
+    return t.detach().to(torch.float64).contiguous()
+
+
+class _PlbStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sim, x, v, Cm, F, pp, so, action, E, nu, ys):
+        L = _lib.lib()
+        B = x.shape[0]
+        x, v, Cm, F, pp, so, action, E, nu, ys = map(_c, (x, v, Cm, F, pp, so, action, E, nu, ys))
+        xo, vo, Co, Fo, po = (torch.empty_like(t) for t in (x, v, Cm, F, pp))
+        ckpt = None
+        if any(ctx.needs_input_grad):
+            ckpt = torch.empty((L.ud_plb_ckpt_bytes(sim._h, C.c_int(B)) // 8,), dtype=torch.float64, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(L.ud_plb_step_fwd(sim._h, C.c_int(B), _p(x), _p(v), _p(Cm), _p(F), _p(pp), _p(so), _p(action), _p(E), _p(nu),
+                                     _p(ys), _p(xo), _p(vo), _p(Co), _p(Fo), _p(po), _p(ckpt), stream), "ud_plb_step_fwd")
+        ctx.sim, ctx.B = sim, B
+        ctx.save_for_backward(ckpt, so, action, E, nu, ys)
+        return xo, vo, Co, Fo, po
+
+    @staticmethod
+    def backward(ctx, gx, gv, gC, gF, gpp):
+        L = _lib.lib()
+        sim, B = ctx.sim, ctx.B
+        ckpt, so, action, E, nu, ys = ctx.saved_tensors
+        if ckpt is None:
+            raise _lib.UnidomError("PLB step backward without a checkpoint (forward ran under no_grad)")
+        N, P, dev = sim.n_particles, sim.n_primitive, so.device
+        g = lambda t: None if t is None else _c(t)
+        gx, gv, gC, gF, gpp = map(g, (gx, gv, gC, gF, gpp))
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        ox, ov, oC, oF, op, oa = mk(B, N, 3), mk(B, N, 3), mk(B, N, 3, 3), mk(B, N, 3, 3), mk(B, P, 3), mk(B, 3)
+        oE, onu, oys, ofr = mk(B), mk(B), mk(B), mk(B)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.ud_plb_step_bwd(sim._h, C.c_int(B), _p(ckpt), _p(so), _p(action), _p(E), _p(nu), _p(ys), _p(gx), _p(gv), _p(gC),
+                                     _p(gF), _p(gpp), _p(ox), _p(ov), _p(oC), _p(oF), _p(op), _p(oa), _p(oE), _p(onu), _p(oys), _p(ofr),
+                                     stream), "ud_plb_step_bwd")
+        sim.ground_friction_grad = ofr if sim.ground_friction_grad is None else sim.ground_friction_grad + ofr
+        return None, ox, ov, oC, oF, op, None, oa, oE, onu, oys
+
+
+class _PlbLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sim, x, pp, td, ts, wt, soft):
+        L = _lib.lib()
+        B = x.shape[0]
+        x, pp = _c(x), _c(pp)
+        loss = torch.empty((B,), dtype=torch.float64, device=x.device)
+        parts = torch.empty((B, 3), dtype=torch.float64, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(L.ud_plb_loss_fwd(sim._h, C.c_int(B), _p(x), _p(pp), _p(td), _p(ts), _p(wt), C.c_int(int(soft)), _p(loss), _p(parts),
+                                     stream), "ud_plb_loss_fwd")
+        ctx.sim, ctx.B, ctx.soft = sim, B, soft
+        ctx.save_for_backward(x, pp, td, ts, wt)
+        ctx.mark_non_differentiable(parts)
+        return loss, parts
+
+    @staticmethod
+    def backward(ctx, gl, _gparts):
+        L = _lib.lib()
+        x, pp, td, ts, wt = ctx.saved_tensors
+        gl = _c(gl)
+        gx, gpp = torch.empty_like(x), torch.empty_like(pp)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(L.ud_plb_loss_bwd(ctx.sim._h, C.c_int(ctx.B), _p(x), _p(pp), _p(td), _p(ts), _p(wt), C.c_int(int(ctx.soft)), _p(gl),
+                                     _p(gx), _p(gpp), stream), "ud_plb_loss_bwd")
+        return None, gx, gpp, None, None, None, None
+
+
 class PlbSimulator:
     def __init__(self, cfg=None, batch_size=1, device="cuda"):
         cfg = PlbConf() if cfg is None else cfg
@@ -67,6 +146,7 @@ class PlbSimulator:
             radius=(C.c_double * 2)(*(list(cfg.prim_radius) + [0.0])[:2]),
             lower_bound=(C.c_double * 3)(*cfg.lower_bound), upper_bound=(C.c_double * 3)(*cfg.upper_bound))
         self._h = C.c_void_p()
+        self.ground_friction_grad = None   # [B], accumulated by backward() (optimize_ground_friction.grad); reset it by hand
         _lib.check(_lib.lib().ud_plb_create(C.byref(cc), C.byref(self._h)), "ud_plb_create")
 
     def __del__(self):
@@ -95,20 +175,24 @@ class PlbSimulator:
                         nu=torch.full((B,), float(cfg.nu), dtype=torch.float64, device=dev),
                         yield_stress=torch.full((B,), float(cfg.yield_stress), dtype=torch.float64, device=dev))
 
-    @torch.no_grad()
     def step(self, state: PlbState, action) -> PlbState:
-        """TaichiEnv.step(action) in copy mode: one call = `substeps` substeps for every env."""
+        """TaichiEnv.step(action) in copy mode: one call = `substeps` substeps for every env.  Differentiable: when any of
+        the state tensors / the action / E / nu / yield_stress requires grad, the forward keeps a checkpoint and backward()
+        runs the adjoint kernels (substep_grad)."""
         B = state.x.shape[0]
-        c = lambda t: t.to(torch.float64).contiguous()
-        x, v, Cm, F, pp, so, E, nu, ys = map(c, (state.x, state.v, state.C, state.F, state.prim_pos, state.softness, state.E,
-                                                 state.nu, state.yield_stress))
-        action = c(torch.as_tensor(action, dtype=torch.float64, device=self.device).reshape(B, 3))
-        xo, vo, Co, Fo, po = (torch.empty_like(t) for t in (x, v, Cm, F, pp))
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(_lib.lib().ud_plb_step_fwd(self._h, C.c_int(B), p(x), p(v), p(Cm), p(F), p(pp), p(so), p(action), p(E), p(nu),
-                                              p(ys), p(xo), p(vo), p(Co), p(Fo), p(po), stream), "ud_plb_step_fwd")
+        action = torch.as_tensor(action, dtype=torch.float64, device=self.device).reshape(B, 3)
+        xo, vo, Co, Fo, po = _PlbStep.apply(self, state.x, state.v, state.C, state.F, state.prim_pos, state.softness, action,
+                                            state.E, state.nu, state.yield_stress)
         return state._replace(x=xo, v=vo, C=Co, F=Fo, prim_pos=po)
+
+    def compute_loss(self, state: PlbState, target_density, target_sdf, weights=(1.0, 1.0, 1.0), soft_contact=True):
+        """Loss.compute_loss_kernel (engine/losses/loss.py:190-214): (loss [B], parts [B,3] = contact, density, sdf).
+        target_density / target_sdf: [n_grid, n_grid, n_grid] float64; weights = (contact, density, sdf) as in :158-162."""
+        td = torch.as_tensor(target_density, dtype=torch.float64, device=self.device).reshape(-1).contiguous()
+        ts = torch.as_tensor(target_sdf, dtype=torch.float64, device=self.device).reshape(-1).contiguous()
+        assert td.numel() == self.n_grid ** 3 == ts.numel()
+        wt = torch.as_tensor(weights, dtype=torch.float64, device=self.device).reshape(3).contiguous()
+        return _PlbLoss.apply(self, state.x, state.prim_pos, td, ts, wt, bool(soft_contact))
 
     @staticmethod
     def set_softness1(state: PlbState, softness) -> PlbState:   # primitives.py: Primitives.set_softness1
