@@ -226,14 +226,19 @@ class APG:
 def init_distributed(gpus: int):
     """One process per GPU. Under torchrun (RANK/WORLD_SIZE set) join the RCCL group; otherwise single GPU.
     UNIDOM_DIST_BACKEND=gloo (tests; rehearsals without GPUs) joins a gloo group on the CPU instead -- only host-side code
-    (the launcher, the collective, the update rule) can run there, the simulators have no CPU path."""
+    (the launcher, the collective, the update rule) can run there, the simulators have no CPU path.  With
+    UNIDOM_DIST_DEVICE=cuda:0 beside it every rank of the gloo group computes on that one GPU: the rehearsal of the whole
+    N-rank flow on a one-GPU box (RCCL refuses two ranks on one device; gloo stages the gradient through the host)."""
     import os
     backend = os.environ.get("UNIDOM_DIST_BACKEND", "nccl")
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         if backend == "gloo":
             if not dist.is_initialized():
                 dist.init_process_group(backend="gloo")
-            return dist.get_rank(), dist.get_world_size(), torch.device("cpu")
+            dev = torch.device(os.environ.get("UNIDOM_DIST_DEVICE", "cpu"))
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            return dist.get_rank(), dist.get_world_size(), dev
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         if not dist.is_initialized():
