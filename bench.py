@@ -511,8 +511,7 @@ def bench_fold_tshirt(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         P = st.x.shape[1]
-        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        cluster = os.environ.get("UD_CLOTH_CLUSTER", "1") != "0" and B * -(-P // 512) <= n_cu     # csrc/cloth.hip::cloth_use_cluster
+        cluster = os.environ.get("UD_CLOTH_CLUSTER", "1") != "0"     # csrc/cloth.hip::cloth_use_cluster; launches of <= n_cu // parts envs
         units = world * B * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)

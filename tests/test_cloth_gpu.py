@@ -428,3 +428,34 @@ def test_big_body_kernels_match_oracle(which, path, monkeypatch):
     for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
         assert np.isfinite(h[key]).all(), key
         assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))
+
+
+def test_big_body_call_with_more_envs_than_fit_at_once_is_cut_into_launches():
+    """The parts of a several-workgroup launch wait for each other, so all of them must be resident together: a call with more
+    envs than floor(CUs / parts) is cut into launches on the caller's stream (csrc/cloth.hip).  38 T-shirt envs x 7 parts =
+    266 workgroups > 256 CUs -> two launches (36 + 2 envs); every env must equal the oracle's, forward bit for bit, whichever
+    launch it was in, and the cotangents of the per-macro-step outputs must land in the right env."""
+    import os
+    import unidom_amd.envs as envs
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    mask = np.load(os.path.join(os.path.dirname(envs.__file__), "others", "tshirt_mask.npy")).astype(np.float32)
+    B, T, S = 38, 2, 3
+    conf = BigConf()
+    conf.substeps = S
+    sim = ClothSimulator(conf, B, lambda x, v, i, j: v, mask)
+    assert torch.cuda.get_device_properties(0).multi_processor_count // 7 < B
+    orc = ClothOracle(mask, N=180, order=2, substeps=S, **{k: getattr(BigConf, k) for k in ("gravity", "damping", "dt", "max_v", "small_num")})
+    rng, case = _big_case(mask, B, T, 21)
+    P = int(mask.sum())
+    g = _grads(rng, B, T, P)
+    o = orc.rollout_fwd(*case, want_lists=True, want_grasp=True, nthreads=8)
+    ob = orc.rollout_bwd(*case, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"], g["gprim_list"], nthreads=8)
+    h = _run_hip(sim, *case, g=g)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gk", "gmu"):
+        for b in (0, 35, 36, 37):              # the last env of the first launch, the two of the second
+            assert _rel(h[key][b], ob[key][b]) < 1e-3, (key, b, _rel(h[key][b], ob[key][b]))
+    assert _rel(h["gactions"], ob["gactions"]) < 1e-3

@@ -836,19 +836,20 @@ struct ud_cloth {
   int arena_B = 0;
 };
 
-// Several workgroups per env when the body qualifies (halo <= CL_HMAX), every part of every env can be resident at once
-// (one 512-lane workgroup per CU) and the caller did not ask for the reference-order kernels (mode 1).
+// Several workgroups per env when the body qualifies (halo <= CL_HMAX, the parts of one env fit on the chip) and the caller
+// did not ask for the reference-order kernels (mode 1).  A call is cut into launches of cloth_cluster_envs() envs so that
+// every workgroup of a launch is resident at once (cloth_cluster.h, "Progress").
 // UD_CLOTH_CLUSTER=0 (read at every call; diagnostics and tests) keeps the one-workgroup kernels.
 static bool cloth_use_cluster(const ud_cloth* h, int B) {
-  if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1) return false;
+  if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1 || h->cl_W > h->n_cu) return false;
   const char* e = getenv("UD_CLOTH_CLUSTER");
-  if (e && e[0] == '0') return false;
-  return (long)B * h->cl_W <= (long)h->n_cu;
+  return !(e && e[0] == '0');
 }
+static int cloth_cluster_envs(const ud_cloth* h, int B) { return std::min(B, std::max(1, h->n_cu / h->cl_W)); }
 
 // (re)size and zero the hand-off arena: tags start at 1, so a zeroed arena matches nothing.  Growing it is the one place
 // that synchronises (see the header: first call / larger B than ever before).
-static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::ClusterArgs* q) {
+static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::ClusterArgs* q) {   // B: envs per launch
   const size_t per = ud::cl_env_granules(h->c.Pp, h->cl_W) * sizeof(ud::cl_granule);
   if (h->arena_B < B) {
     if (h->d_arena) { (void)hipStreamSynchronize(stream); (void)hipFree(h->d_arena); h->d_arena = nullptr; h->arena_B = 0; }
@@ -856,7 +857,7 @@ static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::Clust
     h->arena_B = B;
   }
   UD_HIP_CHECK(hipMemsetAsync(h->d_arena, 0, per * B, stream));
-  q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena;
+  q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena; q->b0 = 0; q->Bl = B;
   return UD_OK;
 }
 
@@ -964,10 +965,14 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   a.prim_list = prim_list; a.ckpt = (float*)ckpt; a.grasp = grasp;
   const size_t shmem = (size_t)2 * 3 * h->c.Pp * sizeof(float);
   if (cloth_use_cluster(h, B)) {
-    ud::ClusterArgs q;
-    const int rc = cloth_cluster_arena(h, B, (hipStream_t)stream, &q);
-    if (rc != UD_OK) return rc;
-    ud::cloth_launch_fwd_cluster(a, q, (hipStream_t)stream);
+    const int per = cloth_cluster_envs(h, B);
+    for (int b0 = 0; b0 < B; b0 += per) {
+      ud::ClusterArgs q;
+      const int rc = cloth_cluster_arena(h, std::min(per, B - b0), (hipStream_t)stream, &q);
+      if (rc != UD_OK) return rc;
+      q.b0 = b0;
+      ud::cloth_launch_fwd_cluster(a, q, (hipStream_t)stream);
+    }
   } else if (h->c.Pp > 1024)
     hipLaunchKernelGGL(ud::cloth_big_fwd_kernel, dim3(B), dim3(UD_BIG_T), (size_t)9 * h->c.Pp * sizeof(float), (hipStream_t)stream, a);
   else if (h->mode == 2 && h->c.Pp <= 512)
@@ -1000,10 +1005,14 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
   a.g_x0 = g_x0; a.g_v0 = g_v0; a.g_prim0 = g_prim0; a.g_actions = g_actions; a.g_k = g_stiffness; a.g_mu = g_mu;
   const size_t shmem = ((size_t)6 * h->c.Pp + 192 + 128) * sizeof(float);
   if (cloth_use_cluster(h, B)) {
-    ud::ClusterArgs q;
-    const int rc = cloth_cluster_arena(h, B, (hipStream_t)stream, &q);
-    if (rc != UD_OK) return rc;
-    ud::cloth_launch_bwd_cluster(a, q, (hipStream_t)stream);
+    const int per = cloth_cluster_envs(h, B);
+    for (int b0 = 0; b0 < B; b0 += per) {
+      ud::ClusterArgs q;
+      const int rc = cloth_cluster_arena(h, std::min(per, B - b0), (hipStream_t)stream, &q);
+      if (rc != UD_OK) return rc;
+      q.b0 = b0;
+      ud::cloth_launch_bwd_cluster(a, q, (hipStream_t)stream);
+    }
   } else if (h->c.Pp > 1024) {
     if (h->park_B < B) {   // scratch of the big-body adjoint, grown on demand
       if (h->d_park) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(h->d_park); h->d_park = nullptr; h->park_B = 0; }

@@ -15,9 +15,9 @@
 // dependence on where a workgroup runs (blocks b and b + 8 usually share an XCD; parts of one env are spread that way,
 // for speed only).  Buffers that are rewritten while a slow part may still read the previous value are double-buffered by
 // step parity (positions, sums); see the reuse arguments at each buffer.
-// Progress: a part waits for other parts of its env, so all W parts must be resident together.  The host only takes
-// this path when B * W <= the number of CUs (one 512-lane workgroup per CU); otherwise the one-workgroup kernels of
-// cloth.hip run.  Every poll is bounded: after CL_SPIN_LIMIT polls (seconds) a part gives up, its siblings time out
+// Progress: a part waits for other parts of its env, so all W parts must be resident together.  The host cuts a call
+// into launches of at most floor(CUs / W) envs (one 512-lane workgroup per CU: the adjoint kernel uses the whole register
+// file of a CU), back to back on the caller's stream, so every workgroup of a launch is resident at once.  Every poll is bounded: after CL_SPIN_LIMIT polls (seconds) a part gives up, its siblings time out
 // in turn, and every output of the launch is filled with NaN -- loud, and every wave reaches the end of the kernel.
 #pragma once
 #include "cloth_common.h"
@@ -34,7 +34,9 @@ typedef unsigned long long cl_granule;               // {value bits (low), tag (
 
 struct ClusterArgs {
   int W, H;                // parts per env; halo width (multiple of 64, <= CL_HMAX)
-  cl_granule* arena;       // [B][cl_env_granules(Pp, W)], zeroed before every launch (tags start at 1)
+  int b0, Bl;              // this launch covers envs b0 .. b0 + Bl - 1 of the call's B (the host cuts a call into launches
+                           // whose parts all fit on the chip at once); the arena is indexed by the env's number in the launch
+  cl_granule* arena;       // [Bl][cl_env_granules(Pp, W)], zeroed before every launch (tags start at 1)
 };
 
 // per-env arena, in granules: XE[2][3][Pp] positions (forward) | GE[2][3][Pp] force cotangents (adjoint) |
@@ -52,9 +54,9 @@ __device__ __forceinline__ bool cl_get(const cl_granule* p, unsigned tag, float&
 
 // blockIdx -> (env, part).  Block ids are dealt round-robin over the 8 XCDs, so ids congruent mod 8 share an XCD's L2:
 // the parts of env b get ids b % 8 + 8 * (W * (b / 8) + w).  Placement is a speed matter only (see above).
-__device__ __forceinline__ void cl_decode(int W, int& b, int& w) {
+__device__ __forceinline__ void cl_decode(int W, int& bl, int& w) {   // bl = the env's number inside this launch
   const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-  b = (j / W) * 8 + xcd;
+  bl = (j / W) * 8 + xcd;
   w = j % W;
 }
 __host__ inline int cl_grid(int B, int W) { return 8 * W * ((B + 7) / 8); }

@@ -35,9 +35,10 @@ __device__ __forceinline__ bool cl_poll_slots(const cl_granule* slots, int W, un
 
 __global__ void __launch_bounds__(CL_T) cloth_cluster_bwd_kernel(ClothBwdArgs a, ClusterArgs q) {
   extern __shared__ float ldsf[];  // Xs[3][CL_STRIDE] | Gs[3][CL_STRIDE] | red[2][8][UD_RSTR] | mac[8*8] | bail[2]
-  int b, w;
-  cl_decode(q.W, b, w);
-  if (b >= a.B) return;
+  int bl, w;
+  cl_decode(q.W, bl, w);
+  if (bl >= q.Bl) return;
+  const int b = q.b0 + bl;
   const ClothConst c = a.c;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T, W = q.W;
   const int i = threadIdx.x, base = w * CL_T, gi = base + i;
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_bwd_kernel(ClothBwdArgs a,
   float gk = 0.f, gmu = 0.f;
   const size_t rec = cloth_rec_floats(Pp);
   const float* ck = a.ckpt + (size_t)b * cloth_env_records(T, S) * rec;
-  cl_granule* ar = q.arena + (size_t)b * cl_env_granules(Pp, W);
+  cl_granule* ar = q.arena + (size_t)bl * cl_env_granules(Pp, W);
   cl_granule* ge = ar + (size_t)6 * Pp;                  // GE[2][3][Pp]
   cl_granule* se = ge + (size_t)6 * Pp;                  // SE[2][W][CL_SLOT]
   cl_granule* sa = se + (size_t)2 * W * CL_SLOT;         // SA[2][W][CL_SLOT]
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_bwd_kernel(ClothBwdArgs a,
 
 void cloth_launch_bwd_cluster(const ClothBwdArgs& a, const ClusterArgs& q, hipStream_t stream) {
   const size_t shmem = (size_t)(6 * CL_STRIDE + 2 * 8 * UD_RSTR + 64 + 2) * sizeof(float);
-  hipLaunchKernelGGL(cloth_cluster_bwd_kernel, dim3(cl_grid(a.B, q.W)), dim3(CL_T), shmem, stream, a, q);
+  hipLaunchKernelGGL(cloth_cluster_bwd_kernel, dim3(cl_grid(q.Bl, q.W)), dim3(CL_T), shmem, stream, a, q);
 }
 
 }  // namespace ud

@@ -10,9 +10,10 @@ namespace ud {
 
 __global__ void __launch_bounds__(CL_T) cloth_cluster_fwd_kernel(ClothFwdArgs a, ClusterArgs q) {
   extern __shared__ float ldsf[];  // Xs[2][3][CL_STRIDE], double-buffered by substep parity | bail[2]
-  int b, w;
-  cl_decode(q.W, b, w);
-  if (b >= a.B) return;
+  int bl, w;
+  cl_decode(q.W, bl, w);
+  if (bl >= q.Bl) return;
+  const int b = q.b0 + bl;
   const ClothConst c = a.c;
   const int P = c.P, Pp = c.Pp, S = c.S, B = a.B, T = a.T;
   const int i = threadIdx.x, base = w * CL_T, gi = base + i;
@@ -41,7 +42,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_fwd_kernel(ClothFwdArgs a,
   th0.init(ps[3]); th1.init(ps[7]);
   const size_t rec = cloth_rec_floats(Pp);
   float* ckb = a.ckpt ? a.ckpt + (size_t)b * cloth_env_records(T, S) * rec : nullptr;
-  cl_granule* ar = q.arena + (size_t)b * cl_env_granules(Pp, q.W);   // XE[2][3][Pp] first
+  cl_granule* ar = q.arena + (size_t)bl * cl_env_granules(Pp, q.W);   // XE[2][3][Pp] first
   __syncthreads();
   unsigned step = 0;
   bool dead = false;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_fwd_kernel(ClothFwdArgs a,
 
 void cloth_launch_fwd_cluster(const ClothFwdArgs& a, const ClusterArgs& q, hipStream_t stream) {
   const size_t shmem = (size_t)(6 * CL_STRIDE + 2) * sizeof(float);
-  hipLaunchKernelGGL(cloth_cluster_fwd_kernel, dim3(cl_grid(a.B, q.W)), dim3(CL_T), shmem, stream, a, q);
+  hipLaunchKernelGGL(cloth_cluster_fwd_kernel, dim3(cl_grid(q.Bl, q.W)), dim3(CL_T), shmem, stream, a, q);
 }
 
 }  // namespace ud

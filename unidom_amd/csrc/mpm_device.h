@@ -72,12 +72,15 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
 // One-sided Jacobi (Hestenes) SVD of a 3x3: A = U diag(S) Vh, S descending >= 0.  The reference calls LAPACK
 // (third party); only U S Vh, U Vh and S -- gauge-invariant -- enter the dynamics.  The rotation angle may be
 // approximate (v_rcp/v_rsq/v_sqrt, 1 ulp): each Givens pair (cs, sn) is orthonormal to round-off regardless.
+#ifndef UD_SVD_SWEEPS
+#define UD_SVD_SWEEPS 4
+#endif
 __device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* Vh) {
   float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = A[i];
 #pragma unroll 1
-  for (int sweep = 0; sweep < 4; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
+  for (int sweep = 0; sweep < UD_SVD_SWEEPS; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
     UD_JROT(0, 1)
     UD_JROT(0, 2)
     UD_JROT(1, 2)
