@@ -131,6 +131,20 @@ __device__ __forceinline__ void load_state(const float* h, int Np, int p, float*
 // distinct cell is then flushed with ONE global atomic per component.  That removes the ~50-way same-address
 // contention plain global atomics suffer on a compact body (measured: 17 us -> see DESIGN.md per env-substep).
 #define LG_SCATTER_T 128   // threads per workgroup in the two scatter kernels
+
+// Diagnostic build only (-DUD_LG_STAMPS, tools/lg_stamps.sh): s_memtime at the phase boundaries of the three particle kernels,
+// summed over wave 0 of every block into ud_lg_stamps[kernel][phase] ([..][7] = number of blocks); vector-memory waits are
+// forced at the stamps (s_waitcnt vmcnt(0)) so that a load's latency is billed to the phase that issued it.
+#ifdef UD_LG_STAMPS
+__device__ unsigned long long ud_lg_stamps[4][8];
+#define LG_STAMP_BEGIN unsigned long long lg_t0_ = __builtin_amdgcn_s_memtime();
+#define LG_STAMP(K, PH) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&ud_lg_stamps[K][PH], t_ - lg_t0_); lg_t0_ = t_; \
+      if ((PH) == 0) atomicAdd(&ud_lg_stamps[K][7], 1ull); } } while (0)
+#else
+#define LG_STAMP_BEGIN
+#define LG_STAMP(K, PH) do {} while (0)
+#endif
 #ifndef LG_LOGH1
 #define LG_LOGH1 9
 #endif
@@ -315,6 +329,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   const BlockTable bt = bt_make<TH>();
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
+  LG_STAMP_BEGIN
   bt_clear<TH>(bt);
   float4* val = a.w.val + (long)b * a.G;
   const bool live = p < c.N;
@@ -325,6 +340,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     float x[3], Cm[9], F[9];
     load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
     const int up = user_index(a, b, p);
+    LG_STAMP(0, 0);   // table clear + state loads
     particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr);
     if (store_F && qi == 0) {
       float* ho = a.hist_out + (long)b * a.hist_stride_b;
@@ -332,7 +348,9 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
       for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
     }
   }
+  LG_STAMP(0, 1);     // pre-pass (F update, SVD, stress)
   const BlockWin win = bt_window(c, live, q.base);
+  LG_STAMP(0, 2);     // window reduction + its two barriers (arrival skew of the block's waves)
   if (live) {
     // The walk is staggered -- each particle starts at a different cell / column -- so that the lanes of a run of particles
     // sharing a base cell (sorted or lattice-seeded neighbours; pour_soup's vegetable cloud has ~26 per cell) never add to the
@@ -421,9 +439,11 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   // flush: one global atomic per distinct cell and component.  Cells this substep sees for the first time (epoch stamp)
   // join the env's active list; the appends of a block are aggregated -- one atomicAdd on the env's counter per block
   // instead of one per cell (~2 k same-address atomics per env-substep at n_grid 256, one per active cell, were 80 % of the whole step).
+  LG_STAMP(0, 3);     // the 27-cell walk
   __shared__ int s_new, s_base;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
+  LG_STAMP(0, 4);     // barrier before the flush
   if (UD_MPM_ABLATE & 128) return;
   constexpr int PER = TH / LG_SCATTER_T;
   unsigned newmask = 0;
@@ -439,6 +459,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
     if (atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
   }
+  LG_STAMP(0, 5);     // flush: value atomics + stamp exchanges
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
   __syncthreads();
   const int cur = a.f & 1;
@@ -451,6 +472,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = bt.key[threadIdx.x + u * LG_SCATTER_T];
     ++e;
   }
+  LG_STAMP(0, 6);     // list append
 }
 
 // grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
@@ -760,6 +782,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   const BlockTable bt = bt_make<TH>();
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
+  LG_STAMP_BEGIN
   bt_clear<TH>(bt);
   float4* gacc = a.w.gacc + (long)b * a.G;
   const bool live = p < c.N;
@@ -776,7 +799,9 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
       w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
     }
   }
+  LG_STAMP(1, 0);     // table clear + position loads
   const BlockWin win = bt_window(c, live, base);
+  LG_STAMP(1, 1);     // window reduction + barriers
   if (live) {
   const float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9];
@@ -784,6 +809,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
+  LG_STAMP(1, 2);     // cotangent loads
   float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
@@ -821,6 +847,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
       gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
     }
   }
+  LG_STAMP(1, 3);     // the 27-cell walk (velocity gathers from HBM / L2 + table adds)
 #pragma unroll
   for (int d = 0; d < 9; ++d) gw[d] = lg_quad_sum<LANES>(gw[d]);
 #pragma unroll
@@ -833,7 +860,9 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     for (int d = 0; d < 3; ++d) ps[9 + d] = gfx[d];
   }
   }
+  LG_STAMP(1, 4);     // partials to the particle scratch
   __syncthreads();
+  LG_STAMP(1, 5);     // barrier before the flush
   for (int sl = threadIdx.x; sl < TH; sl += blockDim.x) {
     const int key = bt.key[sl];
     if (key < 0) continue;
@@ -841,6 +870,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
 #pragma unroll
     for (int r = 0; r < 3; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
   }
+  LG_STAMP(1, 6);     // flush
 }
 
 // grid checkpoint -> dense arrays of the backward for substep f: velocity after the grid op, zeroed cotangent, the cell list.
@@ -1020,14 +1050,22 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
   }
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
-  if (p >= c.N) return;   // whole quads leave together
+  // mu / lamda cotangents: summed per block in LDS, ONE global atomic per block and parameter.  (One per particle -- 7631
+  // same-address atomics per env and substep on pour_soup -- serialises at the memory side: round 2 measurement below.)
+  __shared__ float s_par[2];
+  if (threadIdx.x < 2) s_par[threadIdx.x] = 0.f;
+  __syncthreads();
+  LG_STAMP_BEGIN
+  if (p < c.N) {   // whole quads leave together
   float x[3], v[3], Cm[9], F[9];
   load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
   Pre q;
   PreB kb;
   const int up = user_index(a, b, p);
   const int material = a.material[up];
+  LG_STAMP(2, 0);     // state loads
   particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb);
+  LG_STAMP(2, 1);     // pre-pass with the adjoint's extras
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9], gF[9];
 #pragma unroll
@@ -1041,6 +1079,7 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
 #pragma unroll
   for (int d = 0; d < 3; ++d) gfx[d] = (qi == 0) ? ps[9 + d] : 0.f;
   const float4* gacc = a.w.gacc + (long)b * a.G;
+  LG_STAMP(2, 2);     // cotangent + scratch loads
 #pragma unroll 1
   for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
@@ -1074,18 +1113,24 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
   for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<LANES>(gw[d]); gaff[d] = lg_quad_sum<LANES>(gaff[d]); }
 #pragma unroll
   for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<LANES>(gfx[d]); gvp[d] = lg_quad_sum<LANES>(gvp[d]); }
-  if (qi != 0) return;
+  LG_STAMP(2, 3);     // the 27-cell gather
+  if (qi == 0) {
   float gmu_p, gla_p;
   particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
     const float h = clipf(a.hard[up], 0.1f, 5.f);
-    atomicAdd(&a.w.acc[b * 4 + 1], gmu_p * h);
-    atomicAdd(&a.w.acc[b * 4 + 2], gla_p * h);
+    atomicAdd(&s_par[0], gmu_p * h);
+    atomicAdd(&s_par[1], gla_p * h);
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
+  }
+  LG_STAMP(2, 4);     // particle adjoint (stress, SVD VJP) + stores
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && s_par[threadIdx.x] != 0.f) atomicAdd(&a.w.acc[b * 4 + 1 + threadIdx.x], s_par[threadIdx.x]);
 }
 
 // backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
@@ -1493,3 +1538,11 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
 }
 
 }  // namespace ud
+
+#ifdef UD_LG_STAMPS
+extern "C" int ud_debug_lg_stamps(unsigned long long* out32, int reset) {   // diagnostic builds only: [4][8] counters
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(ud::ud_lg_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ud::ud_lg_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
