@@ -293,7 +293,9 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
 def bench_torus(args, rank, world, device):
     """BASELINE config 5: PlasticineLab Torus (f64 elasto-plastic MPM, N=1000), 8 envs per GPU (64 on 8 GPUs), forward
     only like the reference's scripted rollout (solver.py:290-350).  --n-grid 64 = quality 1 (19 substeps/step),
-    --n-grid 128 = quality 2 (the "128^3 grid" of BASELINE.json, dt 5e-5, 39 substeps/step).  One "step" = 10 env.steps."""
+    --n-grid 128 = quality 2 (the "128^3 grid" of BASELINE.json, dt 5e-5, 39 substeps/step).  One "step" = 10 env.steps.
+    --plb-grad: the differentiable route instead (solver.py:41-54, ti.Tape): 10 env.steps forward with checkpoints, the
+    density / SDF / contact loss of the last state, and the backward through all of them to the actions and E / nu / yield stress."""
     from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
     cfg = PlbConf()
     cfg.quality = 2.0 if args.n_grid == 128 else 1.0
@@ -305,6 +307,15 @@ def bench_torus(args, rank, world, device):
     act = np.diff(np.linspace(p0, start, 200), axis=0)[0]          # solver.py:299-302: constant displacement per env.step
     action = torch.tensor(np.repeat(act[None], B, 0), dtype=torch.float64, device=device)
     inner = 10
+    grad = bool(getattr(args, "plb_grad", False))
+    if grad:
+        G = sim.n_grid ** 3
+        target_density = torch.zeros(G, dtype=torch.float64, device=device)
+        target_sdf = torch.linspace(0.0, 1.0, G, dtype=torch.float64, device=device)
+        st = st._replace(prim_pos=st.prim_pos.clone())
+        st.prim_pos[:, 0] = st.x[:, 7]                               # sphere 0 on the rope: the action gets a gradient
+        leaves = dict(action=action.clone().requires_grad_(True), E=st.E.clone().requires_grad_(True),
+                      nu=st.nu.clone().requires_grad_(True), ys=st.yield_stress.clone().requires_grad_(True))
 
     def sync():
         torch.cuda.synchronize(device)
@@ -312,12 +323,28 @@ def bench_torus(args, rank, world, device):
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def one_grad():
+        for t in leaves.values():
+            t.grad = None
+        s = st._replace(E=leaves["E"], nu=leaves["nu"], yield_stress=leaves["ys"])
+        for _ in range(inner):
+            s = sim.step(s, leaves["action"])
+        loss, _ = sim.compute_loss(s, target_density, target_sdf, (1.0, 1.0, 1.0), True)
+        loss.sum().backward()
+
     for _ in range(args.warmup):
-        st = sim.step(st, action)
+        if grad:
+            one_grad()
+        else:
+            st = sim.step(st, action)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps * inner):
-        st = sim.step(st, action)
+    if grad:
+        for _ in range(args.steps):
+            one_grad()
+    else:
+        for _ in range(args.steps * inner):
+            st = sim.step(st, action)
     sync()
     dt = time.perf_counter() - t0
     tm = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -326,18 +353,21 @@ def bench_torus(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         assert torch.isfinite(st.x).all()
+        if grad:
+            assert all(torch.isfinite(t.grad).all() for t in leaves.values()) and float(leaves["action"].grad.abs().sum()) > 0
         units = world * B * sim.substeps * inner * args.steps
-        g_act = touched_cells(st.x[0].cpu().numpy().astype(np.float64), sim.n_grid)
-        per_sub = 2 * (192 * sim.n_particles + 56 * g_act)          # f64: double the f32 figure
+        g_act = touched_cells(st.x[0].detach().cpu().numpy().astype(np.float64), sim.n_grid)
+        per_sub = 2 * ((480 if grad else 192) * sim.n_particles + (168 if grad else 56) * g_act)   # f64: double the f32 figure
         achieved = units / world * per_sub / dt / 1e9
         print(json.dumps({
-            "metric": "plb_substeps_per_sec_fwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
+            "metric": "plb_substeps_per_sec_fwd_bwd" if grad else "plb_substeps_per_sec_fwd", "value": units / dt, "unit": "substeps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"PlasticineLab Torus (f64 von-Mises MPM, N={sim.n_particles}, n_grid={sim.n_grid}, "
-                                   f"{sim.substeps} substeps/env.step), forward rollout, {B} envs per GPU, step = {inner} env.steps",
+                                   f"{sim.substeps} substeps/env.step), " + ("forward with checkpoints + loss + adjoint" if grad else "forward rollout")
+                                   + f", {B} envs per GPU, step = {inner} env.steps",
                        "touched_cells": g_act, "parity": "unpinned (taichi absent)"},
-            "roofline": {"bound": "hbm", "kernel": "plb path (4 kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "plb path (" + ("3 + 6" if grad else "3") + " kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "note": "launch/latency bound: 8 envs x 1000 particles per substep"}}), flush=True)
     if world > 1:
@@ -621,6 +651,7 @@ def main():
     ap.add_argument("--envs", type=int, default=32, help="whip_rope only: envs per GPU")
     ap.add_argument("--grid-ckpt", type=int, default=2, help="scaled whip_rope only: ud_mpm_conf.grid_ckpt_cells (0 = the backward "
                     "recomputes p2g + grid op instead of restoring the checkpointed grid)")
+    ap.add_argument("--plb-grad", action="store_true", help="torus only: forward with checkpoints + loss + adjoint instead of the forward rollout")
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
     args = ap.parse_args()

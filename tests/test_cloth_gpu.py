@@ -459,3 +459,34 @@ def test_big_body_call_with_more_envs_than_fit_at_once_is_cut_into_launches():
         for b in (0, 35, 36, 37):              # the last env of the first launch, the two of the second
             assert _rel(h[key][b], ob[key][b]) < 1e-3, (key, b, _rel(h[key][b], ob[key][b]))
     assert _rel(h["gactions"], ob["gactions"]) < 1e-3
+
+
+@pytest.mark.parametrize("T,S,normalize,lists", [(1, 1, True, False), (2, 3, False, True), (1, 4, False, False), (3, 2, True, True)])
+def test_big_body_several_workgroups_edge_cases(T, S, normalize, lists):
+    """The several-workgroups-per-env kernels at the edges of their loops: a single substep, odd substep counts (the step-parity
+    double buffers), no per-macro-step outputs, and the un-normalised adjoint (normalize = 0: no block-sum exchange, so the halo
+    hand-off alone has to keep the parts in step -- the reason the force-cotangent buffer is double-buffered).  Disk body of
+    2881 particles (6 parts, the last one ragged)."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    N = 180
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    mask = (((ii - 90) ** 2 + (jj - 87) ** 2) <= 30.3 ** 2).astype(np.float32)
+    P = int(mask.sum())
+    conf = BigConf()
+    conf.substeps = S
+    B = 3
+    sim = ClothSimulator(conf, B, lambda x, v, i, j: v, mask)
+    orc = ClothOracle(mask, N=N, order=2, substeps=S, **{k: getattr(BigConf, k) for k in ("gravity", "damping", "dt", "max_v", "small_num")})
+    rng, case = _big_case(mask, B, T, 40 + T + S)
+    g = _grads(rng, B, T, P, lists=lists)
+    o = orc.rollout_fwd(*case, want_lists=True, want_grasp=True, nthreads=3)
+    gl = (g["gx_list"], g["gv_list"], g["gprim_list"]) if lists else (None, None, None)
+    ob = orc.rollout_bwd(*case, g["gx"], g["gv"], g["gprim"], *gl, normalize=normalize, nthreads=3)
+    h = _run_hip(sim, *case, g=g, want_lists=True, normalize=normalize)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert np.isfinite(h[key]).all(), key
+        assert _rel(h[key], ob[key]) < 1e-3, (key, _rel(h[key], ob[key]))

@@ -353,3 +353,11 @@ def test_hip_losses_match_torch_twin(soft_contact):
     (hloss * T(gl.numpy(), False)).sum().backward()
     assert _rel(hx.grad.cpu().numpy(), tx.grad.numpy()) < 1e-9 and _rel(hp.grad.cpu().numpy(), tp.grad.numpy()) < 1e-9
     assert np.abs(tp.grad.numpy()).max() > 0
+
+
+@pytest.mark.gpu
+def test_hip_step_adjoint_one_lane_kernels(monkeypatch):
+    """The adjoint kernels have the forward's two lane mappings (4 lanes per particle below 100 k particles per launch, 1
+    beyond); UD_PLB_LANES=1 puts the one-lane instantiations in front of the twin too."""
+    monkeypatch.setenv("UD_PLB_LANES", "1")
+    test_hip_step_adjoint_matches_torch_twin(True)

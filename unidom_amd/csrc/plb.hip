@@ -327,7 +327,10 @@ __global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x
   for (int d = 0; d < 9; ++d) { Cm[o9 + d] = h[(6 + d) * c.Np + p]; F[o9 + d] = h[(15 + d) * c.Np + p]; }
 }
 
-void plb_launch_p2g1(const PlbArgs& a, dim3 grid, hipStream_t st) { hipLaunchKernelGGL(plb_p2g<1>, grid, dim3(256), 0, st, a); }
+void plb_launch_p2g(const PlbArgs& a, int lanes, dim3 grid, hipStream_t st) {
+  if (lanes == 4) hipLaunchKernelGGL(plb_p2g<4>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(plb_p2g<1>, grid, dim3(256), 0, st, a);
+}
 
 }  // namespace ud
 

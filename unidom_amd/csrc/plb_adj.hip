@@ -14,8 +14,8 @@
 //   x cotangent through the weights) -> plb_grid_adj (cell by cell: boundary / friction / sticky sphere / normalisation)
 //   -> plb_p2g_adj (gather; stress, von Mises return mapping, SVD and F update in reverse; E / nu / yield-stress sums)
 //   -> plb_adj_clear,
-// over the touched cells only, like the forward.  One lane per particle in the adjoint kernels (the f64 pre-pass adjoint is
-// register-heavy; the forward's four-lane mapping is a later step).  Parity: UNPINNED -- taichi is absent and the reference
+// over the touched cells only, like the forward, and with the forward's two lane mappings (four lanes per particle while
+// the launch is too small to fill the chip, one beyond).  Parity: UNPINNED -- taichi is absent and the reference
 // ships no gradient of this path; the checker is torch.autograd through oracle/twin/plb_twin_torch.py (tests/test_plb.py).
 #include <cstdlib>
 
@@ -57,10 +57,11 @@ __global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
 // ---- g2p adjoint (:234-253 in reverse) -------------------------------------------------------------------------------
 // inputs: cotangent of state f + 1 (gstate slot `gs_in`); outputs: v_out cotangents scattered into gacc, the x cotangent
 // that flows through g2p (weights, dpos, the position clamp) into gxs, and gv1 (with the advection term) kept in gstate.
+template <int LANES>   // lanes per particle, as in plb_g2p: the quad splits the 27 cells 7/7/7/6 and adds its partial sums with DPP
 __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  if (p >= c.N) return;
+  if (p >= c.N) return;   // whole quads leave together
   const double* hi_ = plb_hist(a, b, a.hs_in);
   const double* ho = plb_hist(a, b, a.hs_out);
   const double* g1 = a.w.gstate + ((long)b * 2 + gs_in) * 24 * c.Np;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   double gfx[3] = {0, 0, 0};
   const double k4 = 4 * c.inv_dx;
 #pragma unroll 1
-  for (int cidx = 0; cidx < 27; ++cidx) {
+  for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
     const double weight = wi * wj * wk;
@@ -106,6 +107,9 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
     gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - gdp[1];
     gfx[2] += gw * wi * wj * dsel3(dw, 2, k) - gdp[2];
   }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gfx[d] = plb_quad_sum<LANES>(gfx[d]);
+  if (qi != 0) return;
   double* gxs = a.w.gxs + (long)b * 3 * c.Np;
 #pragma unroll
   for (int d = 0; d < 3; ++d) gxs[d * c.Np + p] = gxp[d] + c.inv_dx * gfx[d];
@@ -207,9 +211,11 @@ __global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
 }
 
 // ---- p2g adjoint + particle pre-pass adjoint (:91-99, :133-195 in reverse) --------------------------------------------
+template <int LANES>   // lanes per particle: every lane of the quad repeats the pre-pass (it needs the affine matrix for its cells), the
+                       // gather is split 7/7/7/6 and summed with DPP, lane 0 carries on with the particle adjoint
 __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
   __shared__ double s_red[3][2];
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
   double accE = 0, accNu = 0, accYs = 0;
   if (p < c.N) {
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
     const double* gacc = a.w.gacc + (long)b * a.G * 4;
     double gv[3] = {0, 0, 0}, gaff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gfx[3] = {0, 0, 0};
 #pragma unroll 1
-    for (int cidx = 0; cidx < 27; ++cidx) {
+    for (int cidx = qi; cidx < 27; cidx += LANES) {
       const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
       const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
       const double weight = wi * wj * wk;
@@ -287,6 +293,11 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
       gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - c.dx * gdp[1];
       gfx[2] += gw * wi * wj * dsel3(dw, 2, k) - c.dx * gdp[2];
     }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gv[d] = plb_quad_sum<LANES>(gv[d]); gfx[d] = plb_quad_sum<LANES>(gfx[d]); }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gaff[d] = plb_quad_sum<LANES>(gaff[d]);
+    if (qi == 0) {
     const double* gxs = a.w.gxs + (long)b * 3 * c.Np;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { g0[d * c.Np + p] = gxs[d * c.Np + p] + c.inv_dx * gfx[d]; g0[(3 + d) * c.Np + p] = gv[d]; }
@@ -390,6 +401,7 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
     accE = gmu / (2 * a1) + glam * nu / (a1 * a2);
     accNu = gmu * (-E / (2 * a1 * a1)) + glam * E * (1 + 2 * nu * nu) / (a1 * a1 * a2 * a2);
     accYs = gys;
+    }
   }
   // block sums -> one atomic per block and parameter
   double vals[3] = {accE, accNu, accYs};
@@ -647,15 +659,21 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   a.slots = h->c.S + 1; a.lb = 0;
   const int S = h->c.S;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B), gpa((h->c.N + 127) / 128, B);
+  const dim3 gq((4 * h->c.N + 255) / 256, B), gqa((4 * h->c.N + 127) / 128, B);
+  const char* lanes_env = getenv("UD_PLB_LANES");          // the forward's diagnostic override (read per call)
+  const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
+  const int lanes = (force_lanes == 1 || force_lanes == 4) ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);
   hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_pack, gp, blk, 0, st, a, S & 1, g_x, g_v, g_C, g_F, g_prim_pos);
   for (int f = S - 1; f >= 0; --f) {
     a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1;
-    ud::plb_launch_p2g1(a, gp, st);                                      // recompute (m, mv) into buffer 0 (rewrites F[f + 1] with the same values)
+    ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);              // recompute (m, mv) into buffer 0 (rewrites F[f + 1] with the same values)
     hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(ud::plb_g2p_adj, gp, blk, 0, st, a, (f + 1) & 1);
+    if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
+    else hipLaunchKernelGGL(ud::plb_g2p_adj<1>, gp, blk, 0, st, a, (f + 1) & 1);
     hipLaunchKernelGGL(ud::plb_grid_adj, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(ud::plb_p2g_adj, gpa, dim3(128), 0, st, a, (f + 1) & 1);
+    if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g_adj<4>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
+    else hipLaunchKernelGGL(ud::plb_p2g_adj<1>, gpa, dim3(128), 0, st, a, (f + 1) & 1);
     hipLaunchKernelGGL(ud::plb_adj_clear, gc, blk, 0, st, a);
     hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   }

@@ -182,7 +182,7 @@ __device__ __forceinline__ void plb_grid_cell(const PlbConst& c, long lin, doubl
   }
 }
 
-void plb_launch_p2g1(const PlbArgs& a, dim3 grid, hipStream_t st);   // plb_p2g<1> (plb.hip), for the adjoint's recompute
+void plb_launch_p2g(const PlbArgs& a, int lanes, dim3 grid, hipStream_t st);   // plb_p2g<lanes> (plb.hip), for the adjoint's recompute
 
 }  // namespace ud
 
