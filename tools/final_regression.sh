@@ -1,7 +1,8 @@
 #!/bin/bash
-# end-of-round regression on the GPU box: the GPU test suite, then every bench line of profiles/README.md.  usage: TAG=r01i bash tools/final_regression.sh
-cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r01i}; O=gpurun_out/final; rm -rf $O; mkdir -p $O
+# end-of-round regression on the GPU box: the GPU test suite, then every bench line of profiles/README.md, then (KS=1) one
+# rocprofv3 kernel-stats CSV per bench workload.   usage: TAG=r02g KS=1 bash tools/final_regression.sh
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${TAG:-r02g}; O=gpurun_out/final; rm -rf $O; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/${TAG}_gpu_tests.log; tail -2 $O/${TAG}_gpu_tests.log
 run() { name=$1; shift; timeout -k 10 300 python bench.py "$@" 2>$O/$name.err | tail -n 1 > $O/${TAG}_bench_line_$name.json
   python - <<PY
@@ -9,6 +10,10 @@ import json
 d = json.load(open("$O/${TAG}_bench_line_$name.json"))
 print("$name", round(d["value"]), "%.2f ms" % d["ms_per_step"], "frac %.4f" % d["roofline"]["frac"], d["roofline"].get("kernel_ms"), "traffic", d["roofline"].get("traffic"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
+  if [ -n "$KS" ]; then
+    rm -rf $O/ks_$name; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ks_$name -o p -f csv -- python3 bench.py "$@" --no-cpu-baseline --no-saturation > $O/ks_$name.log 2>&1 \
+      && cp $O/ks_$name/p_kernel_stats.csv $O/${TAG}_kernel_stats_$name.csv && rm -rf $O/ks_$name
+  fi
 }
 run fold_cloth1
 run fold_cloth1_para_32envs --workload fold_cloth1_para --no-cpu-baseline
@@ -21,3 +26,5 @@ run pour_water --workload pour_water
 run pour_soup --workload pour_soup
 run torus_ngrid64 --workload torus --n-grid 64
 run torus_ngrid128 --workload torus --n-grid 128
+run torus_grad_ngrid64 --workload torus --n-grid 64 --plb-grad
+run torus_grad_ngrid128 --workload torus --n-grid 128 --plb-grad
