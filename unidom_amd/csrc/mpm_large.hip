@@ -255,24 +255,6 @@ __device__ __forceinline__ int bt_find(const BlockTable& t, const BlockWin& w, i
   return bt_slot<H, LOGH>(t, cell);
 }
 
-// ---- block window as a gather tile -----------------------------------------------------------------------
-// When a block's window is on, the 8 x 8 x 8 cells it covers are copied ONCE into LDS (64 coalesced 128-byte rows: k runs
-// fastest in memory, so the tile index is k | j << 3 | i << 6) and the interior particles read their 27 cells from there
-// instead of gathering 27 float4 per lane from L2 -- 64 different lines per wave-instruction, which is what the walk of
-// lg_g2p_adj (45 % of it, profiles/r02e_lg_stamps_pour_soup.txt) and the gather of lg_p2g_adj (63 %) wait for.
-__device__ __forceinline__ void win_stage(const MpmConst& c, const BlockWin& w, const float4* src, float4* tile) {
-  for (int s = threadIdx.x; s < 512; s += blockDim.x) {
-    const int ci = w.ox + (s >> 6), cj = w.oy + ((s >> 3) & 7), ck = w.oz + (s & 7);
-    const bool in = ci < c.res[0] && cj < c.res[1] && ck < c.res[2];
-    tile[s] = in ? src[((long)ci * c.res[1] + cj) * c.res[2] + ck] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-}
-// an interior particle of an open window: every stencil cell inside the grid (no wrap / drop / clamp) and inside the tile
-__device__ __forceinline__ bool win_interior(const MpmConst& c, const BlockWin& w, const int* base) {
-  return w.on && base[0] >= 0 && base[1] >= 0 && base[2] >= 0 && base[0] + 2 < c.res[0] && base[1] + 2 < c.res[1] && base[2] + 2 < c.res[2];
-}
-__device__ __forceinline__ int win_tile0(const BlockWin& w, const int* base) { return (base[2] - w.oz) | ((base[1] - w.oy) << 3) | ((base[0] - w.ox) << 6); }
-
 // ---- forward kernels ---------------------------------------------------------------------------------
 // The kernels over an env's active-cell list are launched for `cap` cells (the host does not know the count).  One 256-cell tile
 // per block meant ~51 k blocks per launch on pour_soup (cap = 54 N = 412 k cells per env, ~2-5 k of them active): lg_clear_fk and
@@ -819,12 +801,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   }
   LG_STAMP(1, 0);     // table clear + position loads
   const BlockWin win = bt_window(c, live, base);
-  __shared__ float4 s_tile[512];
-  const float4* vel = a.w.vel + (long)b * a.G;
-  if (win.on) { win_stage(c, win, vel, s_tile); __syncthreads(); }   // block-uniform
-  LG_STAMP(1, 1);     // window reduction + barriers (+ the velocity tile)
-  const bool fast = live && win_interior(c, win, base);
-  const int tile0 = fast ? win_tile0(win, base) : 0;
+  LG_STAMP(1, 1);     // window reduction + barriers
   if (live) {
   const float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9];
@@ -838,6 +815,10 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
 #pragma unroll
   for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+  const float4* vel = a.w.vel + (long)b * a.G;
+  // (Round 2 tried copying the window's 8 x 8 x 8 velocities into LDS once per block and reading the 27 cells from there: slower
+  // everywhere -- rope at n_grid 256 backward 11.1 -> 12.5 ms, pour_soup 5.7 -> 6.1 -- the extra barrier and the 512 staged
+  // loads cost more than the L2 gathers they replace.)
   const int rot = (p * LANES) % 27;   // staggered stencil walk, as in lg_p2g: no two lanes of a run on the same table slot
 #pragma unroll 1
   for (int it = qi; it < 27; it += LANES) {
@@ -848,7 +829,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
     const int gkey = cell_gather(c, base[0] + i, base[1] + j, base[2] + k);
     const long lin = cell_lin(c, gkey);
-    const float4 v4 = fast ? s_tile[tile0 + k + 8 * j + 64 * i] : vel[lin];
+    const float4 v4 = vel[lin];
     const float vv[3] = {v4.x, v4.y, v4.z};
     float gwt = 0.f;
     const int sl = bt_find<TH, TLOG>(bt, win, gkey);      // one lookup per cell (bt_add per component repeated it three times)
