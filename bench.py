@@ -447,7 +447,8 @@ def bench_mpm_scaled(args, rank, world, device):
                                    f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
             "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch}}), flush=True)
+                         "traffic": pmc_traffic(f"large_path:whip_rope_ngrid{ng}:{dom}") if B == 32 else None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,12 +1,13 @@
 #!/bin/bash
 # rocprofv3 counter passes over a large-path workload (one counter group per pass, kernel trace only), summarised per kernel.
-# usage (GPU box): W=pour_soup bash tools/pmc_large.sh
+# usage (GPU box): W=pour_soup bash tools/pmc_large.sh      |  W=whip_rope ARGS="--n-grid 256" NAME=whip_rope_ngrid256 bash tools/pmc_large.sh
+# then: python3 tools/pmc_large_traffic.py gpurun_out/pmc_large_summary.csv $NAME   (per-step-call HBM bytes -> profiles/pmc_traffic.json)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-W=${W:-pour_soup}
+W=${W:-pour_soup}; NAME=${NAME:-$W}
 i=0
 for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1)); rm -rf gpurun_out/pmc_$i; mkdir -p gpurun_out/pmc_$i
-  timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace -d gpurun_out/pmc_$i -o p -f csv -- python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i/log 2>&1 || echo "pass $i ($G) failed"
+  timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace -d gpurun_out/pmc_$i -o p -f csv -- python3 bench.py --workload $W $ARGS --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i/log 2>&1 || echo "pass $i ($G) failed"
 done
 python3 - <<PY
 import csv, glob, collections
@@ -24,3 +25,5 @@ with open("gpurun_out/pmc_large_summary.csv", "w") as o:
         o.write(k + "," + str(n) + "," + ",".join("%.4g" % (sum(acc[k][c]) / len(acc[k][c])) if acc[k][c] else "" for c in names) + "\n")
 print(open("gpurun_out/pmc_large_summary.csv").read())
 PY
+cp gpurun_out/pmc_large_summary.csv gpurun_out/pmc_large_summary_$NAME.csv
+python3 tools/pmc_large_traffic.py gpurun_out/pmc_large_summary_$NAME.csv $NAME gpurun_out/pmc_traffic_$NAME.json

@@ -1,0 +1,40 @@
+"""HBM bytes of ONE ud_mpm_step_fwd / ud_mpm_step_bwd call of the many-workgroup MPM path, from the per-kernel summary of
+tools/pmc_large.sh (mean FETCH_SIZE / WRITE_SIZE per launch in KB, separate --pmc passes): sum over the kernels of a direction of
+launches-per-call x (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md).
+usage: python tools/pmc_large_traffic.py <summary.csv> <name> [out.json]  -> entries large_path:<name>:fwd / :bwd"""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import src_hash
+
+FWD = ("lg_clear_fk", "lg_p2g<", "lg_grid", "lg_g2p<", "lg_sort", "lg_pack", "lg_unpack", "lg_fwd_out", "lg_prim_in")
+BWD = ("lg_restore", "lg_g2p_adj", "lg_grid_adj", "lg_p2g_adj", "lg_bwd_in", "lg_bwd_out")
+rows = list(csv.DictReader(open(sys.argv[1])))
+name = sys.argv[2]
+dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+by = {r["kernel"]: r for r in rows}
+n_fwd = int(by["lg_fwd_out"]["launches"])
+n_bwd = int(by["lg_bwd_out"]["launches"])
+tot = {"fwd": 0.0, "bwd": 0.0}
+for r in rows:
+    k = r["kernel"]
+    if not r["FETCH_SIZE"] or not r["WRITE_SIZE"]:
+        continue
+    per_launch = (2 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024
+    if k.startswith("lg_grid_adj") or any(k.startswith(p) for p in BWD):
+        tot["bwd"] += per_launch * int(r["launches"]) / n_bwd
+    elif any(k.startswith(p) for p in FWD):
+        # lg_pack also packs the cotangents (one launch per backward call), lg_clear_fk also runs in a recomputing backward: billed to the forward
+        tot["fwd"] += per_launch * int(r["launches"]) / n_fwd
+out = json.load(open(dst)) if os.path.exists(dst) else {}
+for d in ("fwd", "bwd"):
+    out[f"large_path:{name}:{d}"] = {
+        "hbm_bytes_per_launch": tot[d],
+        "note": f"sum over the kernels of one ud_mpm_step_{d} call of 2 x FETCH_SIZE + WRITE_SIZE (KB x 1024, mean per launch x launches per call), "
+                f"from {os.path.basename(sys.argv[1])} (tools/pmc_large.sh: one counter group per pass, gfx950 read correction)",
+        "src_sha16": src_hash.sha16("large_path"), "step_calls_in_the_passes": {"fwd": n_fwd, "bwd": n_bwd}}
+    print(f"large_path:{name}:{d}: {tot[d] / 1e9:.3f} GB per step call")
+json.dump(out, open(dst, "w"), indent=1)

@@ -13,7 +13,8 @@ import os
 import sys
 
 LONG = "--long" in sys.argv      # one long run on the headline env, curve written to gpurun_out/train_fold_cloth1.csv
-RUNS = (("fold_cloth1", 4, 3, 1000, 1e-4),) if LONG else (("fold_cloth1", 4, 3, 150, 1e-4), ("whip_rope", 32, 3, 150, 1e-4), ("pour_water", 8, 3, 60, 1e-4))
+RUNS = (("fold_cloth1", 4, 3, 1000, 1e-4),) if LONG else (("fold_cloth1", 4, 3, 150, 1e-4), ("whip_rope", 32, 3, 150, 1e-4), ("pour_water", 8, 3, 60, 1e-4),
+                                                                 ("shape_rope", 4, 2, 20, 1e-4), ("fold_tshirt", 4, 2, 40, 1e-4))
 for name, num_envs, ep_len, iters, lr in RUNS:
     torch.manual_seed(0)
     np.random.seed(0)
