@@ -800,16 +800,20 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     }
   }
   LG_STAMP(1, 0);     // table clear + position loads
+  // the cotangents are loaded ahead of the window reduction: their latency runs under its two barriers
+  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) gC[d] = 0.f;
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
+  }
   const BlockWin win = bt_window(c, live, base);
   LG_STAMP(1, 1);     // window reduction + barriers
   if (live) {
-  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
-  float gx[3], gv[3], gC[9];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
-#pragma unroll
-  for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
-  LG_STAMP(1, 2);     // cotangent loads
   float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
@@ -819,6 +823,68 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   // (Round 2 tried copying the window's 8 x 8 x 8 velocities into LDS once per block and reading the 27 cells from there: slower
   // everywhere -- rope at n_grid 256 backward 11.1 -> 12.5 ms, pour_soup 5.7 -> 6.1 -- the extra barrier and the 512 staged
   // loads cost more than the L2 gathers they replace.)
+  if (LANES == 1) {
+    // Two walks over the nine (i, j) columns, three k cells -- neighbours in memory, the grid is z-fastest -- per trip.
+    // The scatter into the block table is staggered per particle (no two lanes of a run of particles sharing a base cell on the
+    // same table slot at once) and needs no grid velocity.  The weight / fx partials need the velocity and want the opposite:
+    // every lane on the same column, so that the particles of a cell ask for the same 48 bytes (one cell per trip, staggered,
+    // kept a single 16-B gather in flight per wave, 64 different lines per instruction: the walk was 45 % of the kernel,
+    // profiles/r02e_lg_stamps_pour_soup.txt).  Measured on pour_soup: 88.7 us as it was, 72.3 with three loads per trip
+    // (staggered), 78.2 with the next column prefetched, 87.3 with a whole i plane (nine loads, 190 registers) in flight.
+    const int rot9 = p % 9;
+#pragma unroll 1
+    for (int it = 0; it < 9; ++it) {
+      const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
+      const int i = col / 3, j = col - 3 * i;
+      const float wij = sel3(w, 0, i) * sel3(w, 1, j);
+      const float dp0 = (float)i - fx[0], dp1 = (float)j - fx[1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float weight = wij * w[k * 3 + 2];
+        const float dp2 = (float)k - fx[2];
+        const int gkey = cell_gather(c, base[0] + i, base[1] + j, base[2] + k);
+        const int sl = bt_find<TH, TLOG>(bt, win, gkey);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gCd = gC[r * 3] * dp0 + gC[r * 3 + 1] * dp1 + gC[r * 3 + 2] * dp2;
+          const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+          if (sl >= 0) __hip_atomic_fetch_add(&bt.val[r * TH + sl], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else atomicAdd((float*)(gacc + cell_lin(c, gkey)) + r, gcell);
+        }
+      }
+    }
+    LG_STAMP(1, 2);     // scatter walk (one-lane kernel)
+#pragma unroll 1
+    for (int col = 0; col < 9; ++col) {
+      const int i = col / 3, j = col - 3 * i;
+      const float wi = sel3(w, 0, i), wj = sel3(w, 1, j);
+      const float dp0 = (float)i - fx[0], dp1 = (float)j - fx[1];
+      float4 v4[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v4[k] = vel[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float wk = w[k * 3 + 2];
+        const float weight = wi * wj * wk;
+        const float dp[3] = {dp0, dp1, (float)k - fx[2]};
+        const float vv[3] = {v4[k].x, v4[k].y, v4[k].z};
+        float gwt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+          gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+        }
+        gw[k * 3 + 2] += gwt * wi * wj;
+      }
+    }
+  } else {
   const int rot = (p * LANES) % 27;   // staggered stencil walk, as in lg_p2g: no two lanes of a run on the same table slot
 #pragma unroll 1
   for (int it = qi; it < 27; it += LANES) {
@@ -849,6 +915,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
       gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
       gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
     }
+  }
   }
   LG_STAMP(1, 3);     // the 27-cell walk (velocity gathers from HBM / L2 + table adds)
 #pragma unroll
@@ -1046,7 +1113,7 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
 template <int LANES>
-__global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_blocks) {
+__global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_blocks) {
   if ((int)blockIdx.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
     fk_adj_block(a, (long)(blockIdx.y + a.b0) * a.c.n_prim + ((int)blockIdx.x - particle_blocks));
     return;
@@ -1071,10 +1138,14 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
   LG_STAMP(2, 1);     // pre-pass with the adjoint's extras
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9], gF[9];
+  // one lane per particle: loaded after the gather instead -- 24 registers the walk's loads in flight can use (243 VGPRs, two
+  // waves per SIMD; ahead of it the kernel needs 278 and drops to one)
+  if (LANES != 1) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
 #pragma unroll
-  for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+  }
   const float* ps = a.w.pscr + ((long)b * c.Np + p) * 12;
   float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1083,6 +1154,51 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
   for (int d = 0; d < 3; ++d) gfx[d] = (qi == 0) ? ps[9 + d] : 0.f;
   const float4* gacc = a.w.gacc + (long)b * a.G;
   LG_STAMP(2, 2);     // cotangent + scratch loads
+  // One lane per particle: the 27 cells as nine (i, j) columns, the three k cells of a column -- neighbours in memory, the grid is
+  // z-fastest -- loaded together before any of them is used (one cell per trip left a single 16-B gather in flight per wave, at
+  // two waves per SIMD: the walk was 63 % of this kernel, profiles/r02e_lg_stamps_pour_soup.txt).  (A whole i plane, nine loads,
+  // in flight needs 67 more registers than two waves per SIMD have: spilled it gained 4 us of 52 on pour_soup; parking the SVD
+  // factors in LDS across the gather instead gave wrong gradients -- cause not found -- and was dropped.)
+  if (LANES == 1) {
+#pragma unroll 1
+    for (int col = 0; col < 9; ++col) {
+      const int i = col / 3, j = col - 3 * i;
+      const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j);
+      const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx;
+      int sc[3];
+      float4 g4[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sc[k] = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g4[k] = sc[k] >= 0 ? gacc[cell_lin(c, sc[k])] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (sc[k] < 0) continue;
+        const float wk = q.w[k * 3 + 2];
+        const float weight = wi * wj * wk;
+        const float dpos[3] = {dp0, dp1, ((float)k - q.fx[2]) * c.dx};
+        const float gcv[3] = {g4[k].x, g4[k].y, g4[k].z};
+        float gwt = c.p_mass * g4[k].w;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+          gwt += gcv[r] * (c.p_mass * v[r] + ad);
+          gvp[r] += weight * c.p_mass * gcv[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) {
+            gaff[r * 3 + s2] += weight * gcv[r] * dpos[s2];
+            gfx[s2] -= c.dx * weight * gcv[r] * q.affine[r * 3 + s2];
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+        }
+        gw[k * 3 + 2] += gwt * wi * wj;
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
@@ -1112,12 +1228,19 @@ __global__ void __launch_bounds__(256) lg_p2g_adj(LargeArgs a, int particle_bloc
       gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
     }
   }
+  }
 #pragma unroll
   for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<LANES>(gw[d]); gaff[d] = lg_quad_sum<LANES>(gaff[d]); }
 #pragma unroll
   for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<LANES>(gfx[d]); gvp[d] = lg_quad_sum<LANES>(gvp[d]); }
   LG_STAMP(2, 3);     // the 27-cell gather
   if (qi == 0) {
+  if (LANES == 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+  }
   float gmu_p, gla_p;
   particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
@@ -1266,11 +1389,19 @@ struct MpmLarge {
 #ifndef LG_GROUPS
 #define LG_GROUPS 2
 #endif
-// number of env groups for a launch of B envs
+// number of env groups for a launch of B envs.  Measured (1x MI355X, substeps/s forward+backward, groups 1 / 2 / 4): rope at n_grid 256
+// (32 envs x 6675, position control, one lane per particle) 123 k / 144 k / 151 k -- its grid kernels are short launches of a few hundred
+// blocks and leave the chip to the other groups' particle kernels; pour_soup (32 x 7631, soft contact) 76.0 k / 77.5 k / 74.5 k; the
+// four-lane launches (rope at n_grid 128, shape_rope, pour_water) are best at 2 and lose 5-20 % at 4.
 static int lg_groups(const MpmLarge* L, int B) {
-  static const int want = [] { const char* e = getenv("UD_LG_GROUPS"); return e ? atoi(e) : LG_GROUPS; }();   // diagnostic override
-  const long lanes = (long)B * L->c.N * 4;
-  if (want <= 1 || B < 2 * want || lanes > 200000 || !L->ev_fork) return 1;
+  static const int forced = [] { const char* e = getenv("UD_LG_GROUPS"); return e ? atoi(e) : 0; }();   // diagnostic override
+  if (!L->ev_fork) return 1;
+  const long particles = (long)B * L->c.N;
+  int want = 1;
+  if (particles <= 50000) want = LG_GROUPS;                              // four-lane kernels, up to 200 k lanes
+  if (particles >= 100000) want = L->c.position_control ? 4 : LG_GROUPS;   // one-lane kernels (measurements above)
+  if (forced > 0) want = forced;
+  if (want <= 1 || B < 2 * want) return 1;
   return want < MpmLarge::MAX_GROUPS ? want : MpmLarge::MAX_GROUPS;
 }
 
