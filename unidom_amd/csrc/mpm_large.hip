@@ -5,8 +5,8 @@
 // Per substep the forward runs  clear+FK -> p2g -> grid op -> g2p  and the backward either
 // clear -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint in extra blocks)
 // or, with the grid checkpoint,  restore -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint):
-//   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells with an
-//     epoch stamp; the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
+//   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells in a bitmap
+//     (one bit per cell); the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
 //     the next substep visit only touched cells (never the 32^3..128^3 dense volume the reference sweeps ~10x);
 //   * particle state history (24 floats/particle/substep, SoA) doubles as the backward's checkpoint;
 //   * no host synchronisation: all launches go to the caller's stream in order.
@@ -24,7 +24,7 @@ struct LargeBuf {
   float4* val;      // [B][G]  (m, mvx, mvy, mvz); after the grid op (fwd): (m, vx, vy, vz)
   float4* vel;      // [B][G]  bwd: grid velocity after the grid op
   float4* gacc;     // [B][G]  bwd: cotangent of grid velocity -> (g_mv xyz, g_m)
-  int* stamp;       // [B][G]
+  unsigned* bits;   // [B][W32]  one bit per cell: in the active list of the substep in flight (cleared with the list)
   int* list;        // [2][B][cap]
   int* count;       // [2][B]
   // primitive arrays carry a primitive axis: [B][P][...], P = c.n_prim (1 in position-control mode)
@@ -49,7 +49,8 @@ struct LargeArgs {
   LargeBuf w;
   const int* material;
   const float* hard;
-  int B, f, epoch, cap;
+  int B, f, cap;
+  long W32;               // bitmap words per env
   int b0;                 // first env of this launch (env groups on separate streams)
   long G;
   // grid checkpoint (ud_mpm_conf.grid_ckpt_cells > 0): the forward appends one record {key, m, mv[3], v[3]} per active
@@ -81,8 +82,9 @@ __device__ __forceinline__ int* gck_idx(const LargeArgs& a, int b) { return (int
 __device__ __forceinline__ float4* gck_pool(const LargeArgs& a, int b) { return (float4*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_pool); }
 
 __device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long lin) {
-  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
-  if (old != a.epoch) {
+  const unsigned bit = 1u << (lin & 31);
+  const unsigned old = atomicOr(&a.w.bits[(long)b * a.W32 + (lin >> 5)], bit);
+  if (!(old & bit)) {
     const int cur = a.f & 1;
     const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
     if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = key;
@@ -210,7 +212,8 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
 // ---- block window: the table addressed directly --------------------------------------------------------
 // The particles of a block are spatial neighbours (lattice order, or sort_particles), so their stencils often fit a small box:
 // when the block's base cells span at most 6 per axis the table IS the 8x8x8 cells starting at the smallest base cell,
-// slot = offset inside it -- no key compare, no CAS, nothing returned from LDS inside the walk.  A block whose particles are
+// slot = offset inside it (z fastest, like the grid in memory: a row of 8 slots is 128 contiguous bytes of cells) -- no key
+// compare, no CAS, nothing returned from LDS inside the walk.  A block whose particles are
 // spread wider keeps the open-addressing table above.  Measured (tools/abl_p2g.sh, window forced on / off): n_grid-256 rope
 // lg_p2g 83.8 us with the hash only, 76.9 us adaptive; pour_soup 107 either way (few of its blocks qualify), and 161 us with the
 // window forced on (cells outside it go to HBM atomics) -- hence the per-block choice.
@@ -242,7 +245,7 @@ __device__ __forceinline__ BlockWin bt_window(const MpmConst& c, bool live, cons
 // slot of a packed cell key inside the window (LgTable<>::H == 512), or -1 outside (clamped / wrapped stencil cells)
 __device__ __forceinline__ int bt_win_slot(const BlockWin& w, int key) {
   const unsigned rx = (unsigned)((key & 1023) - w.ox), ry = (unsigned)(((key >> 10) & 1023) - w.oy), rz = (unsigned)(((key >> 20) & 1023) - w.oz);
-  return ((rx | ry | rz) < 8u) ? (int)(rx | (ry << 3) | (rz << 6)) : -1;
+  return ((rx | ry | rz) < 8u) ? (int)(rz | (ry << 3) | (rx << 6)) : -1;
 }
 template <int H, int LOGH>
 __device__ __forceinline__ int bt_find(const BlockTable& t, const BlockWin& w, int cell) {
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
     if (t < n) {
       const long lin = cell_lin(a.c, a.w.list[((long)prev * a.B + b) * a.cap + t]);
       a.w.val[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a.w.bits[(long)b * a.W32 + (lin >> 5)] = 0u;   // every bit set in this word belongs to a cell of this list
       if (clear_bwd) a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
@@ -364,40 +368,41 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     // (3.75 waves per SIMD in a single round: latency of the state loads, the SVD chain and the flush's HBM atomics) is not
     // separated yet.
     // Fast walk: when the block window is on and the particle's stencil is interior (no wrap, drop or clamp on any axis), the
-    // 27 cells are slot0 + i + 8 j + 64 k / key0 + i + (j << 10) + (k << 20): nine (i, j) columns walked dynamically, the three k
-    // cells of a column unrolled with their weights and affine terms hoisted.
+    // 27 cells are slot0 + 64 i + 8 j + k / key0 + i + (j << 10) + (k << 20): nine (j, k) columns walked dynamically (staggered:
+    // their slots fall on nine different bank pairs), the three i cells of a column unrolled with their weights and affine
+    // terms hoisted.
     const bool interior = win.on && !(UD_MPM_ABLATE & 64) && q.base[0] >= 0 && q.base[1] >= 0 && q.base[2] >= 0 &&
                           q.base[0] + 2 < c.res[0] && q.base[1] + 2 < c.res[1] && q.base[2] + 2 < c.res[2];
     if (interior) {
       const int key0 = q.base[0] | (q.base[1] << 10) | (q.base[2] << 20);
-      const int slot0 = (q.base[0] - win.ox) | ((q.base[1] - win.oy) << 3) | ((q.base[2] - win.oz) << 6);
-      float wz[3], az[9];
+      const int slot0 = (q.base[2] - win.oz) | ((q.base[1] - win.oy) << 3) | ((q.base[0] - win.ox) << 6);
+      float wx[3], ax[9];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        wz[k] = q.w[k * 3 + 2];
-        const float dp2 = ((float)k - q.fx[2]) * c.dx;
+      for (int i = 0; i < 3; ++i) {
+        wx[i] = q.w[i * 3];
+        const float dp0 = ((float)i - q.fx[0]) * c.dx;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) az[r * 3 + k] = q.affine[r * 3 + 2] * dp2;
+        for (int r = 0; r < 3; ++r) ax[r * 3 + i] = q.affine[r * 3] * dp0;
       }
       const int rot9 = (p * LANES) % 9;
 #pragma unroll 1
       for (int it = qi; it < 9; it += LANES) {
         const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
-        const int i = col / 3, j = col - 3 * i;
-        const float wij = sel3(q.w, 0, i) * sel3(q.w, 1, j);
-        const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx;
+        const int j = col / 3, k = col - 3 * j;
+        const float wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+        const float dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
         float br[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) br[r] = c.p_mass * v[r] + q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1;
-        const int sl = slot0 + i + 8 * j, key = key0 + i + (j << 10);
+        for (int r = 0; r < 3; ++r) br[r] = c.p_mass * v[r] + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
+        const int sl = slot0 + 8 * j + k, key = key0 + (j << 10) + (k << 20);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float wgt = wij * wz[k];
-          bt.key[sl + 64 * k] = key + (k << 20);
-          __hip_atomic_fetch_add(&bt.val[sl + 64 * k], (double)(wgt * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int i = 0; i < 3; ++i) {
+          const float wgt = wx[i] * wj * wk;
+          bt.key[sl + 64 * i] = key + i;
+          __hip_atomic_fetch_add(&bt.val[sl + 64 * i], (double)(wgt * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
           for (int r = 0; r < 3; ++r)
-            __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl + 64 * k], (double)(wgt * (br[r] + az[r * 3 + k])), __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl + 64 * i], (double)(wgt * (br[r] + ax[r * 3 + i])), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
@@ -436,40 +441,93 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     }
     }
   }
-  // flush: one global atomic per distinct cell and component.  Cells this substep sees for the first time (epoch stamp)
-  // join the env's active list; the appends of a block are aggregated -- one atomicAdd on the env's counter per block
-  // instead of one per cell (~2 k same-address atomics per env-substep at n_grid 256, one per active cell, were 80 % of the whole step).
+  // flush.  Value atomics: four lanes per cell, one per component -- a cell is 16 contiguous bytes and, in a block window, eight
+  // consecutive slots are 128 contiguous bytes, the shape global float atomics want (one lane per cell and component meant 64
+  // lanes on 64 different 64-byte lines: each atomic its own memory-side request, and 4 x the bytes in WRITE_SIZE).
+  // Cells this substep sees for the first time join the env's active list: first toucher = whoever sets the cell's bit in the
+  // env's bitmap -- one returning atomic OR per row of eight slots in a block window (per cell otherwise) instead of an
+  // exchange per cell on a 4-byte stamp -- and the appends of a block are aggregated: one atomicAdd on the env's counter per
+  // block (~2 k same-address atomics per env-substep at n_grid 256, one per active cell, were 80 % of the whole step).
   LG_STAMP(0, 3);     // the 27-cell walk
   __shared__ int s_new, s_base;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
   LG_STAMP(0, 4);     // barrier before the flush
   if (UD_MPM_ABLATE & 128) return;
-  constexpr int PER = TH / LG_SCATTER_T;
-  unsigned newmask = 0;
-  int nnew = 0;
-#pragma unroll
-  for (int u = 0; u < PER; ++u) {   // (issuing the returning stamp exchanges ahead of the adds measured 13 % slower)
-    const int sl = threadIdx.x + u * LG_SCATTER_T;
-    const int key = bt.key[sl];
-    if (key < 0) continue;
-    const long lin = cell_lin(c, key);
-    float* cell = (float*)(val + lin);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
-    if (atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
+  {
+    const int r = threadIdx.x & 3;
+#pragma unroll 4
+    for (int sl = threadIdx.x >> 2; sl < TH; sl += LG_SCATTER_T / 4) {
+      const int key = bt.key[sl];
+      if (key < 0) continue;
+      atomicAdd((float*)(val + cell_lin(c, key)) + r, (float)bt.val[r * TH + sl]);
+    }
   }
-  LG_STAMP(0, 5);     // flush: value atomics + stamp exchanges
+  unsigned* bits = a.w.bits + (long)b * a.W32;
+  const int cur = a.f & 1;
+  int* list = a.w.list + ((long)cur * a.B + b) * a.cap;
+  if (win.on) {             // block-uniform.  64 rows of eight slots: wave 0 alone, no barrier
+    if (threadIdx.x >= 64) return;
+    const int row = threadIdx.x;
+    unsigned m8 = 0;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) m8 |= (bt.key[row * 8 + z] >= 0 ? 1u : 0u) << z;
+    unsigned fresh = 0;
+    if (m8) {
+      const long lin0 = ((long)(win.ox + (row >> 3)) * c.res[1] + (win.oy + (row & 7))) * c.res[2] + win.oz;
+      const int sh = (int)(lin0 & 31);
+      unsigned* wd = bits + (lin0 >> 5);
+      const unsigned lo = atomicOr(wd, m8 << sh);
+      const unsigned hi = (sh > 24) ? atomicOr(wd + 1, m8 >> (32 - sh)) : 0u;
+      const unsigned old8 = ((lo >> sh) | ((sh > 24) ? hi << (32 - sh) : 0u)) & 0xffu;
+      fresh = m8 & ~old8;
+    }
+    LG_STAMP(0, 5);     // flush: value atomics + bitmap
+    const int nnew = __popc(fresh);
+    const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
+    const int total = __hip_atomic_load(&s_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // same wave: after every lane's add
+    int base = 0;
+    if (threadIdx.x == 0 && total) base = atomicAdd(&a.w.count[cur * a.B + b], total);
+    base = __shfl(base, 0);
+    int e = base + mine;
+#pragma unroll
+    for (int z = 0; z < 8; ++z) {
+      if (!(fresh & (1u << z))) continue;
+      if (e < a.cap) list[e] = bt.key[row * 8 + z];
+      ++e;
+    }
+    LG_STAMP(0, 6);     // list append
+    return;
+  }
+  constexpr int PER = TH / LG_SCATTER_T;
+  unsigned fresh = 0;
+  int nnew = 0;
+  {
+    unsigned old[PER], bit[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {   // the returning ORs of a lane go out together
+      const int key = bt.key[threadIdx.x + u * LG_SCATTER_T];
+      bit[u] = 0u; old[u] = 0u;
+      if (key >= 0) {
+        const long lin = cell_lin(c, key);
+        bit[u] = 1u << (lin & 31);
+        old[u] = atomicOr(bits + (lin >> 5), bit[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (bit[u] & ~old[u]) { fresh |= 1u << u; ++nnew; }
+  }
+  LG_STAMP(0, 5);     // flush: value atomics + bitmap
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
   __syncthreads();
-  const int cur = a.f & 1;
   if (threadIdx.x == 0) s_base = s_new ? atomicAdd(&a.w.count[cur * a.B + b], s_new) : 0;
   __syncthreads();
   int e = s_base + mine;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
-    if (!(newmask & (1u << u))) continue;
-    if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = bt.key[threadIdx.x + u * LG_SCATTER_T];
+    if (!(fresh & (1u << u))) continue;
+    if (e < a.cap) list[e] = bt.key[threadIdx.x + u * LG_SCATTER_T];
     ++e;
   }
   LG_STAMP(0, 6);     // list append
@@ -551,6 +609,28 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
   }
   const float4* val = a.w.val + (long)b * a.G;
   float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (LANES == 1) {   // nine (i, j) columns, the three k cells of a column (neighbours in memory) in flight together -- see lg_g2p_adj
+#pragma unroll 1
+    for (int col = 0; col < 9; ++col) {
+      const int i = col / 3, j = col - 3 * i;
+      const float wij = sel3(w, 0, i) * sel3(w, 1, j);
+      float4 g4[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g4[k] = val[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float weight = wij * w[k * 3 + 2];
+        const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+        const float g[3] = {g4[k].y, g4[k].z, g4[k].w};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * g[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+        }
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int cidx = qi; cidx < 27; cidx += LANES) {
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
@@ -564,6 +644,7 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
 #pragma unroll
       for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
     }
+  }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) nv[d] = lg_quad_sum<LANES>(nv[d]);
@@ -933,12 +1014,14 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   LG_STAMP(1, 4);     // partials to the particle scratch
   __syncthreads();
   LG_STAMP(1, 5);     // barrier before the flush
-  for (int sl = threadIdx.x; sl < TH; sl += blockDim.x) {
-    const int key = bt.key[sl];
-    if (key < 0) continue;
-    float* cell = (float*)(gacc + cell_lin(c, key));
-#pragma unroll
-    for (int r = 0; r < 3; ++r) atomicAdd(cell + r, (float)bt.val[r * TH + sl]);
+  {                   // four lanes per cell as in lg_p2g (the fourth component, g_m, is the grid-op adjoint's)
+    const int r = threadIdx.x & 3;
+#pragma unroll 4
+    for (int sl = threadIdx.x >> 2; sl < TH; sl += LG_SCATTER_T / 4) {
+      const int key = bt.key[sl];
+      if (key < 0 || r == 3) continue;
+      atomicAdd((float*)(gacc + cell_lin(c, key)) + r, (float)bt.val[r * TH + sl]);
+    }
   }
   LG_STAMP(1, 6);     // flush
 }
@@ -1373,7 +1456,8 @@ struct MpmLarge {
   MpmConst c;
   const int* d_material;
   const float* d_hard;
-  int B = 0, cap = 0, epoch = 1;
+  int B = 0, cap = 0;
+  long W32 = 0;        // bitmap words per env
   long G = 0;
   LargeBuf w{};
   void* arena = nullptr;
@@ -1410,6 +1494,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   L->c = c; L->d_material = d_material; L->d_hard = d_hard;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
+  L->W32 = (L->G + 31) / 32 + 1;   // + 1: a row of eight cells may straddle into the word behind the last
   // dynamic LDS of the staging kernels (set explicitly so that a table above the 64 KB default keeps working)
   (void)hipFuncSetAttribute((const void*)lg_p2g<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
@@ -1468,7 +1553,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t o_val = take((size_t)B * G * 16), o_vel = take((size_t)B * G * 16), o_gacc = take((size_t)B * G * 16);
-  const size_t o_stamp = take((size_t)B * G * 4), o_list = take((size_t)2 * B * L->cap * 4), o_count = take((size_t)2 * B * 4);
+  const size_t o_bits = take((size_t)B * L->W32 * 4), o_list = take((size_t)2 * B * L->cap * 4), o_count = take((size_t)2 * B * 4);
   const size_t o_ppos = take(BP * S * 3 * 4), o_prot = take(BP * S * 4 * 4), o_ppin = take(BP * S * 3 * 4);
   const size_t o_trq = take((size_t)B * S * 4), o_gppos = take(BP * S * 3 * 4), o_gpv = take(BP * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 12 * 4);
@@ -1477,25 +1562,25 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&L->arena, off);
   if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
-  e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, stamps and counters start at zero
+  e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, bitmap and counters start at zero
   if (e != hipSuccess) { set_error("ud_mpm (large path): memset failed"); return UD_ERR_HIP; }
   char* base = (char*)L->arena;
   L->w.val = (float4*)(base + o_val); L->w.vel = (float4*)(base + o_vel); L->w.gacc = (float4*)(base + o_gacc);
-  L->w.stamp = (int*)(base + o_stamp); L->w.list = (int*)(base + o_list); L->w.count = (int*)(base + o_count);
+  L->w.bits = (unsigned*)(base + o_bits); L->w.list = (int*)(base + o_list); L->w.count = (int*)(base + o_count);
   L->w.ppos = (float*)(base + o_ppos); L->w.prot = (float*)(base + o_prot); L->w.ppin = (float*)(base + o_ppin);
   L->w.trq = (float*)(base + o_trq); L->w.gppos = (float*)(base + o_gppos); L->w.gpv = (float*)(base + o_gpv);
   L->w.acc = (float*)(base + o_acc); L->w.pscr = (float*)(base + o_pscr); L->w.hist = (float*)(base + o_hist);
   L->w.gstate = (float*)(base + o_gstate);
   L->w.grot = (float*)(base + o_grot); L->w.gpw = (float*)(base + o_gpw); L->w.gpsz = (float*)(base + o_gpsz);
   L->w.perm = (int*)(base + o_perm);
-  L->arena_bytes = off; L->B = B; L->epoch = 1;
+  L->arena_bytes = off; L->B = B;
   return UD_OK;
 }
 
 static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* friction, const float* mu, const float* lamda,
                            const float* action) {
   LargeArgs a;
-  a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.epoch = 0; a.cap = L->cap; a.G = L->G;
+  a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.cap = L->cap; a.G = L->G; a.W32 = L->W32;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr;
   a.perm = nullptr; a.perm_stride = 0;
@@ -1554,8 +1639,6 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   a.hist_stride_b = stride_b;
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
-  const int e0 = L->epoch;            // one epoch per substep, shared by the groups (stamps are per env)
-  L->epoch += S + 1;
   // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
   const bool sort = c.sort && N <= LG_SORT_MAX;
   int* perm = nullptr;
@@ -1576,7 +1659,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
   }
   for (int f = 0; f <= S; ++f) {
-    a.f = f; a.epoch = e0 + f;
+    a.f = f;
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
     for (int g = 0; g < G; ++g) {
@@ -1625,8 +1708,6 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const bool gck = ck.budget > 0 && !(clip & 2);
   clip &= 1;
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
-  const int e0 = L->epoch;
-  L->epoch += S + 1;
   if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
@@ -1637,7 +1718,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   }
   for (int f = S - 1; f >= -1; --f) {
     // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
-    a.f = f; a.epoch = e0 + (S - 1 - f);
+    a.f = f;
     a.hist_in = ckpt + (long)max(f, 0) * rec;
     for (int g = 0; g < G; ++g) {
       const int Bg = grp[g].Bg;
