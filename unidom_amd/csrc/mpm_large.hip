@@ -218,10 +218,15 @@ __device__ __forceinline__ int bt_slot(const BlockTable& t, int cell) {
 // lg_p2g 83.8 us with the hash only, 76.9 us adaptive; pour_soup 107 either way (few of its blocks qualify), and 161 us with the
 // window forced on (cells outside it go to HBM atomics) -- hence the per-block choice.
 struct BlockWin { int on, ox, oy, oz; };
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
-  return v;
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int wave_min_i(int v) {   // DPP butterflies inside the rows of 16, the four row minima through readlane (cf. wave_sum)
+  v = min(v, dpp_i<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = min(v, dpp_i<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = min(v, dpp_i<0x141>(v));   // row_half_mirror
+  v = min(v, dpp_i<0x140>(v));   // row_mirror
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 // every thread of the block calls this (it holds the barrier that also publishes bt_clear)
 __device__ __forceinline__ BlockWin bt_window(const MpmConst& c, bool live, const int* base) {
@@ -913,6 +918,32 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     // profiles/r02e_lg_stamps_pour_soup.txt).  Measured on pour_soup: 88.7 us as it was, 72.3 with three loads per trip
     // (staggered), 78.2 with the next column prefetched, 87.3 with a whole i plane (nine loads, 190 registers) in flight.
     const int rot9 = p % 9;
+    const bool interior = win.on && base[0] >= 0 && base[1] >= 0 && base[2] >= 0 &&
+                          base[0] + 2 < c.res[0] && base[1] + 2 < c.res[1] && base[2] + 2 < c.res[2];
+    if (interior) {   // as lg_p2g's fast walk: slots by arithmetic, nine (j, k) columns on nine bank pairs, the three i cells unrolled
+      const int key0 = base[0] | (base[1] << 10) | (base[2] << 20);
+      const int slot0 = (base[2] - win.oz) | ((base[1] - win.oy) << 3) | ((base[0] - win.ox) << 6);
+#pragma unroll 1
+      for (int it = 0; it < 9; ++it) {
+        const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
+        const int j = col / 3, k = col - 3 * j;
+        const float wj = sel3(w, 1, j), wk = sel3(w, 2, k);
+        const float dp1 = (float)j - fx[1], dp2 = (float)k - fx[2];
+        const int sl = slot0 + 8 * j + k, key = key0 + (j << 10) + (k << 20);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float weight = w[i * 3] * wj * wk;
+          const float dp0 = (float)i - fx[0];
+          bt.key[sl + 64 * i] = key + i;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const float gCd = gC[r * 3] * dp0 + gC[r * 3 + 1] * dp1 + gC[r * 3 + 2] * dp2;
+            const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+            __hip_atomic_fetch_add(&bt.val[r * TH + sl + 64 * i], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    } else {
 #pragma unroll 1
     for (int it = 0; it < 9; ++it) {
       const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
@@ -933,6 +964,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
           else atomicAdd((float*)(gacc + cell_lin(c, gkey)) + r, gcell);
         }
       }
+    }
     }
     LG_STAMP(1, 2);     // scatter walk (one-lane kernel)
 #pragma unroll 1
