@@ -264,20 +264,22 @@ __device__ __forceinline__ int bt_find(const BlockTable& t, const BlockWin& w, i
 }
 
 // ---- forward kernels ---------------------------------------------------------------------------------
-// The kernels over an env's active-cell list are launched for `cap` cells (the host does not know the count).  One 256-cell tile
-// per block meant ~51 k blocks per launch on pour_soup (cap = 54 N = 412 k cells per env, ~2-5 k of them active): lg_clear_fk and
-// lg_restore, a few stores per cell, took 15 and 21 us -- block dispatch.  The grid is LG_TILES times smaller now and block x walks
-// tiles x, x + gridDim.x, ... until one lies past the list: the active tiles (8-20 per env) still go to different blocks --
-// giving each block LG_TILES consecutive tiles put them all on one or two blocks per env and made lg_grid_adj 4x slower.
-constexpr int LG_TILES = 8;
-__host__ __device__ constexpr int lg_cell_blocks(int cap) { return (cap + 256 * LG_TILES - 1) / (256 * LG_TILES); }
+// The kernels over an env's active-cell list do not know its length on the host (`cap` = 54 N cells at most; 2-5 k of pour_soup's
+// 412 k are ever active).  One 256-cell tile per block for `cap` cells meant ~51 k blocks per launch there, an eighth of that with
+// eight tiles per block still 6 432, of which ~280 found work: lg_grid_adj took 43 us for 14 us of work inside its blocks
+// (tools/lg_stamps.sh) -- the rest is the dispatch of blocks that read the count and leave.  Now: at most LG_CELL_BLOCKS blocks
+// per env, block x walks tiles x, x + gridDim.x, ... until one lies past the list -- the first 24 tiles (6 144 cells) still go to
+// different blocks (giving a block consecutive tiles put them all on one or two blocks per env and made lg_grid_adj 4x slower);
+// longer lists take a second trip.
+constexpr int LG_CELL_BLOCKS = 24;
+__host__ __device__ constexpr int lg_cell_blocks(int cap) { return (cap + 255) / 256 < LG_CELL_BLOCKS ? (cap + 255) / 256 : LG_CELL_BLOCKS; }
 
 // clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
 __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
   const int b = blockIdx.y + a.b0;
   const int prev = (a.f + 1) & 1, cur = a.f & 1;   // works for f ascending (forward) and descending (backward)
   const int n = min(a.w.count[prev * a.B + b], a.cap);
-  for (int u = 0; u < LG_TILES; ++u) {
+  for (int u = 0;; ++u) {
     const int t = (u * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
     if (t - (int)threadIdx.x >= n) break;
     if (t < n) {
@@ -585,7 +587,7 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
 }
 __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
   const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
-  for (int u = 0; u < LG_TILES; ++u) {
+  for (int u = 0;; ++u) {
     const int base = (u * gridDim.x + blockIdx.x) * 256;
     if (base >= n) break;
     lg_grid_cell(a, b, base + threadIdx.x, to_vel);
@@ -1092,7 +1094,7 @@ __global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
   if (a.f + 1 < S) n = max(n, min(idx[a.f + 2], a.gck_budget) - idx[a.f + 1]);
   if (a.f >= 0) n = max(n, min(idx[a.f + 1], a.gck_budget) - idx[a.f]);
   n = min(n, a.cap);
-  for (int u = 0; u < LG_TILES; ++u) {
+  for (int u = 0;; ++u) {
     const int base = (u * gridDim.x + blockIdx.x) * 256;
     if (base >= n) break;
     lg_restore_tile(a, b, base + threadIdx.x);
@@ -1139,6 +1141,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   // The grid covers `cap` cells per env, most blocks hold no active cell: leave block-uniformly (safe for the barriers
   // below) before any of the collide arithmetic.
   if (tile_base >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  LG_STAMP_BEGIN
   const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
   int ci = 0, cj = 0, ck = 0;
   long lin = 0;
@@ -1157,6 +1160,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   float v0[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+  LG_STAMP(3, 0);     // list / checkpoint / cotangent loads
   // Reverse walk over the primitives.  Primitive ip's input velocity is recomputed by running the chain 0..ip again
   // (one extra collide for two primitives) -- loops are kept rolled: one copy of the collide code in the kernel.
 #pragma unroll 1
@@ -1190,6 +1194,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
       pgv[17] = pg.mu;
     }
+    LG_STAMP(3, 1);   // collide chain forward + this primitive's adjoint
     // this primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
 #pragma unroll
     for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
@@ -1209,17 +1214,19 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       if (tot != 0.f) atomicAdd(dst, tot);
     }
     __syncthreads();
+    LG_STAMP(3, 2);   // wave sums, barriers, the block's atomics
   }
   if (live) {
     float gmm;
     grid_head_adjoint(mv.x, mvv, g, gmm);
     a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
   }
+  LG_STAMP(3, 3);     // head adjoint + store
 }
 __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   __shared__ float red[4][UD_PRIMC_NGRAD];
   const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
-  for (int u = 0; u < LG_TILES; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
+  for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
     const int base = (u * gridDim.x + blockIdx.x) * 256;
     if (base >= n) break;
     lg_grid_adj_tile(a, b, base, red);
