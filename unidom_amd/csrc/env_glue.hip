@@ -313,8 +313,10 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, in
                                                                 const float* __restrict__ g_obs, float* __restrict__ g_x, float* __restrict__ g_v,
                                                                 float* __restrict__ g_C, float* __restrict__ g_F, PrimOut g_pin,
                                                                 float* __restrict__ g_shift) {
+  // grid (blocks of GLUE_T particles, B): one workgroup per env took 0.38 ms at 7631 particles; g_shift is summed with one atomic
+  // per block and axis (the host zeroes it), block 0 takes the primitive arrays along
   __shared__ float red[3][GLUE_T / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x;
   const size_t o3 = (size_t)b * N * 3, o9 = (size_t)b * N * 9;
   float sh[3] = {0.f, 0.f, 0.f};
   if (shift) { sh[0] = shift[b * 3]; sh[1] = shift[b * 3 + 1]; sh[2] = shift[b * 3 + 2]; }
@@ -322,7 +324,8 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, in
   // reward = e^t, t = -10 * l2, l2 = (1/N) sum_n sqrt(m_n), m_n = |x - goal|^2 / 3
   const float gr = g_reward ? g_reward[b] * reward[b] * (-10.0f) / (float)N : 0.f;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int n = tid; n < N; n += GLUE_T) {
+  const int n = blockIdx.x * GLUE_T + tid;
+  if (n < N) {
     float xs[3], df[3], m = 0.f;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -343,11 +346,11 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, in
     }
     s0 += g[0]; s1 += g[1]; s2 += g[2];
   }
-  for (int i = tid; i < N * 9; i += GLUE_T) {
+  for (int i = blockIdx.x * GLUE_T * 9 + tid; i < min(N, (int)(blockIdx.x + 1) * GLUE_T) * 9; i += GLUE_T) {
     g_C[o9 + i] = (g_Co && finitef(Cm[o9 + i])) ? g_Co[o9 + i] : 0.f;
     g_F[o9 + i] = (g_Fo && finitef(F[o9 + i])) ? g_Fo[o9 + i] : 0.f;
   }
-  for (int p = 0; p < n_prim; ++p) {
+  for (int p = 0; p < (blockIdx.x == 0 ? n_prim : 0); ++p) {
     const float* src = g_pout.p[p] ? g_pout.p[p] + (size_t)b * S * 3 : nullptr;
     float* dst = g_pin.p[p] + (size_t)b * S * 3;
     for (int i = tid; i < S * 3; i += GLUE_T) {
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(GLUE_T) mpm_finish_bwd_kernel(int N, int S, in
   }
   if (g_shift) {    // every shifted quantity is (value - shift)
     block_sum3(s0, s1, s2, red);
-    if (tid == 0) { g_shift[b * 3] = -s0; g_shift[b * 3 + 1] = -s1; g_shift[b * 3 + 2] = -s2; }
+    if (tid == 0) { atomicAdd(&g_shift[b * 3], -s0); atomicAdd(&g_shift[b * 3 + 1], -s1); atomicAdd(&g_shift[b * 3 + 2], -s2); }
   }
 }
 
@@ -475,7 +478,8 @@ int ud_mpm_finish_bwd(int B, int N, int n_prim, int S, int Q, const float* x, co
   }
   PrimIn gi{}; PrimOut go{};
   for (int p = 0; p < n_prim; ++p) { gi.p[p] = g_prim_pos_out[p]; go.p[p] = g_prim_pos[p]; }
-  hipLaunchKernelGGL(mpm_finish_bwd_kernel, dim3(B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, Q, x, v, C, F, shift, goal, reward,
+  if (g_shift) UD_HIP_CHECK(hipMemsetAsync(g_shift, 0, (size_t)B * 3 * sizeof(float), (hipStream_t)stream));
+  hipLaunchKernelGGL(mpm_finish_bwd_kernel, dim3((N + GLUE_T - 1) / GLUE_T, B), dim3(GLUE_T), 0, (hipStream_t)stream, N, S, n_prim, Q, x, v, C, F, shift, goal, reward,
                      g_x_out, g_v_out, g_C_out, g_F_out, gi, g_reward, g_obs, g_x, g_v, g_C, g_F, go, g_shift);
   UD_HIP_CHECK(hipGetLastError());
   return UD_OK;
