@@ -762,14 +762,17 @@ __global__ void __launch_bounds__(256) lg_prim_in(LargeArgs a, const float* ppos
 
 __global__ void __launch_bounds__(256) lg_fwd_out(LargeArgs a, const float* J, float* Jo, float* ppos_o, float* prot_o, float* pv_o,
                                                   float* pw_o, float* ck_tail, long ck_stride_b) {
-  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps, N = a.c.N;   // grid (B, n_prim)
-  const long bp = (long)b * a.c.n_prim + ip;
-  if (ip == 0)
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps, N = a.c.N;   // grid (B, n_prim + blocks of 256 particles)
+  if (ip >= a.c.n_prim) {       // J of 256 particles (one block per env walked 7631 of them in 88 us)
+    const int p = (ip - a.c.n_prim) * 256 + threadIdx.x;
+    if (p < N) {
       float Jp = nan_to_num(J[(long)b * N + p]);
       for (int f = 0; f < S; ++f) Jp = Jp * (1.f + a.c.dt * a.w.trq[(long)b * S + f]);   // :327
       Jo[(long)b * N + p] = Jp;
     }
+    return;
+  }
+  const long bp = (long)b * a.c.n_prim + ip;
   float* tail = ck_tail ? ck_tail + (long)b * ck_stride_b + (long)ip * S * 10 : nullptr;   // per primitive: position, rotation, input position
   for (int e = threadIdx.x; e < S * 3; e += blockDim.x) {
     const int row = e / 3, d = e - row * 3;
@@ -1743,7 +1746,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, last, stride_b, xo, vo, Co, Fo, (const int*)perm, perm_stride);
-    hipLaunchKernelGGL(lg_fwd_out, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+    hipLaunchKernelGGL(lg_fwd_out, dim3(grp[g].Bg, c.n_prim + (N + 255) / 256), blk, 0, grp[g].s, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
   }
   lg_join(L, G, st, grp);
   hipError_t e = hipGetLastError();
