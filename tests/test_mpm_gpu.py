@@ -395,6 +395,29 @@ def test_large_path_matches_oracle_n798(grid_ckpt_cells):
     assert _rel(oh2["x"], of["x"]) < 5e-6 and _rel(oh2["v"], of["v"]) < 1e-4
 
 
+@pytest.mark.parametrize("lanes", ["4", "1"])
+def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch):
+    """First toucher of a cell = whoever sets its bit in the env's bitmap; a block window marks a row of eight z-consecutive cells
+    with one OR, or two when the row straddles a 32-bit word (z offset of the window & 31 > 24).  The rope is moved cell by cell
+    in z so that the windows start at z = 25 ... 32: forward vs the oracle each time, twice on the same handle (a cell left
+    marked, or a list entry lost, shows in the second call: the grid would not be all-zero again)."""
+    from oracle.pyoracle import MpmOracle
+    monkeypatch.setenv("UD_LG_LANES", lanes)
+    S = 3
+    sim, st, _, N = _scaled_case(S, 3, B=2)
+    orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
+    z0 = st["x"][..., 2].copy()
+    for cells in (-6, -5, -4, -3, -2, -1, 0, 1):
+        st["x"][..., 2] = z0 + np.float32(cells / 128.0)
+        st["ppos"][..., 2] = st["x"][:, N // 3, 2][:, None]
+        base_z = int(np.floor(st["x"][..., 2].min() * 128 - 0.5))
+        of = orc.step_fwd(st, nthreads=2)
+        for _ in range(2):
+            oh = run_hip(sim, st)
+            assert _rel(oh["x"], of["x"]) < 5e-6 and _rel(oh["v"], of["v"]) < 1e-4, (cells, base_z & 31)
+            assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5, (cells, base_z & 31)
+
+
 def test_grid_checkpoint_pool_overflow_falls_back_to_recompute():
     """A pool of 1 record per particle and substep holds the compact rope (measured 0.58 active cells per particle) but not the
     same particles scattered through the volume (up to 27 cells each): the forward flags the env in status[], the host mirror

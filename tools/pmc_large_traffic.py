@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import src_hash
 
 FWD = ("lg_clear_fk", "lg_p2g<", "lg_grid", "lg_g2p<", "lg_sort", "lg_pack", "lg_unpack", "lg_fwd_out", "lg_prim_in")
-BWD = ("lg_restore", "lg_g2p_adj", "lg_grid_adj", "lg_p2g_adj", "lg_bwd_in", "lg_bwd_out")
+BWD = ("lg_restore", "lg_g2p_adj", "lg_grid_adj", "lg_p2g_adj", "lg_bwd_in", "lg_bwd_norm", "lg_bwd_out")
 rows = list(csv.DictReader(open(sys.argv[1])))
 name = sys.argv[2]
 dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
