@@ -315,9 +315,9 @@ def test_mpm_step_edge_cases_one_lane_kernels(demo, case, one_lane_per_particle)
 
 def test_full_batch_launch_agrees_with_the_oracle_checked_small_one():
     """Size-independent property at bench size: envs are independent, so env b of a 128-env launch (102 k particles -- past the
-    100 k threshold, i.e. the one-lane kernels and a single env group, what bench.py's large workloads run) must equal the same env
-    stepped in a 2-env launch (four-lane kernels, two env groups -- the configuration test_large_path_matches_oracle_n798 pins to
-    the oracle).  Forward and adjoint, grid checkpoint on."""
+    100 k threshold, i.e. the one-lane kernels, four env groups under position control: what bench.py's n_grid-256 workload runs)
+    must equal the same env stepped in a 2-env launch (four-lane kernels, one group -- the configuration
+    test_large_path_matches_oracle_n798 pins to the oracle).  Forward and adjoint, grid checkpoint on."""
     S = 5
     simL, stL, gL, N = _scaled_case(S, 3, B=128, grid_ckpt_cells=6)
     assert 128 * N >= 100000
