@@ -637,21 +637,28 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
         }
       }
     }
-  } else {
-#pragma unroll 1
-  for (int cidx = qi; cidx < 27; cidx += LANES) {
-    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
-    const float weight = sel3(w, 0, i) * sel3(w, 1, j) * sel3(w, 2, k);
-    const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
-    const float4 g4 = val[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
-    const float g[3] = {g4.y, g4.z, g4.w};
+  } else {   // four lanes per particle: the lane's seven cells (qi, qi + 4, ...) requested together, then used
+    float4 g7[7];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      nv[r] += weight * g[r];
-#pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+    for (int t = 0; t < 7; ++t) {
+      const int cidx = min(qi + 4 * t, 26);
+      g7[t] = val[cell_lin(c, cell_gather(c, base[0] + cidx / 9, base[1] + (cidx / 3) % 3, base[2] + cidx % 3))];
     }
-  }
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int cidx = qi + 4 * t;
+      if (cidx >= 27) break;
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const float weight = sel3(w, 0, i) * sel3(w, 1, j) * sel3(w, 2, k);
+      const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+      const float g[3] = {g7[t].y, g7[t].z, g7[t].w};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        nv[r] += weight * g[r];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+      }
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) nv[d] = lg_quad_sum<LANES>(nv[d]);
@@ -1004,17 +1011,28 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
     }
   } else {
   const int rot = (p * LANES) % 27;   // staggered stencil walk, as in lg_p2g: no two lanes of a run on the same table slot
-#pragma unroll 1
-  for (int it = qi; it < 27; it += LANES) {
+  // four lanes per particle: the lane's seven cells requested together, then used
+  int key7[7];
+  float4 v7[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int it = min(qi + 4 * t, 26);
+    const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
+    key7[t] = cell_gather(c, base[0] + cidx / 9, base[1] + (cidx / 3) % 3, base[2] + cidx % 3);
+    v7[t] = vel[cell_lin(c, key7[t])];
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int it = qi + 4 * t;
+    if (it >= 27) break;
     const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
     const float weight = wi * wj * wk;
     const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
-    const int gkey = cell_gather(c, base[0] + i, base[1] + j, base[2] + k);
+    const int gkey = key7[t];
     const long lin = cell_lin(c, gkey);
-    const float4 v4 = vel[lin];
-    const float vv[3] = {v4.x, v4.y, v4.z};
+    const float vv[3] = {v7[t].x, v7[t].y, v7[t].z};
     float gwt = 0.f;
     const int sl = bt_find<TH, TLOG>(bt, win, gkey);      // one lookup per cell (bt_add per component repeated it three times)
 #pragma unroll
