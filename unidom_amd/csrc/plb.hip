@@ -161,15 +161,30 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
   constexpr int PER = PLB_H / 256;
+  // value atomics: four lanes per cell, one per component -- a cell is 32 contiguous bytes (as in mpm_large.hip: one lane per cell
+  // and component put the 64 lanes of an atomic on 64 different lines)
+  {
+    const int r = threadIdx.x & 3;
+#pragma unroll 4
+    for (int sl = threadIdx.x >> 2; sl < PLB_H; sl += 64) {
+      const int key = s_key[sl];
+      if (key < 0) continue;
+      atomicAdd(val + (long)key * 4 + r, s_val[r * PLB_H + sl]);
+    }
+  }
   unsigned newmask = 0;
   int nnew = 0;
+  {
+    int old[PER], key[PER];
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int key = s_key[threadIdx.x + u * 256];
-    if (key < 0) continue;
+    for (int u = 0; u < PER; ++u) {   // the returning exchanges of a lane go out together
+      key[u] = s_key[threadIdx.x + u * 256];
+      old[u] = a.epoch;
+      if (key[u] >= 0) old[u] = atomicExch(&a.w.stamp[(long)b * a.G + key[u]], a.epoch);
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(val + (long)key * 4 + r, s_val[r * PLB_H + threadIdx.x + u * 256]);
-    if (atomicExch(&a.w.stamp[(long)b * a.G + key], a.epoch) != a.epoch) { newmask |= 1u << u; ++nnew; }
+    for (int u = 0; u < PER; ++u)
+      if (old[u] != a.epoch) { newmask |= 1u << u; ++nnew; }
   }
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
   __syncthreads();
@@ -225,19 +240,31 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   }
   const double* val = plb_buf(a, a.lb, b);
   double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;   // four lanes: the lane's seven cells requested together
 #pragma unroll 1
-  for (int cidx = qi; cidx < 27; cidx += LANES) {
-    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
-    const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
-    const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
-    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
-    const double* cell = val + plb_lin(c, ci, cj, ck) * 4;
-    const double g[3] = {cell[1], cell[2], cell[3]};
+  for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
+    double g7[BATCH][3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      nv[r] += weight * g[r];
+    for (int t = 0; t < BATCH; ++t) {
+      const int cidx = min(qi + LANES * (t0 + t), 26);
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+      const double* cell = val + plb_lin(c, ci, cj, ck) * 4;
+      g7[t][0] = cell[1]; g7[t][1] = cell[2]; g7[t][2] = cell[3];
+    }
 #pragma unroll
-      for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4 * c.inv_dx * weight * g[r] * dp[s2];
+    for (int t = 0; t < BATCH; ++t) {
+      const int cidx = qi + LANES * (t0 + t);
+      if (cidx >= 27) break;
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
+      const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        nv[r] += weight * g7[t][r];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4 * c.inv_dx * weight * g7[t][r] * dp[s2];
+      }
     }
   }
 #pragma unroll

@@ -85,15 +85,29 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   double* gacc = a.w.gacc + (long)b * a.G * 4;
   double gfx[3] = {0, 0, 0};
   const double k4 = 4 * c.inv_dx;
+  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;   // four lanes: the lane's seven cells requested together
 #pragma unroll 1
-  for (int cidx = qi; cidx < 27; cidx += LANES) {
+  for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
+  double g7[BATCH][3];
+  long lin7[BATCH];
+#pragma unroll
+  for (int t = 0; t < BATCH; ++t) {
+    const int cidx = min(qi + LANES * (t0 + t), 26);
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+    lin7[t] = plb_lin(c, ci, cj, ck);
+    g7[t][0] = vout[lin7[t] * 4]; g7[t][1] = vout[lin7[t] * 4 + 1]; g7[t][2] = vout[lin7[t] * 4 + 2];
+  }
+#pragma unroll
+  for (int t = 0; t < BATCH; ++t) {
+    const int cidx = qi + LANES * (t0 + t);
+    if (cidx >= 27) break;
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
     const double weight = wi * wj * wk;
     const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
-    const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
-    const long lin = plb_lin(c, ci, cj, ck);
-    const double g[3] = {vout[lin * 4], vout[lin * 4 + 1], vout[lin * 4 + 2]};
+    const long lin = lin7[t];
+    const double g[3] = {g7[t][0], g7[t][1], g7[t][2]};
     double gw = 0, gdp[3] = {0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -106,6 +120,7 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
     gfx[0] += gw * dsel3(dw, 0, i) * wj * wk - gdp[0];
     gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - gdp[1];
     gfx[2] += gw * wi * wj * dsel3(dw, 2, k) - gdp[2];
+  }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) gfx[d] = plb_quad_sum<LANES>(gfx[d]);
