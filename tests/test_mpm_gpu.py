@@ -124,17 +124,16 @@ def test_bwd_matches_oracle(demo, clip, material, S, k):
 def test_config4_default_shape_32_envs_70_substeps_matches_oracle(demo):
     """BASELINE config 4's default launch shape (whip_rope: 256 envs over 8 GPUs = 32 envs per GPU, N = 67, res 32^3, 70
     substeps per step): 32 different rope states / actions / parameters in one launch, one full `step` forward and adjoint,
-    against the CPU oracle env by env.  Forward: the single-env tolerances.  Adjoint: most envs agree with the f64 oracle to
-    ~1e-4 (median over the 32 envs: gx 2e-5, gF 1e-4), a few do not: the reference's SVD cotangent (svd_safe_batch.py:65-102)
-    carries 1 / (s_j^2 - s_i^2), and a particle whose singular values nearly cross (measured on the worst env at 3 substeps:
-    1.1116 / 1.1095, factor 212) turns a 1e-6 difference of the FORWARD state (p2g summation order, FMA: the kernel's C agrees
-    with the oracle's to 1e-3, F to 5e-5) into a percent-level difference of that particle's cotangent; over 70 reverse substeps
-    some particle of some env passes such a crossing (tools/diag_config4*.py: worst gF 7e-4 / 3e-3 / 5e-3 / 4e-2 after 3 / 20 /
-    50 / 70 substeps, always in the env whose particle has the smallest gap; 5, 6 or 8 Jacobi sweeps instead of 4 change the
-    3-substep figure to the f32 oracle's own 2e-4 and leave the 70-substep one at 4-5e-2).  The restatement's own f32 adjoint
-    stays at 2e-4 only because its forward shares the f64 run's operation order.  The reference on a GPU (XLA f32, cuSOLVER)
-    is in the kernel's position, not the oracle's.  Hence: median per output 1e-3, every env within 1e-1, and the action
-    cotangent -- what APG consumes -- within 2e-3 in every env."""
+    against the CPU oracle env by env.  Forward: the single-env tolerances.  Adjoint: every env within 2e-3 of the f64 oracle on
+    every output (measured worst env: gx 1.9e-4, gF 2.3e-4, gaction 2.3e-5 -- the same figures as the restatement's own f32 run,
+    i.e. what 70 substeps of f32 forward state cost).
+    History, because the earlier criterion was wrong about the cause: until round 2 a few envs were off by percents (worst gF
+    7e-4 / 3e-3 / 5e-3 / 4e-2 after 3 / 20 / 50 / 70 substeps, tools/diag_config4*.py) and the test asked for a median of 1e-3 and
+    1e-1 at worst, blaming the 1 / (s_j^2 - s_i^2) of the reference's SVD cotangent (svd_safe_batch.py:65-102) for amplifying
+    forward differences.  The factor is there, but what it amplified was the kernel's own rounding: the rotation's cotangent
+    enters that VJP as two matrix products whose antisymmetric parts cancel only in exact arithmetic (mpm_device.h,
+    particle_adjoint).  Evaluated in closed form -- (W - W^T)_ij (S_j - S_i) / (S_j^2 - S_i^2) from ONE product W -- the outliers
+    are gone and the result no longer depends on how the compiler schedules the products."""
     from oracle.pyoracle import MpmOracle
     S, B = 70, 32
     rng = np.random.default_rng(4)
@@ -157,9 +156,7 @@ def test_config4_default_shape_32_envs_70_substeps_matches_oracle(demo):
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
         assert np.isfinite(oh[key]).all(), key
         errs = np.array([_rel(oh[key][b], ob[key][b]) for b in range(B)])
-        assert np.median(errs) < 1e-3 and errs.max() < 1e-1, (key, np.median(errs), errs.max(), int(errs.argmax()))
-        if key == "gaction":
-            assert errs.max() < 2e-3, (key, errs.max())
+        assert errs.max() < (2e-4 if key == "gaction" else 2e-3), (key, np.median(errs), errs.max(), int(errs.argmax()))
     assert _rel(ob32["gF"], ob["gF"]) < 2e-3           # the restatement's own f32 adjoint, for the record (see the docstring)
     for key in ("gfriction", "gmu", "glamda"):
         assert _rel(oh[key].reshape(-1), ob[key]) < 5e-2, (key, oh[key].reshape(-1), ob[key])
@@ -361,7 +358,9 @@ def test_baseline_config4_size_n_grid_256_matches_oracle(grid_ckpt_cells):
         np.testing.assert_allclose(oh[key][pick], of[key], rtol=0, atol=1e-7)
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
         assert np.isfinite(oh[key]).all(), key
-        assert _rel(oh[key][pick], ob[key]) < 5e-3, (key, _rel(oh[key][pick], ob[key]))
+        # 5e-4: measured 1e-5 ... 2e-5.  With the SVD cotangent evaluated literally this test sat at 9e-5 and jumped to 4e-2 (gC, gF:
+        # one particle in a hundred off by up to 30 %) when an unrelated edit changed the compiler's schedule -- see particle_adjoint
+        assert _rel(oh[key][pick], ob[key]) < 5e-4, (key, _rel(oh[key][pick], ob[key]))
     for key in ("gfriction", "gmu", "glamda"):
         assert _rel(oh[key].reshape(-1)[pick], ob[key]) < 2e-2, (key, oh[key].reshape(-1)[pick], ob[key])
 

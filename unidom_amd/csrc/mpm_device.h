@@ -409,31 +409,58 @@ __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q
   const float trg = gS[0] + gS[4] + gS[8];
   const float gJ = kb.la * (2.f * kb.Jd - 1.f) * trg;
   gla_p = kb.Jd * (kb.Jd - 1.f) * trg;
-  float gU[9], gVh[9], gR[9];
+  // R = U Vh.  Its cotangent gR enters the SVD VJP (svd_safe_batch.py:65-102) as dU = gR Vh^T and dVh = U^T gR, for which
+  // U^T dU = W and V^T dV = W^T with W = U^T gR Vh^T, and the off-diagonal of the VJP's middle factor collapses to
+  // F_ij (S_j - S_i) (W_ij - W_ji), F_ij = 1 / (S_j^2 - S_i^2) (regularised: safe_inv).  Evaluated literally -- W and W^T as two
+  // separate products, their antisymmetric parts times S_j and S_i added, the sum times F_ij -- the roundings of the two
+  // products do not cancel and F_ij amplifies them by 1 / (S_j - S_i): percent-level errors on the particles whose singular
+  // values are close (F = I + 1 % noise: about one particle in a hundred), and which of them depends on how the compiler
+  // schedules the products (measured: the same source with two unrelated branches added moved the worst particle's error in gF
+  // from 3e-4 to 0.18 at n_grid 256).  The rotation part is therefore taken in this closed form, with the same regularised F_ij;
+  // the plastic projection's U S' Vh (material 2) gets the same treatment below; svd3_bwd, the literal VJP, is kept for reference only.
+  float gR[9], T2[9], W[9], MR[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) gR[d] = -gA[d];
-  m_mul_bt(gR, kb.Vh, gU);
-  m_mul_at(kb.U, gR, gVh);
-  float gsig[3] = {gJ * kb.sig[1] * kb.sig[2], gJ * kb.sig[0] * kb.sig[2], gJ * kb.sig[0] * kb.sig[1]};
-  float gFu[9];
-  if (material == 2) {
-    float US[9], SV[9], T2[9];
+  m_mul_at(kb.U, gR, T2);
+  m_mul_bt(T2, kb.Vh, W);
+  // S_j^2 - S_i^2 is formed as (S_j - S_i)(S_j + S_i): the difference of two close floats is exact, the difference of their
+  // rounded squares is not (at a gap of 1e-5 it is off by a percent, and F_ij with it)
+  float Fx[9], dS[9];
+  {
+    const float* S = kb.sig_raw;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { US[i * 3 + j] = kb.U[i * 3 + j] * kb.sig[j]; SV[i * 3 + j] = kb.Vh[i * 3 + j] * kb.sig[i]; }
-    m_mul_bt(gFn, SV, T1);
-#pragma unroll
-    for (int d = 0; d < 9; ++d) gU[d] += T1[d];
-    m_mul_at(US, gFn, T1);
-#pragma unroll
-    for (int d = 0; d < 9; ++d) gVh[d] += T1[d];
+      for (int j = 0; j < 3; ++j) {
+        dS[i * 3 + j] = S[j] - S[i];
+        Fx[i * 3 + j] = (i == j) ? 0.f : safe_inv(dS[i * 3 + j] * (S[j] + S[i]));
+        MR[i * 3 + j] = Fx[i * 3 + j] * dS[i * 3 + j] * (W[i * 3 + j] - W[j * 3 + i]);
+      }
+  }
+  float gsig[3] = {gJ * kb.sig[1] * kb.sig[2], gJ * kb.sig[0] * kb.sig[2], gJ * kb.sig[0] * kb.sig[1]};
+  float gFu[9], dA[9];
+  if (material == 2) {
+    // Fn = U diag(s') Vh, s' = clip(S): its cotangent gFn reaches U and Vh as dU = gFn Vh^T diag(s'), dVh = diag(s') U^T gFn, i.e.
+    // U^T dU = P diag(s') and V^T dV = P^T diag(s') with P = U^T gFn Vh^T -- again one product instead of two, the VJP's
+    // off-diagonal becomes F_ij [P_ij (s'_j S_j - s'_i S_i) + P_ji (S_i s'_j - S_j s'_i)], its diagonal the clipped singular
+    // values' cotangent.  With c = s' - S (exactly zero where the clip is inactive) the two brackets are
+    // (S_j c_j - S_i c_i) + (S_j - S_i)(S_j + S_i) and S_i c_j - S_j c_i: an unclipped pair contributes F_ij x P_ij, x = S_j^2 - S_i^2.
+    float P[9];
     m_mul_at(kb.U, gFn, T1);
-    m_mul_bt(T1, kb.Vh, T2);
+    m_mul_bt(T1, kb.Vh, P);
+    const float* S = kb.sig_raw;
+    const float cl[3] = {kb.sig[0] - S[0], kb.sig[1] - S[1], kb.sig[2] - S[2]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      gsig[i] += T2[i * 4];
+      gsig[i] += P[i * 4];
       gsig[i] *= clip_grad(kb.sig_raw[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (i != j) {
+          const float Aij = (S[j] * cl[j] - S[i] * cl[i]) + dS[i * 3 + j] * (S[j] + S[i]);
+          const float Bij = S[i] * cl[j] - S[j] * cl[i];
+          MR[i * 3 + j] += Fx[i * 3 + j] * (P[i * 3 + j] * Aij + P[j * 3 + i] * Bij);
+        }
     }
 #pragma unroll
     for (int d = 0; d < 9; ++d) gFu[d] = 0.f;
@@ -441,8 +468,10 @@ __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q
 #pragma unroll
     for (int d = 0; d < 9; ++d) gFu[d] = gFn[d];
   }
-  float dA[9];
-  svd3_bwd(kb.U, kb.sig_raw, kb.Vh, gU, gsig, gVh, dA);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) MR[i * 4] = gsig[i];   // the VJP is U (diag(gsig) + off-diagonal) Vh: U, Vh are orthogonal, the projector terms of :95-102 vanish
+  m_mul(kb.U, MR, T1);
+  m_mul(T1, kb.Vh, dA);
 #pragma unroll
   for (int d = 0; d < 9; ++d) gFu[d] += dA[d];
   // Fu = (I + dt C) F
