@@ -1301,7 +1301,8 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   // z-fastest -- loaded together before any of them is used (one cell per trip left a single 16-B gather in flight per wave, at
   // two waves per SIMD: the walk was 63 % of this kernel, profiles/r02e_lg_stamps_pour_soup.txt).  (A whole i plane, nine loads,
   // in flight needs 67 more registers than two waves per SIMD have: spilled it gained 4 us of 52 on pour_soup; parking the SVD
-  // factors in LDS across the gather instead gave wrong gradients -- cause not found -- and was dropped.)
+  // factors in LDS across the gather instead (48 us) moved gF by 14 % on a test: in hindsight the schedule dependence of the SVD
+  // cotangent as it was then evaluated (particle_adjoint, fixed since), not the park; not retried.)
   if (LANES == 1) {
 #pragma unroll 1
     for (int col = 0; col < 9; ++col) {
