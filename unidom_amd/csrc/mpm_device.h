@@ -418,27 +418,25 @@ __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q
   // schedules the products (measured: the same source with two unrelated branches added moved the worst particle's error in gF
   // from 3e-4 to 0.18 at n_grid 256).  The rotation part is therefore taken in this closed form, with the same regularised F_ij;
   // the plastic projection's U S' Vh (material 2) gets the same treatment below; svd3_bwd, the literal VJP, is kept for reference only.
-  float gR[9], T2[9], W[9], MR[9];
+  float T2[9], MR[9];
 #pragma unroll
-  for (int d = 0; d < 9; ++d) gR[d] = -gA[d];
-  m_mul_at(kb.U, gR, T2);
-  m_mul_bt(T2, kb.Vh, W);
+  for (int d = 0; d < 9; ++d) MR[d] = 0.f;
+  m_mul_at(kb.U, gA, T2);     // gR = -gA (A = Fn - R): W = -(T2 Vh^T); only its antisymmetric part is needed
   // S_j^2 - S_i^2 is formed as (S_j - S_i)(S_j + S_i): the difference of two close floats is exact, the difference of their
-  // rounded squares is not (at a gap of 1e-5 it is off by a percent, and F_ij with it)
-  float Fx[9], dS[9];
-  {
-    const float* S = kb.sig_raw;
+  // rounded squares is not (at a gap of 1e-5 it is off by a percent, and F_ij with it).  Three pairs (i < j); F and S_j - S_i are odd.
+  const float* S = kb.sig_raw;
+  float dS[3], Fx[3];   // pairs (0,1), (0,2), (1,2)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        dS[i * 3 + j] = S[j] - S[i];
-        Fx[i * 3 + j] = (i == j) ? 0.f : safe_inv(dS[i * 3 + j] * (S[j] + S[i]));
-        MR[i * 3 + j] = Fx[i * 3 + j] * dS[i * 3 + j] * (W[i * 3 + j] - W[j * 3 + i]);
-      }
+  for (int pr = 0; pr < 3; ++pr) {
+    const int i = pr == 2 ? 1 : 0, j = pr == 0 ? 1 : 2;
+    dS[pr] = S[j] - S[i];
+    Fx[pr] = safe_inv(dS[pr] * (S[j] + S[i]));
+    const float wa = (T2[i * 3] * kb.Vh[j * 3] - T2[j * 3] * kb.Vh[i * 3]) + (T2[i * 3 + 1] * kb.Vh[j * 3 + 1] - T2[j * 3 + 1] * kb.Vh[i * 3 + 1]) +
+                     (T2[i * 3 + 2] * kb.Vh[j * 3 + 2] - T2[j * 3 + 2] * kb.Vh[i * 3 + 2]);   // -(W_ij - W_ji)
+    const float m = -(Fx[pr] * dS[pr] * wa);
+    MR[i * 3 + j] = m; MR[j * 3 + i] = -m;
   }
   float gsig[3] = {gJ * kb.sig[1] * kb.sig[2], gJ * kb.sig[0] * kb.sig[2], gJ * kb.sig[0] * kb.sig[1]};
-  float gFu[9], dA[9];
   if (material == 2) {
     // Fn = U diag(s') Vh, s' = clip(S): its cotangent gFn reaches U and Vh as dU = gFn Vh^T diag(s'), dVh = diag(s') U^T gFn, i.e.
     // U^T dU = P diag(s') and V^T dV = P^T diag(s') with P = U^T gFn Vh^T -- again one product instead of two, the VJP's
@@ -448,33 +446,30 @@ __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q
     float P[9];
     m_mul_at(kb.U, gFn, T1);
     m_mul_bt(T1, kb.Vh, P);
-    const float* S = kb.sig_raw;
     const float cl[3] = {kb.sig[0] - S[0], kb.sig[1] - S[1], kb.sig[2] - S[2]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       gsig[i] += P[i * 4];
       gsig[i] *= clip_grad(kb.sig_raw[i], 1.f - 2.5e-2f * 10.f, 1.f + 4.5e-3f * 100.f);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (i != j) {
-          const float Aij = (S[j] * cl[j] - S[i] * cl[i]) + dS[i * 3 + j] * (S[j] + S[i]);
-          const float Bij = S[i] * cl[j] - S[j] * cl[i];
-          MR[i * 3 + j] += Fx[i * 3 + j] * (P[i * 3 + j] * Aij + P[j * 3 + i] * Bij);
-        }
     }
 #pragma unroll
-    for (int d = 0; d < 9; ++d) gFu[d] = 0.f;
-  } else {
+    for (int pr = 0; pr < 3; ++pr) {
+      const int i = pr == 2 ? 1 : 0, j = pr == 0 ? 1 : 2;
+      const float Aij = (S[j] * cl[j] - S[i] * cl[i]) + dS[pr] * (S[j] + S[i]);
+      const float Bij = S[i] * cl[j] - S[j] * cl[i];
+      MR[i * 3 + j] += Fx[pr] * (P[i * 3 + j] * Aij + P[j * 3 + i] * Bij);
+      MR[j * 3 + i] += Fx[pr] * (P[j * 3 + i] * Aij + P[i * 3 + j] * Bij);   // F, A, B are odd in (i, j): the signs cancel
+    }
 #pragma unroll
-    for (int d = 0; d < 9; ++d) gFu[d] = gFn[d];
+    for (int d = 0; d < 9; ++d) gFn[d] = 0.f;   // Fn = U s' Vh: gFn reaches Fu only through the SVD
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) MR[i * 4] = gsig[i];   // the VJP is U (diag(gsig) + off-diagonal) Vh: U, Vh are orthogonal, the projector terms of :95-102 vanish
   m_mul(kb.U, MR, T1);
-  m_mul(T1, kb.Vh, dA);
+  m_mul(T1, kb.Vh, T2);
+  float* gFu = gFn;       // cotangent of Fu = (I + dt C) F
 #pragma unroll
-  for (int d = 0; d < 9; ++d) gFu[d] += dA[d];
-  // Fu = (I + dt C) F
+  for (int d = 0; d < 9; ++d) gFu[d] += T2[d];
   float IC[9];
   m_mul_bt(gFu, F, T1);
 #pragma unroll

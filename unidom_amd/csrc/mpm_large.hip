@@ -1384,6 +1384,20 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
     for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
 #pragma unroll
     for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+    // Fn is formed again here (as particle_pre forms it) instead of being held across the gather: nine registers fewer there
+    if (material == 2) {
+      float US[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) US[i * 3 + j] = kb.U[i * 3 + j] * kb.sig[j];
+      m_mul(US, kb.Vh, q.Fn);
+    } else {
+      float IC[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[i];
+      m_mul(IC, F, q.Fn);
+    }
   }
   float gmu_p, gla_p;
   particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
