@@ -162,6 +162,57 @@ def test_config4_default_shape_32_envs_70_substeps_matches_oracle(demo):
         assert _rel(oh[key].reshape(-1), ob[key]) < 5e-2, (key, oh[key].reshape(-1), ob[key])
 
 
+def _nearly_equal_singular_values(rng, n, gaps=(1e-3, 1e-4, 3e-5)):
+    """F = Q1 diag(s) Q2 with random rotations and singular values that differ by `gaps` (relative) -- where the SVD cotangent's
+    1 / (s_j^2 - s_i^2) is 5e2 ... 2e4."""
+    def rot(k):
+        q, r = np.linalg.qr(rng.normal(size=(k, 3, 3)))
+        q = q * np.sign(np.linalg.det(q))[:, None, None]
+        return q
+    base = rng.uniform(0.95, 1.05, size=n)
+    gap = np.asarray(gaps)[rng.integers(0, len(gaps), size=(n, 2))]
+    sv = np.stack([base, base * (1 + gap[:, 0]), base * (1 + gap[:, 0]) * (1 + gap[:, 1])], 1)
+    return (rot(n) * sv[:, None, :]) @ rot(n)
+
+
+@pytest.mark.parametrize("material", [1, 2])
+def test_adjoint_with_nearly_equal_singular_values(demo, material):
+    """Every particle's F has singular values 1e-3 ... 3e-5 apart.  The reference's SVD cotangent applied literally lost
+    eps / gap there (two products whose antisymmetric parts cancel only in exact arithmetic, times 1 / (s_j^2 - s_i^2)): percent
+    errors; the closed form of particle_adjoint does not.  One-workgroup kernels, f64 oracle."""
+    from oracle.pyoracle import MpmOracle
+    S = 3
+    st, g = _adjoint_case(demo, S, 40, material, 0, np.float32)
+    st["F"] = _nearly_equal_singular_values(np.random.default_rng(7), 67)[None].astype(np.float32)
+    st64 = {kk: v.astype(np.float64) for kk, v in st.items()}
+    ob = MpmOracle(67, steps=S, material=np.full(67, material)).step_bwd(st64, {kk: v.astype(np.float64) for kk, v in g.items()}, clip=False)
+    oh = run_hip(make_sim(S, 1, material), st, g=g, clip=False)
+    for key in ("gx", "gv", "gC", "gF", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        per = np.linalg.norm((oh[key][0] - ob[key][0]).reshape(len(ob[key][0]), -1), axis=1) / (np.linalg.norm(ob[key][0].reshape(len(ob[key][0]), -1), axis=1) + 1e-30) \
+            if key != "gaction" else np.array([_rel(oh[key], ob[key])])
+        assert _rel(oh[key], ob[key]) < 5e-4, (key, _rel(oh[key], ob[key]))
+        if key in ("gC", "gF"):
+            assert per.max() < 5e-3, (key, per.max(), int(per.argmax()))     # no particle left behind
+
+
+def test_adjoint_with_nearly_equal_singular_values_many_workgroups(one_lane_per_particle):
+    """The same on the many-workgroup path (N = 798, one lane per particle: lg_p2g_adj<1>, the kernel whose register pressure is
+    the tightest and whose schedule the literal form's error depended on)."""
+    from oracle.pyoracle import MpmOracle
+    S = 3
+    sim, st, g, N = _scaled_case(S, 5, B=2)
+    st["F"] = np.stack([_nearly_equal_singular_values(np.random.default_rng(8 + b), N) for b in range(2)]).astype(np.float32)
+    orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()}, clip=False, nthreads=2)
+    oh = run_hip(sim, st, g=g, clip=False)
+    for key in ("gx", "gv", "gC", "gF", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+        assert _rel(oh[key], ob[key]) < 5e-4, (key, _rel(oh[key], ob[key]))
+    per = np.linalg.norm((oh["gF"] - ob["gF"]).reshape(2, N, 9), axis=2) / (np.linalg.norm(ob["gF"].reshape(2, N, 9), axis=2) + 1e-30)
+    assert per.max() < 5e-3, (per.max(), np.unravel_index(per.argmax(), per.shape))
+
+
 @pytest.mark.parametrize("N", [30, 64, 96, 97, 128])
 def test_particle_counts_cover_both_adjoint_kernels(demo, N):
     """N <= 96 runs the wave-specialised adjoint (particle waves + stencil waves), 97..128 the single-mapping one;
