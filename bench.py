@@ -123,6 +123,13 @@ def dist_info(world, allreduce_params=0):
             "allreduce_bytes_per_update": allreduce_params * 4 if world > 1 else 0}
 
 
+def lg_label(dom, grid_ckpt_cells):
+    """kernels per substep of the many-workgroup MPM path: forward clear+FK, p2g, grid op, g2p; backward restore, g2p adjoint, grid-op
+    adjoint, p2g adjoint with the grid checkpoint, clear, p2g, grid op and the three adjoints without"""
+    n = 4 if dom == "fwd" or grid_ckpt_cells > 0 else 6
+    return f"mpm large path ({dom}: {n} kernels/substep)"
+
+
 def pmc_traffic(key):
     """HBM bytes per launch from the committed counter passes (profiles/pmc_traffic.json), or None when there is no
     entry or the kernel sources have changed since the passes were taken (the entry carries their hash)."""
@@ -282,7 +289,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world, learner.n_params),
             "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)" if env.simulator.n_primitive > 1 or N > 128 else
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator.grid_ckpt_cells) if env.simulator.n_primitive > 1 or N > 128 else
                          ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
@@ -449,7 +456,7 @@ def bench_mpm_scaled(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"whip_rope rope seeded at n_grid={ng} (N={N}, res {ng // 2}^3, {S} substeps/step), "
                                    f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, sim.grid_ckpt_cells),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(f"large_path:whip_rope_ngrid{ng}:{dom}") if B == 32 else None,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch}}), flush=True)
@@ -633,7 +640,7 @@ def bench_shape_rope(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"shape_rope (MLS-MPM plastic rope N={N}, res 64x6x64, soft contact, {T} x {S} substeps/env.step) "
                                    f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": f"mpm large path ({dom}: {4 if dom == 'fwd' else 7} kernels/substep)",
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator.grid_ckpt_cells),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
                          "note": "latency bound: 11 small kernels per substep pair on 32 x 582 particles, two env groups on two streams"},
