@@ -1577,13 +1577,14 @@ struct MpmLarge {
 // number of env groups for a launch of B envs.  Measured (1x MI355X, substeps/s forward+backward, groups 1 / 2 / 4): rope at n_grid 256
 // (32 envs x 6675, position control, one lane per particle) 123 k / 144 k / 151 k -- its grid kernels are short launches of a few hundred
 // blocks and leave the chip to the other groups' particle kernels; pour_soup (32 x 7631, soft contact) 76.0 k / 77.5 k / 74.5 k; the
-// four-lane launches (rope at n_grid 128, shape_rope, pour_water) are best at 2 and lose 5-20 % at 4.
+// four-lane launches are best at 2 (rope at n_grid 128 +6 %, shape_rope +3 %) and lose 5-20 % at 4 -- except pour_water (two container
+// primitives: the grid kernels, not the particle kernels, carry its substep): 231 k in one group, 199-227 k from run to run in two.
 static int lg_groups(const MpmLarge* L, int B) {
   static const int forced = [] { const char* e = getenv("UD_LG_GROUPS"); return e ? atoi(e) : 0; }();   // diagnostic override
   if (!L->ev_fork) return 1;
   const long particles = (long)B * L->c.N;
   int want = 1;
-  if (particles <= 50000) want = LG_GROUPS;                              // four-lane kernels, up to 200 k lanes
+  if (particles <= 50000) want = L->c.n_prim >= 2 ? 1 : LG_GROUPS;     // four-lane kernels, up to 200 k lanes (two collide passes per cell: below)
   if (particles >= 100000) want = L->c.position_control ? 4 : LG_GROUPS;   // one-lane kernels (measurements above)
   if (forced > 0) want = forced;
   if (want <= 1 || B < 2 * want) return 1;
