@@ -29,7 +29,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 assert L.ud_debug_lg_stamps(buf, 0) == 0
 t = np.array(list(buf), dtype=np.float64).reshape(4, 8)
-names = {0: ("lg_p2g<1>", ["clear + state loads", "pre-pass (SVD, stress)", "window reduction + barriers", "27-cell walk", "barrier before flush", "flush atomics + stamps", "list append"]),
+names = {0: ("lg_p2g<1>", ["clear + state loads", "pre-pass (SVD, stress)", "window reduction + barriers", "27-cell walk", "barrier before flush", "flush atomics + bitmap OR", "list append"]),
          1: ("lg_g2p_adj<1>", ["clear + x loads", "window reduction + barriers (cotangent loads under them)", "scatter walk (table adds)", "gather walk (velocity loads)", "scratch stores", "barrier before flush", "flush atomics"]),
          2: ("lg_p2g_adj<1>", ["state loads", "pre-pass + adjoint extras", "cotangent loads", "27-cell gather", "particle adjoint + stores"]),
          3: ("lg_grid_adj (soft contact, per 256-cell tile)", ["list / checkpoint / cotangent loads", "collide chains + adjoints (all primitives)", "wave sums + barriers + block atomics (all primitives)", "head adjoint + store"])}
