@@ -69,16 +69,30 @@ typedef struct {
                     *    of that order) AND reference-order adjoint (six reductions per substep);
                     * 2: v2 structure with fast-math (v_rsq, FMA) forward + restructured adjoint (f32 round-off
                     *    differences, which this stiff system amplifies over long rollouts -- see DESIGN.md).
-                    * Bodies above 1024 particles always run the reference-order forward. */
+                    * Bodies above 1024 particles: modes 0 / 2 run the v2-order forward and the restructured adjoint on
+                    *    SEVERAL workgroups per env (512 particles each, halo positions / force cotangents / block sums handed
+                    *    over through HBM every substep; forward still bit-identical to the v2 restatement); mode 1 runs the
+                    *    reference-order kernels on one 1024-lane workgroup per env. */
 } ud_cloth_conf;
 
 /* mask: host pointer, N*N bytes, row-major, non-zero = cloth particle (create_cloth_mask,
  * fold_cloth1_env.py:48-53).  Particle order = row-major nonzero(mask) (cloth_simulator.py:52).
- * Limits: 1 <= P <= 4096 (P <= 1024: one particle per lane; above: up to four particles per lane, one workgroup
- * per env); the mask must not touch the lattice border (UD_ERR_UNSUPPORTED otherwise). */
+ * Limits: 1 <= P <= 4096 (P <= 1024: one workgroup per env, one particle per lane; above: ceil(P / 512) workgroups per
+ * env, one particle per lane -- a call is cut into launches of ud_cloth_launch_envs() envs so that the workgroups that
+ * wait for each other are resident together -- or, in mode 1 / when a spring spans more than 256 particle indices, one
+ * workgroup per env with up to four particles per lane); the mask must not touch the lattice border
+ * (UD_ERR_UNSUPPORTED otherwise). */
 int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** out);
 void ud_cloth_destroy(ud_cloth* h);
 int ud_cloth_num_particles(const ud_cloth* h);
+/* envs per kernel launch of a call with B envs (B itself unless the several-workgroup kernels run: then at most
+ * 8 * floor((CUs / 8) / parts), every XCD holding whole envs) */
+int ud_cloth_launch_envs(const ud_cloth* h, int B);
+/* Several-workgroup kernels only: a part that waits for a sibling longer than ~seconds gives up, the env's outputs are
+ * NaN and a device-side counter is raised.  This call SYNCHRONISES `stream`, returns the number of such workgroups
+ * since the previous call (0 = none; also 0 for handles that never take that path; ud_last_error() holds the text
+ * otherwise) and resets the counter.  The rollout calls themselves stay asynchronous and return UD_OK. */
+int ud_cloth_poll_timeouts(ud_cloth* h, void* stream);
 /* bytes of the per-substep checkpoint arena a forward rollout of T macro steps x B envs writes */
 size_t ud_cloth_ckpt_bytes(const ud_cloth* h, int B, int T);
 

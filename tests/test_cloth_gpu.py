@@ -433,7 +433,7 @@ def test_big_body_kernels_match_oracle(which, path, monkeypatch):
 def test_big_body_call_with_more_envs_than_fit_at_once_is_cut_into_launches():
     """The parts of a several-workgroup launch wait for each other, so all of them must be resident together: a call with more
     envs than floor(CUs / parts) is cut into launches on the caller's stream (csrc/cloth.hip).  38 T-shirt envs x 7 parts =
-    266 workgroups > 256 CUs -> two launches (36 + 2 envs); every env must equal the oracle's, forward bit for bit, whichever
+    266 workgroups > 256 CUs -> two launches (32 + 6 envs: whole envs per XCD); every env must equal the oracle's, forward bit for bit, whichever
     launch it was in, and the cotangents of the per-macro-step outputs must land in the right env."""
     import os
     import unidom_amd.envs as envs
@@ -444,7 +444,13 @@ def test_big_body_call_with_more_envs_than_fit_at_once_is_cut_into_launches():
     conf = BigConf()
     conf.substeps = S
     sim = ClothSimulator(conf, B, lambda x, v, i, j: v, mask)
-    assert torch.cuda.get_device_properties(0).multi_processor_count // 7 < B
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert n_cu // 7 < B
+    # the parts of an env share an XCD (cl_decode) and the adjoint kernel fits once per CU: a launch may hold at most
+    # floor((CUs / 8) / parts) envs per XCD (the chip-wide floor(CUs / parts) = 36 over-subscribed four XCDs: 35 workgroups on 32 CUs)
+    per = sim.launch_envs(B)
+    assert per == 8 * ((n_cu // 8) // 7) and -(-per // 8) * 7 <= n_cu // 8, per
+    assert sim.launch_envs(3) == 3
     orc = ClothOracle(mask, N=180, order=2, substeps=S, **{k: getattr(BigConf, k) for k in ("gravity", "damping", "dt", "max_v", "small_num")})
     rng, case = _big_case(mask, B, T, 21)
     P = int(mask.sum())
@@ -456,9 +462,10 @@ def test_big_body_call_with_more_envs_than_fit_at_once_is_cut_into_launches():
     for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
         np.testing.assert_array_equal(h[key], o[key], err_msg=key)
     for key in ("gx", "gv", "gprim", "gk", "gmu"):
-        for b in (0, 35, 36, 37):              # the last env of the first launch, the two of the second
+        for b in (0, 31, 32, 37):              # the first and last env of either launch
             assert _rel(h[key][b], ob[key][b]) < 1e-3, (key, b, _rel(h[key][b], ob[key][b]))
     assert _rel(h["gactions"], ob["gactions"]) < 1e-3
+    sim.check_status()                         # no part gave up a poll
 
 
 @pytest.mark.parametrize("T,S,normalize,lists", [(1, 1, True, False), (2, 3, False, True), (1, 4, False, False), (3, 2, True, True)])

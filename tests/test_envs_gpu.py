@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -572,6 +572,45 @@ def test_mpm_step_diff_fused_matches_op_by_op(name):
         close(grad_f[k], grad_u[k], grad_r[k], "grad " + k, 2e-3, min_scale=1e-3 * gmax)
     assert not bad, bad
     assert name == "shape_rope" or not ({"grad a", "grad x", "grad v", "grad pos0"} & set(skipped)), skipped
+
+
+SHAPE_ROPE_WIRING_STEPS = 2   # scanned simulator.steps (133 substeps each) of the gradient wiring check below; the longest
+                              # horizon at which the measured one-ulp noise of the adjoint stays under 5 % (profiles/r03_shape_rope_grad_noise.txt)
+
+
+@pytest.mark.gpu
+def test_shape_rope_step_diff_gradient_wiring_short_horizon(monkeypatch):
+    """The full shape_rope env.step (30 x 133 plastic, contacting substeps) has a chaotic adjoint, so the test above compares its
+    values only.  The cotangent ROUTES of the fused step_diff on that env -- shift -> actions (process_pre_step_actions adds it to
+    both end points), primitive position, the push action through 2 scanned steps, x / v / C / F -- are checked here at a horizon
+    where the adjoint is well conditioned (tools/shape_rope_grad_noise.py measures the noise per horizon): fused against op-by-op,
+    every gradient, against the measured sensitivity to a one-ulp move of the cloud."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import shape_rope_grad_noise as srg
+    from unidom_amd.envs import shape_rope_env as sre
+    monkeypatch.setattr(sre.DefaultConf, "primitive_action_steps", sre.DefaultConf.primitive_action_steps)   # restored afterwards
+    T, B = SHAPE_ROPE_WIRING_STEPS, 3
+    env, st = srg.make_env(T, B)
+    act = srg.push_action(st, T, env.device)
+    gf, of = srg.grads(env, st, act, env.step_diff)
+    gu, ou = srg.grads(env, st, act, env.step_diff_unfused)
+    gr, _ = srg.grads(env, st, act, env.step_diff_unfused, nudge=2.0 ** -24)
+    env.simulator.check_status()
+    for k in ("x", "v", "reward"):
+        assert srg.rel(of[k], ou[k]) < 1e-4, (k, srg.rel(of[k], ou[k]))
+    gmax = max(float(t.abs().max()) for t in gu.values())
+    bad = []
+    for k in gu:
+        assert torch.isfinite(gf[k]).all() and float(gu[k].abs().max()) > 0, k
+        scale = max(float(gu[k].abs().max()), 1e-3 * gmax)
+        err, noise = float((gf[k] - gu[k]).abs().max()) / scale, float((gr[k] - gu[k]).abs().max()) / scale
+        assert noise < 0.05, (k, noise, "the horizon is too long for a wiring check: lower SHAPE_ROPE_WIRING_STEPS")
+        if not err <= 10 * noise + 2e-3:
+            bad.append((k, err, noise))
+    assert not bad, bad
+    assert float(gf["a"][:, [0, 2, 3, 5]].abs().min()) > 0        # both end points of the push receive a gradient
 
 
 @pytest.mark.gpu

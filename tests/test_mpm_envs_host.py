@@ -38,7 +38,7 @@ def test_shape_rope_push_expansion_matches_the_reference_lines():
         norm = np.float32(np.linalg.norm(end - start)) + np.float32(1e-8)
         vec = (end - start) / norm
         end = start + vec * np.clip(norm, 0.0, 0.3)
-        push = np.repeat(((end - start))[None], 30, 0) / np.float32(30)
+        push = np.repeat(((end - start))[None], 30, 0) * (np.float32(1.0) / np.float32(30))   # `/ num_sub_steps`, a literal under jit
         push[:, 1] = 0
         want = np.concatenate([push, np.zeros_like(push)], -1)
         np.testing.assert_allclose(sub[:, b].numpy(), want, rtol=0, atol=1e-8)
@@ -57,8 +57,9 @@ def test_pour_water_action_expansion_matches_the_reference_lines():
     assert sub.shape == (1, 4, 12)
     for b in range(4):                          # :79-88
         a = np.concatenate([acts[b], np.zeros(6, np.float32)])[None]
-        a[..., :3] = a[..., :3] / np.float32(500.0)
-        a[..., 3:6] = a[..., 3:6] / np.float32(500.0)
+        r500 = np.float32(1.0) / np.float32(500.0)   # `/ 500.0` under jit: XLA multiplies by the literal's f32 reciprocal
+        a[..., :3] = a[..., :3] * r500
+        a[..., 3:6] = a[..., 3:6] * r500
         a = a + np.float32(1e-12)
         a[..., 1] = 0
         np.testing.assert_array_equal(sub[:, b].numpy(), a)

@@ -105,7 +105,7 @@ def test_hip_matches_restatement_full_torus_state():
 
 @pytest.mark.gpu
 def test_hip_matches_restatement_quality_2():
-    """The same path at quality 2 (n_grid 128, dt 0.5e-4 / 1 -> 40 substeps per step, bench.py --workload torus --n-grid 128):
+    """The same path at quality 2 (n_grid 128, dt 0.5e-4 / 1 -> 39 substeps per step (int(2e-3 // 5e-5), float floor division), bench.py --workload torus --n-grid 128):
     ~1 particle per cell, the regime where the internal spatial order and the four-lane mapping matter most."""
     import torch
     from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
@@ -361,3 +361,57 @@ def test_hip_step_adjoint_one_lane_kernels(monkeypatch):
     beyond); UD_PLB_LANES=1 puts the one-lane instantiations in front of the twin too."""
     monkeypatch.setenv("UD_PLB_LANES", "1")
     test_hip_step_adjoint_matches_torch_twin(True)
+
+
+@pytest.mark.gpu
+def test_hip_smaller_batch_after_larger_stays_inside_the_callers_arrays():
+    """One handle, a call with B = 8 and then one with B = 3 (ud_plb_step_fwd / _bwd take B per call; the handle's arena keeps
+    the larger size): every [B] / [B, ...] array of the second call sits between canaries, and its results equal those of a
+    fresh handle that has only ever seen B = 3.  (The per-env guards of plb_prologue / plb_adj_epilogue once used the arena's
+    B: envs 3..7 of the epilogue's 64-thread block then wrote g_action, g_E, ... past the caller's arrays.)"""
+    import ctypes as C
+    import torch
+    from unidom_amd import _lib
+    N = 200
+    L = _lib.lib()
+    dev = torch.device("cuda")
+    CANARY = -7.25e11
+
+    def run(sim, B, seed):
+        x, v, Cm, F, prim, soft, act, E, nu, ys = _small_case(3, N, seed)
+        rep = lambda a: np.concatenate([a] * 3, 0)[:B]               # B envs out of the 3-env case, cyclically
+        ins = [rep(a) for a in (x, v, Cm, F, prim, soft, act, E, nu, ys)]
+        PAD = 4096
+        bufs = []
+
+        def guarded(shape, fill=None):
+            n = int(np.prod(shape))
+            buf = torch.full((n + 2 * PAD,), CANARY, dtype=torch.float64, device=dev)
+            t = buf[PAD:PAD + n].view(*shape)
+            if fill is not None:
+                t.copy_(torch.tensor(np.asarray(fill, np.float64), device=dev))
+            bufs.append((buf, n))
+            return t
+
+        gi = [guarded(a.shape, a) for a in ins]
+        xo, vo, Co, Fo, po = (guarded(a.shape) for a in ins[:5])
+        ck = guarded((L.ud_plb_ckpt_bytes(sim._h, C.c_int(B)) // 8,))
+        p = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.ud_plb_step_fwd(sim._h, C.c_int(B), *(p(t) for t in gi), p(xo), p(vo), p(Co), p(Fo), p(po), p(ck), st), "fwd")
+        rng = np.random.default_rng(5)
+        gouts = [guarded(a.shape, rng.normal(size=a.shape)) for a in ins[:5]]
+        og = [guarded(a.shape) for a in ins[:5]] + [guarded((B, 3)), guarded((B,)), guarded((B,)), guarded((B,)), guarded((B,))]
+        _lib.check(L.ud_plb_step_bwd(sim._h, C.c_int(B), p(ck), p(gi[5]), p(gi[6]), p(gi[7]), p(gi[8]), p(gi[9]),
+                                     *(p(t) for t in gouts), *(p(t) for t in og), st), "bwd")
+        torch.cuda.synchronize()
+        for buf, n in bufs:
+            assert (buf[:PAD] == CANARY).all() and (buf[PAD + n:] == CANARY).all(), "a kernel wrote outside the caller's array"
+        return [t.cpu().numpy().copy() for t in (xo, vo, Co, Fo, po, *og)]
+
+    big = _hip_sim(N, 8)
+    run(big, 8, 2)                       # the arena now holds 8 envs
+    got = run(big, 3, 3)
+    ref = run(_hip_sim(N, 3), 3, 3)
+    for g, r in zip(got, ref):
+        assert np.isfinite(g).all() and _rel(g, r) < 1e-9

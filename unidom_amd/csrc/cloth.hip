@@ -834,6 +834,7 @@ struct ud_cloth {
   int cl_W = 0, cl_H = 0, n_cu = 0;
   ud::cl_granule* d_arena = nullptr;
   int arena_B = 0;
+  int* d_timeouts = nullptr;   // parts of the several-workgroup kernels that gave up a poll (ud_cloth_poll_timeouts)
 };
 
 // Several workgroups per env when the body qualifies (halo <= CL_HMAX, the parts of one env fit on the chip) and the caller
@@ -841,11 +842,15 @@ struct ud_cloth {
 // every workgroup of a launch is resident at once (cloth_cluster.h, "Progress").
 // UD_CLOTH_CLUSTER=0 (read at every call; diagnostics and tests) keeps the one-workgroup kernels.
 static bool cloth_use_cluster(const ud_cloth* h, int B) {
-  if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1 || h->cl_W > h->n_cu) return false;
+  if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1 || h->cl_W > h->n_cu / 8) return false;   // the parts of an env share an XCD (cl_decode)
   const char* e = getenv("UD_CLOTH_CLUSTER");
   return !(e && e[0] == '0');
 }
-static int cloth_cluster_envs(const ud_cloth* h, int B) { return std::min(B, std::max(1, h->n_cu / h->cl_W)); }
+// Envs per launch.  cl_decode deals the envs of a launch round-robin over the 8 XCDs and keeps the W parts of an env on one, and
+// the adjoint kernel (256 VGPRs, 512 lanes) fits once per CU: an XCD (n_cu / 8 CUs) holds floor((n_cu / 8) / W) whole envs.
+// (floor(n_cu / W) -- the chip-wide count -- gave 36 for the T-shirt's W = 7: in launches of 33-36 envs XCDs 0-3 were dealt
+// 5 x 7 = 35 workgroups for 32 CUs, three parts waited for a CU while their siblings spun: ~2x the time, no deadlock.)
+static int cloth_cluster_envs(const ud_cloth* h, int B) { return std::min(B, std::max(1, 8 * ((h->n_cu / 8) / h->cl_W))); }
 
 // (re)size and zero the hand-off arena: tags start at 1, so a zeroed arena matches nothing.  Growing it is the one place
 // that synchronises (see the header: first call / larger B than ever before).
@@ -857,7 +862,7 @@ static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::Clust
     h->arena_B = B;
   }
   UD_HIP_CHECK(hipMemsetAsync(h->d_arena, 0, per * B, stream));
-  q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena; q->b0 = 0; q->Bl = B;
+  q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena; q->b0 = 0; q->Bl = B; q->timeouts = h->d_timeouts;
   return UD_OK;
 }
 
@@ -919,6 +924,8 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_L0, L0.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_L0, L0.data(), L0.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && Pp > 1024) e = hipMalloc((void**)&h->d_timeouts, sizeof(int));
+  if (e == hipSuccess && Pp > 1024) e = hipMemset(h->d_timeouts, 0, sizeof(int));
   if (e == hipSuccess && Pp > 1024) {   // the kernels for big bodies need more than the default 64 KB of dynamic LDS
     e = hipFuncSetAttribute((const void*)ud::cloth_big_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)9 * Pp * sizeof(float)));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::cloth_big_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)6 * Pp + 192 + 128) * sizeof(float)));
@@ -927,6 +934,7 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
     ud::set_error("ud_cloth_create: %s", hipGetErrorString(e));
     if (h->d_nbr) (void)hipFree(h->d_nbr);
     if (h->d_L0) (void)hipFree(h->d_L0);
+    if (h->d_timeouts) (void)hipFree(h->d_timeouts);
     delete h;
     return UD_ERR_HIP;
   }
@@ -939,11 +947,29 @@ void ud_cloth_destroy(ud_cloth* h) {
   (void)hipFree(h->d_nbr);
   if (h->d_park) (void)hipFree(h->d_park);
   if (h->d_arena) (void)hipFree(h->d_arena);
+  if (h->d_timeouts) (void)hipFree(h->d_timeouts);
   (void)hipFree(h->d_L0);
   delete h;
 }
 
 int ud_cloth_num_particles(const ud_cloth* h) { return h ? h->c.P : UD_ERR_INVALID; }
+
+int ud_cloth_launch_envs(const ud_cloth* h, int B) {
+  if (!h || B < 1) return UD_ERR_INVALID;
+  return cloth_use_cluster(h, B) ? cloth_cluster_envs(h, B) : B;
+}
+
+int ud_cloth_poll_timeouts(ud_cloth* h, void* stream) {
+  if (!h) { ud::set_error("ud_cloth_poll_timeouts: null handle"); return UD_ERR_INVALID; }
+  if (!h->d_timeouts) return 0;
+  int n = 0;
+  UD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  UD_HIP_CHECK(hipMemcpy(&n, h->d_timeouts, sizeof(int), hipMemcpyDeviceToHost));
+  if (n) UD_HIP_CHECK(hipMemset(h->d_timeouts, 0, sizeof(int)));
+  if (n) ud::set_error("ud_cloth: %d workgroup(s) of the several-workgroup kernels gave up waiting for a sibling part since the last poll; "
+                       "the outputs of those envs are NaN", n);
+  return n;
+}
 
 size_t ud_cloth_ckpt_bytes(const ud_cloth* h, int B, int T) {
   if (!h || B < 0 || T < 0) return 0;

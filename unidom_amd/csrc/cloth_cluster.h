@@ -18,7 +18,8 @@
 // Progress: a part waits for other parts of its env, so all W parts must be resident together.  The host cuts a call
 // into launches of at most floor(CUs / W) envs (one 512-lane workgroup per CU: the adjoint kernel uses the whole register
 // file of a CU), back to back on the caller's stream, so every workgroup of a launch is resident at once.  Every poll is bounded: after CL_SPIN_LIMIT polls (seconds) a part gives up, its siblings time out
-// in turn, and every output of the launch is filled with NaN -- loud, and every wave reaches the end of the kernel.
+// in turn, every output of the env is filled with NaN and each part that gave up adds 1 to the handle's time-out counter
+// (ClusterArgs::timeouts -> ud_cloth_poll_timeouts -> ClothSimulator.check_status) -- loud, and every wave reaches the end of the kernel.
 #pragma once
 #include "cloth_common.h"
 
@@ -37,6 +38,7 @@ struct ClusterArgs {
   int b0, Bl;              // this launch covers envs b0 .. b0 + Bl - 1 of the call's B (the host cuts a call into launches
                            // whose parts all fit on the chip at once); the arena is indexed by the env's number in the launch
   cl_granule* arena;       // [Bl][cl_env_granules(Pp, W)], zeroed before every launch (tags start at 1)
+  int* timeouts;           // handle-owned device counter: + 1 for every part that gave up a poll (ud_cloth_poll_timeouts)
 };
 
 // per-env arena, in granules: XE[2][3][Pp] positions (forward) | GE[2][3][Pp] force cotangents (adjoint) |

@@ -359,6 +359,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_bwd_kernel(ClothBwdArgs a,
     if (bail[0]) dead = true;
   }
   if (dead) {   // a part of this env never showed up: make it loud
+    if (i == 0 && q.timeouts) atomicAdd(q.timeouts, 1);
 #pragma unroll
     for (int d = 0; d < 3; ++d) { gx[d] = NAN; gv[d] = NAN; }
     gpl = NAN;

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(CL_T) cloth_cluster_fwd_kernel(ClothFwdArgs a,
     }
   }
   if (dead) {   // a part of this env never showed up: make it loud
+    if (i == 0 && q.timeouts) atomicAdd(q.timeouts, 1);
 #pragma unroll
     for (int d = 0; d < 3; ++d) { x[d] = NAN; v[d] = NAN; }
 #pragma unroll

@@ -490,9 +490,13 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
       fresh = m8 & ~old8;
     }
     LG_STAMP(0, 5);     // flush: value atomics + bitmap
+    // offsets inside the block's share of the list: an inclusive wave scan of the per-row counts (no LDS counter: a relaxed
+    // load of one "after every lane's add" has no ordering against the adds of the lanes in the other arm of `nnew ?`)
     const int nnew = __popc(fresh);
-    const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
-    const int total = __hip_atomic_load(&s_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // same wave: after every lane's add
+    int incl = nnew;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (threadIdx.x >= d) incl += up; }
+    const int mine = incl - nnew, total = __shfl(incl, 63);
     int base = 0;
     if (threadIdx.x == 0 && total) base = atomicAdd(&a.w.count[cur * a.B + b], total);
     base = __shfl(base, 0);

@@ -22,7 +22,7 @@ namespace ud {
 // primitive positions for the whole step: pos[s+1] = clamp(pos[s] + v), v = clip(action)*scale/substeps for primitive 0
 __global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* action) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  if (b >= a.Bcall) return;   // the caller's arrays (and a checkpoint laid out for this call) hold Bcall envs, the arena may hold more
   const PlbConst& c = a.c;
   double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
   for (int i = 0; i < c.np * 3; ++i) P[i] = prim_pos[(long)b * c.np * 3 + i];
@@ -451,7 +451,7 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   int rc = plb_reserve(h, B, st, false, false);
   if (rc) return rc;
   ud::PlbArgs a;
-  a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
+  a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0;
   if (ckpt) {   // keep every substep's particle state, the primitive trajectory and the spatial order for ud_plb_step_bwd
     size_t o_hist, o_pos, o_perm, total;

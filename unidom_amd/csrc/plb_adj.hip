@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) plb_adj_clear(PlbArgs a) {
 }
 __global__ void plb_adj_reset_counts(PlbArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < a.B) { a.w.count[b] = 0; a.w.count[a.B + b] = 0; }
+  if (b < a.Bcall) { a.w.count[b] = 0; a.w.count[a.B + b] = 0; }
 }
 
 // cotangent of the step outputs -> gstate slot (in the spatial order of the checkpoint); zero the accumulators
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(256) plb_adj_unpack(PlbArgs a, int slot, doubl
 // forward_kinematics.grad + set_action in reverse: pos[s+1] = clamp(pos[s] + pv), pv = clip(action, -1, 1) / S for primitive 0
 __global__ void plb_adj_epilogue(PlbArgs a, const double* action, double* g_prim_pos0, double* g_action, double* g_E, double* g_nu, double* g_ys, double* g_fric) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  if (b >= a.Bcall) return;   // g_action, g_E, ... are the caller's [Bcall] arrays
   const PlbConst& c = a.c;
   const double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
   double* G = a.w.gpos + (long)b * (c.S + 1) * c.np * 3;
@@ -666,7 +666,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   int rc = plb_reserve(h, B, st, true, false);
   if (rc) return rc;
   ud::PlbArgs a;
-  a.c = h->c; a.w = h->w; a.B = h->B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
+  a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   size_t o_hist, o_pos, o_perm, total;
   plb_ckpt_layout(h->c, B, &o_hist, &o_pos, &o_perm, &total);

@@ -29,7 +29,8 @@ struct PlbBuf {
 struct PlbArgs {
   PlbConst c;
   PlbBuf w;
-  int B, f, epoch, cap;
+  int B, f, epoch, cap;     // B = envs the handle's arena was sized for (the arena stride), NOT the envs of this call
+  int Bcall;                  // envs of this call (<= B): the bound of every per-env guard that touches caller-owned arrays
   int slots, hs_in, hs_out;   // hist slots per env; slot of this substep's input state / output state
   int lb;                     // active list and grid buffer of this substep (forward: f & 1, the other one is being retired)
   long G;

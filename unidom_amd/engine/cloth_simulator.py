@@ -186,6 +186,19 @@ class ClothSimulator:
             ev[2].record(torch.cuda.current_stream(self.device))
             self.profile[ev[0]].append((ev[1], ev[2]))
 
+    def check_status(self):
+        """Device-side failure flags of this handle (include/unidom_hip.h: ud_cloth_poll_timeouts): a part of the
+        several-workgroup kernels that gave up waiting for a sibling.  Synchronises the current stream; raises UnidomError.
+        apg.train calls it once per iteration (the update has synchronised by then); one-workgroup bodies return at once."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        n = _lib.lib().ud_cloth_poll_timeouts(self._h, stream)
+        if n != 0:
+            raise _lib.UnidomError(f"cloth kernels (status {n}): {_lib.lib().ud_last_error().decode()}")
+
+    def launch_envs(self, B=None):
+        """envs per kernel launch of a call with B envs (ud_cloth_launch_envs)"""
+        return int(_lib.lib().ud_cloth_launch_envs(self._h, C.c_int(self.batch_size if B is None else B)))
+
     # -- state helpers -------------------------------------------------------------------------------
     def reset_jax(self) -> ClothState:  # :339-364
         N, c = self.N, self.cell_size

@@ -14,6 +14,7 @@ from ..utils import prng
 from .basic.mpm_env import MPMEnv
 
 my_path = os.path.dirname(os.path.abspath(__file__))
+_R500 = float(np.float32(1.0) / np.float32(500.0))   # f32 reciprocal of the literal in get_primitive_actions (:80)
 
 
 @dataclass
@@ -64,7 +65,7 @@ class PourWaterEnv(MPMEnv):
     @staticmethod
     def get_primitive_actions(actions, state):   # :77-90 (vmapped over envs in the reference)
         actions = torch.cat([actions, torch.zeros_like(actions)], -1)          # second bowl: dummy action
-        actions = torch.cat([actions[..., :6] / 500.0, actions[..., 6:]], -1)  # normalise translation and rotation of bowl 0
+        actions = torch.cat([actions[..., :6] * _R500, actions[..., 6:]], -1)  # `/ 500.0`: normalise translation and rotation of bowl 0 (XLA: A * (1 / Const))
         actions = actions + 1e-12
         actions = torch.cat([actions[..., :1], torch.zeros_like(actions[..., :1]), actions[..., 2:]], -1)   # no vertical motion
         return actions[None], state

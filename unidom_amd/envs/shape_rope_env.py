@@ -85,7 +85,7 @@ class ShapeRopeEnv(MPMEnv):
         position = torch.cat([start[:, None, :], p.position[:, 1:]], 1)
         state = state._replace(primitives=[p._replace(position=position)] + list(state.primitives[1:]))
         num_sub_steps = DefaultConf.primitive_action_steps
-        act_push = (end - start) / num_sub_steps
+        act_push = (end - start) * float(np.float32(1.0) / np.float32(num_sub_steps))   # `/ num_sub_steps`, a literal under jit: A * (1 / Const)
         act_push = torch.cat([act_push[:, 0:1], zero, act_push[:, 2:3]], -1)
         n_primitive = DefaultConf.n_primitive
         sub = torch.cat([act_push, torch.zeros_like(act_push)] + [torch.zeros_like(act_push)] * (2 * (n_primitive - 1)), -1)

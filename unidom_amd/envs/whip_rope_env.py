@@ -12,6 +12,7 @@ from ..utils import prng
 from .basic.mpm_env import MPMEnv
 
 my_path = os.path.dirname(os.path.abspath(__file__))
+_R50 = float(np.float32(1.0) / np.float32(50.0))   # f32 reciprocal of the literal in get_primitive_actions (:112)
 
 
 @dataclass
@@ -80,7 +81,7 @@ class WhipRopeEnv(MPMEnv):
     @staticmethod
     def get_primitive_actions(actions, state):   # :108-115
         actions = actions + 1e-12  # hack to avoid nan
-        actions = actions / 50.0
+        actions = actions * _R50   # `/ 50.0` as XLA executes a division by a literal under jit: A * (1 / Const)
         actions = torch.cat([actions[..., :3], torch.zeros_like(actions[..., 3:])], -1)
         return actions[None, ...], state
 
