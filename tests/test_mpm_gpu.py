@@ -339,6 +339,26 @@ def _scaled_case(S, seed, B=1, grid_ckpt_cells=0, conf_cls=ScaledConf):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
+@pytest.fixture(params=["cluster_64", "cluster_128", "multi_kernel"])
+def large_path(request, monkeypatch):
+    """The many-workgroup path below 100 k particles per launch has two implementations: the persistent cluster kernels
+    (csrc/mpm_cluster.h; one launch per step call, parts of 16 or 32 particles -- UD_MPM_CLUSTER_T) and the multi-kernel path they
+    replace (UD_MPM_CLUSTER=0; a few launches per substep).  Both are read at every step call, so a test can put each in front
+    of the oracle."""
+    if request.param == "multi_kernel":
+        monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+    else:
+        monkeypatch.setenv("UD_MPM_CLUSTER", "1")
+        monkeypatch.setenv("UD_MPM_CLUSTER_T", request.param.split("_")[1])
+    return request.param
+
+
+@pytest.fixture
+def multi_kernel_path(monkeypatch):
+    """for the tests of the multi-kernel path's own machinery (active list, bitmap, grid checkpoint)"""
+    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+
+
 @pytest.fixture
 def one_lane_per_particle(monkeypatch):
     """The many-workgroup kernels come in two lane mappings: 4 lanes per particle below 100 k particles per launch, 1 beyond --
@@ -353,12 +373,12 @@ def test_large_path_one_lane_kernels_match_oracle_n798(grid_ckpt_cells, one_lane
 
 
 def test_collide_shape_rope_geometry_one_lane_kernels(one_lane_per_particle):
-    test_collide_shape_rope_geometry_fwd_bwd()
+    test_collide_shape_rope_geometry_fwd_bwd(None)
 
 
 @pytest.mark.parametrize("case", ["body_at_the_domain_corner", "across_the_upper_grid_edge", "negative_weights", "four_box_primitives"])
 def test_mpm_step_edge_cases_one_lane_kernels(demo, case, one_lane_per_particle):
-    test_mpm_step_edge_cases(demo, case)
+    test_mpm_step_edge_cases(demo, case, None)
 
 
 def test_full_batch_launch_agrees_with_the_oracle_checked_small_one():
@@ -417,7 +437,7 @@ def test_baseline_config4_size_n_grid_256_matches_oracle(grid_ckpt_cells):
 
 
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
-def test_large_path_matches_oracle_n798(grid_ckpt_cells):
+def test_large_path_matches_oracle_n798(grid_ckpt_cells, large_path):
     """grid_ckpt_cells = 0: the backward recomputes p2g + grid op; 6: it restores the grid from the forward's checkpoint."""
     from oracle.pyoracle import MpmOracle
     S = 5   # dt=1e-4 at dx=1/128 is 4x the CFL number of the default config (SURVEY.md 8d): keep the window short
@@ -446,7 +466,7 @@ def test_large_path_matches_oracle_n798(grid_ckpt_cells):
 
 
 @pytest.mark.parametrize("lanes", ["4", "1"])
-def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch):
+def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch, multi_kernel_path):
     """First toucher of a cell = whoever sets its bit in the env's bitmap; a block window marks a row of eight z-consecutive cells
     with one OR, or two when the row straddles a 32-bit word (z offset of the window & 31 > 24).  The rope is moved cell by cell
     in z so that the windows start at z = 25 ... 32: forward vs the oracle each time, twice on the same handle (a cell left
@@ -468,7 +488,7 @@ def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch):
             assert _rel(oh["C"], of["C"]) < 1e-3 and _rel(oh["F"], of["F"]) < 5e-5, (cells, base_z & 31)
 
 
-def test_grid_checkpoint_pool_overflow_falls_back_to_recompute():
+def test_grid_checkpoint_pool_overflow_falls_back_to_recompute(multi_kernel_path):
     """A pool of 1 record per particle and substep holds the compact rope (measured 0.58 active cells per particle) but not the
     same particles scattered through the volume (up to 27 cells each): the forward flags the env in status[], the host mirror
     sees the flag without a sync and asks that step's backward to recompute the grid (clip bit 1) -- same gradients as a
@@ -551,7 +571,7 @@ def test_collide_zero_rotation_action_laundered(demo):
     assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()
 
 
-def test_collide_shape_rope_geometry_fwd_bwd():
+def test_collide_shape_rope_geometry_fwd_bwd(large_path):
     """shape_rope's sizes (582 plastic particles, 64x6x64 grid, dt 0.5e-4, ground friction 0.9; 4 lanes per particle on
     the many-workgroup path): a pusher overlapping the rope -- forward vs the f32 oracle, adjoint vs the f64 oracle."""
     from oracle.pyoracle import MpmOracle
@@ -596,7 +616,7 @@ def test_collide_shape_rope_geometry_fwd_bwd():
 
 
 @pytest.mark.parametrize("clip", [False, True])
-def test_two_container_primitives_match_oracle(demo, clip):
+def test_two_container_primitives_match_oracle(demo, clip, large_path):
     """n_primitive = 2, container SDF, liquid material (pour_water's configuration): forward vs the f32 oracle, adjoint
     (every primitive's position / rotation rows, the 12 action components) vs the f64 oracle."""
     from oracle.pyoracle import MpmOracle
@@ -671,7 +691,7 @@ def test_two_upright_containers_forward_tracks_f32_oracle(demo):
                                   "one_workgroup_one_substep", "one_workgroup_domain_corner",
                                   "across_the_upper_grid_edge", "one_workgroup_across_the_upper_grid_edge",
                                   "negative_weights", "one_workgroup_negative_weights"])
-def test_mpm_step_edge_cases(demo, case):
+def test_mpm_step_edge_cases(demo, case, large_path):
     """Edges vs the oracle (forward f32, adjoint f64), on the many-workgroup path and (one_workgroup_*) the one-workgroup
     path: a single substep per step (copy_frame and the primitive recurrences degenerate, Q5), the smallest particle count
     that takes the many-workgroup path, a body pressed into the domain corner (base truncates to 0, every cell sits in the
@@ -682,6 +702,8 @@ def test_mpm_step_edge_cases(demo, case):
     S, N, P, pc = 4, 160, 1, True
     if case.startswith("one_workgroup"):                             # N <= 128, position control: the one-workgroup kernels
         N = 100
+        if large_path not in (None, "cluster_64"):
+            pytest.skip("the one-workgroup path has no cluster / multi-kernel variants")
     if case.endswith("one_substep"):
         S = 1
     elif case == "n129_just_over_the_one_workgroup_limit":
@@ -784,3 +806,39 @@ def test_internal_spatial_order_is_invisible(demo, grid_ckpt_cells):
     np.testing.assert_allclose(srt["J"], of["J"], rtol=1e-5)           # Q6: the trace runs over the caller's particles 0, 1, 2
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
         assert _rel(srt[key], ob[key]) < 5e-3, (key, _rel(srt[key], ob[key]))
+
+
+def test_cluster_call_cut_into_several_launches(monkeypatch):
+    """The parts of a cluster launch wait for each other, so a call with more envs than fit on the chip at once is cut into
+    launches on the caller's stream (csrc/mpm_large.hip: clm_envs_per_launch).  UD_MPM_CLUSTER_ENVS caps the envs per launch:
+    5 envs as 2 + 2 + 1 must give what one launch gives, forward and adjoint, whichever launch an env was in, and a second call
+    on the same handle must find the rotating grids at rest."""
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
+    sim, st, g, N = _scaled_case(4, 7, B=5)
+    for b in range(5):
+        st["action"][b] = np.float32([0.1 * b - 0.2, 0.05 * b, 0.3 - 0.1 * b, 0, 0, 0]) / 50
+    one = run_hip(sim, st, g=g, clip=True)
+    monkeypatch.setenv("UD_MPM_CLUSTER_ENVS", "2")
+    for _ in range(2):
+        cut = run_hip(sim, st, g=g, clip=True)
+        for key in ("x", "v", "C", "F", "J"):
+            assert _rel(cut[key], one[key]) < 2e-6, (key, _rel(cut[key], one[key]))
+        for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+            assert np.isfinite(cut[key]).all() and _rel(cut[key], one[key]) < 1e-4, (key, _rel(cut[key], one[key]))
+
+
+def test_cluster_scattered_cloud_cannot_overflow_its_tables(monkeypatch):
+    """Parts of 16 particles touch at most 16 x 27 = 432 cells: the 512-slot table of a part cannot overflow however the cloud is
+    scattered (the same particles thrown uniformly through the volume: every part falls back from its window to open addressing).
+    Result = the multi-kernel path's, which sends what does not fit its tables to HBM atomics."""
+    sim, st, g, N = _scaled_case(3, 0, B=2)
+    st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)   # env 1 scattered
+    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+    ref = run_hip(sim, st, g=g, clip=True)
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
+    monkeypatch.setenv("UD_MPM_CLUSTER_T", "64")
+    got = run_hip(sim, st, g=g, clip=True)          # run_hip ends with check_status(): no overflow flag
+    for key in ("x", "v", "C", "F"):
+        assert _rel(got[key], ref[key]) < 2e-6, (key, _rel(got[key], ref[key]))
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 1e-4, (key, _rel(got[key], ref[key]))

@@ -1,0 +1,761 @@
+// Persistent per-env CLUSTER kernels of the many-workgroup MPM path: all `steps` substeps of a simulator.step in ONE launch per
+// direction (included by mpm_large.hip, which holds the helpers it uses; same C ABI, same checkpoint layout).
+//
+// What it replaces: the 4 (forward) / 4-6 (backward) launches per substep of mpm_large.hip for launches that do not fill the chip
+// (B x N < 100 k particles: shape_rope 582, the rope at n_grid 128 798, pour_water 702 particles per env, 32 envs).  Those
+// kernels sit at 4-14 us each on chains of dependent global round trips (state load -> SVD -> LDS table -> flush atomics ->
+// bitmap OR -> list counter -> list store -> next launch: count -> list -> cell -> ...); rocprofv3: 32 + 41 us of kernel time
+// per substep pair on shape_rope (profiles/r02j_kernel_stats_shape_rope.csv).  Reference: mpm_simulator.py:413-429 (step =
+// fori_loop over substep), :223-330 (substep), :178-221 (p2g / g2p), :332-363 (what the backward differentiates).
+//
+// Mapping.  An env is cut into W = ceil(N / (T / 4)) PARTS of T / 4 = 16 or 32 consecutive particles (lattice order, or the Morton order of
+// lg_sort): one T-lane workgroup per part, 4 lanes per particle (the quad splits the 27 stencil cells 7/7/7/6), the particle
+// state in REGISTERS for the whole launch (HBM sees it once per substep, as the checkpoint record), the part's cells in the LDS
+// staging table of lg_p2g (8 x 8 x 8 window when the part's base cells span <= 6 per axis, open addressing otherwise).
+// What crosses a part boundary is the grid: per substep every part adds its table to a dense HBM grid with float atomics
+// (memory-side on gfx950: nothing lives in an L2), the parts of the env meet at ONE barrier, and every part reads the summed
+// (m, mv) of ITS OWN cells back, runs the grid op on them (redundantly where parts share cells: same inputs, same result) and
+// gathers from LDS.  No active list, no bitmap, no counters: a part only ever asks for the cells in its own table.
+//   forward   p2g -> flush -> BARRIER -> read back + grid op -> g2p                                   1 barrier / substep
+//   backward  p2g (recompute) -> flush -> BARRIER -> read back + grid op -> g2p adjoint -> flush of the cotangent grid ->
+//             BARRIER -> read back + grid-op adjoint -> p2g adjoint + particle adjoint                  2 barriers / substep
+// Grid buffers rotate so that nobody adds into a buffer another part may still be zeroing: three for the forward (flush f,
+// read f after barrier f, zero f after barrier f + 1 with the keys kept from substep f, next flush f + 3), two for each grid of
+// the backward (its two barriers per substep already separate "everybody has read" from "the next flush").
+//
+// Hand-off rules (MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1 is never
+// refreshed, so EVERY access to data another part may have written inside this launch is an agent-scope operation: float /
+// integer atomics (performed at the memory side), sc1 write-through stores for the zeroing, sc1 (L1-bypassing) loads for the
+// read-back and the poll.  Each wave drains its own stores / atomics (s_waitcnt vmcnt(0)) before the workgroup barrier in front
+// of the arrival; one lane per part arrives with an agent-scope atomic add on the env's monotonic counter and polls it with sc1
+// loads (bounded: ~seconds, then the env is flagged in status[] = 2 and every wave still reaches the end of the kernel); the
+// other waves read after a workgroup barrier that lane joins.  Parts of one env get block ids congruent mod 8 (usually one XCD;
+// speed only).  Progress needs every part of a launch resident at once: the host cuts a call into launches that fit
+// (occupancy query x CUs), back to back on the caller's stream.
+#pragma once
+
+namespace ud {
+
+// lanes per part: a template parameter T of the kernels, 4 lanes per particle.  T = 64 (one wave, 16 particles: 16 x 27 = 432
+// cells at most, so the 512-slot table can never overflow and the workgroup barriers are free) or 128 (32 particles: half the
+// parts per env and less duplicated grid work, but a part whose particles are spread over more than 512 cells is an error).
+constexpr int CLM_H = 512, CLM_LOGH = 9;   // staging-table slots per part (= LgTable<4>)
+constexpr unsigned CLM_SPIN = 1u << 22;    // polls (~1 us each) before a part gives up
+
+struct ClusterGrid {
+  float4* cg[3];      // [Bl][G] (m, mv): forward rotates three, the backward's recompute two
+  float4* gg[2];      // [Bl][G] backward: cotangent of the grid velocity (xyz)
+  int* own[2];        // [Bl][G] backward: smallest part number that touched the cell (the part that books its parameter cotangents)
+  unsigned* bar;      // [Bl] arrival counters, zeroed before every launch
+  int W, Bl;          // parts per env; envs of this launch (a.b0 = the first one)
+};
+
+// ---- agent-scope accesses -------------------------------------------------------------------------------------------
+// (ldc / stc for single floats: mpm_large.hip)
+__device__ __forceinline__ int ldci(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 ldc4(const float4* p) {
+  const unsigned long long* q = (const unsigned long long*)p;
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__builtin_bit_cast(float, (unsigned)a), __builtin_bit_cast(float, (unsigned)(a >> 32)),
+                     __builtin_bit_cast(float, (unsigned)b), __builtin_bit_cast(float, (unsigned)(b >> 32)));
+}
+__device__ __forceinline__ void stc4_zero(float4* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  __hip_atomic_store(q, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void clm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// blockIdx -> (env inside the launch, part): ids congruent mod 8 share an XCD's L2 under round-robin placement (speed only)
+__device__ __forceinline__ void clm_decode(int W, int& bl, int& w) {
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  bl = (j / W) * 8 + xcd;
+  w = j % W;
+}
+__host__ inline int clm_grid(int Bl, int W) { return 8 * W * ((Bl + 7) / 8); }
+
+// The parts of an env meet: every wave has drained its global traffic; returns false once the env is dead (a part gave up).
+__device__ __forceinline__ bool clm_barrier(unsigned* bar, unsigned target, int* s_dead) {
+  clm_drain();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+      if (spins > CLM_SPIN) { *s_dead = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  return *s_dead == 0;
+}
+
+// slot of `cell` in the part's table: the window's arithmetic, or open addressing probed over the WHOLE table (bt_slot gives up
+// after 64 probes: fine where a miss falls back to HBM atomics, not here); -1 = the table is full
+__device__ __forceinline__ int clm_find(const BlockTable& t, const BlockWin& w, int cell) {
+  if (w.on) {
+    const int s = bt_win_slot(w, cell);
+    if (s >= 0) t.key[s] = cell;
+    return s;
+  }
+  unsigned s = lg_hash<CLM_LOGH>(cell);
+  for (int probe = 0; probe < CLM_H; ++probe) {
+    const int cur = t.key[s];
+    if (cur == cell) return (int)s;
+    if (cur == -1) {
+      const int old = atomicCAS(&t.key[s], -1, cell);
+      if (old == -1 || old == cell) return (int)s;
+    }
+    s = (s + 1) & (CLM_H - 1);
+  }
+  return -1;
+}
+// read-only slot of a cell that the walk of this substep has put into the table (-1 never happens for such a cell)
+__device__ __forceinline__ int clm_lookup(const int* key, const BlockWin& w, int cell) {
+  if (w.on) return bt_win_slot(w, cell);
+  unsigned s = lg_hash<CLM_LOGH>(cell);
+  for (int probe = 0; probe < CLM_H; ++probe) {
+    if (key[s] == cell) return (int)s;
+    s = (s + 1) & (CLM_H - 1);
+  }
+  return -1;
+}
+
+// p2g of one quad lane into the part's table (the walk of lg_p2g<4>, without its HBM fall-backs: a full table is an error here).
+// Returns false when a cell did not fit.
+__device__ __forceinline__ bool clm_scatter(const MpmConst& c, const BlockTable& bt, const BlockWin& win, const Pre& q, const float* v,
+                                            int p, int qi) {
+  constexpr int TH = CLM_H;
+  bool ok = true;
+  const bool interior = win.on && q.base[0] >= 0 && q.base[1] >= 0 && q.base[2] >= 0 &&
+                        q.base[0] + 2 < c.res[0] && q.base[1] + 2 < c.res[1] && q.base[2] + 2 < c.res[2];
+  if (interior) {
+    const int key0 = q.base[0] | (q.base[1] << 10) | (q.base[2] << 20);
+    const int slot0 = (q.base[2] - win.oz) | ((q.base[1] - win.oy) << 3) | ((q.base[0] - win.ox) << 6);
+    float wx[3], ax[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      wx[i] = q.w[i * 3];
+      const float dp0 = ((float)i - q.fx[0]) * c.dx;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) ax[r * 3 + i] = q.affine[r * 3] * dp0;
+    }
+    const int rot9 = (p * 4) % 9;
+#pragma unroll 1
+    for (int it = qi; it < 9; it += 4) {
+      const int col = it + rot9 >= 9 ? it + rot9 - 9 : it + rot9;
+      const int j = col / 3, k = col - 3 * j;
+      const float wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+      const float dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+      float br[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) br[r] = c.p_mass * v[r] + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
+      const int sl = slot0 + 8 * j + k, key = key0 + (j << 10) + (k << 20);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float wgt = wx[i] * wj * wk;
+        bt.key[sl + 64 * i] = key + i;
+        __hip_atomic_fetch_add(&bt.val[sl + 64 * i], (double)(wgt * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl + 64 * i], (double)(wgt * (br[r] + ax[r * 3 + i])), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    return true;
+  }
+  const int rot = (p * 4) % 27;
+#pragma unroll 1
+  for (int it = qi; it < 27; it += 4) {
+    const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+    const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    const int gc = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+    if (sc >= 0) {
+      const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
+      const int sl = clm_find(bt, win, sc);
+      if (sl >= 0) {
+        __hip_atomic_fetch_add(&bt.val[sl], (double)(weight * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
+          __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl], (double)(weight * (c.p_mass * v[r] + ad)), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      } else {
+        ok = false;
+      }
+    }
+    if (gc != sc) ok = (clm_find(bt, win, gc) >= 0) && ok;   // Q5: a clamped gather cell takes part with m = 0
+  }
+  return ok;
+}
+
+// A window only holds cells inside it: a part whose window is on may still own particles whose stencil leaves it (wrap / clamp
+// at the domain edge).  Such cells return slot -1 from bt_find and would be lost -> the part falls back to the hash for the
+// substep.  (lg_p2g sends them to HBM atomics instead; here there is no list to put them on.)
+__device__ __forceinline__ bool clm_stencil_in_window(const MpmConst& c, const BlockWin& win, const int* base) {
+  bool in = true;
+#pragma unroll
+  for (int i = 0; i < 3; i += 2)
+#pragma unroll
+    for (int j = 0; j < 3; j += 2)
+#pragma unroll
+      for (int k = 0; k < 3; k += 2) {
+        const int sc = cell_scatter(c, base[0] + i, base[1] + j, base[2] + k), gc = cell_gather(c, base[0] + i, base[1] + j, base[2] + k);
+        in = in && (sc < 0 || bt_win_slot(win, sc) >= 0) && bt_win_slot(win, gc) >= 0;
+      }
+  return in;
+}
+
+// the grid op of one cell as lg_grid_cell runs it: (m, mv) -> velocity after gravity, primitives, ground friction, boundary
+__device__ __forceinline__ void clm_grid_op(const LargeArgs& a, int b, int f, int key, const float4& mv, float* vo) {
+  int ci, cj, ck;
+  decode_cell(a.c, key, ci, cj, ck);
+  const float mvv[3] = {mv.y, mv.z, mv.w};
+  if (a.c.position_control) {
+    PrimF pf;
+    float pv[3];
+    load_prim_f(a, b, f, pf, pv);
+    grid_op<false>(a.c, pf, ci, cj, ck, mv.x, mvv, vo, nullptr);
+  } else {
+    float v0[3], v1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+    const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+#pragma unroll 1
+    for (int ip = 0; ip < a.c.n_prim; ++ip) {
+      PrimC pc;
+      load_primc_f(a, b, ip, f, pc);
+      CollideRec cr;
+      collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v0[d] = v1[d];
+    }
+    grid_tail<false>(a.c, a.friction[b], ci, cj, ck, v1, vo, nullptr);
+  }
+}
+
+// forward kinematics of the whole step, once per launch (the per-substep form of primitives.py:185-194 is a recurrence on rows
+// nothing else reads): row 0 = clip(in[0]); row f + 1 = clip(P'[f] + v) with P'[0] = in[0] (read before its clip) and P'[f] =
+// row f afterwards; rotation[f + 1] = normalise(qmul(w2quat(w), rotation[f])).  Rows f and f + 1 are final when the grid op of
+// substep f reads them -- exactly what lg_clear_fk's per-substep update gives it.  One block per (env, primitive).
+__global__ void __launch_bounds__(64) lg_fk_all(LargeArgs a) {
+  const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps, tid = threadIdx.x;
+  const long bp = (long)b * a.c.n_prim + ip;
+  float* pp = a.w.ppos + bp * S * 3;
+  float* pr = a.w.prot + bp * S * 4;
+  if (tid < 3) {
+    const float pva = clipf(a.action[bp * 6 + tid], -1.f, 1.f) * 1.f / (float)S;
+    float prev = pp[tid];
+    pp[tid] = clipf(prev, -2.f, 2.f);
+    for (int f = 0; f + 1 < S; ++f) {
+      const float nxt = clipf(prev + pva, -2.f, 2.f);
+      pp[(f + 1) * 3 + tid] = nxt;
+      prev = nxt;
+    }
+  }
+  if (tid == 32) {
+    float pw[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pw[d] = clipf(a.action[bp * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
+    const float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;
+    const float sn = sinf(ang / 2.f);
+    const float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
+    float r[4] = {pr[0], pr[1], pr[2], pr[3]};
+    for (int f = 0; f + 1 < S; ++f) {
+      const float o0 = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+      const float o1 = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+      const float o2 = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+      const float o3 = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+      const float nn = clipf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3), 1e-12f, INFINITY);
+      r[0] = o0 / nn; r[1] = o1 / nn; r[2] = o2 / nn; r[3] = o3 / nn;
+      float* w = pr + (f + 1) * 4;
+      w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; w[3] = r[3];
+    }
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------------
+// LDS per part: key[2][512] ints (the keys of substep f - 1 are needed to zero its buffer) | val[4][512] doubles, reused after the
+// flush as vel[512] float4 (grid velocity, .w = m)
+// hist: env b's records at hist + b * a.hist_stride_b; record 0 = the input state (lg_pack).  keep != 0 (a checkpoint): every
+// substep's input state is kept, record f + 1 at (f + 1) * rec; keep == 0: only the final state is written, at last_off.
+template <int T>
+__global__ void __launch_bounds__(T) clm_fwd_kernel(const LargeArgs a, const ClusterGrid g, float* hist, long rec, int keep, long last_off) {
+  __shared__ int s_key[2][CLM_H];
+  __shared__ double s_val[4 * CLM_H];
+  __shared__ int s_dead, s_ovf, s_hash;
+  int bl, w;
+  clm_decode(g.W, bl, w);
+  if (bl >= g.Bl) return;
+  const int b = a.b0 + bl, tid = threadIdx.x, p = w * (T / 4) + (tid >> 2), qi = tid & 3;
+  const MpmConst& c = a.c;
+  const bool live = p < c.N;
+  const int S = c.steps;
+  if (tid == 0) { s_dead = 0; s_ovf = 0; }
+  float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, Cm[9], F[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { Cm[d] = 0.f; F[d] = (d % 4 == 0) ? 1.f : 0.f; }
+  float* hw = hist + (long)b * a.hist_stride_b;
+  if (live) load_state(hw, c.Np, p, x, v, Cm, F);          // record 0: written by lg_pack (an earlier launch)
+  const int up = live ? user_index(a, b, p) : 0;
+  const int material = a.material[up];
+  const float hard = a.hard[up], mu_s = a.mu[b], la_s = a.lamda[b];
+  float4* vel = (float4*)s_val;
+  unsigned* bar = g.bar + bl;
+  for (int s = tid; s < CLM_H; s += T) { s_key[0][s] = -1; s_key[1][s] = -1; }
+  __syncthreads();
+  bool alive = true;
+  for (int f = 0; f < S && alive; ++f) {
+    int* key = s_key[f & 1];
+    int* kprev = s_key[(f + 1) & 1];
+    const BlockTable bt{key, s_val};
+    float4* gcur = g.cg[f % 3] + (long)bl * a.G;
+    float4* gold = g.cg[(f + 2) % 3] + (long)bl * a.G;    // substep f - 1's buffer
+    // ---- table clear, pre-pass, window ----
+    for (int s = tid; s < CLM_H; s += T) { key[s] = -1; s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0; }
+    if (tid == 0) s_hash = 0;
+    Pre q;
+    q.base[0] = q.base[1] = q.base[2] = 0;
+    if (live) {
+      particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
+      if (qi == 0 && keep) {
+        float* ho = hw + (long)(f + 1) * rec;
+#pragma unroll
+        for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.Fn[d];
+      }
+    }
+    BlockWin win = bt_window(c, live, q.base);              // two workgroup barriers: they also publish the clear
+    if (win.on && live && !clm_stencil_in_window(c, win, q.base)) s_hash = 1;
+    __syncthreads();
+    if (s_hash) win.on = 0;
+    // ---- p2g into the table, flush to the env's grid ----
+    if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
+    __syncthreads();
+    {
+      const int r = tid & 3;
+#pragma unroll 4
+      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
+        const int k = key[sl];
+        if (k < 0) continue;
+        atomicAdd((float*)(gcur + cell_lin(c, k)) + r, (float)s_val[r * CLM_H + sl]);
+      }
+    }
+    alive = clm_barrier(bar, (unsigned)(f + 1) * (unsigned)g.W, &s_dead);
+    if (!alive) break;
+    // ---- read the summed cells back, grid op, zero the cells of substep f - 1 ----
+    for (int sl = tid; sl < CLM_H; sl += T) {
+      const int k = key[sl];
+      if (k >= 0) {
+        const float4 mv = ldc4(gcur + cell_lin(c, k));
+        float vo[3];
+        clm_grid_op(a, b, f, k, mv, vo);
+        vel[sl] = make_float4(vo[0], vo[1], vo[2], mv.x);
+      }
+      const int ko = kprev[sl];
+      if (ko >= 0) stc4_zero(gold + cell_lin(c, ko));
+    }
+    __syncthreads();
+    // ---- g2p + advect ----
+    if (live) {
+      float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int cidx = qi + 4 * t;
+        if (cidx >= 27) break;
+        const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+        const int sl = clm_lookup(key, win, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k));
+        const float4 g4 = vel[max(sl, 0)];
+        const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
+        const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
+        const float gv[3] = {g4.x, g4.y, g4.z};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * gv[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (gv[r] * dp[s2]) * c.inv_dx;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) nv[d] = lg_quad_sum<4>(nv[d]);
+#pragma unroll
+      for (int d = 0; d < 9; ++d) nC[d] = lg_quad_sum<4>(nC[d]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = x[d] + c.dt * nv[d]; v[d] = nv[d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = q.Fn[d]; }
+      if (qi == 0) {
+        if (keep) {
+          float* ho = hw + (long)(f + 1) * rec;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = x[d]; ho[(3 + d) * c.Np + p] = v[d]; }
+#pragma unroll
+          for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+        }
+        if (up < 3) {   // Q6: row `up` of the caller's particle `up`
+          const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
+          atomicAdd(&a.w.trq[(long)b * S + f], (up == 0) ? r0 : ((up == 1) ? r1 : r2));
+        }
+      }
+    }
+    __syncthreads();    // vel (= val) and the key buffer of substep f - 1 are rewritten by the next substep's clear
+  }
+  // the buffers go back all-zero: the cells of the last substep, once every part has read them
+  if (alive) alive = clm_barrier(bar, (unsigned)(S + 1) * (unsigned)g.W, &s_dead);
+  if (alive) {
+    float4* glast = g.cg[(S - 1) % 3] + (long)bl * a.G;
+    const int* key = s_key[(S - 1) & 1];
+    for (int sl = tid; sl < CLM_H; sl += T) {
+      const int k = key[sl];
+      if (k >= 0) stc4_zero(glast + cell_lin(c, k));
+    }
+  }
+  if (!keep && live && qi == 0) {
+    float* ho = hw + last_off;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = x[d]; ho[(3 + d) * c.Np + p] = v[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { ho[(6 + d) * c.Np + p] = Cm[d]; ho[(15 + d) * c.Np + p] = F[d]; }
+  }
+  // status: 2 = a part's cell table overflowed, 4 = a part gave up waiting for its siblings (outputs invalid either way)
+  if (tid == 0 && a.status && (s_ovf || s_dead)) atomicOr(&a.status[b], s_dead ? 4 : 2);
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------------
+// grid-op adjoint of one table slot (lg_grid_adj_tile, with the cell's data handed in instead of read from the env's list).
+// g: cotangent of the cell's output velocity (summed over the parts) -> cotangent of mv; gmm: cotangent of m.  `own`: this part
+// books the cell's contributions to the parameter / primitive cotangents (every part that holds the cell computes the same
+// numbers; exactly one may add them).  All lanes of the workgroup call this together (block reductions inside).
+template <int T>
+__device__ __forceinline__ void clm_grid_adj_cell(const LargeArgs& a, int b, int f, bool live, bool own, int key, const float4& mv,
+                                                  float* g, float& gmm, float (*red)[UD_PRIMC_NGRAD]) {
+  int ci = 0, cj = 0, ck = 0;
+  if (live) decode_cell(a.c, key, ci, cj, ck);
+  const float mvv[3] = {mv.y, mv.z, mv.w};
+  gmm = 0.f;
+  if (a.c.position_control) {
+    if (!live) return;
+    float dfric, pv[3], dpv[3];
+    PrimF pf;
+    load_prim_f(a, b, f, pf, pv);
+    const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
+    if (own) {
+      if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+      if (ctrl) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + f * 3 + d], dpv[d]);
+      }
+    }
+    return;
+  }
+  const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
+  const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+  float v0[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
+#pragma unroll 1
+  for (int ip = P - 1; ip >= 0; --ip) {       // reverse walk over the primitives; primitive ip's input velocity by running 0..ip again
+    float pgv[UD_PRIMC_NGRAD];
+#pragma unroll
+    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) pgv[d] = 0.f;
+    if (live) {
+      PrimC pc;
+      CollideRec cr;
+      float vi[3] = {v0[0], v0[1], v0[2]}, v1[3];
+#pragma unroll 1
+      for (int j = 0; j <= ip; ++j) {
+        load_primc_f(a, b, j, f, pc);
+        collide_cell(pc, a.c.dt, gp, vi, v1, cr);
+        if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
+      }
+      if (ip == P - 1) {
+        CellRec rec;
+        float vo[3], dfric;
+        grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
+        grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
+        if (own && dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+      }
+      PrimCGrad pg;
+      float gin[3];
+      collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[d] = gin[d];
+      if (own) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
+        pgv[17] = pg.mu;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
+      const float sum = wave_sum(pgv[d]);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < UD_PRIMC_NGRAD) {
+      const int d = threadIdx.x;
+      const long bp = (long)b * P + ip;
+      const float tot = T > 64 ? red[0][d] + red[1][d] : red[0][d];
+      float* dst = (d < 3)    ? a.w.gppos + bp * S * 3 + f0 * 3 + d
+                   : (d < 7)  ? a.w.grot + bp * S * 4 + f0 * 4 + (d - 3)
+                   : (d < 10) ? a.w.gppos + bp * S * 3 + f1 * 3 + (d - 7)
+                   : (d < 14) ? a.w.grot + bp * S * 4 + f1 * 4 + (d - 10)
+                              : a.w.gpsz + bp * 4 + (d - 14);
+      if (tot != 0.f) atomicAdd(dst, tot);
+    }
+    __syncthreads();
+  }
+  if (live) grid_head_adjoint(mv.x, mvv, g, gmm);
+}
+
+// LDS per part: key[2][512] | val[4][512] doubles = the p2g staging, after barrier 1 raw[512] float4 (m, mv) + vel[512] float4
+// (grid velocity, .w = 1 where this part owns the cell) | gsc[3][512] doubles = the g2p adjoint's staging, after barrier 2
+// gres[512] float4 (cotangent of mv, of m)
+template <int T>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))) clm_bwd_kernel(const LargeArgs a, const ClusterGrid g, const float* ckpt, long rec) {
+  __shared__ int s_key[2][CLM_H];
+  __shared__ double s_val[4 * CLM_H];
+  __shared__ double s_gsc[3 * CLM_H];
+  __shared__ float s_red[2][UD_PRIMC_NGRAD];
+  __shared__ float s_par[2];
+  __shared__ int s_dead, s_ovf, s_hash;
+  int bl, w;
+  clm_decode(g.W, bl, w);
+  if (bl >= g.Bl) return;
+  const int b = a.b0 + bl, tid = threadIdx.x, p = w * (T / 4) + (tid >> 2), qi = tid & 3;
+  const MpmConst& c = a.c;
+  const bool live = p < c.N;
+  const int S = c.steps, P = c.n_prim;
+  if (tid == 0) { s_dead = 0; s_ovf = 0; }
+  if (tid < 2) s_par[tid] = 0.f;
+  const float* hb = ckpt + (long)b * a.hist_stride_b;
+  float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9], gF[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = 0.f; }
+  if (live) {                                         // cotangent of the step's outputs: lg_pack (an earlier launch)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+  }
+  const int up = live ? user_index(a, b, p) : 0;
+  const int material = a.material[up];
+  const float hard = a.hard[up], mu_s = a.mu[b], la_s = a.lamda[b];
+  float acc_mu = 0.f, acc_la = 0.f;
+  float4* raw = (float4*)s_val;
+  float4* vel = raw + CLM_H;
+  float4* gres = (float4*)s_gsc;
+  unsigned* bar = g.bar + bl;
+  for (int s = tid; s < CLM_H; s += T) { s_key[0][s] = -1; s_key[1][s] = -1; }
+  __syncthreads();
+  bool alive = true;
+  for (int k = 0; k < S && alive; ++k) {
+    const int f = S - 1 - k;
+    int* key = s_key[k & 1];
+    int* kprev = s_key[(k + 1) & 1];
+    const BlockTable bt{key, s_val};
+    float4* gcur = g.cg[k & 1] + (long)bl * a.G;
+    int* ocur = g.own[k & 1] + (long)bl * a.G;
+    float4* ggcur = g.gg[k & 1] + (long)bl * a.G;
+    float4* ggold = g.gg[(k + 1) & 1] + (long)bl * a.G;
+    // ---- checkpointed state of substep f, pre-pass with the adjoint's extras, p2g again ----
+    float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, Cm[9], F[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = 0.f; F[d] = (d % 4 == 0) ? 1.f : 0.f; }
+    if (live) load_state(hb + (long)f * rec, c.Np, p, x, v, Cm, F);
+    for (int s = tid; s < CLM_H; s += T) {
+      key[s] = -1; s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0;
+      s_gsc[s] = 0.0; s_gsc[CLM_H + s] = 0.0; s_gsc[2 * CLM_H + s] = 0.0;
+    }
+    if (tid == 0) s_hash = 0;
+    Pre q;
+    PreB kb;
+    q.base[0] = q.base[1] = q.base[2] = 0;
+    if (live) particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
+    BlockWin win = bt_window(c, live, q.base);
+    if (win.on && live && !clm_stencil_in_window(c, win, q.base)) s_hash = 1;
+    __syncthreads();
+    if (s_hash) win.on = 0;
+    if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
+    __syncthreads();
+    {
+      const int r = tid & 3;
+#pragma unroll 4
+      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
+        const int kk = key[sl];
+        if (kk < 0) continue;
+        const long lin = cell_lin(c, kk);
+        atomicAdd((float*)(gcur + lin) + r, (float)s_val[r * CLM_H + sl]);
+        if (r == 0) atomicMin(ocur + lin, w);
+      }
+    }
+    alive = clm_barrier(bar, (unsigned)(2 * k + 1) * (unsigned)g.W, &s_dead);
+    if (!alive) break;
+    // FK adjoint of substep f + 1: every part's grid-op adjoint of that substep has landed (it preceded the barrier)
+    if (w == 0 && k > 0)
+      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<true>(a, (long)b * P + ip, f + 1);
+    // ---- read back (m, mv) and the owner, grid op; zero the cotangent cells of the previous substep ----
+    for (int sl = tid; sl < CLM_H; sl += T) {
+      const int kk = key[sl];
+      if (kk >= 0) {
+        const long lin = cell_lin(c, kk);
+        const float4 mv = ldc4(gcur + lin);
+        const bool mine = ldci(ocur + lin) == w;
+        float vo[3];
+        clm_grid_op(a, b, f, kk, mv, vo);
+        raw[sl] = mv;
+        vel[sl] = make_float4(vo[0], vo[1], vo[2], mine ? 1.f : 0.f);
+      }
+      const int ko = kprev[sl];
+      if (ko >= 0) stc4_zero(ggold + cell_lin(c, ko));
+    }
+    __syncthreads();
+    // ---- g2p adjoint: scatter the cotangent of the grid velocity, weight / fx partials ----
+    float gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+    if (live) {
+      float gnv[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
+      const int rot = (p * 4) % 27;
+#pragma unroll 1
+      for (int it = qi; it < 27; it += 4) {
+        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
+        const int i = cidx / 9, j = (cidx / 3) % 3, kq = cidx % 3;
+        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, kq);
+        const float weight = wi * wj * wk;
+        const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)kq - q.fx[2]};
+        const int sl = max(clm_lookup(key, win, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + kq)), 0);
+        const float4 v4 = vel[sl];
+        const float vv[3] = {v4.x, v4.y, v4.z};
+        float gwt = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+          const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+          __hip_atomic_fetch_add(&s_gsc[r * CLM_H + sl], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+          gw[kk * 3 + 2] += (kq == kk) ? gwt * wi * wj : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int r = tid & 3;
+#pragma unroll 4
+      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
+        const int kk = key[sl];
+        if (kk < 0 || r == 3) continue;
+        atomicAdd((float*)(ggcur + cell_lin(c, kk)) + r, (float)s_gsc[r * CLM_H + sl]);
+      }
+    }
+    alive = clm_barrier(bar, (unsigned)(2 * k + 2) * (unsigned)g.W, &s_dead);
+    if (!alive) break;
+    // ---- read the summed cotangent back, grid-op adjoint; the recomputed (m, mv) cells and their owners go back to rest ----
+#pragma unroll 1
+    for (int s0 = 0; s0 < CLM_H; s0 += T) {        // block-uniform trips: the cell adjoint holds workgroup barriers
+      const int sl = s0 + tid;
+      const int kk = key[sl];
+      const bool lv = kk >= 0;
+      float gg3[3] = {0.f, 0.f, 0.f}, gmm = 0.f;
+      float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool mine = false;
+      if (lv) {
+        const long lin = cell_lin(c, kk);
+        const float4 g4 = ldc4(ggcur + lin);
+        gg3[0] = g4.x; gg3[1] = g4.y; gg3[2] = g4.z;
+        mv = raw[sl];
+        mine = vel[sl].w != 0.f;
+        stc4_zero(gcur + lin);
+        __hip_atomic_store(ocur + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      clm_grid_adj_cell<T>(a, b, f, lv, mine, kk, mv, gg3, gmm, s_red);
+      if (lv) gres[sl] = make_float4(gg3[0], gg3[1], gg3[2], gmm);
+    }
+    __syncthreads();
+    // ---- p2g adjoint (gather) + particle adjoint: cotangent of the state at substep f ----
+    if (live) {
+      float gaff[9], gvp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gaff[d] = 0.f;
+#pragma unroll 1
+      for (int cidx = qi; cidx < 27; cidx += 4) {
+        const int i = cidx / 9, j = (cidx / 3) % 3, kq = cidx % 3;
+        const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + kq);
+        if (sc < 0) continue;
+        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, kq);
+        const float weight = wi * wj * wk;
+        const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)kq - q.fx[2]) * c.dx};
+        const float4 g4 = gres[max(clm_lookup(key, win, sc), 0)];
+        const float gcv[3] = {g4.x, g4.y, g4.z};
+        float gwt = c.p_mass * g4.w;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+          gwt += gcv[r] * (c.p_mass * v[r] + ad);
+          gvp[r] += weight * c.p_mass * gcv[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) {
+            gaff[r * 3 + s2] += weight * gcv[r] * dpos[s2];
+            gfx[s2] -= c.dx * weight * gcv[r] * q.affine[r * 3 + s2];
+          }
+        }
+#pragma unroll
+        for (int kk2 = 0; kk2 < 3; ++kk2) {
+          gw[kk2 * 3 + 0] += (i == kk2) ? gwt * wj * wk : 0.f;
+          gw[kk2 * 3 + 1] += (j == kk2) ? gwt * wi * wk : 0.f;
+          gw[kk2 * 3 + 2] += (kq == kk2) ? gwt * wi * wj : 0.f;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<4>(gw[d]); gaff[d] = lg_quad_sum<4>(gaff[d]); }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<4>(gfx[d]); gvp[d] = lg_quad_sum<4>(gvp[d]); }
+      float gmu_p, gla_p;                      // every lane of the quad runs the particle adjoint: the cotangent state stays in registers
+      particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+      if (qi == 0 && material != 0) {
+        const float h = clipf(hard, 0.1f, 5.f);
+        acc_mu += gmu_p * h; acc_la += gla_p * h;
+      }
+    }
+    __syncthreads();
+  }
+  // the last substep's FK adjoint and cotangent cells, once every part is through its grid-op adjoint
+  if (alive) alive = clm_barrier(bar, (unsigned)(2 * S + 1) * (unsigned)g.W, &s_dead);
+  if (alive) {
+    if (w == 0)
+      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<true>(a, (long)b * P + ip, 0);
+    float4* gglast = g.gg[(S - 1) & 1] + (long)bl * a.G;
+    const int* key = s_key[(S - 1) & 1];
+    for (int sl = tid; sl < CLM_H; sl += T) {
+      const int kk = key[sl];
+      if (kk >= 0) stc4_zero(gglast + cell_lin(c, kk));
+    }
+  }
+  if (live && qi == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
+    if (acc_mu != 0.f) atomicAdd(&s_par[0], acc_mu);
+    if (acc_la != 0.f) atomicAdd(&s_par[1], acc_la);
+  }
+  __syncthreads();
+  if (tid < 2 && s_par[tid] != 0.f) atomicAdd(&a.w.acc[b * 4 + 1 + tid], s_par[tid]);
+  if (tid == 0 && a.status && (s_ovf || s_dead)) atomicOr(&a.status[b], s_dead ? 4 : 2);
+}
+
+}  // namespace ud

@@ -69,6 +69,12 @@ struct LargeArgs {
   const float *psize, *friction, *mu, *lamda, *action;
 };
 
+// ---- agent-scope accesses (persistent cluster kernels, mpm_cluster.h): sc1 loads bypass the CU's L1, sc1 stores write through
+__device__ __forceinline__ float ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COH> __device__ __forceinline__ float ld_f(const float* p) { return COH ? ldc(p) : *p; }
+template <bool COH> __device__ __forceinline__ void st_f(float* p, float v) { if (COH) stc(p, v); else *p = v; }
+
 __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   int ci, cj, ck;
   decode_cell(c, key, ci, cj, ck);
@@ -91,8 +97,8 @@ __device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long l
   }
 }
 
-__device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, float* pv) {
-  const int S = a.c.steps, fc = min(max(a.f, 0), S - 1);
+__device__ __forceinline__ void load_prim_f(const LargeArgs& a, int b, int f, PrimF& pf, float* pv) {
+  const int S = a.c.steps, fc = min(max(f, 0), S - 1);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     pv[d] = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
@@ -105,9 +111,11 @@ __device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, 
   pf.friction = a.friction[b];
 }
 
+__device__ __forceinline__ void load_prim(const LargeArgs& a, int b, PrimF& pf, float* pv) { load_prim_f(a, b, a.f, pf, pv); }
+
 // soft contact: rows f and f + 1 (clamped, Q5) of the primitive arrays
-__device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, PrimC& pc) {
-  const int S = a.c.steps, f0 = min(max(a.f, 0), S - 1), f1 = min(max(a.f + 1, 0), S - 1);
+__device__ __forceinline__ void load_primc_f(const LargeArgs& a, int b, int ip, int f, PrimC& pc) {
+  const int S = a.c.steps, f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
   const long bp = (long)b * a.c.n_prim + ip;
   const float* pp = a.w.ppos + bp * S * 3;
   const float* pr = a.w.prot + bp * S * 4;
@@ -118,6 +126,7 @@ __device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, Pr
   pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction; pc.kind = a.c.sdf_kind;
   primc_finish(pc);
 }
+__device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, PrimC& pc) { load_primc_f(a, b, ip, a.f, pc); }
 
 __device__ __forceinline__ void load_state(const float* h, int Np, int p, float* x, float* v, float* Cm, float* F) {
 #pragma unroll
@@ -811,8 +820,11 @@ __device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pi
 // FK adjoint of substep f (one block per env)
 // Runs in the extra blocks of lg_p2g_adj (one 256-thread block per env and primitive): both only need the grid-op adjoint
 // of this substep, neither needs the other, and a launch of its own cost 5 us per reverse substep for microseconds of work.
-__device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env, primitive) row of the primitive arrays */) {
-  const int S = a.c.steps, f = a.f;
+// COH: the cotangent arrays are read and written with agent-scope accesses (the persistent cluster kernel: other workgroups of
+// the same launch add to them with atomics between two calls)
+template <bool COH>
+__device__ __forceinline__ void fk_adj_block_f(const LargeArgs& a, long b /* (env, primitive) row of the primitive arrays */, int f) {
+  const int S = a.c.steps;
   const float* pp = a.w.ppos + b * S * 3;
   const float* pin = a.w.ppin + b * S * 3;
   float* gp = a.w.gppos + b * S * 3;
@@ -823,14 +835,14 @@ __device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env,
     if (e < S * 3) {
       const int row = e / 3, d = e - row * 3;
       const float pva = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
-      val = gp[e] * clip_grad(ppos_preclip_g(pp, pin, f, row, d, pva), -2.f, 2.f);
+      val = ld_f<COH>(gp + e) * clip_grad(ppos_preclip_g(pp, pin, f, row, d, pva), -2.f, 2.f);
       if (f + 1 < S) {
         if (row == f + 1) val = 0.f;
-        if (row == f) { t = gp[e + 3] * clip_grad(ppos_preclip_g(pp, pin, f, f + 1, d, pva), -2.f, 2.f); val += t; }
+        if (row == f) { t = ld_f<COH>(gp + e + 3) * clip_grad(ppos_preclip_g(pp, pin, f, f + 1, d, pva), -2.f, 2.f); val += t; }
       }
     }
     __syncthreads();
-    if (e < S * 3) { gp[e] = val; gpv[e] += t; }
+    if (e < S * 3) { st_f<COH>(gp + e, val); if (!COH || t != 0.f) st_f<COH>(gpv + e, ld_f<COH>(gpv + e) + t); }
     __syncthreads();
   }
   // soft contact: rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))  (primitives.py:190, :73-92)
@@ -839,7 +851,7 @@ __device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env,
     const float* rr = a.w.prot + b * S * 4 + f * 4;
     float go[4], w[3];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) { go[d] = gr_[(f + 1) * 4 + d]; gr_[(f + 1) * 4 + d] = 0.f; }
+    for (int d = 0; d < 4; ++d) { go[d] = ld_f<COH>(gr_ + (f + 1) * 4 + d); st_f<COH>(gr_ + (f + 1) * 4 + d, 0.f); }
 #pragma unroll
     for (int d = 0; d < 3; ++d) w[d] = clipf(a.action[b * 6 + 3 + d], -1.f, 1.f) * 1.f / (float)S;
     const float s2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
@@ -857,10 +869,10 @@ __device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env,
     float gO[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) gO[d] = go[d] / nn + goo * o[d] / oo;
-    gr_[f * 4 + 0] += gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3];
-    gr_[f * 4 + 1] += -gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2];
-    gr_[f * 4 + 2] += -gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1];
-    gr_[f * 4 + 3] += -gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0];
+    st_f<COH>(gr_ + f * 4 + 0, ld_f<COH>(gr_ + f * 4 + 0) + (gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3]));
+    st_f<COH>(gr_ + f * 4 + 1, ld_f<COH>(gr_ + f * 4 + 1) + (-gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2]));
+    st_f<COH>(gr_ + f * 4 + 2, ld_f<COH>(gr_ + f * 4 + 2) + (-gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1]));
+    st_f<COH>(gr_ + f * 4 + 3, ld_f<COH>(gr_ + f * 4 + 3) + (-gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0]));
     const float gq[4] = {gO[0] * rr[0] + gO[1] * rr[1] + gO[2] * rr[2] + gO[3] * rr[3],
                          -gO[0] * rr[1] + gO[1] * rr[0] - gO[2] * rr[3] + gO[3] * rr[2],
                          -gO[0] * rr[2] + gO[1] * rr[3] + gO[2] * rr[0] - gO[3] * rr[1],
@@ -873,9 +885,10 @@ __device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b /* (env,
     // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule is 0.5/0 * 0 = NaN, laundered by nan_to_num at `step`
     const float gs = gang * (0.5f / nrm);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) a.w.gpw[b * S * 3 + f * 3 + d] += gw[d] + gs * (2.f * w[d]);
+    for (int d = 0; d < 3; ++d) { float* pw_ = a.w.gpw + b * S * 3 + f * 3 + d; st_f<COH>(pw_, ld_f<COH>(pw_) + (gw[d] + gs * (2.f * w[d]))); }
   }
 }
+__device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b) { fk_adj_block_f<false>(a, b, a.f); }
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
 template <int LANES>
@@ -1557,6 +1570,10 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
   }
 }
 
+}  // namespace ud
+#include "mpm_cluster.h"
+namespace ud {
+
 struct MpmLarge {
   MpmConst c;
   const int* d_material;
@@ -1573,6 +1590,10 @@ struct MpmLarge {
   static constexpr int MAX_GROUPS = 4;
   hipStream_t side[MAX_GROUPS - 1] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS - 1] = {};
+  // persistent cluster kernels (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated on first use
+  ClusterGrid cl{};
+  void* cl_arena = nullptr;
+  int n_cu = 0, occ_fwd[2] = {0, 0}, occ_bwd[2] = {0, 0};   // CUs; resident parts per CU of the two kernels (occupancy query), [0] 64-lane, [1] 128-lane parts
 };
 
 #ifndef LG_GROUPS
@@ -1607,6 +1628,18 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_sort, hipFuncAttributeMaxDynamicSharedMemorySize, LG_SORT_MAX * 8);
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&L->n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    for (int i = 0; i < 2; ++i) {   // i = 0: 64-lane parts, 1: 128-lane parts
+      const void* kf = i ? (const void*)clm_fwd_kernel<128> : (const void*)clm_fwd_kernel<64>;
+      const void* kb = i ? (const void*)clm_bwd_kernel<128> : (const void*)clm_bwd_kernel<64>;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&L->occ_fwd[i], kf, i ? 128 : 64, 0) != hipSuccess) L->occ_fwd[i] = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&L->occ_bwd[i], kb, i ? 128 : 64, 0) != hipSuccess) L->occ_bwd[i] = 0;
+    }
+    (void)hipGetLastError();
+  }
   bool ok = hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming) == hipSuccess;
   for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
     ok = ok && hipStreamCreateWithFlags(&L->side[g], hipStreamNonBlocking) == hipSuccess;
@@ -1619,6 +1652,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
 void mpm_large_destroy(MpmLarge* L) {
   if (!L) return;
   if (L->arena) (void)hipFree(L->arena);
+  if (L->cl_arena) (void)hipFree(L->cl_arena);
   for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
     if (L->side[g]) (void)hipStreamDestroy(L->side[g]);
     if (L->ev_join[g]) (void)hipEventDestroy(L->ev_join[g]);
@@ -1725,6 +1759,55 @@ static int lg_lanes(int B, int N) {
   return ((long)B * N < 100000) ? 4 : 1;
 }
 
+// ---- persistent cluster path (mpm_cluster.h) ----------------------------------------------------------------------
+// Taken when the launch does not fill the chip (the four-lane regime) and the body's parts fit: envs per launch =
+// 8 * floor(resident parts per XCD / parts per env), the parts of an env sharing an XCD under round-robin placement.
+// UD_MPM_CLUSTER=0 (read at every call; diagnostics and the tests that compare the two paths) keeps the multi-kernel path.
+// lanes per part: 64 (default: the table cannot overflow, see mpm_cluster.h) or 128 (UD_MPM_CLUSTER_T=128, read at every call)
+static int clm_lanes() {
+  const char* e = getenv("UD_MPM_CLUSTER_T");
+  return (e && atoi(e) == 128) ? 128 : 64;
+}
+static int clm_parts(const MpmConst& c, int T) { return (c.N + T / 4 - 1) / (T / 4); }
+static int clm_envs_per_launch(const MpmLarge* L, int B, int T) {
+  const char* e = getenv("UD_MPM_CLUSTER");
+  if (e && e[0] == '0') return 0;
+  const int i = T == 128 ? 1 : 0;
+  const int occ = std::min(L->occ_bwd[i], L->occ_fwd[i]);   // one answer for both directions of a step
+  if (occ <= 0 || L->n_cu < 8 || lg_lanes(B, L->c.N) != 4) return 0;
+  const int W = clm_parts(L->c, T);
+  const int per_xcd = ((L->n_cu / 8) * occ) / W;
+  if (per_xcd < 1) return 0;
+  int per = std::min(B, 8 * per_xcd);
+  if (const char* m = getenv("UD_MPM_CLUSTER_ENVS")) { const int cap = atoi(m); if (cap > 0) per = std::min(per, cap); }   // tests: several launches per call
+  return per;
+}
+
+static int clm_reserve(MpmLarge* L, int Bl, hipStream_t stream) {
+  if (L->cl_arena && Bl <= L->cl.Bl) return UD_OK;
+  if (L->cl_arena) { (void)hipStreamSynchronize(stream); (void)hipFree(L->cl_arena); L->cl_arena = nullptr; L->cl.Bl = 0; }
+  const size_t cells = (size_t)Bl * L->G;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  size_t o_cg[3], o_gg[2], o_own[2];
+  for (int i = 0; i < 3; ++i) o_cg[i] = take(cells * 16);
+  for (int i = 0; i < 2; ++i) o_gg[i] = take(cells * 16);
+  const size_t zero_bytes = off;                         // grids rest at zero, the owner stamps at INT_MAX
+  for (int i = 0; i < 2; ++i) o_own[i] = take(cells * 4);
+  const size_t o_bar = take((size_t)Bl * 4);
+  hipError_t e = hipMalloc(&L->cl_arena, off);
+  if (e != hipSuccess) { set_error("ud_mpm (cluster path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); return UD_ERR_HIP; }
+  char* base = (char*)L->cl_arena;
+  e = hipMemsetAsync(base, 0, zero_bytes, stream);
+  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(base + o_own[0]), 0x7fffffff, (o_bar - o_own[0]) / 4, stream);
+  if (e != hipSuccess) { set_error("ud_mpm (cluster path): memset failed"); (void)hipFree(L->cl_arena); L->cl_arena = nullptr; return UD_ERR_HIP; }
+  for (int i = 0; i < 3; ++i) L->cl.cg[i] = (float4*)(base + o_cg[i]);
+  for (int i = 0; i < 2; ++i) { L->cl.gg[i] = (float4*)(base + o_gg[i]); L->cl.own[i] = (int*)(base + o_own[i]); }
+  L->cl.bar = (unsigned*)(base + o_bar);
+  L->cl.Bl = Bl;
+  return UD_OK;
+}
+
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,
@@ -1756,6 +1839,36 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   }
   int npow2 = 64;
   while (npow2 < N) npow2 <<= 1;
+  const int clT = clm_lanes();
+  if (const int per = clm_envs_per_launch(L, B, clT)) {
+    // persistent cluster kernel: one launch runs all S substeps of `per` envs (mpm_cluster.h); no grid checkpoint (its backward
+    // recomputes the grid next to the barrier it needs anyway)
+    rc = clm_reserve(L, per, st);
+    if (rc) return rc;
+    a.gck_base = nullptr; a.status = status;
+    const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
+    float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
+    for (int b0 = 0; b0 < B; b0 += per) {
+      const int Bl = std::min(per, B - b0);
+      a.b0 = b0; a.f = 0;
+      hipLaunchKernelGGL(lg_prim_in, dim3(Bl, c.n_prim), blk, 0, st, a, ppos, prot);
+      if (sort) hipLaunchKernelGGL(lg_sort, dim3(Bl), dim3(1024), (size_t)npow2 * 8, st, c, b0, x, perm, perm_stride, npow2);
+      hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
+      hipLaunchKernelGGL(lg_fk_all, dim3(Bl, c.n_prim), dim3(64), 0, st, a);
+      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * sizeof(unsigned), st);
+      ClusterGrid g = L->cl;
+      g.Bl = Bl; g.W = clm_parts(c, clT);
+      const long last_off = ckpt ? (long)S * rec : (long)(S & 1) * rec;
+      if (clT == 128) hipLaunchKernelGGL(clm_fwd_kernel<128>, dim3(clm_grid(Bl, g.W)), dim3(128), 0, st, a, g, hist, rec, ckpt ? 1 : 0, last_off);
+      else hipLaunchKernelGGL(clm_fwd_kernel<64>, dim3(clm_grid(Bl, g.W)), dim3(64), 0, st, a, g, hist, rec, ckpt ? 1 : 0, last_off);
+      a.f = S;
+      hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, last, stride_b, xo, vo, Co, Fo, (const int*)perm, perm_stride);
+      hipLaunchKernelGGL(lg_fwd_out, dim3(Bl, c.n_prim + (N + 255) / 256), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("ud_mpm_step_fwd (cluster path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+    return UD_OK;
+  }
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
   for (int g = 0; g < G; ++g) {
@@ -1815,6 +1928,31 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   clip &= 1;
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
+  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
+  const int clT = clm_lanes();
+  if (const int per = clm_envs_per_launch(L, B, clT)) {   // the forward of this step took the same branch (same B, same handle)
+    rc = clm_reserve(L, per, st);
+    if (rc) return rc;
+    a.gck_base = nullptr; a.status = status;
+    for (int b0 = 0; b0 < B; b0 += per) {
+      const int Bl = std::min(per, B - b0);
+      a.b0 = b0; a.f = S - 1;
+      hipLaunchKernelGGL(lg_bwd_in, dim3(Bl, c.n_prim), blk, 0, st, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
+      hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
+      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * sizeof(unsigned), st);
+      ClusterGrid g = L->cl;
+      g.Bl = Bl; g.W = clm_parts(c, clT);
+      if (clT == 128) hipLaunchKernelGGL(clm_bwd_kernel<128>, dim3(clm_grid(Bl, g.W)), dim3(128), 0, st, a, g, ckpt, rec);
+      else hipLaunchKernelGGL(clm_bwd_kernel<64>, dim3(clm_grid(Bl, g.W)), dim3(64), 0, st, a, g, ckpt, rec);
+      a.f = -1;
+      const dim3 gp((N + 255) / 256, Bl);
+      if (clip) hipLaunchKernelGGL(lg_bwd_norm, gp, blk, 0, st, a);
+      hipLaunchKernelGGL(lg_bwd_out, gp, blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("ud_mpm_step_bwd (cluster path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+    return UD_OK;
+  }
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp);
   for (int g = 0; g < G; ++g) {
@@ -1854,7 +1992,6 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     hipLaunchKernelGGL(lg_bwd_out, gp, blk, 0, grp[g].s, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
   }
   lg_join(L, G, st, grp);
-  if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_error("ud_mpm_step_bwd (large path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;

@@ -141,6 +141,7 @@ class SimpleMPMSimulator:
         self.profile = None
         self.status_log = []
         self._status_acc = None          # flags folded out of status_log (device scalar), read by check_status()
+        self._staged = []                # (pinned flags, event) of recent forwards on the many-workgroup path
         self._h = None
         self._h_large = False            # the handle runs the many-workgroup path (N > 128 or soft contact)
         self._flag_stream = None
@@ -249,14 +250,26 @@ class SimpleMPMSimulator:
             host.copy_(status, non_blocking=True)
             done.record(self._flag_stream)
         status.record_stream(self._flag_stream)
+        self._staged.append((host, done))
+        if len(self._staged) > 64:           # the oldest are long complete: look at them now, without a sync
+            for h, d in self._staged[:32]:
+                if d.query() and bool((h & 6).any()):
+                    raise _lib.UnidomError("MPM cluster kernels: device-side failure flags in an earlier step (cell table overflow / time-out)")
+            self._staged = self._staged[32:]
         return host, done
 
     def _overflowed(self, staged):
+        """status[] of a forward on the many-workgroup path (include/unidom_hip.h): bit 0 = the grid-checkpoint pool ran out (not an
+        error: that step's backward recomputes the grid); bits 1-2 = a part of the persistent cluster kernel overflowed its cell
+        table / gave up waiting for its siblings (the step's outputs are invalid: raise)."""
         if staged is None:
             return False
         host, done = staged
         done.synchronize()            # long complete by the time the backward of this step runs
-        over = bool(host.any())
+        if bool((host & 6).any()):
+            raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = cell table of a part "
+                                   "overflowed, 4 = a part gave up waiting for its siblings); outputs of this step are invalid")
+        over = bool((host & 1).any())
         self.grid_ckpt_overflows += int(over)
         return over
 
@@ -274,6 +287,13 @@ class SimpleMPMSimulator:
 
     def check_status(self):
         """Host sync: raise if any launch since the last check overflowed its LDS cell table."""
+        for host, done in self._staged:      # forwards whose flags travelled on the side stream (error bits only; bit 0 is the pool)
+            done.synchronize()
+            if bool((host & 6).any()):
+                self._staged = []
+                raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = cell table of a "
+                                       "part overflowed, 4 = a part gave up waiting for its siblings)")
+        self._staged = []
         if self.status_log or self._status_acc is not None:
             self._fold_status(0)
             bad = self._status_acc.item()
