@@ -574,8 +574,12 @@ def test_mpm_step_diff_fused_matches_op_by_op(name):
     assert name == "shape_rope" or not ({"grad a", "grad x", "grad v", "grad pos0"} & set(skipped)), skipped
 
 
-SHAPE_ROPE_WIRING_STEPS = 2   # scanned simulator.steps (133 substeps each) of the gradient wiring check below; the longest
-                              # horizon at which the measured one-ulp noise of the adjoint stays under 5 % (profiles/r03_shape_rope_grad_noise.txt)
+SHAPE_ROPE_WIRING_STEPS = 8   # scanned simulator.steps (133 substeps each) of the gradient wiring check below: the longest horizon at
+                              # which the measured noise of the adjoint (one-ulp nudge, run-to-run) stays under 5 % for the action, x, v
+                              # and C cotangents -- 1e-3 ... 1e-2 up to 8 steps, O(1) from 12 on (profiles/r03_shape_rope_grad_noise.txt).
+                              # The F cotangent is the exception: 0.3 ... 1 at EVERY horizon, one step included (a plastic body's F enters
+                              # only through the SVD of (I + dt C) F, with 1 / (s_j^2 - s_i^2) factors on an almost isotropic F); it is
+                              # compared wherever its noise allows and reported otherwise.
 
 
 @pytest.mark.gpu
@@ -602,14 +606,18 @@ def test_shape_rope_step_diff_gradient_wiring_short_horizon(monkeypatch):
         assert srg.rel(of[k], ou[k]) < 1e-4, (k, srg.rel(of[k], ou[k]))
     gmax = max(float(t.abs().max()) for t in gu.values())
     bad = []
+    noisy = []
     for k in gu:
-        assert torch.isfinite(gf[k]).all() and float(gu[k].abs().max()) > 0, k
+        assert torch.isfinite(gf[k]).all(), k
+        assert k == "pos0" or float(gu[k].abs().max()) > 0, k     # (get_primitive_actions overwrites position[0]: the start point gets it)
         scale = max(float(gu[k].abs().max()), 1e-3 * gmax)
         err, noise = float((gf[k] - gu[k]).abs().max()) / scale, float((gr[k] - gu[k]).abs().max()) / scale
-        assert noise < 0.05, (k, noise, "the horizon is too long for a wiring check: lower SHAPE_ROPE_WIRING_STEPS")
-        if not err <= 10 * noise + 2e-3:
+        if noise >= 0.05:
+            noisy.append(k)
+        elif not err <= 10 * noise + 2e-3:
             bad.append((k, err, noise))
     assert not bad, bad
+    assert set(noisy) <= {"F"}, (noisy, "the horizon is too long for a wiring check: lower SHAPE_ROPE_WIRING_STEPS")
     assert float(gf["a"][:, [0, 2, 3, 5]].abs().min()) > 0        # both end points of the push receive a gradient
 
 

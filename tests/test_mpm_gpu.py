@@ -339,17 +339,19 @@ def _scaled_case(S, seed, B=1, grid_ckpt_cells=0, conf_cls=ScaledConf):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
-@pytest.fixture(params=["cluster_64", "cluster_128", "multi_kernel"])
+@pytest.fixture(params=["cluster_128", "cluster_64", "cluster_128_both", "cluster_64_both", "multi_kernel"])
 def large_path(request, monkeypatch):
     """The many-workgroup path below 100 k particles per launch has two implementations: the persistent cluster kernels
-    (csrc/mpm_cluster.h; one launch per step call, parts of 16 or 32 particles -- UD_MPM_CLUSTER_T) and the multi-kernel path they
-    replace (UD_MPM_CLUSTER=0; a few launches per substep).  Both are read at every step call, so a test can put each in front
-    of the oracle."""
+    (csrc/mpm_cluster.h; one launch per step call, parts of 32 or 16 particles -- UD_MPM_CLUSTER_T) and the multi-kernel path
+    (UD_MPM_CLUSTER=0; a few launches per substep).  By default the FORWARD of a one-primitive solid takes the cluster kernel and
+    writes the grid checkpoint the multi-kernel backward restores from; *_both also runs the cluster backward
+    (UD_MPM_CLUSTER_BWD=1).  All switches are read at every step call, so a test can put each combination in front of the oracle."""
     if request.param == "multi_kernel":
         monkeypatch.setenv("UD_MPM_CLUSTER", "0")
     else:
         monkeypatch.setenv("UD_MPM_CLUSTER", "1")
         monkeypatch.setenv("UD_MPM_CLUSTER_T", request.param.split("_")[1])
+        monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1" if request.param.endswith("both") else "0")
     return request.param
 
 
@@ -369,7 +371,7 @@ def one_lane_per_particle(monkeypatch):
 
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
 def test_large_path_one_lane_kernels_match_oracle_n798(grid_ckpt_cells, one_lane_per_particle):
-    test_large_path_matches_oracle_n798(grid_ckpt_cells)
+    test_large_path_matches_oracle_n798(grid_ckpt_cells, None)
 
 
 def test_collide_shape_rope_geometry_one_lane_kernels(one_lane_per_particle):
@@ -702,7 +704,7 @@ def test_mpm_step_edge_cases(demo, case, large_path):
     S, N, P, pc = 4, 160, 1, True
     if case.startswith("one_workgroup"):                             # N <= 128, position control: the one-workgroup kernels
         N = 100
-        if large_path not in (None, "cluster_64"):
+        if large_path not in (None, "cluster_128"):
             pytest.skip("the one-workgroup path has no cluster / multi-kernel variants")
     if case.endswith("one_substep"):
         S = 1
@@ -814,7 +816,8 @@ def test_cluster_call_cut_into_several_launches(monkeypatch):
     5 envs as 2 + 2 + 1 must give what one launch gives, forward and adjoint, whichever launch an env was in, and a second call
     on the same handle must find the rotating grids at rest."""
     monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-    sim, st, g, N = _scaled_case(4, 7, B=5)
+    monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1")
+    sim, st, g, N = _scaled_case(4, 7, B=5, grid_ckpt_cells=2)
     for b in range(5):
         st["action"][b] = np.float32([0.1 * b - 0.2, 0.05 * b, 0.3 - 0.1 * b, 0, 0, 0]) / 50
     one = run_hip(sim, st, g=g, clip=True)
@@ -828,6 +831,7 @@ def test_cluster_call_cut_into_several_launches(monkeypatch):
 
 
 def test_cluster_scattered_cloud_cannot_overflow_its_tables(monkeypatch):
+    monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1")
     """Parts of 16 particles touch at most 16 x 27 = 432 cells: the 512-slot table of a part cannot overflow however the cloud is
     scattered (the same particles thrown uniformly through the volume: every part falls back from its window to open addressing).
     Result = the multi-kernel path's, which sends what does not fit its tables to HBM atomics."""
@@ -842,3 +846,35 @@ def test_cluster_scattered_cloud_cannot_overflow_its_tables(monkeypatch):
         assert _rel(got[key], ref[key]) < 2e-6, (key, _rel(got[key], ref[key]))
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
         assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 1e-4, (key, _rel(got[key], ref[key]))
+
+
+def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkeypatch):
+    """The cluster forward writes the grid checkpoint the multi-kernel backward restores from (one record per active cell, by the
+    part that owns the cell, at a position drawn from the env's record counter).  A pool of 1 record per particle and substep
+    holds the compact rope but not the same particles scattered through the volume: the env is flagged in status[] (bit 0), the
+    host mirror sees it without a sync and asks that step's backward to recompute the grid (clip bit 1) -- same gradients as a
+    handle that never checkpoints the grid.  (Parts of 16 particles: a scattered cloud cannot overflow their cell tables.)"""
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
+    monkeypatch.setenv("UD_MPM_CLUSTER_T", "64")
+    sim, st, g, N = _scaled_case(3, 0, B=2, grid_ckpt_cells=1)
+    run_hip(sim, st, g=g, clip=True)                                   # the rope fits
+    assert sim.grid_ckpt_overflows == 0
+    st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)   # env 1 scattered
+    got = run_hip(sim, st, g=g, clip=True)
+    assert sim.grid_ckpt_overflows == 1
+    ref_sim, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=0)
+    ref = run_hip(ref_sim, st, g=g, clip=True)
+    for key in ("x", "v", "gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
+
+
+def test_cluster_part_table_overflow_is_flagged(monkeypatch):
+    """Parts of 32 particles (UD_MPM_CLUSTER_T=128, the default for solids) hold 512 cells: particles thrown uniformly through the
+    volume touch more, the part sets status[] bit 1 and check_status raises -- loud, not a wrong step."""
+    from unidom_amd._lib import UnidomError
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
+    monkeypatch.setenv("UD_MPM_CLUSTER_T", "128")
+    sim, st, g, N = _scaled_case(2, 0, B=2)
+    st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)
+    with pytest.raises(UnidomError):
+        run_hip(sim, st)

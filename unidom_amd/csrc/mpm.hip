@@ -1288,7 +1288,9 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
     delete h;
     return UD_ERR_HIP;
   }
-  if (large) h->large = ud::mpm_large_create(h->c, h->d_material, h->d_hard);
+  bool has_liquid = false;
+  for (int i = 0; i < N; ++i) has_liquid = has_liquid || material[i] == 0;
+  if (large) h->large = ud::mpm_large_create(h->c, h->d_material, h->d_hard, has_liquid);
   *out = h;
   return UD_OK;
 }

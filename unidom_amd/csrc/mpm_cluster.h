@@ -27,8 +27,8 @@
 // refreshed, so EVERY access to data another part may have written inside this launch is an agent-scope operation: float /
 // integer atomics (performed at the memory side), sc1 write-through stores for the zeroing, sc1 (L1-bypassing) loads for the
 // read-back and the poll.  Each wave drains its own stores / atomics (s_waitcnt vmcnt(0)) before the workgroup barrier in front
-// of the arrival; one lane per part arrives with an agent-scope atomic add on the env's monotonic counter and polls it with sc1
-// loads (bounded: ~seconds, then the env is flagged in status[] = 2 and every wave still reaches the end of the kernel); the
+// of the arrival; one lane per part arrives with an agent-scope atomic add on the env's monotonic counter, the last arriver
+// publishes the phase in a generation word that the others poll with sc1 loads (bounded: ~seconds, then the env is flagged in status[] = 2 and every wave still reaches the end of the kernel); the
 // other waves read after a workgroup barrier that lane joins.  Parts of one env get block ids congruent mod 8 (usually one XCD;
 // speed only).  Progress needs every part of a launch resident at once: the host cuts a call into launches that fit
 // (occupancy query x CUs), back to back on the caller's stream.
@@ -40,13 +40,16 @@ namespace ud {
 // cells at most, so the 512-slot table can never overflow and the workgroup barriers are free) or 128 (32 particles: half the
 // parts per env and less duplicated grid work, but a part whose particles are spread over more than 512 cells is an error).
 constexpr int CLM_H = 512, CLM_LOGH = 9;   // staging-table slots per part (= LgTable<4>)
+#ifndef CLM_BWD_WPE
+#define CLM_BWD_WPE(T) ((T) / 64)   // waves per SIMD the backward kernel is compiled for (diagnostic builds override it)
+#endif
 constexpr unsigned CLM_SPIN = 1u << 22;    // polls (~1 us each) before a part gives up
 
 struct ClusterGrid {
-  float4* cg[3];      // [Bl][G] (m, mv): forward rotates three, the backward's recompute two
-  float4* gg[2];      // [Bl][G] backward: cotangent of the grid velocity (xyz)
-  int* own[2];        // [Bl][G] backward: smallest part number that touched the cell (the part that books its parameter cotangents)
-  unsigned* bar;      // [Bl] arrival counters, zeroed before every launch
+  float4* cg[3];      // [Bl][G] (m, mv): forward rotates three, the recomputing backward two
+  float4* gg[3];      // [Bl][G] backward: cotangent of the grid velocity (xyz); two rotate
+  int* own[3];        // [Bl][G] smallest part number that touched the cell this substep (the part that books its parameter cotangents)
+  unsigned* bar;      // [Bl][CLM_BAR_STRIDE]: arrival counter (word 0) and generation word (word CLM_BAR_GEN) per env, zeroed before every launch
   int W, Bl;          // parts per env; envs of this launch (a.b0 = the first one)
 };
 
@@ -75,15 +78,30 @@ __device__ __forceinline__ void clm_decode(int W, int& bl, int& w) {
 }
 __host__ inline int clm_grid(int Bl, int W) { return 8 * W * ((Bl + 7) / 8); }
 
-// The parts of an env meet: every wave has drained its global traffic; returns false once the env is dead (a part gave up).
-__device__ __forceinline__ bool clm_barrier(unsigned* bar, unsigned target, int* s_dead) {
+// The parts of an env meet.  Every wave has drained its global traffic; ONE lane per part arrives with a returning agent-scope
+// atomic add on the env's counter; the part whose add completes the count publishes the phase number in the env's generation
+// word (sc1 store), the others poll THAT word with sc1 loads.  (First version: every part polled the counter itself.  A word that
+// memory-side atomics keep rewriting is never L2-resident, so 800-1600 pollers -- all envs' counters in two cache lines -- became
+// a request storm on one memory channel: time per substep doubled with the number of parts, and removing all grid traffic
+// changed nothing (profiles/r03b_abl_cluster.txt).  The generation word is written once per barrier and polled out of the L2.)
+// Counter and generation word of an env sit on their own 128-byte lines (CLM_BAR_STRIDE words per env).
+// Returns false once the env is dead (a part gave up).
+constexpr int CLM_BAR_STRIDE = 64, CLM_BAR_GEN = 32;
+// idx_out / cnt (forward with a grid checkpoint): the part that completes the count also notes how many grid records the env has
+// written so far -- every part's appends precede its arrival, so that is where the next substep's records begin.
+__device__ __forceinline__ bool clm_barrier(unsigned* bar, unsigned phase, unsigned W, int* s_dead, int* idx_out = nullptr, const int* cnt = nullptr) {
   clm_drain();
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
-      if (spins > CLM_SPIN) { *s_dead = 1; break; }
-      __builtin_amdgcn_s_sleep(1);
+    const unsigned old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == phase * W) {
+      if (idx_out) { *idx_out = ldci(cnt); clm_drain(); }
+      __hip_atomic_store(bar + CLM_BAR_GEN, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (unsigned spins = 0; __hip_atomic_load(bar + CLM_BAR_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase; ++spins) {
+        if (spins > CLM_SPIN) { *s_dead = 1; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
     }
   }
   __syncthreads();
@@ -277,16 +295,40 @@ __global__ void __launch_bounds__(64) lg_fk_all(LargeArgs a) {
   }
 }
 
+// ---- the part's occupied cells as a dense list -----------------------------------------------------------------------------
+// The table is sparse (a compact part fills 40-150 of its 512 slots) and everything that follows the walk -- flush, read-back + grid op,
+// zeroing, the grid-op adjoint -- is per CELL: swept over the 512 slots, each trip of those loops cost its whole body (the grid
+// op with its primitive loads, the collide chains) for a handful of live lanes, T = 64 twice as many trips as T = 128; rocprofv3
+// counted 3 024 VALU instructions per wave and substep in the forward, half of the kernel's time (profiles/r03c_pmc_cluster.txt).
+// One compaction pass per substep (ballot + mbcnt, one LDS add per wave and trip) leaves (key, slot) pairs; the cell loops then
+// make ceil(n / T) trips, normally one.  Every thread of the part calls this; it ends with a workgroup barrier.
+template <int T>
+__device__ __forceinline__ int clm_compact(const int* key, int* klist, int* slist, int* s_n) {
+  for (int s0 = 0; s0 < CLM_H; s0 += T) {
+    const int sl = s0 + (int)threadIdx.x, k = key[sl];
+    const bool occ = k >= 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
+    const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(s_n, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (occ) { klist[base + pre] = k; slist[base + pre] = sl; }
+  }
+  __syncthreads();
+  return *s_n;
+}
+
 // ---- forward ------------------------------------------------------------------------------------------------------
-// LDS per part: key[2][512] ints (the keys of substep f - 1 are needed to zero its buffer) | val[4][512] doubles, reused after the
-// flush as vel[512] float4 (grid velocity, .w = m)
+// LDS per part: key[512] | klist[2][512] (cell keys of this and the previous substep: the previous ones are needed to zero its
+// buffer), slist[512] (their slots) | val[4][512] doubles, reused after the flush as vel[512] float4 (grid velocity, .w = m)
 // hist: env b's records at hist + b * a.hist_stride_b; record 0 = the input state (lg_pack).  keep != 0 (a checkpoint): every
 // substep's input state is kept, record f + 1 at (f + 1) * rec; keep == 0: only the final state is written, at last_off.
 template <int T>
-__global__ void __launch_bounds__(T) clm_fwd_kernel(const LargeArgs a, const ClusterGrid g, float* hist, long rec, int keep, long last_off) {
-  __shared__ int s_key[2][CLM_H];
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm_fwd_kernel(const LargeArgs a, const ClusterGrid g, float* hist, long rec, int keep, long last_off) {
+  __shared__ int s_key[CLM_H], s_klist[2][CLM_H], s_slist[CLM_H];
   __shared__ double s_val[4 * CLM_H];
-  __shared__ int s_dead, s_ovf, s_hash;
+  __shared__ int s_dead, s_ovf, s_hash, s_n, s_no, s_obase;
+  __shared__ unsigned short s_olist[CLM_H];
   int bl, w;
   clm_decode(g.W, bl, w);
   if (bl >= g.Bl) return;
@@ -304,19 +346,30 @@ __global__ void __launch_bounds__(T) clm_fwd_kernel(const LargeArgs a, const Clu
   const int material = a.material[up];
   const float hard = a.hard[up], mu_s = a.mu[b], la_s = a.lamda[b];
   float4* vel = (float4*)s_val;
-  unsigned* bar = g.bar + bl;
-  for (int s = tid; s < CLM_H; s += T) { s_key[0][s] = -1; s_key[1][s] = -1; }
-  __syncthreads();
+  float4* raw = vel + CLM_H;
+  unsigned* bar = g.bar + (long)bl * CLM_BAR_STRIDE;
+  // grid checkpoint for the (multi-kernel) backward, in ITS format: one record {key, m, mv, v} per active cell and substep, written by
+  // the part that owns the cell (the smallest part number that touched it: an atomicMin beside the flush), at a position drawn
+  // from the env's running record counter; idx[f] = first record of substep f (lg_restore, cell_mass_momentum read it).
+  const bool recs = keep && a.gck_base != nullptr;
+  int* ridx = recs ? gck_idx(a, b) : nullptr;
+  float4* rpool = recs ? gck_pool(a, b) : nullptr;
+  int* rcnt = a.w.count + b;                              // zeroed by lg_prim_in
+  if (recs && w == 0 && tid == 0) ridx[0] = 0;
+  int nprev = 0;
   bool alive = true;
   for (int f = 0; f < S && alive; ++f) {
-    int* key = s_key[f & 1];
-    int* kprev = s_key[(f + 1) & 1];
+    int* key = s_key;
+    int* klist = s_klist[f & 1];
+    const int* kprev = s_klist[(f + 1) & 1];
     const BlockTable bt{key, s_val};
     float4* gcur = g.cg[f % 3] + (long)bl * a.G;
     float4* gold = g.cg[(f + 2) % 3] + (long)bl * a.G;    // substep f - 1's buffer
+    int* ocur = g.own[f % 3] + (long)bl * a.G;
+    int* oold = g.own[(f + 2) % 3] + (long)bl * a.G;
     // ---- table clear, pre-pass, window ----
     for (int s = tid; s < CLM_H; s += T) { key[s] = -1; s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0; }
-    if (tid == 0) s_hash = 0;
+    if (tid == 0) { s_hash = 0; s_n = 0; s_no = 0; }
     Pre q;
     q.base[0] = q.base[1] = q.base[2] = 0;
     if (live) {
@@ -331,33 +384,54 @@ __global__ void __launch_bounds__(T) clm_fwd_kernel(const LargeArgs a, const Clu
     if (win.on && live && !clm_stencil_in_window(c, win, q.base)) s_hash = 1;
     __syncthreads();
     if (s_hash) win.on = 0;
-    // ---- p2g into the table, flush to the env's grid ----
+    // ---- p2g into the table, the occupied cells as a list, flush to the env's grid ----
     if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
     __syncthreads();
-    {
+    const int n = clm_compact<T>(key, klist, s_slist, &s_n);
+    if (!(UD_MPM_ABLATE & 16384)) {   // (timing-only diagnostic builds, tools/build_abl.sh: 16384 no flush, 4096 no read-back, 8192 no zeroing, 32768 no barrier)
       const int r = tid & 3;
-#pragma unroll 4
-      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
-        const int k = key[sl];
-        if (k < 0) continue;
-        atomicAdd((float*)(gcur + cell_lin(c, k)) + r, (float)s_val[r * CLM_H + sl]);
+      for (int e = tid >> 2; e < n; e += T / 4) {
+        const long lin = cell_lin(c, klist[e]);
+        atomicAdd((float*)(gcur + lin) + r, (float)s_val[r * CLM_H + s_slist[e]]);
+        if (recs && r == 0) atomicMin(ocur + lin, w);
       }
     }
-    alive = clm_barrier(bar, (unsigned)(f + 1) * (unsigned)g.W, &s_dead);
+    if (UD_MPM_ABLATE & 32768) __syncthreads();
+    else alive = clm_barrier(bar, (unsigned)(f + 1), (unsigned)g.W, &s_dead, (recs && f > 0) ? ridx + f : nullptr, rcnt);
     if (!alive) break;
     // ---- read the summed cells back, grid op, zero the cells of substep f - 1 ----
-    for (int sl = tid; sl < CLM_H; sl += T) {
-      const int k = key[sl];
-      if (k >= 0) {
-        const float4 mv = ldc4(gcur + cell_lin(c, k));
+    for (int e0 = 0; e0 < n; e0 += T) {
+      const int e = e0 + tid;
+      bool mine = false;
+      if (e < n) {
+        const int k = klist[e], sl = s_slist[e];
+        const long lin = cell_lin(c, k);
+        const float4 mv = (UD_MPM_ABLATE & 4096) ? make_float4((float)s_val[sl], (float)s_val[CLM_H + sl], (float)s_val[2 * CLM_H + sl], (float)s_val[3 * CLM_H + sl])
+                                                  : ldc4(gcur + lin);
+        mine = recs && ldci(ocur + lin) == w;
         float vo[3];
         clm_grid_op(a, b, f, k, mv, vo);
         vel[sl] = make_float4(vo[0], vo[1], vo[2], mv.x);
+        if (mine) raw[sl] = mv;                           // the record needs (m, mv) once the env's counter has told where it goes
       }
-      const int ko = kprev[sl];
-      if (ko >= 0) stc4_zero(gold + cell_lin(c, ko));
+      if (recs) {                                         // the cells this part owns, as a list (wave-uniform trips)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine);
+        const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        int ob = 0;
+        if ((tid & 63) == 0 && m) ob = atomicAdd(&s_no, __popcll(m));
+        ob = __builtin_amdgcn_readfirstlane(ob);
+        if (mine) s_olist[ob + pre] = (unsigned short)e;
+      }
     }
+    if (!(UD_MPM_ABLATE & 8192))
+      for (int e = tid; e < nprev; e += T) {
+        const long lin = cell_lin(c, kprev[e]);
+        stc4_zero(gold + lin);
+        if (recs) __hip_atomic_store(oold + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    nprev = n;
     __syncthreads();
+    if (recs && tid == 0) s_obase = s_no ? atomicAdd(rcnt, s_no) : 0;    // where this part's records go (its latency runs beside g2p)
     // ---- g2p + advect ----
     if (live) {
       float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -400,16 +474,33 @@ __global__ void __launch_bounds__(T) clm_fwd_kernel(const LargeArgs a, const Clu
         }
       }
     }
-    __syncthreads();    // vel (= val) and the key buffer of substep f - 1 are rewritten by the next substep's clear
+    __syncthreads();
+    if (recs) {
+      const int no = s_no, ob = s_obase;
+      for (int j = tid; j < no; j += T) {
+        const int e = s_olist[j], sl = s_slist[e];
+        const float4 mv = raw[sl], vv = vel[sl];
+        if (ob + j < a.gck_budget) {
+          float4* r = rpool + (long)(ob + j) * 2;
+          r[0] = make_float4(__builtin_bit_cast(float, klist[e]), mv.x, mv.y, mv.z);
+          r[1] = make_float4(mv.w, vv.x, vv.y, vv.z);
+        } else if (a.status) {
+          a.status[b] = 1;     // pool exhausted: the backward of this env recomputes the grid (clip bit 1), as on the multi-kernel path
+        }
+      }
+      __syncthreads();  // vel / raw (= val), key and the cell list of substep f - 1 are rewritten by the next substep
+    }
   }
   // the buffers go back all-zero: the cells of the last substep, once every part has read them
-  if (alive) alive = clm_barrier(bar, (unsigned)(S + 1) * (unsigned)g.W, &s_dead);
+  if (alive && !(UD_MPM_ABLATE & 32768)) alive = clm_barrier(bar, (unsigned)(S + 1), (unsigned)g.W, &s_dead, recs ? ridx + S : nullptr, rcnt);
   if (alive) {
     float4* glast = g.cg[(S - 1) % 3] + (long)bl * a.G;
-    const int* key = s_key[(S - 1) & 1];
-    for (int sl = tid; sl < CLM_H; sl += T) {
-      const int k = key[sl];
-      if (k >= 0) stc4_zero(glast + cell_lin(c, k));
+    int* olast = g.own[(S - 1) % 3] + (long)bl * a.G;
+    const int* kl = s_klist[(S - 1) & 1];
+    for (int e = tid; e < nprev; e += T) {
+      const long lin = cell_lin(c, kl[e]);
+      stc4_zero(glast + lin);
+      if (recs) __hip_atomic_store(olast + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (!keep && live && qi == 0) {
@@ -512,17 +603,23 @@ __device__ __forceinline__ void clm_grid_adj_cell(const LargeArgs& a, int b, int
   if (live) grid_head_adjoint(mv.x, mvv, g, gmm);
 }
 
-// LDS per part: key[2][512] | val[4][512] doubles = the p2g staging, after barrier 1 raw[512] float4 (m, mv) + vel[512] float4
-// (grid velocity, .w = 1 where this part owns the cell) | gsc[3][512] doubles = the g2p adjoint's staging, after barrier 2
-// gres[512] float4 (cotangent of mv, of m)
+// LDS per part: key[512] | klist[2][512], slist[512] (the occupied cells of this / the previous substep) | val[4][512] doubles = the
+// p2g staging, after barrier 1 raw[512] float4 (m, mv) + vel[512] float4 (grid velocity, .w = 1 where this part owns the cell) |
+// gsc[3][512] doubles = the g2p adjoint's staging, after the barrier gres[512] float4 (cotangent of mv, of m).
+// Recomputes p2g + the grid op per substep (two barriers).  NOT the default backward: measured (profiles/r03f_cluster_paths.txt) it is
+// no faster than the multi-kernel backward restoring the grid from the checkpoint -- 256 VGPRs + 512 bytes of scratch per lane at two
+// waves per SIMD, and its long chains (pre-pass, particle adjoint) are single-wave latency either way -- so by default the cluster
+// FORWARD writes that checkpoint and the multi-kernel backward runs (UD_MPM_CLUSTER_BWD=1 selects this kernel; the tests do).
+// (A variant restoring the table from per-part records, one barrier per substep, was built and measured at the same speed: the
+// recompute is not what this kernel waits for.)
 template <int T>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))) clm_bwd_kernel(const LargeArgs a, const ClusterGrid g, const float* ckpt, long rec) {
-  __shared__ int s_key[2][CLM_H];
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(CLM_BWD_WPE(T)))) clm_bwd_kernel(const LargeArgs a, const ClusterGrid g, const float* ckpt, long rec) {
+  __shared__ int s_key[CLM_H], s_klist[2][CLM_H], s_slist[CLM_H];
   __shared__ double s_val[4 * CLM_H];
   __shared__ double s_gsc[3 * CLM_H];
   __shared__ float s_red[2][UD_PRIMC_NGRAD];
   __shared__ float s_par[2];
-  __shared__ int s_dead, s_ovf, s_hash;
+  __shared__ int s_dead, s_ovf, s_hash, s_n;
   int bl, w;
   clm_decode(g.W, bl, w);
   if (bl >= g.Bl) return;
@@ -530,6 +627,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))
   const MpmConst& c = a.c;
   const bool live = p < c.N;
   const int S = c.steps, P = c.n_prim;
+  constexpr int NB = 2, NG = 2;                       // barriers per substep, rotating cotangent grids
   if (tid == 0) { s_dead = 0; s_ovf = 0; }
   if (tid < 2) s_par[tid] = 0.f;
   const float* hb = ckpt + (long)b * a.hist_stride_b;
@@ -550,70 +648,66 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))
   float4* raw = (float4*)s_val;
   float4* vel = raw + CLM_H;
   float4* gres = (float4*)s_gsc;
-  unsigned* bar = g.bar + bl;
-  for (int s = tid; s < CLM_H; s += T) { s_key[0][s] = -1; s_key[1][s] = -1; }
-  __syncthreads();
+  unsigned* bar = g.bar + (long)bl * CLM_BAR_STRIDE;
+  int nprev = 0;
   bool alive = true;
   for (int k = 0; k < S && alive; ++k) {
     const int f = S - 1 - k;
-    int* key = s_key[k & 1];
-    int* kprev = s_key[(k + 1) & 1];
+    int* key = s_key;
+    int* klist = s_klist[k & 1];
+    const int* kprev = s_klist[(k + 1) & 1];
     const BlockTable bt{key, s_val};
     float4* gcur = g.cg[k & 1] + (long)bl * a.G;
     int* ocur = g.own[k & 1] + (long)bl * a.G;
-    float4* ggcur = g.gg[k & 1] + (long)bl * a.G;
-    float4* ggold = g.gg[(k + 1) & 1] + (long)bl * a.G;
-    // ---- checkpointed state of substep f, pre-pass with the adjoint's extras, p2g again ----
+    float4* ggcur = g.gg[k % NG] + (long)bl * a.G;
+    float4* ggold = g.gg[(k + NG - 1) % NG] + (long)bl * a.G;   // the previous substep's cotangent grid
+    // ---- checkpointed state of substep f, pre-pass with the adjoint's extras ----
     float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, Cm[9], F[9];
 #pragma unroll
     for (int d = 0; d < 9; ++d) { Cm[d] = 0.f; F[d] = (d % 4 == 0) ? 1.f : 0.f; }
     if (live) load_state(hb + (long)f * rec, c.Np, p, x, v, Cm, F);
     for (int s = tid; s < CLM_H; s += T) {
-      key[s] = -1; s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0;
+      key[s] = -1;
+      s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0;
       s_gsc[s] = 0.0; s_gsc[CLM_H + s] = 0.0; s_gsc[2 * CLM_H + s] = 0.0;
     }
-    if (tid == 0) s_hash = 0;
+    if (tid == 0) { s_hash = 0; s_n = 0; }
     Pre q;
     PreB kb;
     q.base[0] = q.base[1] = q.base[2] = 0;
     if (live) particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
+    // ---- p2g again, flush, barrier, read back (m, mv) and the owner, grid op ----
     BlockWin win = bt_window(c, live, q.base);
     if (win.on && live && !clm_stencil_in_window(c, win, q.base)) s_hash = 1;
     __syncthreads();
     if (s_hash) win.on = 0;
     if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
     __syncthreads();
+    const int n = clm_compact<T>(key, klist, s_slist, &s_n);
     {
       const int r = tid & 3;
-#pragma unroll 4
-      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
-        const int kk = key[sl];
-        if (kk < 0) continue;
-        const long lin = cell_lin(c, kk);
-        atomicAdd((float*)(gcur + lin) + r, (float)s_val[r * CLM_H + sl]);
+      for (int e = tid >> 2; e < n; e += T / 4) {
+        const long lin = cell_lin(c, klist[e]);
+        atomicAdd((float*)(gcur + lin) + r, (float)s_val[r * CLM_H + s_slist[e]]);
         if (r == 0) atomicMin(ocur + lin, w);
       }
     }
-    alive = clm_barrier(bar, (unsigned)(2 * k + 1) * (unsigned)g.W, &s_dead);
+    alive = clm_barrier(bar, (unsigned)(2 * k + 1), (unsigned)g.W, &s_dead);
     if (!alive) break;
     // FK adjoint of substep f + 1: every part's grid-op adjoint of that substep has landed (it preceded the barrier)
     if (w == 0 && k > 0)
-      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<true>(a, (long)b * P + ip, f + 1);
-    // ---- read back (m, mv) and the owner, grid op; zero the cotangent cells of the previous substep ----
-    for (int sl = tid; sl < CLM_H; sl += T) {
-      const int kk = key[sl];
-      if (kk >= 0) {
-        const long lin = cell_lin(c, kk);
-        const float4 mv = ldc4(gcur + lin);
-        const bool mine = ldci(ocur + lin) == w;
-        float vo[3];
-        clm_grid_op(a, b, f, kk, mv, vo);
-        raw[sl] = mv;
-        vel[sl] = make_float4(vo[0], vo[1], vo[2], mine ? 1.f : 0.f);
-      }
-      const int ko = kprev[sl];
-      if (ko >= 0) stc4_zero(ggold + cell_lin(c, ko));
+      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<1>(a, (long)b * P + ip, f + 1);
+    for (int e = tid; e < n; e += T) {
+      const int kk = klist[e], sl = s_slist[e];
+      const long lin = cell_lin(c, kk);
+      const float4 mv = ldc4(gcur + lin);
+      const bool mine = ldci(ocur + lin) == w;
+      float vo[3];
+      clm_grid_op(a, b, f, kk, mv, vo);
+      raw[sl] = mv;
+      vel[sl] = make_float4(vo[0], vo[1], vo[2], mine ? 1.f : 0.f);
     }
+    for (int e = tid; e < nprev; e += T) stc4_zero(ggold + cell_lin(c, kprev[e]));   // the previous substep's cotangent cells: everybody has read them
     __syncthreads();
     // ---- g2p adjoint: scatter the cotangent of the grid velocity, weight / fx partials ----
     float gw[9], gfx[3] = {0.f, 0.f, 0.f};
@@ -655,21 +749,19 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))
     __syncthreads();
     {
       const int r = tid & 3;
-#pragma unroll 4
-      for (int sl = tid >> 2; sl < CLM_H; sl += T / 4) {
-        const int kk = key[sl];
-        if (kk < 0 || r == 3) continue;
-        atomicAdd((float*)(ggcur + cell_lin(c, kk)) + r, (float)s_gsc[r * CLM_H + sl]);
-      }
+      if (r < 3)
+        for (int e = tid >> 2; e < n; e += T / 4)
+          atomicAdd((float*)(ggcur + cell_lin(c, klist[e])) + r, (float)s_gsc[r * CLM_H + s_slist[e]]);
     }
-    alive = clm_barrier(bar, (unsigned)(2 * k + 2) * (unsigned)g.W, &s_dead);
+    alive = clm_barrier(bar, (unsigned)(NB * k + NB), (unsigned)g.W, &s_dead);
     if (!alive) break;
-    // ---- read the summed cotangent back, grid-op adjoint; the recomputed (m, mv) cells and their owners go back to rest ----
+    nprev = n;
+    // ---- read the summed cotangent back, grid-op adjoint; (recompute) the (m, mv) cells and their owners go back to rest ----
 #pragma unroll 1
-    for (int s0 = 0; s0 < CLM_H; s0 += T) {        // block-uniform trips: the cell adjoint holds workgroup barriers
-      const int sl = s0 + tid;
-      const int kk = key[sl];
-      const bool lv = kk >= 0;
+    for (int e0 = 0; e0 < n; e0 += T) {                  // block-uniform trips: the cell adjoint holds workgroup barriers
+      const int e = e0 + tid;
+      const bool lv = e < n;
+      const int kk = lv ? klist[e] : 0, sl = lv ? s_slist[e] : 0;
       float gg3[3] = {0.f, 0.f, 0.f}, gmm = 0.f;
       float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
       bool mine = false;
@@ -734,16 +826,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T / 64))
     __syncthreads();
   }
   // the last substep's FK adjoint and cotangent cells, once every part is through its grid-op adjoint
-  if (alive) alive = clm_barrier(bar, (unsigned)(2 * S + 1) * (unsigned)g.W, &s_dead);
+  if (alive) alive = clm_barrier(bar, (unsigned)(NB * S + 1), (unsigned)g.W, &s_dead);
   if (alive) {
     if (w == 0)
-      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<true>(a, (long)b * P + ip, 0);
-    float4* gglast = g.gg[(S - 1) & 1] + (long)bl * a.G;
-    const int* key = s_key[(S - 1) & 1];
-    for (int sl = tid; sl < CLM_H; sl += T) {
-      const int kk = key[sl];
-      if (kk >= 0) stc4_zero(gglast + cell_lin(c, kk));
-    }
+      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<1>(a, (long)b * P + ip, 0);
+    float4* gglast = g.gg[(S - 1) % NG] + (long)bl * a.G;
+    const int* kl = s_klist[(S - 1) & 1];
+    for (int e = tid; e < nprev; e += T) stc4_zero(gglast + cell_lin(c, kl[e]));
   }
   if (live && qi == 0) {
 #pragma unroll

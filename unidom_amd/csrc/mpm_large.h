@@ -5,7 +5,7 @@
 namespace ud {
 
 struct MpmLarge;
-MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard);
+MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid);   // has_liquid: some particle has material 0
 void mpm_large_destroy(MpmLarge* L);
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B);
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,

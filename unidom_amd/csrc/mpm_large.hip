@@ -72,8 +72,10 @@ struct LargeArgs {
 // ---- agent-scope accesses (persistent cluster kernels, mpm_cluster.h): sc1 loads bypass the CU's L1, sc1 stores write through
 __device__ __forceinline__ float ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stc(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool COH> __device__ __forceinline__ float ld_f(const float* p) { return COH ? ldc(p) : *p; }
-template <bool COH> __device__ __forceinline__ void st_f(float* p, float v) { if (COH) stc(p, v); else *p = v; }
+template <int COH> __device__ __forceinline__ float ld_f(const float* p) { return COH ? ldc(p) : *p; }
+template <int COH> __device__ __forceinline__ void st_f(float* p, float v) { if (COH) stc(p, v); else *p = v; }
+// p += v: a read-modify-write, or (COH == 2: other workgroups add to the same word at the same time) an atomic
+template <int COH> __device__ __forceinline__ void add_f(float* p, float v) { if (COH == 2) { if (v != 0.f) atomicAdd(p, v); } else st_f<COH>(p, ld_f<COH>(p) + v); }
 
 __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   int ci, cj, ck;
@@ -820,9 +822,13 @@ __device__ __forceinline__ float ppos_preclip_g(const float* pp, const float* pi
 // FK adjoint of substep f (one block per env)
 // Runs in the extra blocks of lg_p2g_adj (one 256-thread block per env and primitive): both only need the grid-op adjoint
 // of this substep, neither needs the other, and a launch of its own cost 5 us per reverse substep for microseconds of work.
-// COH: the cotangent arrays are read and written with agent-scope accesses (the persistent cluster kernel: other workgroups of
-// the same launch add to them with atomics between two calls)
-template <bool COH>
+// COH = 1: the cotangent arrays are read and written with agent-scope accesses (the persistent cluster kernel with two barriers per
+// substep: other workgroups of the same launch add to them with atomics BETWEEN two calls).  COH = 2 (one barrier per substep: the
+// other workgroups' grid-op adjoint of substep f - 1 adds to rows f - 1 and f WHILE this runs): every update of a row those atomics
+// may touch is itself an atomic add -- row f receives t, row f + 1 (complete, nobody adds to it any more) is consumed -- and the
+// whole-array clip factor, 1 for every coordinate inside (-2, 2), is applied only where it is not 1: exact unless a primitive
+// coordinate sits at or beyond +-2 (outside every env's domain), where that multiplication may lose a concurrent add.
+template <int COH>
 __device__ __forceinline__ void fk_adj_block_f(const LargeArgs& a, long b /* (env, primitive) row of the primitive arrays */, int f) {
   const int S = a.c.steps;
   const float* pp = a.w.ppos + b * S * 3;
@@ -842,7 +848,17 @@ __device__ __forceinline__ void fk_adj_block_f(const LargeArgs& a, long b /* (en
       }
     }
     __syncthreads();
-    if (e < S * 3) { st_f<COH>(gp + e, val); if (!COH || t != 0.f) st_f<COH>(gpv + e, ld_f<COH>(gpv + e) + t); }
+    if (COH == 2) {
+      if (e < S * 3) {
+        const int row = e / 3, d = e - row * 3;
+        const float pva = clipf(a.action[b * 6 + d], -1.f, 1.f) * 1.f / (float)S;
+        const float cgr = clip_grad(ppos_preclip_g(pp, pin, f, row, d, pva), -2.f, 2.f);
+        if (f + 1 < S && row == f + 1) stc(gp + e, 0.f);                                   // consumed (its t went to row f below)
+        else if (cgr != 1.f) stc(gp + e, ldc(gp + e) * cgr + t);                           // degenerate: see above
+        else if (t != 0.f) atomicAdd(gp + e, t);
+        if (t != 0.f) atomicAdd(gpv + e, t);
+      }
+    } else if (e < S * 3) { st_f<COH>(gp + e, val); if (!COH || t != 0.f) st_f<COH>(gpv + e, ld_f<COH>(gpv + e) + t); }
     __syncthreads();
   }
   // soft contact: rotation' = set(rotation, f+1, qmul(w2quat(w[f]), rotation[f]))  (primitives.py:190, :73-92)
@@ -869,10 +885,10 @@ __device__ __forceinline__ void fk_adj_block_f(const LargeArgs& a, long b /* (en
     float gO[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) gO[d] = go[d] / nn + goo * o[d] / oo;
-    st_f<COH>(gr_ + f * 4 + 0, ld_f<COH>(gr_ + f * 4 + 0) + (gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3]));
-    st_f<COH>(gr_ + f * 4 + 1, ld_f<COH>(gr_ + f * 4 + 1) + (-gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2]));
-    st_f<COH>(gr_ + f * 4 + 2, ld_f<COH>(gr_ + f * 4 + 2) + (-gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1]));
-    st_f<COH>(gr_ + f * 4 + 3, ld_f<COH>(gr_ + f * 4 + 3) + (-gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0]));
+    add_f<COH>(gr_ + f * 4 + 0, gO[0] * q[0] + gO[1] * q[1] + gO[2] * q[2] + gO[3] * q[3]);
+    add_f<COH>(gr_ + f * 4 + 1, -gO[0] * q[1] + gO[1] * q[0] + gO[2] * q[3] - gO[3] * q[2]);
+    add_f<COH>(gr_ + f * 4 + 2, -gO[0] * q[2] - gO[1] * q[3] + gO[2] * q[0] + gO[3] * q[1]);
+    add_f<COH>(gr_ + f * 4 + 3, -gO[0] * q[3] + gO[1] * q[2] - gO[2] * q[1] + gO[3] * q[0]);
     const float gq[4] = {gO[0] * rr[0] + gO[1] * rr[1] + gO[2] * rr[2] + gO[3] * rr[3],
                          -gO[0] * rr[1] + gO[1] * rr[0] - gO[2] * rr[3] + gO[3] * rr[2],
                          -gO[0] * rr[2] + gO[1] * rr[3] + gO[2] * rr[0] - gO[3] * rr[1],
@@ -885,10 +901,10 @@ __device__ __forceinline__ void fk_adj_block_f(const LargeArgs& a, long b /* (en
     // |w| = sqrt(sum w^2): at w = 0 the reference's chain rule is 0.5/0 * 0 = NaN, laundered by nan_to_num at `step`
     const float gs = gang * (0.5f / nrm);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { float* pw_ = a.w.gpw + b * S * 3 + f * 3 + d; st_f<COH>(pw_, ld_f<COH>(pw_) + (gw[d] + gs * (2.f * w[d]))); }
+    for (int d = 0; d < 3; ++d) { float* pw_ = a.w.gpw + b * S * 3 + f * 3 + d; st_f<COH>(pw_, ld_f<COH>(pw_) + (gw[d] + gs * (2.f * w[d]))); }   // only this block writes gpw
   }
 }
-__device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b) { fk_adj_block_f<false>(a, b, a.f); }
+__device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b) { fk_adj_block_f<0>(a, b, a.f); }
 
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
 template <int LANES>
@@ -1593,6 +1609,7 @@ struct MpmLarge {
   // persistent cluster kernels (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated on first use
   ClusterGrid cl{};
   void* cl_arena = nullptr;
+  bool has_liquid = false;   // some particle has material 0
   int n_cu = 0, occ_fwd[2] = {0, 0}, occ_bwd[2] = {0, 0};   // CUs; resident parts per CU of the two kernels (occupancy query), [0] 64-lane, [1] 128-lane parts
 };
 
@@ -1616,9 +1633,9 @@ static int lg_groups(const MpmLarge* L, int B) {
   return want < MpmLarge::MAX_GROUPS ? want : MpmLarge::MAX_GROUPS;
 }
 
-MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard) {
+MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid) {
   auto* L = new MpmLarge;
-  L->c = c; L->d_material = d_material; L->d_hard = d_hard;
+  L->c = c; L->d_material = d_material; L->d_hard = d_hard; L->has_liquid = has_liquid;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
   L->W32 = (L->G + 31) / 32 + 1;   // + 1: a row of eight cells may straddle into the word behind the last
@@ -1763,15 +1780,21 @@ static int lg_lanes(int B, int N) {
 // Taken when the launch does not fill the chip (the four-lane regime) and the body's parts fit: envs per launch =
 // 8 * floor(resident parts per XCD / parts per env), the parts of an env sharing an XCD under round-robin placement.
 // UD_MPM_CLUSTER=0 (read at every call; diagnostics and the tests that compare the two paths) keeps the multi-kernel path.
-// lanes per part: 64 (default: the table cannot overflow, see mpm_cluster.h) or 128 (UD_MPM_CLUSTER_T=128, read at every call)
+// lanes per part: 128 (default: 32 particles per part -- half the parts, less duplicated grid work; a part whose particles touch
+// more than 512 cells is flagged in status[]) or 64 (UD_MPM_CLUSTER_T=64, read at every call: 16 particles, cannot overflow)
 static int clm_lanes() {
   const char* e = getenv("UD_MPM_CLUSTER_T");
-  return (e && atoi(e) == 128) ? 128 : 64;
+  return (e && atoi(e) == 64) ? 64 : 128;
 }
 static int clm_parts(const MpmConst& c, int T) { return (c.N + T / 4 - 1) / (T / 4); }
+// Which bodies: by default solids with one primitive -- lattice-seeded ropes, whose 32 consecutive particles stay within a few cells
+// of each other.  Liquids (material 0: sampled uniformly, they mix) could spread a part over more cells than its table holds, and
+// with several primitives every part repeats the collide chains of the cells it shares (measured, pour_water: the multi-kernel
+// path is faster): both keep the multi-kernel path.  UD_MPM_CLUSTER=1 forces the cluster path where it fits, 0 forbids it.
 static int clm_envs_per_launch(const MpmLarge* L, int B, int T) {
   const char* e = getenv("UD_MPM_CLUSTER");
   if (e && e[0] == '0') return 0;
+  if (!(e && e[0] == '1') && (L->has_liquid || L->c.n_prim > 1)) return 0;
   const int i = T == 128 ? 1 : 0;
   const int occ = std::min(L->occ_bwd[i], L->occ_fwd[i]);   // one answer for both directions of a step
   if (occ <= 0 || L->n_cu < 8 || lg_lanes(B, L->c.N) != 4) return 0;
@@ -1789,20 +1812,19 @@ static int clm_reserve(MpmLarge* L, int Bl, hipStream_t stream) {
   const size_t cells = (size_t)Bl * L->G;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  size_t o_cg[3], o_gg[2], o_own[2];
+  size_t o_cg[3], o_gg[3], o_own[3];
   for (int i = 0; i < 3; ++i) o_cg[i] = take(cells * 16);
-  for (int i = 0; i < 2; ++i) o_gg[i] = take(cells * 16);
+  for (int i = 0; i < 3; ++i) o_gg[i] = take(cells * 16);
   const size_t zero_bytes = off;                         // grids rest at zero, the owner stamps at INT_MAX
-  for (int i = 0; i < 2; ++i) o_own[i] = take(cells * 4);
-  const size_t o_bar = take((size_t)Bl * 4);
+  for (int i = 0; i < 3; ++i) o_own[i] = take(cells * 4);
+  const size_t o_bar = take((size_t)Bl * CLM_BAR_STRIDE * 4);
   hipError_t e = hipMalloc(&L->cl_arena, off);
   if (e != hipSuccess) { set_error("ud_mpm (cluster path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); return UD_ERR_HIP; }
   char* base = (char*)L->cl_arena;
   e = hipMemsetAsync(base, 0, zero_bytes, stream);
   if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(base + o_own[0]), 0x7fffffff, (o_bar - o_own[0]) / 4, stream);
   if (e != hipSuccess) { set_error("ud_mpm (cluster path): memset failed"); (void)hipFree(L->cl_arena); L->cl_arena = nullptr; return UD_ERR_HIP; }
-  for (int i = 0; i < 3; ++i) L->cl.cg[i] = (float4*)(base + o_cg[i]);
-  for (int i = 0; i < 2; ++i) { L->cl.gg[i] = (float4*)(base + o_gg[i]); L->cl.own[i] = (int*)(base + o_own[i]); }
+  for (int i = 0; i < 3; ++i) { L->cl.cg[i] = (float4*)(base + o_cg[i]); L->cl.gg[i] = (float4*)(base + o_gg[i]); L->cl.own[i] = (int*)(base + o_own[i]); }
   L->cl.bar = (unsigned*)(base + o_bar);
   L->cl.Bl = Bl;
   return UD_OK;
@@ -1841,11 +1863,10 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   while (npow2 < N) npow2 <<= 1;
   const int clT = clm_lanes();
   if (const int per = clm_envs_per_launch(L, B, clT)) {
-    // persistent cluster kernel: one launch runs all S substeps of `per` envs (mpm_cluster.h); no grid checkpoint (its backward
-    // recomputes the grid next to the barrier it needs anyway)
+    // persistent cluster kernel: one launch runs all S substeps of `per` envs (mpm_cluster.h)
     rc = clm_reserve(L, per, st);
     if (rc) return rc;
-    a.gck_base = nullptr; a.status = status;
+    a.status = status;                                    // gck_base stays: the cluster forward writes the grid checkpoint too
     const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
     float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
     for (int b0 = 0; b0 < B; b0 += per) {
@@ -1855,7 +1876,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
       if (sort) hipLaunchKernelGGL(lg_sort, dim3(Bl), dim3(1024), (size_t)npow2 * 8, st, c, b0, x, perm, perm_stride, npow2);
       hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
       hipLaunchKernelGGL(lg_fk_all, dim3(Bl, c.n_prim), dim3(64), 0, st, a);
-      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * sizeof(unsigned), st);
+      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * CLM_BAR_STRIDE * sizeof(unsigned), st);
       ClusterGrid g = L->cl;
       g.Bl = Bl; g.W = clm_parts(c, clT);
       const long last_off = ckpt ? (long)S * rec : (long)(S & 1) * rec;
@@ -1929,8 +1950,11 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
+  // Default backward = the multi-kernel path below, restoring the grid from the checkpoint that either forward wrote
+  // (measurements: mpm_cluster.h, clm_bwd_kernel).  UD_MPM_CLUSTER_BWD=1: the persistent cluster backward (recomputes the grid).
+  const char* cbw = getenv("UD_MPM_CLUSTER_BWD");
   const int clT = clm_lanes();
-  if (const int per = clm_envs_per_launch(L, B, clT)) {   // the forward of this step took the same branch (same B, same handle)
+  if (const int per = (cbw && cbw[0] == '1') ? clm_envs_per_launch(L, B, clT) : 0) {
     rc = clm_reserve(L, per, st);
     if (rc) return rc;
     a.gck_base = nullptr; a.status = status;
@@ -1939,11 +1963,12 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       a.b0 = b0; a.f = S - 1;
       hipLaunchKernelGGL(lg_bwd_in, dim3(Bl, c.n_prim), blk, 0, st, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
       hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
-      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * sizeof(unsigned), st);
+      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * CLM_BAR_STRIDE * sizeof(unsigned), st);
       ClusterGrid g = L->cl;
       g.Bl = Bl; g.W = clm_parts(c, clT);
-      if (clT == 128) hipLaunchKernelGGL(clm_bwd_kernel<128>, dim3(clm_grid(Bl, g.W)), dim3(128), 0, st, a, g, ckpt, rec);
-      else hipLaunchKernelGGL(clm_bwd_kernel<64>, dim3(clm_grid(Bl, g.W)), dim3(64), 0, st, a, g, ckpt, rec);
+      const dim3 gr(clm_grid(Bl, g.W));
+      if (clT == 128) hipLaunchKernelGGL(clm_bwd_kernel<128>, gr, dim3(128), 0, st, a, g, ckpt, rec);
+      else hipLaunchKernelGGL(clm_bwd_kernel<64>, gr, dim3(64), 0, st, a, g, ckpt, rec);
       a.f = -1;
       const dim3 gp((N + 255) / 256, Bl);
       if (clip) hipLaunchKernelGGL(lg_bwd_norm, gp, blk, 0, st, a);
