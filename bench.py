@@ -144,6 +144,59 @@ def pmc_traffic(key):
     return e.get("hbm_bytes_per_launch")
 
 
+VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: a SIMD issues one wave64 VALU instruction per 4 clocks -> 0.6e9 per SIMD and second at the peak clock
+# static VALU + SALU wave-instructions per lane-substep of the one-workgroup cloth kernels (tools/asm_loop_stats.py on the inner loops,
+# DESIGN.md 3.1) -- used when profiles/pmc_traffic.json holds no SQ_INSTS_* pass for the current sources
+STATIC_INSTR_PER_SUBSTEP = {"cloth_rollout_fwd_v2_kernel": 392, "cloth_rollout_bwd_fast_kernel": 707}
+
+
+def issue_roof(kname, kernel_ms, waves, busy_cus, substeps, static_only=False):
+    """What bounds a one-workgroup-per-env kernel is instruction issue on the few CUs it occupies, not HBM: `frac` = wave-instructions
+    the launch executes per second / what the busy SIMDs can issue (busy CUs x 4 SIMDs x clock / 4).  Counts from the SQ_INSTS_VALU
+    (+ SALU: they share the issue port with VALU at 2 waves per SIMD) PMC pass when profiles/pmc_traffic.json has one
+    for the current sources, else the static per-substep count of the inner loop."""
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    src, per_launch = None, None
+    if os.path.exists(tj) and not static_only:   # the counter pass belongs to the headline launch shape
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import src_hash
+        e = json.load(open(tj)).get(kname) or {}
+        if e.get("insts") and e.get("src_sha16") == src_hash.sha16(kname):
+            per_launch = e["insts"].get("SQ_INSTS_VALU", 0.0) + e["insts"].get("SQ_INSTS_SALU", 0.0)
+            src = "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (profiles/pmc_traffic.json)"
+    if per_launch is None and kname in STATIC_INSTR_PER_SUBSTEP:
+        per_launch = STATIC_INSTR_PER_SUBSTEP[kname] * waves * substeps
+        src = "static count of the inner loop (tools/asm_loop_stats.py) x waves x substeps"
+    if per_launch is None:
+        return None
+    rate = per_launch / (kernel_ms * 1e-3)
+    peak = busy_cus * 4 * VALU_CLOCK_HZ / 4
+    return {"bound": "valu_issue", "wave_instructions_per_launch": per_launch, "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+            "frac": rate / peak, "busy_cus": busy_cus, "waves": waves, "source": src,
+            "note": "the binding roof of this kernel: one workgroup per env, the substeps of a launch are sequential (see roofline.note)"}
+
+
+def host_cores():
+    """Cores this process may really use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box shows 256 logical CPUs but
+    gives one GPU's job a share of 16: round 2's "all cores" leg started 256 threads on them and scaled 8x -- that was the quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
     """Oracle (CPU restatement, NOT JAX-CPU), rebuilt here with -O3 -march=native, timed on the host cores: forward + adjoint
     of the headline workload (4 envs x ep_len step_diffs) on min(4, nproc) threads (`value`), the same on ONE thread, and
@@ -156,7 +209,7 @@ def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
     except Exception as e:      # no compiler on this host: time the portable build that travelled with the repo, and say so
         build = f"-O3 baseline x86-64 (the native rebuild failed: {type(e).__name__})"
     orc = pyoracle.ClothOracle(fold_cloth1_mask())
-    nproc = os.cpu_count() or 1
+    nproc = host_cores()
 
     def run(envs, threads, reps):
         rng = np.random.default_rng(0)
@@ -179,13 +232,16 @@ def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
     nn, t_fn, t_bn = run(nproc, nproc, ep_len)
     return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
             "sample": f"CPU restatement (C++ {build}, f32, reference op order, no FMA contraction; not "
-                      f"JAX-CPU): {sample_envs} envs x {ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint "
+                      f"JAX-CPU) on a SYNTHETIC cloth state (tests/conftest.make_cloth_case: deformed lattice + a lifting macro-action sequence, "
+                      f"not the env state the GPU leg runs; the work per substep does not depend on the data): "
+                      f"{sample_envs} envs x {ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint "
                       f"{t_b:.2f}s; the adjoint call recomputes the forward states itself (it keeps no checkpoint), so its time "
                       f"includes one more forward; OpenMP over envs ({threads} threads; substeps are sequential)",
             "fwd_only_value": n / t_f,
             "one_thread": {"value": n1 / (t_f1 + t_b1), "fwd_only_value": n1 / t_f1, "cores": 1, "sample": f"1 env x {ep_len} step_diff"},
             "all_cores": {"value": nn / (t_fn + t_bn), "fwd_only_value": nn / t_fn, "cores": nproc,
-                          "sample": f"{nproc} envs x {ep_len} step_diff on {nproc} threads (more envs than the headline workload has)"}}
+                          "sample": f"{nproc} envs x {ep_len} step_diff on {nproc} threads = the cores this job may use (affinity mask and cgroup quota; "
+                                    f"the box shows {os.cpu_count()} logical CPUs); more envs than the headline workload has"}}
 
 
 def saturation_probe(env, device, num_envs=1024, reps=3):
@@ -215,11 +271,22 @@ def saturation_probe(env, device, num_envs=1024, reps=3):
     ms = {kk: float(np.mean([a.elapsed_time(b) for a, b in vv[1:]])) for kk, vv in sim.profile.items()}
     n = num_envs * MACRO * SUBSTEPS
     tot = (ms["fwd"] + ms["bwd"]) * 1e-3
-    return {"note": "same kernels, chip filled; not the headline workload", "num_envs": num_envs,
-            "kernel_ms": ms, "substeps_per_sec_fwd_bwd": n / tot,
-            "achieved_GBs": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9, "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9},
-            "hbm_frac": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    # what the kernels really move: the per-substep checkpoint stream (written by the forward, read back by the adjoint); state and
+    # cotangents never leave registers / LDS.  The PMC passes at the headline shape measure exactly that (98.9 MB per launch =
+    # 4 envs x 2001 records x 12 352 B, profiles/pmc_traffic.json), so the counter bytes of a 1024-env launch are its checkpoint size.
+    from unidom_amd import _lib
+    import ctypes as C
+    ck = float(_lib.lib().ud_cloth_ckpt_bytes(sim._h, C.c_int(num_envs), C.c_int(MACRO)))
+    return {"note": "same kernels, chip filled; not the headline workload.  hbm_frac = checkpoint-stream bytes (what the FETCH_SIZE / WRITE_SIZE "
+                    "counters see) / kernel time / 8 TB/s; hbm_frac_algorithmic uses SURVEY 8(d)'s 48 / 72 B per particle-substep, bytes these "
+                    "kernels never move (state and cotangents stay on chip) -- quoted only for comparison with round 2's line",
+            "num_envs": num_envs, "kernel_ms": ms, "substeps_per_sec_fwd_bwd": n / tot, "hbm_bytes_per_launch": ck,
+            "achieved_GBs": {"fwd": ck / (ms["fwd"] * 1e-3) / 1e9, "bwd": ck / (ms["bwd"] * 1e-3) / 1e9},
+            "hbm_frac": {"fwd": ck / (ms["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "bwd": ck / (ms["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "hbm_frac_algorithmic": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "issue": {k: issue_roof({"fwd": "cloth_rollout_fwd_v2_kernel", "bwd": "cloth_rollout_bwd_fast_kernel"}[k], ms[k], 8 * num_envs,
+                                    min(256, num_envs), MACRO * SUBSTEPS, static_only=True) for k in ("fwd", "bwd")} if sim.mode == 0 else None}
 
 
 def touched_cells(x, n_grid=64):
@@ -253,8 +320,10 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    restore, box = capture_step_inputs(env.simulator)        # the first simulator.step's inputs, for the CPU baseline (untimed)
     for _ in range(args.warmup):
         learner.minimize(state)
+    restore()
     env.simulator.check_status()
     env.simulator.profile = {"fwd": [], "bwd": []}
     sync()
@@ -278,6 +347,11 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
         per_sub = (192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act)
         per_launch = B * S * per_sub
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
+        cpu = None
+        if not args.no_cpu_baseline and world == 1 and "st" in box:
+            big = N > 2000
+            cpu = cpu_baseline_mpm(env.simulator, env.conf, box["st"], 4 if big else 8, 1 if big else 6,
+                                   f"the first simulator.step of the timed update ({name}: the env's own state and primitive actions)")
         traffic = None          # PMC passes exist for the default shapes only (32 envs per launch)
         if name == "whip_rope" and B == 32:
             traffic = pmc_traffic("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel")
@@ -294,11 +368,62 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
+                         **({"issue": issue_roof("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", k_ms[dom],
+                                                 B * ((4 * N + 63) // 64 + (0 if dom == "fwd" else (N + 63) // 64)), B, S)}
+                            if N <= 128 and env.simulator.n_primitive == 1 else {}),
                          "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
-                         else f"latency bound: small kernels on {B} x {N} particles" + (", two env groups on two streams" if B * N <= 200000 else "")}}), flush=True)
+                         else f"latency bound: small kernels on {B} x {N} particles" + (", two env groups on two streams" if B * N <= 200000 else "")},
+            **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_torus(sim, st, action, grad, budget_s=20.0):
+    """CPU beside the PlasticineLab lines (parity of this path is unpinned: taichi is absent).  Forward: the C++ restatement
+    (oracle/csrc/plb_oracle.hpp: f64, dense n_grid^3 grid, OpenMP over envs) on the bench's own envs.  Forward + adjoint: the C++
+    restatement has no adjoint -- the CPU reference of the adjoint is torch.autograd through the twin (oracle/twin/plb_twin_torch.py,
+    dense grid, all substeps taped), timed on ONE env.step of ONE env and only at n_grid 64 (at 128 the tape needs ~10 GB and minutes)."""
+    pyoracle, build = _oracle_native()
+    cfg = sim.cfg
+    B = min(8, st.x.shape[0])
+    npy = lambda t: t.detach().cpu().numpy()[:B]
+    cur = dict(x=npy(st.x), v=npy(st.v), C=npy(st.C), F=npy(st.F), prim_pos=npy(st.prim_pos))
+    soft, E, nu, ys, act = npy(st.softness), npy(st.E), npy(st.nu), npy(st.yield_stress), npy(action)
+    orc = pyoracle.PlbOracle(N=sim.n_particles, n_grid=sim.n_grid, substeps=sim.substeps, dt=sim.dt, gravity=tuple(cfg.gravity),
+                             ground_friction=float(cfg.ground_friction), radius=tuple(cfg.prim_radius))
+    threads = min(B, host_cores())
+    t, done = 0.0, 0
+    while done < 10 and t < budget_s * (0.4 if grad else 1.0):
+        t0 = time.time()
+        cur = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act, E, nu, ys, nthreads=threads)
+        t += time.time() - t0
+        done += 1
+    fwd_rate = B * done * sim.substeps / t
+    out = {"value": fwd_rate, "unit": "substeps/s", "cores": threads, "kind": "port",
+           "sample": f"forward only: C++ restatement ({build}, f64, dense {sim.n_grid}^3 grid; not Taichi): {B} envs x {done} env.steps x {sim.substeps} "
+                     f"substeps in {t:.2f}s, OpenMP over envs ({threads} threads)"}
+    if grad and sim.n_grid <= 64:
+        import torch as _t
+        from oracle.twin.plb_twin import PlbConf as TwinConf
+        from oracle.twin.plb_twin_torch import PlbTorchTwin
+        nthr = min(8, host_cores())
+        _t.set_num_threads(nthr)
+        tw = PlbTorchTwin(TwinConf(quality=float(cfg.quality), n_particles=sim.n_particles))
+        T = lambda a, r=False: _t.tensor(np.asarray(a, np.float64)[:1], requires_grad=r)
+        x = T(npy(st.x), True)
+        t0 = time.time()
+        o = tw.step(x, T(npy(st.v)), T(npy(st.C)), T(npy(st.F)), T(npy(st.prim_pos)), T(act, True), T(soft), T(E, True), T(nu), T(ys),
+                    _t.full((1,), float(cfg.ground_friction), dtype=_t.float64))
+        (o[0].sum() + o[1].sum()).backward()
+        tt = time.time() - t0
+        out = {"value": sim.substeps / tt, "unit": "substeps/s", "cores": nthr, "kind": "port", "fwd_only_value": fwd_rate,
+               "sample": f"forward + adjoint: torch.autograd through the twin (f64, dense {sim.n_grid}^3 grid, {nthr} torch threads): 1 env x 1 env.step x "
+                         f"{sim.substeps} substeps in {tt:.2f}s; fwd_only_value = the C++ restatement's forward ({out['sample']})"}
+    elif grad:
+        out["sample"] = ("forward ONLY (no CPU adjoint at this grid: the autograd twin's tape of 39 dense 128^3 substeps needs ~10 GB and minutes; "
+                         "the n_grid 64 line carries the forward + adjoint CPU figure) -- ") + out["sample"]
+    return out
 
 
 def bench_torus(args, rank, world, device):
@@ -366,6 +491,7 @@ def bench_torus(args, rank, world, device):
         assert torch.isfinite(st.x).all()
         if grad:
             assert all(torch.isfinite(t.grad).all() for t in leaves.values()) and float(leaves["action"].grad.abs().sum()) > 0
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_torus(sim, st, action, grad)
         units = world * B * sim.substeps * inner * args.steps
         g_act = touched_cells(st.x[0].detach().cpu().numpy().astype(np.float64), sim.n_grid)
         per_sub = 2 * ((480 if grad else 192) * sim.n_particles + (168 if grad else 56) * g_act)   # f64: double the f32 figure
@@ -379,8 +505,9 @@ def bench_torus(args, rank, world, device):
                                    + f", {B} envs per GPU, step = {inner} env.steps",
                        "touched_cells": g_act, "parity": "unpinned (taichi absent)"},
             "roofline": {"bound": "hbm", "kernel": "plb path (" + ("3 + 6" if grad else "3") + " kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "launch/latency bound: 8 envs x 1000 particles per substep"}}), flush=True)
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"plb:{'grad' if grad else 'fwd'}:ngrid{sim.n_grid}") if B == 8 else None,
+                         "note": "launch/latency bound: 8 envs x 1000 particles per substep"},
+            **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -445,6 +572,12 @@ def bench_mpm_scaled(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         units = world * B * S * args.steps
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            npy = lambda t: t.detach().float().cpu().numpy()
+            sto = dict(x=npy(x), v=npy(v), C=npy(Cm), F=npy(F), J=npy(J), ppos=npy(ppos), prot=npy(prot), psize=npy(psize), friction=npy(fr).reshape(-1),
+                       mu=npy(mu).reshape(-1), lamda=npy(la).reshape(-1), action=npy(act))
+            cpu = cpu_baseline_mpm(sim, conf, sto, 8 if N < 2000 else 2, 2 if N < 2000 else 1, f"the bench's own inputs (rope seeded at n_grid {ng})")
         g_act = touched_cells(st0.x.detach().cpu().numpy(), ng)
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
@@ -459,10 +592,80 @@ def bench_mpm_scaled(args, rank, world, device):
             "roofline": {"bound": "hbm", "kernel": lg_label(dom, sim.grid_ckpt_cells),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(f"large_path:whip_rope_ngrid{ng}:{dom}") if B == 32 else None,
-                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch}}), flush=True)
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch},
+            **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _oracle_native():
+    from oracle import pyoracle
+    try:
+        pyoracle.use_native()
+        return pyoracle, "-O3 -march=native built on this host"
+    except Exception as e:
+        return pyoracle, f"-O3 baseline x86-64 (the native rebuild failed: {type(e).__name__})"
+
+
+def capture_step_inputs(sim):
+    """Record the arguments of the next simulator.step_jax call (the exact inputs the HIP step receives inside env.step_diff):
+    returns (restore, box) -- box["st"] is the oracle's input dict once a step has run."""
+    box = {}
+    orig = sim.step_jax
+
+    def spy(state, action):
+        if "st" not in box:
+            P = sim.n_primitive
+            npy = lambda t: t.detach().float().cpu().numpy()
+            prims = state.primitives
+            if P == 1:
+                ppos, prot, psize = npy(prims[0].position), npy(prims[0].rotation), npy(prims[0].size)
+            else:
+                ppos, prot, psize = (np.stack([npy(getattr(q, k)) for q in prims], 1) for k in ("position", "rotation", "size"))
+            box["st"] = dict(x=npy(state.x), v=npy(state.v), C=npy(state.C), F=npy(state.F), J=npy(state.J), ppos=ppos, prot=prot, psize=psize,
+                             friction=npy(state.friction).reshape(-1), mu=npy(state.mu).reshape(-1), lamda=npy(state.lamda).reshape(-1),
+                             action=npy(action[:, :6 * P]))
+        return orig(state, action)
+
+    sim.step_jax = spy
+    return (lambda: setattr(sim, "step_jax", orig)), box
+
+
+def cpu_baseline_mpm(sim, conf, st, sample_envs, steps, what, budget_s=25.0):
+    """Oracle (CPU restatement of mpm_simulator.py:413-429 + adjoint, dense `res` grid like the reference; NOT JAX-CPU), rebuilt
+    here with -O3 -march=native, timed on the host cores: `steps` chained simulator.steps (conf.steps substeps each) forward +
+    adjoint for `sample_envs` envs (OpenMP over envs, substeps sequential), stopping early once `budget_s` is spent.  The oracle's
+    adjoint call recomputes the forward states itself.  Checker only, never the product path."""
+    pyoracle, build = _oracle_native()
+    N, S = st["x"].shape[1], int(conf.steps)
+    st = {k: np.ascontiguousarray(v[:sample_envs]) for k, v in st.items()}
+    orc = pyoracle.MpmOracle(N, n_grid=int(conf.n_grid), res=tuple(conf.res), steps=S, dt=float(conf.dt), position_control=bool(sim.use_position_control),
+                             material=np.asarray(sim.material), hardness=np.asarray(sim.h), prim_friction=float(sim.prim_friction),
+                             prim_softness=float(sim.prim_softness), n_prim=int(sim.n_primitive), sdf=sim.sdf_kind)
+    rng = np.random.default_rng(0)
+    pa = (sim.n_primitive,) if sim.n_primitive > 1 else ()
+    g = dict(gx=rng.normal(size=st["x"].shape).astype(np.float32), gv=np.zeros_like(st["x"]), gC=np.zeros_like(st["C"]), gF=np.zeros_like(st["F"]),
+             gppos=np.zeros((sample_envs,) + pa + (S, 3), np.float32))
+    threads = min(sample_envs, host_cores())
+    t_f = t_b = 0.0
+    done = 0
+    for _ in range(steps):
+        t0 = time.time()
+        o = orc.step_fwd(st, nthreads=threads)
+        t_f += time.time() - t0
+        t0 = time.time()
+        orc.step_bwd(st, g, clip=True, nthreads=threads)
+        t_b += time.time() - t0
+        st.update(x=o["x"], v=o["v"], C=o["C"], F=o["F"], J=o["J"], ppos=o["ppos"], prot=o["prot"])
+        done += 1
+        if t_f + t_b > budget_s:
+            break
+    n = sample_envs * done * S
+    return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port", "fwd_only_value": n / t_f,
+            "sample": f"CPU restatement (C++ {build}, f32, dense res grid like the reference; not JAX-CPU) on {what}: {sample_envs} envs x {done} "
+                      f"simulator.steps x {S} substeps, forward {t_f:.2f}s + adjoint (with its own state recompute) {t_b:.2f}s, OpenMP over envs "
+                      f"({threads} threads)"}
 
 
 def cpu_baseline_shape_rope(env, st, act, sample_envs=8, steps=6):   # ~11 s of host work
@@ -769,7 +972,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
-                         "note": "latency/occupancy bound: 4 envs = 4 workgroups on 256 CUs, 2000 sequential substeps"},
+                         "note": "latency/occupancy bound: 4 envs = 4 workgroups on 256 CUs, 2000 sequential substeps; the HBM fraction says nothing "
+                                 "about this kernel -- see `issue` (instruction issue on the busy CUs) and `saturation`",
+                         "issue": issue_roof(kname, k_ms[dom], 8 * NUM_ENVS_PER_GPU, NUM_ENVS_PER_GPU, MACRO * SUBSTEPS)},
         }
         if not args.no_saturation:
             out["saturation"] = saturation_probe(env, device)

@@ -497,3 +497,24 @@ def test_big_body_several_workgroups_edge_cases(T, S, normalize, lists):
     for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
         assert np.isfinite(h[key]).all(), key
         assert _rel(h[key], ob[key]) < 1e-3, (key, _rel(h[key], ob[key]))
+
+
+@pytest.mark.parametrize("which", ["reference_order", "default"])
+def test_undisturbed_particles_follow_the_recurrence_the_recordings_pin(sim, dsim, which):
+    """The reference's fold_cloth1 recordings pin, bit for bit, the f32 recurrence of a particle the gripper never reaches --
+    v_y <- (v_y - g dt) exp(-damping dt) 2000 times per step_diff, y = dt v_y, with the correctly rounded damping factor
+    (tests/test_oracle_cloth.py::test_recorded_cloth_states_pin_...; the recorder applied gravity once, the current code twice).
+    The HIP kernels, both operation orders, land every particle of a flat cloth on the same recurrence with the current code's
+    second gravity application: the arithmetic the data pins is the arithmetic the kernels run."""
+    from conftest import cloth_reset_x
+    from oracle.pyoracle import damp_factor
+    s = sim if which == "reference_order" else dsim
+    f = np.float32
+    dt, g, damp = f(2e-3), f(0.5), f(damp_factor(2, 2e-3, np.float32))
+    v = f(0)
+    for _ in range(2000):
+        v = f(f(f(v - g * dt) + f(-g) * dt) * damp)
+    x0 = np.repeat(cloth_reset_x()[None], 4, 0)
+    prim = np.tile(np.array([[0.9, 0.9, 0.9, 0.01]], f), (4, 2, 1))
+    h = _run_hip(s, x0, np.zeros_like(x0), prim, np.full(4, 900, f), np.full(4, 0.9, f), np.zeros((40, 4, 8), f), want_lists=False)
+    assert (h["v"][..., 1] == v).all() and (h["x"][..., 1] == f(dt * v)).all()

@@ -868,6 +868,29 @@ def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkey
         assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
 
 
+@pytest.mark.parametrize("S", [1, 2, 5, 8])
+@pytest.mark.parametrize("forward", ["cluster", "multi_kernel"])
+def test_two_launch_backward_is_the_four_kernel_backward(S, forward, monkeypatch):
+    """With the grid checkpoint and four lanes per particle the backward runs two launches per reverse substep (lg_gadj_restore,
+    lg_padj_gadj: the cotangent grids of odd and even substeps in two arrays); UD_LG_FUSED_BWD=0 keeps the four-kernel sequence.
+    Same arithmetic per particle and per cell -- the float atomics' order is the only difference -- for odd and even numbers of
+    substeps, a single one included, behind either forward.  The third step on the same handle recomputes the grid (clip bit 1
+    through an overflowing pool is test_cluster_forward_grid_checkpoint_overflow...; here grid_ckpt_cells = 0 on a second handle)
+    and must see all-zero grids, so the two-launch sequence has cleaned both of its cotangent arrays."""
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1" if forward == "cluster" else "0")
+    sim, st, g, N = _scaled_case(S, 4, B=3, grid_ckpt_cells=6)
+    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
+    ref = run_hip(sim, st, g=g, clip=True)
+    monkeypatch.setenv("UD_LG_FUSED_BWD", "1")
+    got = run_hip(sim, st, g=g, clip=True)
+    again = run_hip(sim, st, g=g, clip=True)
+    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
+    after = run_hip(sim, st, g=g, clip=True)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gfriction", "gmu", "glamda"):
+        for name, r in (("two-launch", got), ("two-launch again", again), ("four-kernel after", after)):
+            assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (key, name, _rel(r[key], ref[key]))
+
+
 def test_cluster_part_table_overflow_is_flagged(monkeypatch):
     """Parts of 32 particles (UD_MPM_CLUSTER_T=128, the default for solids) hold 512 cells: particles thrown uniformly through the
     volume touch more, the part sets status[] bit 1 and check_status raises -- loud, not a wrong step."""

@@ -50,6 +50,8 @@ struct LargeArgs {
   const int* material;
   const float* hard;
   int B, f, cap;
+  int gpar;               // backward with the grid checkpoint, fused kernels: the cotangent grid of substep f is w.gacc for even f and
+                          // w.val (untouched by that backward otherwise) for odd f, so that substep f - 1's scatter can run beside f's gather
   long W32;               // bitmap words per env
   int b0;                 // first env of this launch (env groups on separate streams)
   long G;
@@ -82,6 +84,8 @@ __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   decode_cell(c, key, ci, cj, ck);
   return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
 }
+
+__device__ __forceinline__ float4* lg_gacc(const LargeArgs& a, int f) { return (a.gpar && (f & 1)) ? a.w.val : a.w.gacc; }
 
 // caller's index of the particle in slot p
 __device__ __forceinline__ int user_index(const LargeArgs& a, int b, int p) { return a.perm ? a.perm[(long)b * a.perm_stride + p] : p; }
@@ -915,7 +919,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   const MpmConst& c = a.c;
   LG_STAMP_BEGIN
   bt_clear<TH>(bt);
-  float4* gacc = a.w.gacc + (long)b * a.G;
+  float4* gacc = lg_gacc(a, a.f) + (long)b * a.G;
   const bool live = p < c.N;
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
   int base[3] = {0, 0, 0};
@@ -1173,24 +1177,33 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   const int cur = a.f & 1;
   const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
   if (a.c.position_control) {
-    if (!live) return;
-    const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
-    int ci, cj, ck;
-    decode_cell(a.c, key, ci, cj, ck);
-    const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-    const float4 mv = cell_mass_momentum(a, b, t, lin);
-    const float mvv[3] = {mv.y, mv.z, mv.w};
-    const float4 g4 = a.w.gacc[(long)b * a.G + lin];
-    float g[3] = {g4.x, g4.y, g4.z}, gmm, dfric, pv[3], dpv[3];
-    PrimF pf;
-    load_prim(a, b, pf, pv);
-    const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
-    if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-    if (ctrl) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + a.f * 3 + d], dpv[d]);
+    // The friction and controlled-velocity cotangents are per ENV: one atomic per cell put every ground-layer cell of an env on
+    // one word (the envs' words share four cache lines) and the memory side serialises them -- 11 us for a launch with 3 us of
+    // work on the rope at n_grid 128.  Summed over the wave first: one atomic per wave and word.
+    if (tile_base >= min(a.w.count[cur * a.B + b], a.cap)) return;   // block-uniform
+    float dfric = 0.f, dpv[3] = {0.f, 0.f, 0.f};
+    if (live) {
+      const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
+      int ci, cj, ck;
+      decode_cell(a.c, key, ci, cj, ck);
+      const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
+      const float4 mv = cell_mass_momentum(a, b, t, lin);
+      const float mvv[3] = {mv.y, mv.z, mv.w};
+      const float4 g4 = lg_gacc(a, a.f)[(long)b * a.G + lin];
+      float g[3] = {g4.x, g4.y, g4.z}, gmm, pv[3], dp[3];
+      PrimF pf;
+      load_prim(a, b, pf, pv);
+      if (grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dp)) { dpv[0] = dp[0]; dpv[1] = dp[1]; dpv[2] = dp[2]; }
+      lg_gacc(a, a.f)[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
     }
-    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+    const float sf = wave_sum(dfric), s0 = wave_sum(dpv[0]), s1 = wave_sum(dpv[1]), s2 = wave_sum(dpv[2]);
+    if ((threadIdx.x & 63) == 0) {
+      if (sf != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], sf);
+      float* gp = a.w.gpv + (long)b * a.c.steps * 3 + a.f * 3;
+      if (s0 != 0.f) atomicAdd(gp + 0, s0);
+      if (s1 != 0.f) atomicAdd(gp + 1, s1);
+      if (s2 != 0.f) atomicAdd(gp + 2, s2);
+    }
     return;
   }
   // ---- soft contact: collide_batch of each primitive in turn (forward), reversed here --------------------------------
@@ -1202,13 +1215,13 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   int ci = 0, cj = 0, ck = 0;
   long lin = 0;
   float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
-  float g[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f};
+  float g[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f}, dfric_cell = 0.f;   // dfric_cell: this cell's ground-friction cotangent
   if (live) {
     const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
     decode_cell(a.c, key, ci, cj, ck);
     lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
     mv = cell_mass_momentum(a, b, t, lin);
-    const float4 g4 = a.w.gacc[(long)b * a.G + lin];
+    const float4 g4 = lg_gacc(a, a.f)[(long)b * a.G + lin];
     g[0] = g4.x; g[1] = g4.y; g[2] = g4.z;
     gp[0] = (float)ci * a.c.dx; gp[1] = (float)cj * a.c.dx; gp[2] = (float)ck * a.c.dx;
   }
@@ -1239,7 +1252,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
         float vo[3], dfric;
         grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
         grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
-        if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
+        dfric_cell = dfric;
       }
       PrimCGrad pg;
       float gin[3];
@@ -1272,10 +1285,14 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
     __syncthreads();
     LG_STAMP(3, 2);   // wave sums, barriers, the block's atomics
   }
+  {                  // one atomic per wave onto the env's friction word (see the position-control branch)
+    const float sf = wave_sum(dfric_cell);
+    if ((threadIdx.x & 63) == 0 && sf != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], sf);
+  }
   if (live) {
     float gmm;
     grid_head_adjoint(mv.x, mvv, g, gmm);
-    a.w.gacc[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+    lg_gacc(a, a.f)[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
   }
   LG_STAMP(3, 3);     // head adjoint + store
 }
@@ -1330,7 +1347,7 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   for (int d = 0; d < 9; ++d) { gw[d] = 0.f; gaff[d] = 0.f; }
 #pragma unroll
   for (int d = 0; d < 3; ++d) gfx[d] = (qi == 0) ? ps[d * c.Np] : 0.f;   // the g2p adjoint's share (already through d w / d fx) enters the quad sum once
-  const float4* gacc = a.w.gacc + (long)b * a.G;
+  const float4* gacc = lg_gacc(a, a.f) + (long)b * a.G;
   LG_STAMP(2, 2);     // cotangent + scratch loads
   // One lane per particle: the 27 cells as nine (i, j) columns, the three k cells of a column -- neighbours in memory, the grid is
   // z-fastest -- loaded together before any of them is used (one cell per trip left a single 16-B gather in flight per wave, at
@@ -1450,6 +1467,252 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   }
   __syncthreads();
   if (threadIdx.x < 2 && s_par[threadIdx.x] != 0.f) atomicAdd(&a.w.acc[b * 4 + 1 + threadIdx.x], s_par[threadIdx.x]);
+}
+
+// ---- backward with the grid checkpoint, four lanes per particle: TWO launches per reverse substep instead of four ------------
+// The four kernels (restore, g2p adjoint, grid-op adjoint, p2g adjoint) sit at 4-14 us each on 37 k lanes: launch ramps and
+// chains of dependent round trips, not work (profiles/r02j_kernel_stats_shape_rope.csv).  Two of the hand-overs are per PARTICLE
+// (the p2g adjoint of substep f produces the cotangent state that the g2p adjoint of substep f - 1 scatters) and two per CELL
+// (the grid-op adjoint of f and the restore of f - 1 touch different lists), so:
+//   K1(f) = lg_gadj_restore : grid-op adjoint of substep f  ||  restore of substep f - 1 (other blocks of the same launch)
+//   K2(f) = lg_padj_gadj    : p2g adjoint + particle adjoint of f, then -- cotangent state in registers -- g2p adjoint of f - 1
+// The cotangent grids of consecutive substeps must then be different arrays (K2 gathers f's while it scatters f - 1's):
+// a.gpar, even substeps in w.gacc, odd ones in w.val (which this backward does not touch otherwise).  Buffer f & 1 was last
+// used by substep f + 2: the restore of f also zeroes those cells (consumed by K2(f + 2)), and two trailing calls (f = -1, -2)
+// leave both grids all-zero, the invariant every other path of the handle relies on.
+__device__ __forceinline__ void lg_restore_par_tile(const LargeArgs& a, int b, int f, int t) {
+  const int S = a.c.steps;
+  const int* idx = gck_idx(a, b);
+  if (f + 2 < S) {                                  // cells of substep f + 2, same buffer: consumed by its p2g adjoint
+    const int first = idx[f + 2], n = min(min(idx[f + 3], a.gck_budget) - first, a.cap);
+    if (t < n) {
+      const int key = __builtin_bit_cast(int, gck_pool(a, b)[(long)(first + t) * 2].x);
+      lg_gacc(a, f)[(long)b * a.G + cell_lin(a.c, key)] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (f < 0) return;
+  const int cur = f & 1;
+  const int first = idx[f], n = min(min(idx[f + 1], a.gck_budget) - first, a.cap);
+  if (t == 0) a.w.count[cur * a.B + b] = max(n, 0);
+  if (t >= n) return;
+  const float4* r = gck_pool(a, b) + (long)(first + t) * 2;
+  const float4 r0 = r[0], r1 = r[1];
+  const int key = __builtin_bit_cast(int, r0.x);
+  const long lin = cell_lin(a.c, key);
+  a.w.list[((long)cur * a.B + b) * a.cap + t] = key;
+  a.w.vel[(long)b * a.G + lin] = make_float4(r1.y, r1.z, r1.w, 0.f);   // (its cotangent cells are zero already: the buffer's last user was f + 2)
+}
+__device__ __forceinline__ void lg_restore_par(const LargeArgs& a, int b, int f, int nblocks, int block) {
+  const int S = a.c.steps;
+  const int* idx = gck_idx(a, b);
+  int n = 1;                                        // tile 0 always runs: it publishes the count
+  if (f + 2 < S) n = max(n, min(idx[f + 3], a.gck_budget) - idx[f + 2]);
+  if (f >= 0) n = max(n, min(idx[f + 1], a.gck_budget) - idx[f]);
+  n = min(n, a.cap);
+  for (int u = 0;; ++u) {
+    const int base = (u * nblocks + block) * 256;
+    if (base >= n) break;
+    lg_restore_par_tile(a, b, f, base + threadIdx.x);
+  }
+}
+// blocks [0, nb): grid-op adjoint of substep a.f (none when a.f is not a substep: the first and the last launch of a step);
+// blocks [nb, 2 nb): restore of substep a.f - 1
+__global__ void __launch_bounds__(256) lg_gadj_restore(LargeArgs a, int nb) {
+  __shared__ float red[4][UD_PRIMC_NGRAD];
+  const int b = blockIdx.y + a.b0;
+  if ((int)blockIdx.x < nb) {
+    if (a.f < 0 || a.f >= a.c.steps) return;
+    const int n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+    for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
+      const int base = (u * nb + (int)blockIdx.x) * 256;
+      if (base >= n) break;
+      lg_grid_adj_tile(a, b, base, red);
+    }
+    return;
+  }
+  lg_restore_par(a, b, a.f - 1, nb, (int)blockIdx.x - nb);
+}
+
+// K2: p2g adjoint + particle adjoint of substep a.f, then the g2p adjoint of substep a.f - 1 (hist_prev = its input state; nullptr:
+// none, the last launch).  do_a == 0 (the first launch): only the g2p adjoint, of substep a.f - 1 = S - 1, cotangents from w.gstate.
+__global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_eu(2))) lg_padj_gadj(LargeArgs a, int particle_blocks, int do_a, const float* hist_prev) {
+  if ((int)blockIdx.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
+    if (do_a) fk_adj_block(a, (long)(blockIdx.y + a.b0) * a.c.n_prim + ((int)blockIdx.x - particle_blocks));
+    return;
+  }
+  constexpr int TH = LgTable<4>::H, TLOG = LgTable<4>::LOGH;
+  const BlockTable bt = bt_make<TH>();
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid >> 2, qi = gid & 3;
+  const MpmConst& c = a.c;
+  __shared__ float s_par[2];
+  if (threadIdx.x < 2) s_par[threadIdx.x] = 0.f;
+  if (hist_prev) bt_clear<TH>(bt);
+  __syncthreads();
+  const bool live = p < c.N;
+  float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9], gF[9];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = 0.f; }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+  }
+  // ---- A: p2g adjoint (gather) + particle adjoint of substep f: cotangent state at f + 1 -> at f ----
+  if (do_a && live) {
+    float x[3], v[3], Cm[9], F[9];
+    load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+    Pre q;
+    PreB kb;
+    const int up = user_index(a, b, p);
+    const int material = a.material[up];
+    particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb);
+    const float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
+    float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gw[d] = 0.f; gaff[d] = 0.f; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gfx[d] = (qi == 0) ? ps[d * c.Np] : 0.f;   // the g2p adjoint's share (already through d w / d fx) enters the quad sum once
+    const float4* gacc = lg_gacc(a, a.f) + (long)b * a.G;
+#pragma unroll 1
+    for (int cidx = qi; cidx < 27; cidx += 4) {
+      const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+      const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+      if (sc < 0) continue;
+      const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, k);
+      const float weight = wi * wj * wk;
+      const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
+      const float4 g4 = gacc[cell_lin(c, sc)];
+      const float gcv[3] = {g4.x, g4.y, g4.z};
+      float gwt = c.p_mass * g4.w;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
+        gwt += gcv[r] * (c.p_mass * v[r] + ad);
+        gvp[r] += weight * c.p_mass * gcv[r];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) {
+          gaff[r * 3 + s2] += weight * gcv[r] * dpos[s2];
+          gfx[s2] -= c.dx * weight * gcv[r] * q.affine[r * 3 + s2];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+        gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+        gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<4>(gw[d]); gaff[d] = lg_quad_sum<4>(gaff[d]); }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<4>(gfx[d]); gvp[d] = lg_quad_sum<4>(gvp[d]); }
+    float gmu_p, gla_p;     // every lane of the quad: the g2p adjoint below wants the result in all four
+    particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+    if (qi == 0) {
+      if (material != 0) {
+        const float h = clipf(a.hard[up], 0.1f, 5.f);
+        atomicAdd(&s_par[0], gmu_p * h);
+        atomicAdd(&s_par[1], gla_p * h);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
+    }
+  }
+  // ---- B: g2p adjoint of substep f - 1 (lg_g2p_adj<4>), its input cotangents in registers ----
+  if (hist_prev) {                    // kernel-uniform
+    const int fb = a.f - 1;
+    const float* hp = hist_prev + (long)b * a.hist_stride_b;
+    int base[3] = {0, 0, 0};
+    float fx[3] = {0.f, 0.f, 0.f}, w[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) w[d] = 0.f;
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float xd = hp[d * c.Np + p];
+        base[d] = (int)(xd * c.inv_dx - 0.5f);
+        const float f = xd * c.inv_dx - (float)base[d];
+        fx[d] = f;
+        w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+      }
+    }
+    const BlockWin win = bt_window(c, live, base);
+    float4* gaccb = lg_gacc(a, fb) + (long)b * a.G;
+    if (live) {
+      float gnv[3], gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gw[d] = 0.f;
+      const float4* vel = a.w.vel + (long)b * a.G;
+      const int rot = (p * 4) % 27;
+      int key7[7];
+      float4 v7[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int it = min(qi + 4 * t, 26);
+        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
+        key7[t] = cell_gather(c, base[0] + cidx / 9, base[1] + (cidx / 3) % 3, base[2] + cidx % 3);
+        v7[t] = vel[cell_lin(c, key7[t])];
+      }
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int it = qi + 4 * t;
+        if (it >= 27) break;
+        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
+        const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+        const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
+        const float weight = wi * wj * wk;
+        const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+        const int gkey = key7[t];
+        const float vv[3] = {v7[t].x, v7[t].y, v7[t].z};
+        float gwt = 0.f;
+        const int sl = bt_find<TH, TLOG>(bt, win, gkey);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+          const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+          if (sl >= 0) __hip_atomic_fetch_add(&bt.val[r * TH + sl], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else atomicAdd((float*)(gaccb + cell_lin(c, gkey)) + r, gcell);
+          gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+          gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gw[d] = lg_quad_sum<4>(gw[d]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gfx[d] = lg_quad_sum<4>(gfx[d]);
+      if (qi == 0) {
+        float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          ps[d * c.Np] = gfx[d] + gw[0 * 3 + d] * (-(1.5f - fx[d])) + gw[1 * 3 + d] * (-2.f * (fx[d] - 1.f)) + gw[2 * 3 + d] * (fx[d] - 0.5f);
+      }
+    }
+    __syncthreads();
+    {
+      const int r = threadIdx.x & 3;
+#pragma unroll 4
+      for (int sl = threadIdx.x >> 2; sl < TH; sl += LG_SCATTER_T / 4) {
+        const int key = bt.key[sl];
+        if (key < 0 || r == 3) continue;
+        atomicAdd((float*)(gaccb + cell_lin(c, key)) + r, (float)bt.val[r * TH + sl]);
+      }
+    }
+  }
+  __syncthreads();
+  if (do_a && threadIdx.x < 2 && s_par[threadIdx.x] != 0.f) atomicAdd(&a.w.acc[b * 4 + 1 + threadIdx.x], s_par[threadIdx.x]);
 }
 
 // backward prologue: cotangent state, primitive arrays from the checkpoint tail, copy_frame adjoint
@@ -1622,7 +1885,8 @@ struct MpmLarge {
 // four-lane launches are best at 2 (rope at n_grid 128 +6 %, shape_rope +3 %) and lose 5-20 % at 4 -- except pour_water (two container
 // primitives: the grid kernels, not the particle kernels, carry its substep): 231 k in one group, 199-227 k from run to run in two.
 static int lg_groups(const MpmLarge* L, int B) {
-  static const int forced = [] { const char* e = getenv("UD_LG_GROUPS"); return e ? atoi(e) : 0; }();   // diagnostic override
+  const char* ge = getenv("UD_LG_GROUPS");                        // diagnostic override, read at every call
+  const int forced = ge ? atoi(ge) : 0;
   if (!L->ev_fork) return 1;
   const long particles = (long)B * L->c.N;
   int want = 1;
@@ -1739,7 +2003,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   LargeArgs a;
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.cap = L->cap; a.G = L->G; a.W32 = L->W32;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
-  a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr;
+  a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr; a.gpar = 0;
   a.perm = nullptr; a.perm_stride = 0;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
@@ -1748,8 +2012,9 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
 
 // env groups: group g covers envs [b0, b0 + Bg) on stream s (group 0 = the caller's stream)
 struct LgGroup { int b0, Bg; hipStream_t s; };
-static int lg_fork(MpmLarge* L, int B, hipStream_t st, LgGroup* grp) {
-  const int G = lg_groups(L, B);
+static int lg_fork(MpmLarge* L, int B, hipStream_t st, LgGroup* grp, int want = 0) {   // want > 0: that many groups where lg_groups allows any
+  int G = lg_groups(L, B);
+  if (want > 0 && L->ev_fork && !getenv("UD_LG_GROUPS")) G = (B >= 2 * want) ? std::min(want, (int)MpmLarge::MAX_GROUPS) : 1;
   for (int g = 0; g < G; ++g) {
     const int b0 = (int)((long)B * g / G), b1 = (int)((long)B * (g + 1) / G);
     grp[g] = LgGroup{b0, b1 - b0, g == 0 ? st : L->side[g - 1]};
@@ -1978,13 +2243,46 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     if (e != hipSuccess) { set_error("ud_mpm_step_bwd (cluster path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
     return UD_OK;
   }
+  // Two launches per reverse substep (lg_gadj_restore, lg_padj_gadj) where the backward restores the grid, four lanes work on a
+  // particle and one primitive touches the grid.  Measured on 1x MI355X, 32 envs, backward ms per step, four-kernel / two-launch
+  // (profiles/r03c_fused_bwd_groups.txt): rope at n_grid 128 (position control) 2.88 / 2.45 in one env group, 2.76 / 2.92 in two;
+  // shape_rope (soft contact: the grid-op adjoint is the long launch and overlaps the other groups' particle launches)
+  // 6.08 / 6.00 in one, 5.98 / 5.65 in two, 7.24 / 5.25 in four; pour_water (two container primitives) 1.35 / 1.61: kept on four.
+  const char* fe = getenv("UD_LG_FUSED_BWD");                     // diagnostic: 0 = the four-kernel sequence, 1 = two launches wherever possible
+  const bool fused = gck && lanes == 4 && (fe ? atoi(fe) != 0 : c.n_prim == 1);
   LgGroup grp[MpmLarge::MAX_GROUPS];
-  const int G = lg_fork(L, B, st, grp);
+  const int G = lg_fork(L, B, st, grp, fused ? (c.position_control ? 1 : 4) : 0);
   for (int g = 0; g < G; ++g) {
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
   }
+  if (fused) {
+    a.gpar = 1;
+    (void)hipFuncSetAttribute((const void*)lg_padj_gadj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+    for (int g = 0; g < G; ++g) {
+      const int Bg = grp[g].Bg;
+      hipStream_t s = grp[g].s;
+      a.b0 = grp[g].b0;
+      const int nb = lg_cell_blocks(L->cap);
+      const dim3 gc2(2 * nb, Bg);
+      const int pb = (4 * N + LG_SCATTER_T - 1) / LG_SCATTER_T;
+      const dim3 gk2(pb + c.n_prim, Bg);
+      // prologue: restore of substep S - 1, then its g2p adjoint alone (cotangents from w.gstate)
+      a.f = S; a.hist_in = ckpt;
+      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
+      hipLaunchKernelGGL(lg_padj_gadj, gk2, blks, lg_table_bytes<4>(), s, a, pb, 0, ckpt + (long)(S - 1) * rec);
+      for (int f = S - 1; f >= 0; --f) {
+        a.f = f; a.hist_in = ckpt + (long)f * rec;
+        hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
+        hipLaunchKernelGGL(lg_padj_gadj, gk2, blks, lg_table_bytes<4>(), s, a, pb, 1, f > 0 ? ckpt + (long)(f - 1) * rec : nullptr);
+      }
+      // lg_padj_gadj(0) consumed the cotangent cells of substep 0: "restore" of substep -2 zeroes them (those of substep 1 went beside
+      // the grid-op adjoint of substep 0) -- both grids all-zero again
+      a.f = -1;
+      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
+    }
+  } else
   for (int f = S - 1; f >= -1; --f) {
     // list parity: cur = f & 1, "previous" = (f + 1) & 1 = the substep processed just before (f + 1) -- same rule as forward
     a.f = f;
