@@ -123,11 +123,25 @@ def dist_info(world, allreduce_params=0):
             "allreduce_bytes_per_update": allreduce_params * 4 if world > 1 else 0}
 
 
-def lg_label(dom, grid_ckpt_cells):
-    """kernels per substep of the many-workgroup MPM path: forward clear+FK, p2g, grid op, g2p; backward restore, g2p adjoint, grid-op
-    adjoint, p2g adjoint with the grid checkpoint, clear, p2g, grid op and the three adjoints without"""
-    n = 4 if dom == "fwd" or grid_ckpt_cells > 0 else 6
-    return f"mpm large path ({dom}: {n} kernels/substep)"
+def lg_label(dom, sim, B):
+    """kernels of the many-workgroup MPM path for this call shape, as the library reports them (ud_mpm_launch_plan): forward = one
+    persistent launch per step call (parts of 32 particles handing grid cells to each other through HBM) or clear+FK, p2g, grid op, g2p
+    per substep; backward with the grid checkpoint = two launches per substep (grid-op adjoint || restore; p2g adjoint -> g2p adjoint)
+    or four (restore, g2p adjoint, grid-op adjoint, p2g adjoint); six when it recomputes the grid"""
+    plan = sim.launch_plan(B)
+    if dom == "fwd":
+        return "mpm many-workgroup path (fwd: clm_fwd_kernel, one persistent launch per step call)" if plan & 2 else "mpm many-workgroup path (fwd: 4 kernels/substep)"
+    n = (2 if plan & 4 else 4) if sim.grid_ckpt_cells > 0 else 6
+    return f"mpm many-workgroup path (bwd: {n} kernels/substep)"
+
+
+def lg_issue(key, kernel_ms):
+    """instruction-issue roof of the many-workgroup kernels of one step call: VALU + SALU wave-instructions of all its launches (PMC pass,
+    tools/pmc_large.sh) per second / what 256 CUs can issue -- they are VALU-bound where they are not latency-bound"""
+    r = issue_roof(key, kernel_ms, None, 256, None)
+    if r:
+        r["note"] = "all launches of one step call; 256 CUs x 4 SIMDs x 0.6 G wave-instr/s"
+    return r
 
 
 def pmc_traffic(key):
@@ -163,6 +177,7 @@ def issue_roof(kname, kernel_ms, waves, busy_cus, substeps, static_only=False):
         e = json.load(open(tj)).get(kname) or {}
         if e.get("insts") and e.get("src_sha16") == src_hash.sha16(kname):
             per_launch = e["insts"].get("SQ_INSTS_VALU", 0.0) + e["insts"].get("SQ_INSTS_SALU", 0.0)
+            waves = int(e["insts"].get("SQ_WAVES", 0)) or waves
             src = "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (profiles/pmc_traffic.json)"
     if per_launch is None and kname in STATIC_INSTR_PER_SUBSTEP:
         per_launch = STATIC_INSTR_PER_SUBSTEP[kname] * waves * substeps
@@ -363,16 +378,16 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world, learner.n_params),
             "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator.grid_ckpt_cells) if env.simulator.n_primitive > 1 or N > 128 else
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator, B) if env.simulator.n_primitive > 1 or N > 128 else
                          ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
                          **({"issue": issue_roof("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", k_ms[dom],
                                                  B * ((4 * N + 63) // 64 + (0 if dom == "fwd" else (N + 63) // 64)), B, S)}
-                            if N <= 128 and env.simulator.n_primitive == 1 else {}),
+                            if N <= 128 and env.simulator.n_primitive == 1 else {"issue": lg_issue(f"large_path:{name}:{dom}", k_ms[dom]) if B == 32 else None}),
                          "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
-                         else f"latency bound: small kernels on {B} x {N} particles" + (", two env groups on two streams" if B * N <= 200000 else "")},
+                         else f"latency / issue bound: small launches on {B} x {N} particles"},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
@@ -589,9 +604,10 @@ def bench_mpm_scaled(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"whip_rope rope seeded at n_grid={ng} (N={N}, res {ng // 2}^3, {S} substeps/step), "
                                    f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": lg_label(dom, sim.grid_ckpt_cells),
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, sim, B),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(f"large_path:whip_rope_ngrid{ng}:{dom}") if B == 32 else None,
+                         "issue": lg_issue(f"large_path:whip_rope_ngrid{ng}:{dom}", k_ms[dom]) if B == 32 else None,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
@@ -843,10 +859,12 @@ def bench_shape_rope(args, rank, world, device):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"shape_rope (MLS-MPM plastic rope N={N}, res 64x6x64, soft contact, {T} x {S} substeps/env.step) "
                                    f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act},
-            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator.grid_ckpt_cells),
+            "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator, B),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
-                         "note": "latency bound: 11 small kernels per substep pair on 32 x 582 particles, two env groups on two streams"},
+                         "traffic": pmc_traffic(f"large_path:shape_rope:{dom}") if B == 32 else None,
+                         "issue": lg_issue(f"large_path:shape_rope:{dom}", k_ms[dom]) if B == 32 else None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
+                         "note": f"latency / issue bound: {B} x {N} particles do not fill the chip (four lanes per particle)"},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()

@@ -172,12 +172,22 @@ typedef struct {
 int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* hardness, ud_mpm** out);
 void ud_mpm_destroy(ud_mpm* h);
 size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B);
+/* Which kernels a call with B envs runs (the choice is the library's, by measurement: DESIGN.md 3.2); for logs and benchmark
+ * labels, nothing at this boundary depends on it.  0: one workgroup per env (bodies up to 128 particles, one box primitive).
+ * Bit 0: the many-workgroup path.  Bit 1: its forward is one persistent launch per group of envs (several workgroups per
+ * env that hand grid cells to each other through HBM), else four launches per substep.  Bit 2: its backward, restoring
+ * the grid from the checkpoint (grid_ckpt_cells > 0), takes two launches per substep, else four (six when it recomputes).
+ * Negative: bad arguments. */
+int ud_mpm_launch_plan(const ud_mpm* h, int B);
 
 /* Forward `step`: state (x,v [B,N,3]; C,F [B,N,3,3]; J [B,N]), primitive 0 (position [B,steps,3], rotation
  * [B,steps,4] (w,x,y,z), size [B,3]), friction/mu/lamda [B], action [B,6] -> new state, primitive position /
  * rotation after copy_frame(steps,0) and the v,w [B,steps,3] written by set_action.
- * ckpt (may be NULL = no backward): ud_mpm_ckpt_bytes() bytes. status [B] int32: 0 ok, 1 = LDS cell table
- * overflow in that env (outputs invalid; the caller checks it when it next synchronises). */
+ * ckpt (may be NULL = no backward): ud_mpm_ckpt_bytes() bytes. status [B] int32, written asynchronously, the caller reads
+ * it when it next synchronises: 0 ok.  One-workgroup path: 1 = LDS cell table overflow in that env (outputs invalid).
+ * Many-workgroup path, a bit mask: 1 = the grid-checkpoint pool ran out in that env (outputs valid; that step's backward
+ * must recompute: clip bit 1 of ud_mpm_step_bwd), 2 = a workgroup's cell table overflowed (persistent forward: a part of 32
+ * particles touched more than 512 cells; outputs invalid), 4 = a workgroup gave up waiting for a sibling (outputs invalid). */
 int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                     const float* prim_position, const float* prim_rotation, const float* prim_size,
                     const float* friction, const float* mu, const float* lamda, const float* action, float* x_out,

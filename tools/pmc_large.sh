@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ud::", "")
-        if k.startswith("lg_"):
+        if k.startswith("lg_") or k.startswith("clm_"):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 names = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE"]
 with open("gpurun_out/pmc_large_summary.csv", "w") as o:

@@ -14,9 +14,10 @@ GROUPS = {   # kernel-name prefix (or "large_path:" key) -> the sources its code
     "mpm_step": ["mpm.hip", "mpm_device.h", "common.h"],
     "mpm_focus": ["env_glue.hip", "common.h"],
     "mpm_finish": ["env_glue.hip", "common.h"],
-    "large_path": ["mpm_large.hip", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
-    "lg_": ["mpm_large.hip", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
-    "plb": ["plb.hip", "common.h"],
+    "large_path": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
+    "lg_": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
+    "clm_": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
+    "plb": ["plb.hip", "plb_adj.hip", "plb_common.h", "common.h"],
 }
 
 

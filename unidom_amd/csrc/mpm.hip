@@ -1309,6 +1309,11 @@ size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B) {
   return (size_t)B * ((size_t)h->c.steps * 24 * h->c.Np + (size_t)h->c.steps * 10) * sizeof(float);
 }
 
+int ud_mpm_launch_plan(const ud_mpm* h, int B) {
+  if (!h || B < 1) return -1;
+  return h->large ? ud::mpm_large_plan(h->large, B) : 0;
+}
+
 int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                     const float* prim_position, const float* prim_rotation, const float* prim_size,
                     const float* friction, const float* mu, const float* lamda, const float* action, float* x_out,

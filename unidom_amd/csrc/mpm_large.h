@@ -8,6 +8,7 @@ struct MpmLarge;
 MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid);   // has_liquid: some particle has material 0
 void mpm_large_destroy(MpmLarge* L);
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B);
+int mpm_large_plan(MpmLarge* L, int B);   // ud_mpm_launch_plan's bits for a call with B envs
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,

@@ -2041,6 +2041,12 @@ static int lg_lanes(int B, int N) {
   return ((long)B * N < 100000) ? 4 : 1;
 }
 
+// backward with the grid checkpoint: two launches per reverse substep (lg_gadj_restore, lg_padj_gadj) or four -- measurements at the call
+static bool lg_two_launch_bwd(const MpmConst& c, int lanes) {
+  const char* fe = getenv("UD_LG_FUSED_BWD");                     // diagnostic: 0 = the four-kernel sequence, 1 = two launches wherever possible
+  return lanes == 4 && (fe ? atoi(fe) != 0 : c.n_prim == 1);
+}
+
 // ---- persistent cluster path (mpm_cluster.h) ----------------------------------------------------------------------
 // Taken when the launch does not fill the chip (the four-lane regime) and the body's parts fit: envs per launch =
 // 8 * floor(resident parts per XCD / parts per env), the parts of an env sharing an XCD under round-robin placement.
@@ -2093,6 +2099,14 @@ static int clm_reserve(MpmLarge* L, int Bl, hipStream_t stream) {
   L->cl.bar = (unsigned*)(base + o_bar);
   L->cl.Bl = Bl;
   return UD_OK;
+}
+
+int mpm_large_plan(MpmLarge* L, int B) {
+  const MpmConst& c = L->c;
+  int plan = 1;
+  if (clm_envs_per_launch(L, B, clm_lanes())) plan |= 2;
+  if (ck_layout(c).budget > 0 && lg_two_launch_bwd(c, lg_lanes(B, c.N))) plan |= 4;
+  return plan;
 }
 
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
@@ -2248,8 +2262,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   // (profiles/r03c_fused_bwd_groups.txt): rope at n_grid 128 (position control) 2.88 / 2.45 in one env group, 2.76 / 2.92 in two;
   // shape_rope (soft contact: the grid-op adjoint is the long launch and overlaps the other groups' particle launches)
   // 6.08 / 6.00 in one, 5.98 / 5.65 in two, 7.24 / 5.25 in four; pour_water (two container primitives) 1.35 / 1.61: kept on four.
-  const char* fe = getenv("UD_LG_FUSED_BWD");                     // diagnostic: 0 = the four-kernel sequence, 1 = two launches wherever possible
-  const bool fused = gck && lanes == 4 && (fe ? atoi(fe) != 0 : c.n_prim == 1);
+  const bool fused = gck && lg_two_launch_bwd(c, lanes);
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp, fused ? (c.position_control ? 1 : 4) : 0);
   for (int g = 0; g < G; ++g) {

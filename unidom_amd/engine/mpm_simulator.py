@@ -285,6 +285,10 @@ class SimpleMPMSimulator:
             ev[2].record(torch.cuda.current_stream(self.device))
             self.profile[ev[0]].append((ev[1], ev[2]))
 
+    def launch_plan(self, B):
+        """ud_mpm_launch_plan: 0 = one workgroup per env; bit 0 many-workgroup path, bit 1 persistent forward, bit 2 two-launch backward"""
+        return int(_lib.lib().ud_mpm_launch_plan(self._h, C.c_int(B)))
+
     def check_status(self):
         """Host sync: raise if any launch since the last check overflowed its LDS cell table."""
         for host, done in self._staged:      # forwards whose flags travelled on the side stream (error bits only; bit 0 is the pool)
