@@ -375,7 +375,7 @@ int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
   const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
   const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
   const size_t o_perm = take((size_t)B * c.Np * 4);
-  const size_t o_gacc = adj ? take((size_t)B * h->G * 32) : 0, o_gstate = adj ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
+  const size_t o_gacc = adj ? take((size_t)B * h->G * 32) : 0, o_vout = adj ? take((size_t)B * h->G * 32) : 0, o_gstate = adj ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
   const size_t o_gxs = adj ? take((size_t)B * 3 * c.Np * 8) : 0, o_gpos = adj ? take((size_t)B * (c.S + 1) * c.np * 3 * 8 + 64) : 0, o_gpar = adj ? take((size_t)B * 4 * 8) : 0;
   const size_t o_gm = loss ? take((size_t)B * h->G * 8) : 0, o_lred = loss ? take((size_t)B * 16 * 8) : 0;
   hipError_t e = hipMalloc(&h->arena, off);
@@ -386,7 +386,7 @@ int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
   h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
   h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
   h->w.perm = (int*)(base + o_perm);
-  h->w.gacc = adj ? (double*)(base + o_gacc) : nullptr; h->w.gstate = adj ? (double*)(base + o_gstate) : nullptr;
+  h->w.gacc = adj ? (double*)(base + o_gacc) : nullptr; h->w.vout = adj ? (double*)(base + o_vout) : nullptr; h->w.gstate = adj ? (double*)(base + o_gstate) : nullptr;
   h->w.gxs = adj ? (double*)(base + o_gxs) : nullptr; h->w.gpos = adj ? (double*)(base + o_gpos) : nullptr; h->w.gpar = adj ? (double*)(base + o_gpar) : nullptr;
   h->gm = loss ? (double*)(base + o_gm) : nullptr; h->lred = loss ? (double*)(base + o_lred) : nullptr;
   h->B = B; h->epoch = 1; h->has_adj = adj; h->has_loss = loss;

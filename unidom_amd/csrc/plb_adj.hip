@@ -45,23 +45,40 @@ __device__ __forceinline__ void plb_weights(const PlbConst& c, const double* x, 
 __global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
-  if (t >= min(a.w.count[a.lb * a.B + b], a.cap)) return;
-  const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
-  const double* cell = plb_buf(a, 0, b) + lin * 4;
+  const int cur = a.lb, prev = cur ^ 1;
+  if (t < min(a.w.count[prev * a.B + b], a.cap)) {   // the cells of substep f + 1 (the other list and buffer): its p2g adjoint has gathered them
+    const long lin = a.w.list[((long)prev * a.B + b) * a.cap + t];
+    double* old = plb_buf(a, prev, b) + lin * 4;
+    double* g = a.w.gacc + ((long)b * a.G + lin) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { old[k] = 0.0; g[k] = 0.0; }
+  }
+  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
+  const double* cell = plb_buf(a, cur, b) + lin * 4;
   double vv[3];
   plb_grid_cell(c, lin, cell[0], cell + 1, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, vv);
-  double* out = plb_buf(a, 1, b) + lin * 4;
+  double* out = plb_vout(a, b) + lin * 4;   // never cleared: read only at cells this launch has just written
   out[0] = vv[0]; out[1] = vv[1]; out[2] = vv[2];
 }
 
 // ---- g2p adjoint (:234-253 in reverse) -------------------------------------------------------------------------------
 // inputs: cotangent of state f + 1 (gstate slot `gs_in`); outputs: v_out cotangents scattered into gacc, the x cotangent
 // that flows through g2p (weights, dpos, the position clamp) into gxs, and gv1 (with the advection term) kept in gstate.
+// The v_out cotangents are summed per block in an LDS table first (plb_p2g's staging: open addressing over PLB_H slots, f64 LDS
+// atomics), then flushed with one global atomic per touched cell and component: 81 global f64 atomics per particle were this
+// kernel (30-35 us of a 105 us reverse substep on Torus, profiles/r02j_kernel_stats_torus_grad_ngrid64.csv).
 template <int LANES>   // lanes per particle, as in plb_g2p: the quad splits the 27 cells 7/7/7/6 and adds its partial sums with DPP
 __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
+  __shared__ int s_key[PLB_H];
+  __shared__ double s_val[PLB_H * 3];   // component-major [3][PLB_H]
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  if (p >= c.N) return;   // whole quads leave together
+  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; }
+  if (gid == 0) a.w.count[(a.lb ^ 1) * a.B + b] = 0;   // the other list: plb_grid_keep has just retired it, p2g of substep f - 1 refills it
+  __syncthreads();
+  double* gacc = a.w.gacc + (long)b * a.G * 4;
+  if (p < c.N) {   // whole quads together
   const double* hi_ = plb_hist(a, b, a.hs_in);
   const double* ho = plb_hist(a, b, a.hs_out);
   const double* g1 = a.w.gstate + ((long)b * 2 + gs_in) * 24 * c.Np;
@@ -81,10 +98,10 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   int base[3];
   double fx[3], w[9], dw[9];
   plb_weights(c, x, base, fx, w, dw);
-  const double* vout = plb_buf(a, 1, b);
-  double* gacc = a.w.gacc + (long)b * a.G * 4;
+  const double* vout = plb_vout(a, b);
   double gfx[3] = {0, 0, 0};
   const double k4 = 4 * c.inv_dx;
+  const int rot = (p * LANES) % 27;   // staggered stencil walk, as in plb_p2g: neighbours never on the same table slot at once
   constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;   // four lanes: the lane's seven cells requested together
 #pragma unroll 1
   for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
@@ -92,7 +109,8 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   long lin7[BATCH];
 #pragma unroll
   for (int t = 0; t < BATCH; ++t) {
-    const int cidx = min(qi + LANES * (t0 + t), 26);
+    const int it = min(qi + LANES * (t0 + t), 26);
+    const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
     lin7[t] = plb_lin(c, ci, cj, ck);
@@ -100,22 +118,36 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   }
 #pragma unroll
   for (int t = 0; t < BATCH; ++t) {
-    const int cidx = qi + LANES * (t0 + t);
-    if (cidx >= 27) break;
+    const int it = qi + LANES * (t0 + t);
+    if (it >= 27) break;
+    const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
     const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
     const double wi = dsel3(w, 0, i), wj = dsel3(w, 1, j), wk = dsel3(w, 2, k);
     const double weight = wi * wj * wk;
     const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
     const long lin = lin7[t];
     const double g[3] = {g7[t][0], g7[t][1], g7[t][2]};
+    unsigned s = plb_hash((int)lin);
+    int slot = -1;
+    for (int probe = 0; probe < 64; ++probe) {
+      const int cur = s_key[s];
+      if (cur == (int)lin) { slot = (int)s; break; }
+      if (cur == -1) {
+        const int old = atomicCAS(&s_key[s], -1, (int)lin);
+        if (old == -1 || old == (int)lin) { slot = (int)s; break; }
+      }
+      s = (s + 1) & (PLB_H - 1);
+    }
     double gw = 0, gdp[3] = {0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const double cd = gC1[r * 3] * dp[0] + gC1[r * 3 + 1] * dp[1] + gC1[r * 3 + 2] * dp[2];
-      atomicAdd(gacc + lin * 4 + r, weight * (gv1[r] + k4 * cd));
+      const double gcell = weight * (gv1[r] + k4 * cd);
+      if (slot >= 0) __hip_atomic_fetch_add(&s_val[r * PLB_H + slot], gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else atomicAdd(gacc + lin * 4 + r, gcell);
       gw += g[r] * (gv1[r] + k4 * cd);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) gdp[s] += k4 * weight * gC1[r * 3 + s] * g[r];
+      for (int s2 = 0; s2 < 3; ++s2) gdp[s2] += k4 * weight * gC1[r * 3 + s2] * g[r];
     }
     gfx[0] += gw * dsel3(dw, 0, i) * wj * wk - gdp[0];
     gfx[1] += gw * wi * dsel3(dw, 1, j) * wk - gdp[1];
@@ -124,23 +156,39 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) gfx[d] = plb_quad_sum<LANES>(gfx[d]);
-  if (qi != 0) return;
-  double* gxs = a.w.gxs + (long)b * 3 * c.Np;
+  if (qi == 0) {
+    double* gxs = a.w.gxs + (long)b * 3 * c.Np;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) gxs[d * c.Np + p] = gxp[d] + c.inv_dx * gfx[d];
+    for (int d = 0; d < 3; ++d) gxs[d * c.Np + p] = gxp[d] + c.inv_dx * gfx[d];
+  }
+  }
+  __syncthreads();
+  {                  // flush: four lanes per cell (a cell is 32 contiguous bytes), the fourth component is the grid-op adjoint's
+    const int r = threadIdx.x & 3;
+#pragma unroll 4
+    for (int sl = threadIdx.x >> 2; sl < PLB_H; sl += 64) {
+      const int key = s_key[sl];
+      if (key < 0 || r == 3) continue;
+      atomicAdd(gacc + (long)key * 4 + r, s_val[r * PLB_H + sl]);
+    }
+  }
 }
 
 // ---- grid op adjoint (:200-232 in reverse), one touched cell per lane -------------------------------------------------
 __global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
-  if (t >= min(a.w.count[a.lb * a.B + b], a.cap)) return;
-  const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
-  const double* cell = plb_buf(a, 0, b) + lin * 4;
+  // per-env cotangents (sticky-sphere positions, ground friction): summed over the wave, one atomic per wave and word -- one per cell
+  // put every cell near a sphere on the same few words of its env (cf. lg_grid_adj_tile, mpm_large.hip)
+  double qs[2][3] = {{0, 0, 0}, {0, 0, 0}}, gfric = 0;
+  const bool inlist = t < min(a.w.count[a.lb * a.B + b], a.cap);
+  const long lin = inlist ? a.w.list[((long)a.lb * a.B + b) * a.cap + t] : 0;
+  const double* cell = plb_buf(a, a.lb, b) + lin * 4;
   double* ga = a.w.gacc + ((long)b * a.G + lin) * 4;
+  const double m = inlist ? cell[0] : 0.0;
+  if (inlist && !(m > 1e-12)) { ga[0] = 0; ga[1] = 0; ga[2] = 0; ga[3] = 0; }
+  if (inlist && m > 1e-12) {
   double g[3] = {ga[0], ga[1], ga[2]};
-  const double m = cell[0];
-  if (!(m > 1e-12)) { ga[0] = 0; ga[1] = 0; ga[2] = 0; ga[3] = 0; return; }
   const int n = c.n_grid;
   const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
   const double* P0 = a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
@@ -185,7 +233,6 @@ __global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
     if (hiz[d]) vv[d] = 0;
   }
   // reverse
-  double gfric = 0;
 #pragma unroll
   for (int d = 2; d >= 0; --d) {
     if (hiz[d]) g[d] = 0;
@@ -208,22 +255,36 @@ __global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
       g[0] = gvit[0]; g[2] = gvit[2]; g[1] = gvit[1] + glin;
     }
   }
-  double* gpos = a.w.gpos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
-  for (int pi = c.np - 1; pi >= 0; --pi) {
-    if (stick[pi]) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double q = g[k] / c.dt;
-        if (q != 0.0) { atomicAdd(gpos + c.np * 3 + pi * 3 + k, q); atomicAdd(gpos + pi * 3 + k, -q); }
-        g[k] = 0;
-      }
+  for (int pi = 1; pi >= 0; --pi) {
+    if (pi < c.np && stick[pi]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { qs[pi][k] = g[k] / c.dt; g[k] = 0; }
     }
   }
-  if (gfric != 0.0) atomicAdd(a.w.gpar + b * 4 + 3, gfric);
   const double im = 1.0 / m;
   ga[0] = g[0] * im; ga[1] = g[1] * im; ga[2] = g[2] * im;
   ga[3] = -(g[0] * cell[1] + g[1] * cell[2] + g[2] * cell[3]) * im * im;
+  }
+  double* gpos = a.w.gpos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
+  const bool lead = (threadIdx.x & 63) == 0;
+#pragma unroll
+  for (int pi = 0; pi < 2; ++pi) {
+    if (pi >= c.np) break;
+    if (!__any(qs[pi][0] != 0.0 || qs[pi][1] != 0.0 || qs[pi][2] != 0.0)) continue;   // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double q = plb_wave_sum(qs[pi][k]);
+      if (lead && q != 0.0) { atomicAdd(gpos + c.np * 3 + pi * 3 + k, q); atomicAdd(gpos + pi * 3 + k, -q); }
+    }
+  }
+  if (__any(gfric != 0.0)) {
+    const double q = plb_wave_sum(gfric);
+    if (lead && q != 0.0) atomicAdd(a.w.gpar + b * 4 + 3, q);
+  }
 }
+
+
 
 // ---- p2g adjoint + particle pre-pass adjoint (:91-99, :133-195 in reverse) --------------------------------------------
 template <int LANES>   // lanes per particle: every lane of the quad repeats the pre-pass (it needs the affine matrix for its cells), the
@@ -439,11 +500,10 @@ __global__ void __launch_bounds__(256) plb_adj_clear(PlbArgs a) {
   const int n = min(a.w.count[a.lb * a.B + b], a.cap);
   if (t < n) {
     const long lin = a.w.list[((long)a.lb * a.B + b) * a.cap + t];
-    double* c0 = plb_buf(a, 0, b) + lin * 4;
-    double* c1 = plb_buf(a, 1, b) + lin * 4;
+    double* c0 = plb_buf(a, a.lb, b) + lin * 4;
     double* g = a.w.gacc + ((long)b * a.G + lin) * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c0[k] = 0.0; c1[k] = 0.0; g[k] = 0.0; }
+    for (int k = 0; k < 4; ++k) { c0[k] = 0.0; g[k] = 0.0; }
   }
 }
 __global__ void plb_adj_reset_counts(PlbArgs a) {
@@ -680,18 +740,22 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   const int lanes = (force_lanes == 1 || force_lanes == 4) ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);
   hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_pack, gp, blk, 0, st, a, S & 1, g_x, g_v, g_C, g_F, g_prim_pos);
+  // Five launches per reverse substep.  List and (m, mv) buffer alternate with the substep like the forward's: plb_grid_keep retires
+  // the cells of substep f + 1 (their buffer and cotangent cells back to zero) beside its own work, plb_g2p_adj resets that list's
+  // count -- the separate clear and count-reset launches of every substep are gone; one clear after the loop for substep 0.
   for (int f = S - 1; f >= 0; --f) {
-    a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1;
-    ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);              // recompute (m, mv) into buffer 0 (rewrites F[f + 1] with the same values)
+    a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1; a.lb = f & 1;
+    ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);              // recompute (m, mv) (rewrites F[f + 1] with the same values)
     hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_g2p_adj<1>, gp, blk, 0, st, a, (f + 1) & 1);
     hipLaunchKernelGGL(ud::plb_grid_adj, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g_adj<4>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_p2g_adj<1>, gpa, dim3(128), 0, st, a, (f + 1) & 1);
-    hipLaunchKernelGGL(ud::plb_adj_clear, gc, blk, 0, st, a);
-    hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   }
+  a.lb = 0;
+  hipLaunchKernelGGL(ud::plb_adj_clear, gc, blk, 0, st, a);
+  hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_unpack, gp, blk, 0, st, a, 0, g_x0, g_v0, g_C0, g_F0);
   hipLaunchKernelGGL(ud::plb_adj_epilogue, dim3((B + 63) / 64), dim3(64), 0, st, a, action, g_prim_pos0, g_action, g_E, g_nu, g_yield_stress, g_ground_friction);
   hipError_t e = hipGetLastError();

@@ -20,6 +20,7 @@ struct PlbBuf {
   int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
   // adjoint only (plb_adj.hip)
   double* gacc;   // [B][G][4] cotangent of the cell's v_out (xyz), then of (mv xyz, m)
+  double* vout;   // [B][G][4] the cell's v_out of the substep being reversed (xyz; never cleared: read only where just written)
   double* gstate; // [B][2][24][Np] cotangent of the particle state, ping-pong over substeps
   double* gxs;    // [B][3][Np] the part of x's cotangent that g2p's adjoint produces, handed to p2g's adjoint
   double* gpos;   // [B][S+1][np][3] cotangent of the primitive positions
@@ -122,6 +123,12 @@ __device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin) {
 // can then be zeroed while substep f runs -- plb_grid(f) does it next to its own work -- instead of in a launch of their own
 // between g2p(f - 1) and p2g(f).  One launch less per substep (4 -> 3) on a path whose kernels sit near the launch floor.
 __device__ __forceinline__ double* plb_buf(const PlbArgs& a, int k, int b) { return a.w.val + (((long)k * a.B + b) * a.G) * 4; }
+__device__ __forceinline__ double* plb_vout(const PlbArgs& a, int b) { return a.w.vout + ((long)b * a.G) * 4; }
+__device__ __forceinline__ double plb_wave_sum(double v) {   // all 64 lanes get the sum
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
 
 #define PLB_H 1024
 #define PLB_LOGH 10
