@@ -324,7 +324,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
     from unidom_amd.algorithms.apg.core import APG
     from unidom_amd.envs.registration import env_functions
     from unidom_amd.utils import prng
-    B, ep = 32, EP_LEN
+    B, ep = (args.envs if name == "whip_rope" else 32), EP_LEN
     env = env_functions[name](batch_size=B, seed=0, aux_reward=True, device=device)
     _, state = env.reset(prng.split(prng.PRNGKey(0), world)[rank])
     learner = APG(env, ep, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
@@ -335,19 +335,43 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    want_graph = name == "whip_rope" and world == 1 and not args.no_graph
+    if want_graph:                                           # the learner's whole life on one non-default stream (APG.capture)
+        work = torch.cuda.Stream(device)
+        work.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(work)
     restore, box = capture_step_inputs(env.simulator)        # the first simulator.step's inputs, for the CPU baseline (untimed)
     for _ in range(args.warmup):
         learner.minimize(state)
     restore()
     env.simulator.check_status()
-    env.simulator.profile = {"fwd": [], "bwd": []}
+    # whip_rope (one workgroup per env, ~200 launches per update of which 6 are the simulator's): the update replayed as ONE HIP graph
+    # (APG.capture).  Kernel times for the roofline come from an eager pass beside the timed region (a graph has no event hooks).
+    graphed = False
+    if want_graph:
+        env.simulator.profile = {"fwd": [], "bwd": []}
+        learner.minimize(state)
+        sync()
+        prof, env.simulator.profile = env.simulator.profile, None
+        try:
+            learner.capture(state)
+            learner.minimize_captured()
+            graphed = True
+        except Exception as e:                               # stays a measured eager line, and says so
+            print(f"[bench] graph capture failed, eager update instead: {type(e).__name__}: {e}", file=sys.stderr)
+    if not graphed:
+        env.simulator.profile = {"fwd": [], "bwd": []}
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        learner.minimize(state)
+        if graphed:
+            learner.minimize_captured()
+        else:
+            learner.minimize(state)
     sync()
     dt = time.perf_counter() - t0
-    prof, env.simulator.profile = env.simulator.profile, None
+    if not graphed:
+        prof, env.simulator.profile = env.simulator.profile, None
     env.simulator.check_status()
     tm = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
@@ -377,16 +401,17 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world, learner.n_params),
             "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
-                                   f"{B} envs per GPU, ep_len={ep}", "touched_cells": g_act},
+                                   f"{B} envs per GPU, ep_len={ep}" + (", the update replayed as one HIP graph" if graphed else ""), "touched_cells": g_act,
+                       "hip_graph": graphed},
             "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator, B) if env.simulator.n_primitive > 1 or N > 128 else
                          ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": per_launch,
                          **({"issue": issue_roof("mpm_step_fwd_kernel" if dom == "fwd" else "mpm_step_bwd_ws_kernel", k_ms[dom],
-                                                 B * ((4 * N + 63) // 64 + (0 if dom == "fwd" else (N + 63) // 64)), B, S)}
+                                                 B * ((4 * N + 63) // 64 + (0 if dom == "fwd" else (N + 63) // 64)), min(B, 256), S)}
                             if N <= 128 and env.simulator.n_primitive == 1 else {"issue": lg_issue(f"large_path:{name}:{dom}", k_ms[dom]) if B == 32 else None}),
-                         "note": "one workgroup per env (32 of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
+                         "note": f"one workgroup per env ({min(B, 256)} of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
                          else f"latency / issue bound: small launches on {B} x {N} particles"},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
@@ -878,6 +903,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
+    ap.add_argument("--no-graph", action="store_true", help="whip_rope: eager update instead of the captured HIP graph")
     ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water", "pour_soup", "selftest"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")

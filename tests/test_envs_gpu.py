@@ -122,6 +122,39 @@ def test_apg_update_runs(name, num_envs, ep_len):
     assert m["reward"].shape == (ep_len, num_envs)
 
 
+def test_apg_update_captured_as_one_hip_graph_is_the_eager_update():
+    """APG.capture replays one update (policy, 2 x step_diff, loss, backward, clip, Adam) as ONE HIP graph.  Same key schedule and
+    arithmetic as minimize(): after three updates from the same seed the losses agree and the parameters have moved alike (Adam's
+    first steps are ~lr * sign(g): an element whose gradient is at the float atomics' noise level may land on the other side, so
+    the comparison allows a per-mille of the elements to differ by more than a tenth of one step).  The learner lives on one
+    non-default stream, eager updates included (capture()'s docstring says why); capture() leaves parameters and moments untouched."""
+    from unidom_amd.algorithms.apg.core import APG
+    from unidom_amd.envs.registration import env_functions
+    dev = torch.device("cuda", 0)
+    work = torch.cuda.Stream(dev)
+    lr = 1e-4
+    with torch.cuda.stream(work):
+        out = {}
+        for mode in ("eager", "graph"):
+            env = env_functions["whip_rope"](batch_size=4, seed=0, aux_reward=True)
+            _, st = env.reset(np.array([0, 3], np.uint32))
+            learner = APG(env, 2, learning_rate=lr, max_gradient_norm=0.3, seed=0)
+            w0 = [p.detach().clone() for p in learner.params]
+            if mode == "graph":
+                learner.capture(st)
+                assert all(torch.equal(a, b) for a, b in zip(w0, learner.params))
+            ms = [(learner.minimize_captured() if mode == "graph" else learner.minimize(st)) for _ in range(3)]
+            torch.cuda.synchronize(dev)
+            env.simulator.check_status()
+            out[mode] = (float(ms[-1]["loss"]), float(ms[-1]["grad_norm"]), torch.cat([(p.detach() - a).reshape(-1) for p, a in zip(learner.params, w0)]))
+    (le, ge, de), (lg, gg, dg) = out["eager"], out["graph"]
+    assert math.isfinite(le) and abs(le - lg) < 1e-5 * max(1.0, abs(le)) and abs(ge - gg) < 1e-3 * ge, (le, lg, ge, gg)
+    assert float(de.abs().max()) > lr                                    # the parameters did move
+    assert float(((de - dg).abs() > 0.1 * lr).float().mean()) < 1e-3, float(((de - dg).abs() > 0.1 * lr).float().mean())
+    with pytest.raises(RuntimeError):                                    # on the default stream capture refuses (instead of crashing the runtime)
+        learner.capture(st)
+
+
 def test_apg_entry_point_cli(tmp_path):
     """`python -m unidom_amd.algorithms.apg.apg_no_para` with the reference's flags (train_no_para.sh), 2 iterations."""
     import json

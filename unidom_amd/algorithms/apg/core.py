@@ -207,6 +207,82 @@ class APG:
         raw_norm = self.sync.step()
         return {"grad_norm": raw_norm, "reward": rewards.detach(), "loss": loss.detach()}
 
+    # ---- one update as ONE graph launch ----------------------------------------------------------------------------
+    def capture(self, state, warmup=3):
+        """Capture one APG update on `state` (policy, episode_length x step_diff, loss, backward, clip, Adam) into a HIP graph.
+        An update of a small MPM env is ~200 launches, most of them a few microseconds of policy / reward / optimizer arithmetic
+        between the simulator's kernels; replayed as one graph the GPU runs them back to back, the host issues a single launch.
+        What makes it legal: every simulator call takes the capturing stream and allocates through torch (graph-private pool);
+        the episode's noise is drawn on the host as before and copied into a static buffer before the replay; Adam runs in its
+        capturable form (step count on the device).  `state` is bound at capture: minimize_captured() re-runs the update from THAT
+        state (APG restarts every update from the reset state, apg.py:217-258).  Single process only (the gradient all-reduce
+        stays eager).  Device-side status flags are written by every replay into the tensors recorded at capture."""
+        if self.world > 1:
+            raise RuntimeError("APG.capture: single-process only")
+        dev = torch.device(self.device)
+        T, B, A = self.episode_length, self.env.batch_size, self.env.action_size
+        self._cap_noise = torch.zeros((T, B, A), device=dev)
+        if not self.optimizer.defaults.get("capturable", False):
+            sd = self.optimizer.state_dict()
+            self.optimizer = self.sync.optimizer = torch.optim.Adam(self.params, lr=self.optimizer.defaults["lr"], betas=(0.9, 0.999), eps=1e-8, capturable=True)
+            self.optimizer.load_state_dict({**sd, "param_groups": [{**g, "capturable": True} for g in sd["param_groups"]]})
+        sim = getattr(self.env, "simulator", None)
+        prof, had = (sim.profile, True) if sim is not None and hasattr(sim, "profile") else (None, False)
+        if had:
+            sim.profile = None                       # timing events cannot be queried from inside a graph
+        # The capture runs on the CURRENT stream, which must be a non-default one and the stream every earlier eager update of this
+        # learner ran on: autograd's per-parameter accumulator nodes remember the stream they were created on (they stay alive with
+        # the last rollout's graph, e.g. through env state), and a backward that touches another stream inside a capture takes the
+        # ROCm runtime down in hipStreamEndCapture rather than raising.  So: `with torch.cuda.stream(s):` around the learner's whole
+        # life (bench.py does), capture() inside it.
+        cur = torch.cuda.current_stream(dev)
+        if cur == torch.cuda.default_stream(dev):
+            raise RuntimeError("APG.capture: run the learner under a non-default stream (with torch.cuda.stream(s): ...), eager updates included")
+        # the warm-up updates below are real updates (with zero noise): parameters and Adam moments are put back afterwards, IN PLACE --
+        # the graph holds the addresses of these very tensors
+        saved_p = [p.detach().clone() for p in self.params]
+        saved_s = [{k: v.detach().clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)} for p in self.params]
+        for _ in range(warmup):                      # eager warm-up: lazy initialisations, arenas, Adam state
+            self._update(state, self._cap_noise)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=cur):
+            self._cap_out = self._update(state, self._cap_noise)
+        with torch.no_grad():
+            for p, sp, ss in zip(self.params, saved_p, saved_s):
+                p.copy_(sp)
+                for k, v in self.optimizer.state[p].items():
+                    if torch.is_tensor(v):
+                        v.copy_(ss[k]) if k in ss else v.zero_()     # no earlier state: a fresh Adam (zero moments, step 0)
+        if had:
+            sim.profile = prof
+        return self
+
+    def _update(self, state, noise):
+        # torch.autograd.grad, not .backward(): the parameters' AccumulateGrad nodes were created by the eager updates on the default
+        # stream and would run there, outside the capture (torch warns; hipStreamEndCapture then crashes).  The gradients land in the
+        # flat buffer by copy -- the same values .backward() accumulates into its zeroed views.
+        loss, (rewards, _, _) = self.loss(state, None, noise)
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        off = 0
+        for p, g in zip(self.params, grads):
+            dst = self.flat_grad[off:off + p.numel()]
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g.reshape(-1))
+            off += p.numel()
+        raw_norm = self.sync.step()
+        return {"grad_norm": raw_norm, "reward": rewards.detach(), "loss": loss.detach()}
+
+    def minimize_captured(self):
+        """minimize() through the captured graph: same key schedule, same arithmetic; returns the (static) metric tensors."""
+        self.key, key_grad = prng.split(self.key)
+        _, noise = self.draw_noise(key_grad, self.episode_length)
+        self._cap_noise.copy_(noise, non_blocking=True)
+        self._graph.replay()
+        return self._cap_out
+
     @torch.no_grad()
     def evaluate(self, state, steps, key=None):
         """run_eval (apg.py:127-149): `steps` scanned do_one_step_eval calls drawing their noise from `key` (key_debug)."""
