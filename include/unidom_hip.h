@@ -166,6 +166,15 @@ typedef struct {
                                 sampled liquids, mpm_simulator.py:87-91); bodies above 8192 particles keep their order (the
                                 sort runs in the LDS of one workgroup per env).  Invisible at this boundary: inputs, outputs and
                                 gradients stay in the caller's order; only the summation order of the scatters changes */
+  int deterministic;         /* != 0: ud_mpm_step_fwd sums every grid cell over the particles in index order and each particle's
+                                27 offsets in (i, j, k) order, in f32 -- the order of the reference's scatter-add on XLA's CPU
+                                backend (mpm_simulator.py:178-194) -- and g2p adds its cells in (i, j, k) order; no float atomics,
+                                IEEE arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same
+                                inputs return the same bits, and x, v, C, F equal the CPU build of the same source bit for bit
+                                (tests/test_mpm_det.py).  A test mode: one thread per touched cell walks all particles, about
+                                30x the default forward on the rope at n_grid 128.  Position control with one box primitive only
+                                (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the backward is
+                                the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */

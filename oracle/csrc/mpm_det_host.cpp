@@ -1,0 +1,72 @@
+// TEST INFRASTRUCTURE.  The same-order checker of the deterministic MPM forward (ud_mpm_conf.deterministic): the device's own
+// per-element source -- unidom_amd/csrc/mpm_det.h and mpm_device.h -- compiled by the host compiler (UD_HOST_BUILD: no HIP, IEEE
+// arithmetic, -ffp-contract=off) and driven by plain loops in the order the kernels of mpm_det.hip define: per substep every
+// particle's pre-pass, every stamped cell summed over the particles in index order, every particle's gather in (i, j, k) order.
+// It pins ORDER and ARITHMETIC of the GPU run bit for bit; that this arithmetic is the reference's algorithm is what the
+// independent restatement (mpm_oracle.hpp, mpm_simulator.py:178-328) is for -- tests/test_mpm_det.py holds the two against each
+// other on the CPU, within the tolerance the different SVD and summation order leave.
+#define UD_HOST_BUILD 1
+#include <cstring>
+#include <vector>
+
+#include "../../unidom_amd/csrc/mpm_det.h"
+
+extern "C" {
+
+// x, v [B][N][3], C, F [B][N][3][3] -> the same after `steps` substeps; ppos [B][S][3] / prot [B][S][4] in: the input arrays,
+// out: the rows forward kinematics leaves.  Returns 0.
+int oc_mpm_det_forward(int B, int N, int n_grid, const int* res, int steps, float dt, float p_mass, float p_vol, const float* gravity,
+                       const int* material, const float* hard, const float* x, const float* v, const float* Cm, const float* F,
+                       float* ppos, float* prot, const float* psize, const float* friction, const float* mu, const float* lamda,
+                       const float* action, float* xo, float* vo, float* Co, float* Fo) {
+  ud::MpmConst c;
+  std::memset(&c, 0, sizeof(c));
+  c.N = N; c.Np = (N + 15) / 16 * 16; c.n_grid = n_grid; c.steps = steps;
+  for (int d = 0; d < 3; ++d) c.res[d] = res[d];
+  const double dx = 1.0 / n_grid;                       // as ud_mpm_create derives them (mpm.hip)
+  c.dt = dt; c.dx = (float)dx; c.inv_dx = (float)(double)n_grid;
+  c.p_mass = p_mass; c.p_vol = p_vol;
+  c.stress_c = (float)(-(double)dt * (double)p_vol * 4.0);
+  c.dx2 = (float)(dx * dx);
+  for (int d = 0; d < 3; ++d) c.dtg[d] = dt * gravity[d];
+  c.position_control = 1; c.n_prim = 1; c.det = 1;
+  const long G = (long)res[0] * res[1] * res[2];
+  const int Np = c.Np, S = steps;
+  std::vector<float> h0((size_t)24 * Np), h1((size_t)24 * Np), pre((size_t)UD_DET_PRE * Np), vel((size_t)G * 4);
+  std::vector<int> flag((size_t)G, 0);
+  for (int b = 0; b < B; ++b) {
+    float* pp = ppos + (long)b * S * 3;
+    float* pr = prot + (long)b * S * 4;
+    ud::det_fk_rows(S, action + (long)b * 6, pp, pr);
+    std::fill(h0.begin(), h0.end(), 0.f); std::fill(h1.begin(), h1.end(), 0.f);
+    for (int p = 0; p < N; ++p) {                      // lg_pack: SoA record, nan_to_num on the way in
+      for (int d = 0; d < 3; ++d) { h0[d * Np + p] = ud::nan_to_num(x[((long)b * N + p) * 3 + d]); h0[(3 + d) * Np + p] = ud::nan_to_num(v[((long)b * N + p) * 3 + d]); }
+      for (int d = 0; d < 9; ++d) { h0[(6 + d) * Np + p] = ud::nan_to_num(Cm[((long)b * N + p) * 9 + d]); h0[(15 + d) * Np + p] = ud::nan_to_num(F[((long)b * N + p) * 9 + d]); }
+    }
+    std::fill(flag.begin(), flag.end(), 0);
+    float* h = h0.data();
+    float* hn = h1.data();
+    for (int f = 0; f < S; ++f) {
+      const int epoch = f + 1;
+      for (int p = 0; p < N; ++p) ud::det_pre_particle(c, h, hn, p, mu[b], lamda[b], material[p], hard[p], pre.data(), flag.data(), epoch);
+      ud::PrimF pf;
+      ud::det_prim(S, f, pp, pr, psize + (long)b * 3, action + (long)b * 6, friction[b], pf);
+      for (long lin = 0; lin < G; ++lin) {
+        if (flag[lin] != epoch) continue;
+        const int ck = (int)(lin % res[2]), cj = (int)((lin / res[2]) % res[1]), ci = (int)(lin / ((long)res[2] * res[1]));
+        float o[3];
+        ud::det_cell(c, ci, cj, ck, pre.data(), pf, o);
+        vel[lin * 4] = o[0]; vel[lin * 4 + 1] = o[1]; vel[lin * 4 + 2] = o[2]; vel[lin * 4 + 3] = 0.f;
+      }
+      for (int p = 0; p < N; ++p) (void)ud::det_g2p_particle(c, h, hn, p, pre.data(), vel.data());
+      std::swap(h, hn);
+    }
+    for (int p = 0; p < N; ++p) {
+      for (int d = 0; d < 3; ++d) { xo[((long)b * N + p) * 3 + d] = h[d * Np + p]; vo[((long)b * N + p) * 3 + d] = h[(3 + d) * Np + p]; }
+      for (int d = 0; d < 9; ++d) { Co[((long)b * N + p) * 9 + d] = h[(6 + d) * Np + p]; Fo[((long)b * N + p) * 9 + d] = h[(15 + d) * Np + p]; }
+    }
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -196,6 +196,29 @@ class MpmOracle:
         return o
 
 
+def mpm_det_forward(st, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0), material=None, hardness=None):
+    """The deterministic MPM forward's own source (unidom_amd/csrc/mpm_det.h) compiled for the CPU (csrc/mpm_det_host.cpp): the
+    same-order, same-arithmetic checker of ud_mpm_conf.deterministic.  f32 only; position control, one box primitive.
+    st as MpmOracle.step_fwd takes it; returns x v C F after the step and the primitive rows forward kinematics leaves."""
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    x, v, Cm, F = f(st["x"]), f(st["v"]), f(st["C"]), f(st["F"])
+    B = x.shape[0]
+    dx = 1 / n_grid
+    p_vol = (dx * 0.5) ** 2
+    mat = np.ascontiguousarray(np.full(N, 1) if material is None else material, dtype=np.int32)
+    hd = f(np.full(N, 1.0) if hardness is None else hardness)
+    ppos, prot = f(st["ppos"]).copy(), f(st["prot"]).copy()
+    o = dict(x=np.empty_like(x), v=np.empty_like(v), C=np.empty_like(Cm), F=np.empty_like(F))
+    rc = lib().oc_mpm_det_forward(
+        C.c_int(B), C.c_int(N), C.c_int(n_grid), _p(np.ascontiguousarray(res, dtype=np.int32)), C.c_int(steps), C.c_float(dt),
+        C.c_float(p_vol * p_rho), C.c_float(p_vol), _p(f(gravity)), _p(mat), _p(hd), _p(x), _p(v), _p(Cm), _p(F), _p(ppos), _p(prot),
+        _p(f(st["psize"])), _p(f(st["friction"])), _p(f(st["mu"])), _p(f(st["lamda"])), _p(f(st["action"])),
+        _p(o["x"]), _p(o["v"]), _p(o["C"]), _p(o["F"]))
+    assert rc == 0
+    o["ppos_rows"], o["prot_rows"] = ppos, prot
+    return o
+
+
 def svd3(A):
     A = np.ascontiguousarray(A)
     U, S, Vh = np.empty_like(A), np.empty(3, A.dtype), np.empty_like(A)

@@ -1,0 +1,115 @@
+"""Deterministic MPM mode (ud_mpm_conf.deterministic, include/unidom_hip.h).
+
+The reference's p2g is a scatter-add that XLA's CPU backend applies in the order of the flattened (particle, offset) index array
+(mpm_simulator.py:178-194, :233-274); the fast kernels sum in the arrival order of atomics, so every other MPM comparison carries
+a tolerance.  In this mode each cell is summed by one thread in that order, in IEEE f32, and the tests below are bit-for-bit:
+  * two GPU runs of the same step are identical,
+  * x, v, C, F after 70 substeps equal the CPU build of the same per-element source (oracle/csrc/mpm_det_host.cpp),
+and, on the CPU, that source is held against the independent restatement of the reference (oracle/csrc/mpm_oracle.hpp) within the
+tolerance their different SVDs leave -- the same-order checker pins order and arithmetic, the independent one the algorithm."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_oracle_mpm import S_LEGACY, _rel, legacy_state
+
+
+@pytest.fixture(scope="module")
+def demo():
+    return np.load(os.path.join(GOLDEN, "whip_rope_demo0.npz"))
+
+
+def _batch(demo, ks, S):
+    sts = [legacy_state(demo, k, S=S)[0] for k in ks]
+    return {key: np.concatenate([s[key] for s in sts]) for key in sts[0]}
+
+
+def test_same_order_source_follows_the_reference_restatement(demo):
+    """whip_rope's recorded states, 70 substeps: the deterministic mode's source (CPU build) against the independent oracle."""
+    from oracle.pyoracle import MpmOracle, mpm_det_forward
+    st = _batch(demo, [0, 20, 40], 70)
+    ref = MpmOracle(67, steps=70).step_fwd(st)
+    got = mpm_det_forward(st, 67, steps=70)
+    assert _rel(got["x"], ref["x"]) < 2e-6 and _rel(got["v"], ref["v"]) < 1e-4, (_rel(got["x"], ref["x"]), _rel(got["v"], ref["v"]))
+    assert _rel(got["C"], ref["C"]) < 1e-3 and _rel(got["F"], ref["F"]) < 5e-5, (_rel(got["C"], ref["C"]), _rel(got["F"], ref["F"]))
+    # the recorded next states themselves (50 substeps, the legacy step of the recording: SURVEY.md F3)
+    st50 = _batch(demo, [5], S_LEGACY)
+    o = mpm_det_forward(st50, 67, steps=S_LEGACY)
+    shift = legacy_state(demo, 5)[1]
+    assert np.abs(o["x"][0] - shift - demo["x"][6]).max() < 5e-7
+    assert _rel(o["v"][0], demo["v"][6]) < 3e-5
+
+
+def _det_sim(steps, B, deterministic, N=67, conf_cls=None):
+    from test_mpm_gpu import LegacyConf
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    conf = (conf_cls or LegacyConf)()
+    conf.steps = steps
+    conf.deterministic = deterministic
+    sim = SimpleMPMSimulator(conf, B, use_position_control=True)
+    sim.n_particles = N
+    sim.material = np.full(N, 1, np.int32)
+    sim.h = np.ones(N, np.float32)
+    sim._make_handle()
+    return sim
+
+
+@pytest.mark.gpu
+def test_deterministic_forward_is_bit_identical_to_the_same_order_checker_over_70_substeps(demo):
+    from oracle.pyoracle import mpm_det_forward
+    from test_mpm_gpu import run_hip
+    st = _batch(demo, [0, 20, 40, 60], 70)
+    sim = _det_sim(70, 4, 1)
+    a = run_hip(sim, st)
+    b = run_hip(sim, st)
+    for key in ("x", "v", "C", "F", "J", "ppos", "prot"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key + ": two runs differ")
+    chk = mpm_det_forward(st, 67, steps=70)
+    for key in ("x", "v", "C", "F"):
+        np.testing.assert_array_equal(a[key], chk[key], err_msg=key + ": GPU != CPU build of the same source")
+    # and it is the same physics as the default kernels, to their tolerance
+    fast = run_hip(_det_sim(70, 4, 0), st)
+    assert _rel(a["x"], fast["x"]) < 5e-6 and _rel(a["v"], fast["v"]) < 1e-4 and _rel(a["F"], fast["F"]) < 5e-5
+    np.testing.assert_array_equal(a["J"].shape, fast["J"].shape)
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_on_a_many_workgroup_body(demo):
+    """rope seeded at n_grid 128 (N = 798, res 64^3): the shape the many-workgroup kernels serve by default"""
+    from oracle.pyoracle import mpm_det_forward
+    from test_mpm_gpu import ScaledConf, _scaled_case, run_hip
+
+    class DetScaled(ScaledConf):
+        deterministic = 1
+    S = 6
+    sim, st, g, N = _scaled_case(S, 3, B=2, conf_cls=DetScaled)
+    assert sim.deterministic == 1
+    a = run_hip(sim, st, g=g, clip=True)
+    b = run_hip(sim, st)
+    conf = ScaledConf()
+    chk = mpm_det_forward(st, N, n_grid=conf.n_grid, res=conf.res, steps=S, dt=conf.dt)
+    for key in ("x", "v", "C", "F"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key + ": two runs differ")
+        np.testing.assert_array_equal(a[key], chk[key], err_msg=key + ": GPU != CPU build of the same source")
+    # the backward of a deterministic handle is the many-workgroup recomputing backward, on the deterministic forward's history
+    sim0, _, _, _ = _scaled_case(S, 3, B=2)
+    ref = run_hip(sim0, st, g=g, clip=True)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(a[key]).all() and _rel(a[key], ref[key]) < 2e-4, (key, _rel(a[key], ref[key]))
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_refuses_soft_contact():
+    from test_mpm_gpu import LegacyConf
+    from unidom_amd._lib import UnidomError
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    conf = LegacyConf()
+    conf.deterministic = 1
+    sim = SimpleMPMSimulator(conf, 1, use_position_control=False)
+    sim.n_particles = 67
+    sim.material = np.full(67, 1, np.int32)
+    sim.h = np.ones(67, np.float32)
+    with pytest.raises(UnidomError):
+        sim._make_handle()

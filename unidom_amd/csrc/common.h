@@ -1,5 +1,17 @@
 // Shared host/device helpers of libunidom_hip (gfx950 only).
 #pragma once
+#ifdef UD_HOST_BUILD
+// oracle/csrc/mpm_det_host.cpp: the plain-arithmetic device headers (mpm_device.h, mpm_det.h) compiled by the host compiler, so that
+// the deterministic mode's CPU restatement IS the device source (no HIP runtime, no device intrinsics on that side)
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+using std::max;
+using std::min;
+#else
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -7,10 +19,13 @@
 #include <cstdio>
 
 #include "../../include/unidom_hip.h"
+#endif
 
 namespace ud {
 
+#ifndef UD_HOST_BUILD
 void set_error(const char* fmt, ...);
+#endif
 
 #define UD_HIP_CHECK(expr)                                                                   \
   do {                                                                                       \
@@ -45,6 +60,7 @@ __device__ __forceinline__ float nan_to_num(float x) {  // jnp.nan_to_num defaul
   return x;
 }
 
+#ifndef UD_HOST_BUILD   // ---- wave-level helpers: device only from here on ----
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -88,5 +104,7 @@ __device__ __forceinline__ float wave_sum8_t(const float (&v)[8], int lane) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s0), "+v"(s1));
   return s0 + s1;
 }
+
+#endif  // !UD_HOST_BUILD
 
 }  // namespace ud

@@ -1244,7 +1244,12 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
     return UD_ERR_UNSUPPORTED;
   }
   // soft contact (collide_batch) runs on the many-workgroup path whatever N is: every reference env that uses it has N > 128
-  const bool large = N > 128 || !conf->use_position_control;
+  if (conf->deterministic && (!conf->use_position_control || n_prim != 1)) {
+    ud::set_error("ud_mpm_create: deterministic mode covers position control with one box primitive");
+    return UD_ERR_UNSUPPORTED;
+  }
+  // the deterministic forward lives beside the many-workgroup kernels (dense grid in HBM), whatever N is
+  const bool large = N > 128 || !conf->use_position_control || conf->deterministic;
   if (!large && S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
   if (conf->res[0] > 1024 || conf->res[1] > 1024 || conf->res[2] > 1024) { ud::set_error("ud_mpm_create: res > 1024"); return UD_ERR_UNSUPPORTED; }
   auto* h = new ud_mpm;
@@ -1263,6 +1268,8 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   c.sdf_kind = conf->sdf_kind;
   c.gck = conf->grid_ckpt_cells > 0 ? conf->grid_ckpt_cells : 0;
   c.sort = conf->sort_particles ? 1 : 0;
+  c.det = conf->deterministic ? 1 : 0;
+  if (c.det) { c.gck = 0; c.sort = 0; }   // particle order = the caller's; the backward recomputes the grid
   int Hh = 1024, lg = 10;
   while (Hh < 16 * N) { Hh *= 2; ++lg; }                                 // load factor <= ~0.3 for a compact body
   const size_t per_particle = (N <= 96) ? 64 : 48;   // floats of LDS hand-off per particle in the adjoint (stage+ret / park)

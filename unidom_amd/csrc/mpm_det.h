@@ -1,0 +1,144 @@
+// Deterministic MPM forward (ud_mpm_conf.deterministic): the per-element arithmetic, plain C++ shared by the kernels of
+// mpm_det.hip and -- compiled by the host compiler, UD_HOST_BUILD -- by the same-order CPU restatement the tests compare them
+// with bit for bit (oracle/csrc/mpm_det_host.cpp).
+//
+// What "deterministic" fixes: the reference's p2g is a scatter-add that XLA's CPU backend applies update by update, in the order
+// of the flattened (particle, 27 offsets) index array (mpm_simulator.py:178-194, :233-274); the fast kernels sum each cell in the
+// arrival order of LDS / memory atomics instead, so two runs differ in the last bits.  Here every touched cell is summed by ONE
+// thread, over the particles in index order and each particle's offsets in (i, j, k) order, in f32 -- the reference's order -- and
+// g2p adds its 27 cells in (i, j, k) order in one lane.  Nothing is accumulated through atomics.
+// Scope: position control, one box primitive (whip_rope's configuration); soft contact is refused at ud_mpm_create.
+// Reference lines as in mpm.hip / mpm_device.h: particle pre-pass :233-258, p2g :259-274, grid op :283-313, g2p :196-221, :318-328,
+// forward kinematics primitives.py:185-194, position control primitives.py:232-239.
+#pragma once
+#include "mpm_device.h"
+
+namespace ud {
+
+#define UD_DET_PRE 27   // floats per particle handed from the pre-pass to the cell sums: base[3] (int bits), fx[3], w[9], affine[9], v[3]
+
+// forward kinematics of the whole step, in place on the [S][3] / [S][4] rows the caller filled with the input arrays
+// (the recurrence of lg_fk_all, mpm_cluster.h)
+__host__ __device__ inline void det_fk_rows(int S, const float* action6, float* pp, float* pr) {
+  for (int d = 0; d < 3; ++d) {
+    const float pva = clipf(action6[d], -1.f, 1.f) * 1.f / (float)S;
+    float prev = pp[d];
+    pp[d] = clipf(prev, -2.f, 2.f);
+    for (int f = 0; f + 1 < S; ++f) {
+      const float nxt = clipf(prev + pva, -2.f, 2.f);
+      pp[(f + 1) * 3 + d] = nxt;
+      prev = nxt;
+    }
+  }
+  float pw[3];
+  for (int d = 0; d < 3; ++d) pw[d] = clipf(action6[3 + d], -1.f, 1.f) * 1.f / (float)S;
+  const float ang = sqrtf(pw[0] * pw[0] + pw[1] * pw[1] + pw[2] * pw[2]) + 1e-12f;
+  const float sn = sinf(ang / 2.f);
+  const float q[4] = {cosf(ang / 2.f), pw[0] / ang * sn, pw[1] / ang * sn, pw[2] / ang * sn};
+  float r[4] = {pr[0], pr[1], pr[2], pr[3]};
+  for (int f = 0; f + 1 < S; ++f) {
+    const float o0 = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    const float o1 = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+    const float o2 = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+    const float o3 = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+    const float nn = clipf(sqrtf(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3), 1e-12f, INFINITY);
+    r[0] = o0 / nn; r[1] = o1 / nn; r[2] = o2 / nn; r[3] = o3 / nn;
+    float* w = pr + (f + 1) * 4;
+    w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; w[3] = r[3];
+  }
+}
+
+// primitive 0 as the grid op of substep f sees it (load_prim_f, mpm_large.hip)
+__host__ __device__ inline void det_prim(int S, int f, const float* pp, const float* pr, const float* psize3, const float* action6,
+                                         float friction, PrimF& pf) {
+  const int fc = min(max(f, 0), S - 1);
+  for (int d = 0; d < 3; ++d) {
+    pf.pv[d] = clipf(action6[d], -1.f, 1.f) * 1.f / (float)S;
+    pf.pos[d] = pp[fc * 3 + d]; pf.size[d] = psize3[d];
+  }
+  const float* r = pr + fc * 4;
+  const float r0 = r[0], r1 = -r[1], r2 = -r[2], r3 = -r[3];
+  const float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;
+  pf.iq[0] = r0 / n; pf.iq[1] = r1 / n; pf.iq[2] = r2 / n; pf.iq[3] = r3 / n;
+  pf.friction = friction;
+}
+
+__host__ __device__ inline long det_lin(const MpmConst& c, int key) {
+  int ci, cj, ck;
+  decode_cell(c, key, ci, cj, ck);
+  return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
+}
+
+// particle p of one env: state at substep f (SoA record `h`: x, v, C, F rows of Np floats) -> pre[UD_DET_PRE][Np], F of substep
+// f + 1 into `hn`, and the epoch stamp on every cell its scatter or its gather will touch
+__host__ __device__ inline void det_pre_particle(const MpmConst& c, const float* h, float* hn, int p, float mu, float la, int material,
+                                                 float hard, float* pre, int* flag, int epoch) {
+  const int Np = c.Np;
+  float x[3], v[3], Cm[9], F[9];
+  for (int d = 0; d < 3; ++d) { x[d] = h[d * Np + p]; v[d] = h[(3 + d) * Np + p]; }
+  for (int d = 0; d < 9; ++d) { Cm[d] = h[(6 + d) * Np + p]; F[d] = h[(15 + d) * Np + p]; }
+  Pre q;
+  particle_pre<false>(c, x, Cm, F, mu, la, material, hard, q, nullptr);
+  for (int d = 0; d < 9; ++d) hn[(15 + d) * Np + p] = q.Fn[d];
+  for (int d = 0; d < 3; ++d) { pre[d * Np + p] = __builtin_bit_cast(float, q.base[d]); pre[(3 + d) * Np + p] = q.fx[d]; pre[(24 + d) * Np + p] = v[d]; }
+  for (int d = 0; d < 9; ++d) { pre[(6 + d) * Np + p] = q.w[d]; pre[(15 + d) * Np + p] = q.affine[d]; }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+        if (sc >= 0) flag[det_lin(c, sc)] = epoch;
+        flag[det_lin(c, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k))] = epoch;   // a clamped gather may read a cell nobody scatters to
+      }
+}
+
+// one touched cell: (m, mv) summed over the particles in index order, each particle's offsets in (i, j, k) order; then the grid op
+__host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int ck, const float* pre, const PrimF& pf, float* vo) {
+  const int Np = c.Np, key = ci | (cj << 10) | (ck << 20);
+  float m = 0.f, mv[3] = {0.f, 0.f, 0.f};
+  for (int p = 0; p < c.N; ++p) {
+    const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
+    // away from the wrap-around of negative indices the stencil is base .. base + 2 per axis: most particles leave here
+    if (b0 >= 0 && b1 >= 0 && b2 >= 0 && (ci < b0 || ci > b0 + 2 || cj < b1 || cj > b1 + 2 || ck < b2 || ck > b2 + 2)) continue;
+    float fx[3], w[9], aff[9], v[3];
+    for (int d = 0; d < 3; ++d) { fx[d] = pre[(3 + d) * Np + p]; v[d] = pre[(24 + d) * Np + p]; }
+    for (int d = 0; d < 9; ++d) { w[d] = pre[(6 + d) * Np + p]; aff[d] = pre[(15 + d) * Np + p]; }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        for (int k = 0; k < 3; ++k) {
+          if (cell_scatter(c, b0 + i, b1 + j, b2 + k) != key) continue;
+          const float weight = w[i * 3 + 0] * w[j * 3 + 1] * w[k * 3 + 2];
+          const float dpos[3] = {((float)i - fx[0]) * c.dx, ((float)j - fx[1]) * c.dx, ((float)k - fx[2]) * c.dx};
+          m += weight * c.p_mass;
+          for (int r = 0; r < 3; ++r)
+            mv[r] += weight * (c.p_mass * v[r] + (aff[r * 3] * dpos[0] + aff[r * 3 + 1] * dpos[1] + aff[r * 3 + 2] * dpos[2]));
+        }
+  }
+  grid_op<false>(c, pf, ci, cj, ck, m, mv, vo, nullptr);
+}
+
+// particle p: gather of the 27 cell velocities in (i, j, k) order, advection; x, v, C of substep f + 1 into `hn`.
+// vel: [G][4] floats per env (v in .x .y .z).  Returns the particle's Q6 row sum (used for rows 0..2 only).
+__host__ __device__ inline float det_g2p_particle(const MpmConst& c, const float* h, float* hn, int p, const float* pre, const float* vel) {
+  const int Np = c.Np;
+  const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
+  float fx[3], w[9];
+  for (int d = 0; d < 3; ++d) fx[d] = pre[(3 + d) * Np + p];
+  for (int d = 0; d < 9; ++d) w[d] = pre[(6 + d) * Np + p];
+  float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const float* g = vel + det_lin(c, cell_gather(c, b0 + i, b1 + j, b2 + k)) * 4;
+        const float weight = w[i * 3 + 0] * w[j * 3 + 1] * w[k * 3 + 2];
+        const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * g[r];
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+        }
+      }
+  for (int d = 0; d < 3; ++d) { hn[d * Np + p] = h[d * Np + p] + c.dt * nv[d]; hn[(3 + d) * Np + p] = nv[d]; }
+  for (int d = 0; d < 9; ++d) hn[(6 + d) * Np + p] = nC[d];
+  return (p == 0) ? nC[0] + nC[1] + nC[2] : ((p == 1) ? nC[3] + nC[4] + nC[5] : nC[6] + nC[7] + nC[8]);
+}
+
+}  // namespace ud

@@ -20,6 +20,7 @@ struct MpmConst {
   int n_prim, sdf_kind;            // primitives per env (collide_batch: 1..UD_MAX_PRIM); 0 box SDF, 1 container SDF
   int gck;                         // many-workgroup path: grid-checkpoint records per particle and substep (0 = recompute in the backward)
   int sort;                        // many-workgroup path: re-order the particles by cell inside the handle at every step
+  int det;                         // ud_mpm_conf.deterministic: the forward sums every cell in particle order (mpm_det.hip)
 };
 
 // ---- 3x3 helpers (row-major float[9]) ------------------------------------------------------------
@@ -42,15 +43,28 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
     for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
 }
 
+// The Jacobi rotation's sqrt / reciprocal / rsqrt: the 1-ulp hardware instructions by default; UD_MPM_EXACT (mpm_det.hip, compiled with
+// -ffp-contract=off and correctly rounded divide / sqrt, and the host build of the same source) takes the IEEE operations instead, so
+// that the deterministic mode computes the same bits on the GPU and on the CPU.
+#if defined(UD_MPM_EXACT) || defined(UD_HOST_BUILD)
+#define UD_FSQRT(x) sqrtf(x)
+#define UD_FRCP(x) (1.f / (x))
+#define UD_FRSQ(x) (1.f / sqrtf(x))
+#else
+#define UD_FSQRT(x) __builtin_amdgcn_sqrtf(x)
+#define UD_FRCP(x) __builtin_amdgcn_rcpf(x)
+#define UD_FRSQ(x) __builtin_amdgcn_rsqf(x)
+#endif
+
 #define UD_JROT(p, q)                                                                                       \
   {                                                                                                         \
     float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
     float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
     float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
-    const bool rot = fabsf(ga) > 1.5e-8f * __builtin_amdgcn_sqrtf(al * be);                                  \
-    float zeta = (be - al) * __builtin_amdgcn_rcpf(2.f * (rot ? ga : 1.f));                                  \
-    float t = copysignf(1.f, zeta) * __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta)); \
-    float cs = __builtin_amdgcn_rsqf(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */ \
+    const bool rot = fabsf(ga) > 1.5e-8f * UD_FSQRT(al * be);                                                \
+    float zeta = (be - al) * UD_FRCP(2.f * (rot ? ga : 1.f));                                                \
+    float t = copysignf(1.f, zeta) * UD_FRCP(fabsf(zeta) + UD_FSQRT(1.f + zeta * zeta));                     \
+    float cs = UD_FRSQ(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */            \
     cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
       float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \

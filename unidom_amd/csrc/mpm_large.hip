@@ -16,6 +16,7 @@
 
 #include "mpm_device.h"
 #include "mpm_large.h"
+#include "mpm_det_host.h"
 #include "mpm_collide.h"
 
 namespace ud {
@@ -1872,6 +1873,8 @@ struct MpmLarge {
   // persistent cluster kernels (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated on first use
   ClusterGrid cl{};
   void* cl_arena = nullptr;
+  void* det_arena = nullptr; // deterministic forward (mpm_det.hip): flag [B][G] int, pre [B][27][Np], trq3 [B][S][3]
+  int det_B = 0, det_epoch = 0;
   bool has_liquid = false;   // some particle has material 0
   int n_cu = 0, occ_fwd[2] = {0, 0}, occ_bwd[2] = {0, 0};   // CUs; resident parts per CU of the two kernels (occupancy query), [0] 64-lane, [1] 128-lane parts
 };
@@ -1931,6 +1934,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
 }
 
 void mpm_large_destroy(MpmLarge* L) {
+  if (L && L->det_arena) (void)hipFree(L->det_arena);
   if (!L) return;
   if (L->arena) (void)hipFree(L->arena);
   if (L->cl_arena) (void)hipFree(L->cl_arena);
@@ -2140,6 +2144,36 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   }
   int npow2 = 64;
   while (npow2 < N) npow2 <<= 1;
+  if (c.det) {
+    // deterministic forward (mpm_det.hip): the data movement around it is this file's, the arithmetic is compiled there
+    const size_t flag_b = ((size_t)B * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)B * 27 * c.Np * 4 + 255) / 256 * 256, trq_b = (size_t)B * S * 3 * 4;
+    if (B > L->det_B) {
+      if (L->det_arena) { (void)hipStreamSynchronize(st); (void)hipFree(L->det_arena); L->det_arena = nullptr; L->det_B = 0; }
+      if (hipMalloc(&L->det_arena, flag_b + pre_b + trq_b) != hipSuccess) { set_error("ud_mpm_step_fwd (deterministic): hipMalloc failed"); return UD_ERR_HIP; }
+      (void)hipMemsetAsync(L->det_arena, 0, flag_b + pre_b + trq_b, st);
+      L->det_B = B; L->det_epoch = 0;
+    }
+    a.b0 = 0; a.f = 0;
+    hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
+    hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, B), blk, 0, st, c, 0, x, v, C, F, hist, stride_b, 1, (const int*)nullptr, 0L);
+    DetArgs d;
+    d.c = c; d.B = B; d.G = L->G; d.material = L->d_material; d.hard = L->d_hard;
+    d.ppos = L->w.ppos; d.prot = L->w.prot; d.psize = psize; d.friction = friction; d.mu = mu; d.lamda = lamda; d.action = action;
+    d.hist = hist; d.rec = rec; d.stride_b = stride_b; d.pingpong = ckpt ? 0 : 1;
+    d.vel = (float*)L->w.vel;
+    d.flag = (int*)L->det_arena; d.pre = (float*)((char*)L->det_arena + flag_b); d.trq3 = (float*)((char*)L->det_arena + flag_b + pre_b);
+    d.trq = L->w.trq;
+    rc = mpm_det_forward(d, &L->det_epoch, st);
+    if (rc) { set_error("ud_mpm_step_fwd (deterministic): launch failed"); return rc; }
+    a.f = S;
+    const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
+    float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
+    hipLaunchKernelGGL(lg_unpack, dim3((N + 255) / 256, B), blk, 0, st, c, 0, last, stride_b, xo, vo, Co, Fo, (const int*)nullptr, 0L);
+    hipLaunchKernelGGL(lg_fwd_out, dim3(B, c.n_prim + (N + 255) / 256), blk, 0, st, a, J, Jo, ppos_o, prot_o, pv_o, pw_o, tail, stride_b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("ud_mpm_step_fwd (deterministic): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+    return UD_OK;
+  }
   const int clT = clm_lanes();
   if (const int per = clm_envs_per_launch(L, B, clT)) {
     // persistent cluster kernel: one launch runs all S substeps of `per` envs (mpm_cluster.h)

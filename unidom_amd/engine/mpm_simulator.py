@@ -138,6 +138,7 @@ class SimpleMPMSimulator:
         self.n_primitive, self.sdf_kind = 1, "box"             # fixed at reset_jax (state.primitives, primitives.set_sdf)
         self.grid_ckpt_cells = int(getattr(conf, "grid_ckpt_cells", 0))   # include/unidom_hip.h: 0 = recompute the grid in the backward
         self.sort_particles = int(getattr(conf, "sort_particles", 0))     # include/unidom_hip.h: internal spatial order (liquids)
+        self.deterministic = int(getattr(conf, "deterministic", 0))       # include/unidom_hip.h: particle-order cell sums, IEEE arithmetic (test mode)
         self.profile = None
         self.status_log = []
         self._status_acc = None          # flags folded out of status_log (device scalar), read by check_status()
@@ -223,7 +224,8 @@ class SimpleMPMSimulator:
                               gravity=(C.c_float * 3)(*g), use_position_control=int(bool(self.use_position_control)),
                               prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness),
                               n_primitive=int(self.n_primitive), sdf_kind={"box": 0, "container": 1}[self.sdf_kind],
-                              grid_ckpt_cells=int(self.grid_ckpt_cells), sort_particles=int(self.sort_particles))
+                              grid_ckpt_cells=int(self.grid_ckpt_cells), sort_particles=int(self.sort_particles),
+                              deterministic=int(self.deterministic))
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
         self._h = C.c_void_p()
