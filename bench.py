@@ -544,8 +544,10 @@ def bench_torus(args, rank, world, device):
                                    f"{sim.substeps} substeps/env.step), " + ("forward with checkpoints + loss + adjoint" if grad else "forward rollout")
                                    + f", {B} envs per GPU, step = {inner} env.steps",
                        "touched_cells": g_act, "parity": "unpinned (taichi absent)"},
-            "roofline": {"bound": "hbm", "kernel": "plb path (" + ("3 + 6" if grad else "3") + " kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "plb path (" + ("3 + 5" if grad else "3") + " kernels/substep)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"plb:{'grad' if grad else 'fwd'}:ngrid{sim.n_grid}") if B == 8 else None,
+                         "algorithmic_bytes_per_launch": units / world / args.steps * per_sub,
+                         "launch": "one bench step: all plb_* kernels of " + f"{inner} env.steps" + (" + loss + adjoint" if grad else ""),
                          "note": "launch/latency bound: 8 envs x 1000 particles per substep"},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:

@@ -6,7 +6,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${W:-pour_soup}; NAME=${NAME:-$W}
 export UD_LG_GROUPS=1   # one launch per kernel and substep for the whole batch (env groups split it; the bytes are the same)
 i=0
-for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+GROUPS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE")
+[ -n "$QUICK" ] && GROUPS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE")   # QUICK=1: what pmc_traffic.json needs
+rm -rf gpurun_out/pmc_[0-9]*
+for G in "${GROUPS[@]}"; do
   i=$((i+1)); rm -rf gpurun_out/pmc_$i; mkdir -p gpurun_out/pmc_$i
   timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace -d gpurun_out/pmc_$i -o p -f csv -- python3 bench.py --workload $W $ARGS --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i/log 2>&1 || echo "pass $i ($G) failed"
 done
@@ -27,4 +30,6 @@ with open("gpurun_out/pmc_large_summary.csv", "w") as o:
 print(open("gpurun_out/pmc_large_summary.csv").read())
 PY
 cp gpurun_out/pmc_large_summary.csv gpurun_out/pmc_large_summary_$NAME.csv
+cp profiles/pmc_traffic.json gpurun_out/pmc_traffic_$NAME.json
 python3 tools/pmc_large_traffic.py gpurun_out/pmc_large_summary_$NAME.csv $NAME gpurun_out/pmc_traffic_$NAME.json
+rm -rf gpurun_out/pmc_[0-9]*

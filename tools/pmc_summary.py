@@ -1,6 +1,7 @@
 """Summarise rocprofv3 --pmc passes into profiles/pmc_traffic.json (HBM bytes per launch of the ud:: kernels).
 
-usage: python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json]
+usage: python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json] [SQ_INSTS counter_collection.csv]
+The optional fourth file (a pass with SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU) adds `insts`: mean wave-instructions per launch (bench.py: roofline.issue).
 FETCH_SIZE / WRITE_SIZE are reported in KB; per MI355X_MICROARCH.md (HBM / rocprofv3 section) gfx950 tallies 128-B read
 requests at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 as is.  Each counter comes from its own pass.
 """
@@ -21,6 +22,7 @@ def load(path, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+insts = {c: load(sys.argv[4], c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU")} if len(sys.argv) > 4 else {}
 dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
 out = json.load(open(dst)) if os.path.exists(dst) else {}      # entries of kernels not in these passes are kept
 for k in sorted(set(fetch) | set(write)):
@@ -33,6 +35,11 @@ for k in sorted(set(fetch) | set(write)):
               "src_sha16": src_hash.sha16(k),   # bench.py reports traffic only while the kernel sources still hash to this
               "note": "2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, KB x 1024, separate --pmc passes; "
                       "max over launches (forward launches under no_grad write no checkpoints)"}
+for c, per in insts.items():
+    for k, vals in per.items():
+        k = k[5:] if k.startswith("void ") else k
+        if k in out and vals:
+            out[k].setdefault("insts", {})[c] = max(vals)      # max over launches: the launches that write checkpoints (as for the bytes)
 json.dump(out, open(dst, "w"), indent=1)
 for k, v in out.items():
     if k not in fetch and k not in write:
