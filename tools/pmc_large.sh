@@ -6,10 +6,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${W:-pour_soup}; NAME=${NAME:-$W}
 export UD_LG_GROUPS=1   # one launch per kernel and substep for the whole batch (env groups split it; the bytes are the same)
 i=0
-GROUPS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE")
-[ -n "$QUICK" ] && GROUPS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE")   # QUICK=1: what pmc_traffic.json needs
+PASSES=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE")
+[ -n "$QUICK" ] && PASSES=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE")   # QUICK=1: what pmc_traffic.json needs
 rm -rf gpurun_out/pmc_[0-9]*
-for G in "${GROUPS[@]}"; do
+for G in "${PASSES[@]}"; do
   i=$((i+1)); rm -rf gpurun_out/pmc_$i; mkdir -p gpurun_out/pmc_$i
   timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace -d gpurun_out/pmc_$i -o p -f csv -- python3 bench.py --workload $W $ARGS --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$i/log 2>&1 || echo "pass $i ($G) failed"
 done

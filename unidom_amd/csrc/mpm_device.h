@@ -46,6 +46,11 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
 // The Jacobi rotation's sqrt / reciprocal / rsqrt: the 1-ulp hardware instructions by default; UD_MPM_EXACT (mpm_det.hip, compiled with
 // -ffp-contract=off and correctly rounded divide / sqrt, and the host build of the same source) takes the IEEE operations instead, so
 // that the deterministic mode computes the same bits on the GPU and on the CPU.
+#ifdef UD_HOST_BUILD
+#define UD_WAVE_ANY(x) (x)
+#else
+#define UD_WAVE_ANY(x) __any(x)
+#endif
 #if defined(UD_MPM_EXACT) || defined(UD_HOST_BUILD)
 #define UD_FSQRT(x) sqrtf(x)
 #define UD_FRCP(x) (1.f / (x))
@@ -65,7 +70,7 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
     float zeta = (be - al) * UD_FRCP(2.f * (rot ? ga : 1.f));                                                \
     float t = copysignf(1.f, zeta) * UD_FRCP(fabsf(zeta) + UD_FSQRT(1.f + zeta * zeta));                     \
     float cs = UD_FRSQ(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */            \
-    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
+    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f; any_rot |= rot;                                                \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
       float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \
       a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                                    \
@@ -93,11 +98,17 @@ __device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* 
   float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = A[i];
+  // A sweep in which no pair rotates (all three off-diagonal products below the threshold) is the identity, and so is every sweep
+  // after it: leave then -- same bits as running them.  Per WAVE on the device (the wave leaves when none of its lanes rotated): a rope's
+  // F is near a rotation and its particles converge in two or three sweeps; the chain of dependent rotations is the longest serial
+  // stretch of the pre-pass, which at one or two waves per SIMD is what a launch waits for (lanes probe).
 #pragma unroll 1
   for (int sweep = 0; sweep < UD_SVD_SWEEPS; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
+    bool any_rot = false;
     UD_JROT(0, 1)
     UD_JROT(0, 2)
     UD_JROT(1, 2)
+    if (!UD_WAVE_ANY(any_rot)) break;
   }
   float sv[3];
 #pragma unroll
