@@ -891,6 +891,26 @@ def test_two_launch_backward_is_the_four_kernel_backward(S, forward, monkeypatch
             assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (key, name, _rel(r[key], ref[key]))
 
 
+@pytest.mark.parametrize("forward", ["cluster", "multi_kernel"])
+@pytest.mark.parametrize("material", [1, 2])
+def test_backward_reads_the_svd_factors_the_forward_checkpointed(forward, material, monkeypatch):
+    """Every history record of the many-workgroup path carries the SVD factors (U, S, Vh) of its substep's F beside the state; the
+    backward's pre-pass reads them instead of running the Jacobi iteration again (UD_LG_SVD_ROWS=0: iterate).  Same code on the same
+    inputs produced them, so the per-particle arithmetic is unchanged; only the float atomics' order separates the two runs.  Plastic
+    material too (the clamp uses the raw singular values), behind either forward."""
+    monkeypatch.setenv("UD_MPM_CLUSTER", "1" if forward == "cluster" else "0")
+    sim, st, g, N = _scaled_case(6, 5, B=2, grid_ckpt_cells=6)
+    if material == 2:
+        sim.material = np.full(N, 2, np.int32)
+        sim._make_handle()
+    monkeypatch.setenv("UD_LG_SVD_ROWS", "0")
+    ref = run_hip(sim, st, g=g, clip=True)
+    monkeypatch.setenv("UD_LG_SVD_ROWS", "1")
+    got = run_hip(sim, st, g=g, clip=True)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gmu", "glamda"):
+        assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
+
+
 def test_cluster_part_table_overflow_is_flagged(monkeypatch):
     """Parts of 32 particles (UD_MPM_CLUSTER_T=128, the default for solids) hold 512 cells: particles thrown uniformly through the
     volume touch more, the part sets status[] bit 1 and check_status raises -- loud, not a wrong step."""

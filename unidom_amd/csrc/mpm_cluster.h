@@ -373,7 +373,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
     Pre q;
     q.base[0] = q.base[1] = q.base[2] = 0;
     if (live) {
-      particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr);
+      particle_pre<false>(c, x, Cm, F, mu_s, la_s, material, hard, q, nullptr,
+                          (qi == 0 && keep && a.svd_rows) ? hw + (long)f * rec + (long)24 * c.Np + p : nullptr, nullptr, c.Np);
       if (qi == 0 && keep) {
         float* ho = hw + (long)(f + 1) * rec;
 #pragma unroll

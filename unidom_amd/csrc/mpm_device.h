@@ -283,9 +283,14 @@ struct PreB {                   // extras the adjoint needs
   float U[9], Vh[9], sig_raw[3], sig[3], Jd, mu, la, A[9];
 };
 
+// svd_out / svd_in (many-workgroup path, UD_SVD_ROWS floats per particle at stride `svd_stride`: U[9], S[3], Vh[9]): the forward hands the
+// factors of this substep's F to the checkpoint right after the Jacobi iteration (no register lives longer for it), the backward
+// takes them from there instead of iterating again -- the same bits, the longest serial stretch of its pre-pass gone.
+#define UD_SVD_ROWS 21
 template <bool KEEP>
 __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, const float* Cm, const float* F,
-                                             float mu_s, float la_s, int material, float hard, Pre& q, PreB* kb) {
+                                             float mu_s, float la_s, int material, float hard, Pre& q, PreB* kb,
+                                             float* svd_out = nullptr, const float* svd_in = nullptr, long svd_stride = 0) {
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     q.base[d] = (int)(x[d] * c.inv_dx - 0.5f);   // truncation (:233)
@@ -306,8 +311,19 @@ __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, 
   if (UD_MPM_ABLATE & 1) {
     for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.f : 0.f; Vh[i] = U[i]; }
     sr[0] = Fu[0]; sr[1] = Fu[4]; sr[2] = Fu[8];
+  } else if (svd_in) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { U[i] = svd_in[i * svd_stride]; Vh[i] = svd_in[(12 + i) * svd_stride]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sr[i] = svd_in[(9 + i) * svd_stride];
   } else {
     svd3(Fu, U, sr, Vh);
+    if (svd_out) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { svd_out[i * svd_stride] = U[i]; svd_out[(12 + i) * svd_stride] = Vh[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) svd_out[(9 + i) * svd_stride] = sr[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) sg[i] = sr[i];

@@ -66,6 +66,7 @@ struct LargeArgs {
   // spatial order (ud_mpm_conf.sort_particles): slot p of the SoA history holds the caller's particle perm[p]; nullptr = as given
   const int* perm;        // [B][perm_stride]
   long perm_stride;
+  int svd_rows;           // the history records carry the SVD factors of each substep's F (rows 24 .. 44; ck_layout): the backward reads them
   const float* hist_in;   // state at substep f      [B][*][24][Np] with stride
   float* hist_out;        // state at substep f + 1
   long hist_stride_b;     // floats between envs
@@ -368,7 +369,9 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
     const int up = user_index(a, b, p);
     LG_STAMP(0, 0);   // table clear + state loads
-    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr);
+    // (store_F = the caller's checkpoint is being written: the SVD factors go into this substep's record, one lane of the quad)
+    float* svd_o = (store_F && a.svd_rows && qi == 0) ? const_cast<float*>(a.hist_in) + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr;
+    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr, svd_o, nullptr, c.Np);
     if (store_F && qi == 0) {
       float* ho = a.hist_out + (long)b * a.hist_stride_b;
 #pragma unroll
@@ -1330,7 +1333,8 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   const int up = user_index(a, b, p);
   const int material = a.material[up];
   LG_STAMP(2, 0);     // state loads
-  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb);
+  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
+                     a.svd_rows ? a.hist_in + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr, c.Np);
   LG_STAMP(2, 1);     // pre-pass with the adjoint's extras
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3], gv[3], gC[9], gF[9];
@@ -1568,7 +1572,8 @@ __global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_
     PreB kb;
     const int up = user_index(a, b, p);
     const int material = a.material[up];
-    particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb);
+    particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
+                       a.svd_rows ? a.hist_in + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr, c.Np);
     const float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
     float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1867,7 +1872,7 @@ struct MpmLarge {
   // Small launches (a few hundred workgroups of latency-bound work) leave most of the chip idle and every kernel waits
   // for the previous one: the envs are split into groups that run the same kernel sequence on separate streams, forked
   // from and joined back into the caller's stream with events (no host synchronisation).
-  static constexpr int MAX_GROUPS = 4;
+  static constexpr int MAX_GROUPS = 4;   // (6 and 8 groups measured: shape_rope backward 5.0 -> 9.4 ms, profiles/r03c_fused_bwd_groups.txt)
   hipStream_t side[MAX_GROUPS - 1] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS - 1] = {};
   // persistent cluster kernels (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated on first use
@@ -1952,7 +1957,7 @@ struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int b
 static CkLayout ck_layout(const MpmConst& c) {
   CkLayout k;
   const long S = c.steps;
-  k.rec = (long)24 * c.Np;
+  k.rec = (long)(24 + (c.det ? 0 : UD_SVD_ROWS)) * c.Np;      // state rows + (not in deterministic mode) the SVD factors of the substep's F
   k.off_tail = (S + 1) * k.rec;
   k.off_idx = k.off_tail + (long)c.n_prim * S * 10;
   k.off_idx = (k.off_idx + 3) / 4 * 4;                         // float4 alignment of the pool behind it
@@ -1982,7 +1987,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_ppos = take(BP * S * 3 * 4), o_prot = take(BP * S * 4 * 4), o_ppin = take(BP * S * 3 * 4);
   const size_t o_trq = take((size_t)B * S * 4), o_gppos = take(BP * S * 3 * 4), o_gpv = take(BP * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 3 * 4);
-  const size_t o_hist = take((size_t)B * 2 * 24 * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
+  const size_t o_hist = take((size_t)B * 2 * ck_layout(c).rec * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
   const size_t o_grot = take(BP * S * 4 * 4), o_gpw = take(BP * S * 3 * 4), o_gpsz = take(BP * 4 * 4);
   const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&L->arena, off);
@@ -2131,6 +2136,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   const long rec = ck.rec;
   const long stride_b = ckpt ? ck.stride : 2 * rec;
   a.hist_stride_b = stride_b;
+  a.svd_rows = (ckpt && !c.det) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
   // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
@@ -2256,6 +2262,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const long rec = ck.rec;
   const long stride_b = ck.stride;
   a.hist_stride_b = stride_b;
+  { const char* e = getenv("UD_LG_SVD_ROWS"); a.svd_rows = (c.det || (e && e[0] == '0')) ? 0 : 1; }   // diagnostic: 0 = iterate again instead of reading the checkpointed factors
   // restore the grid from the checkpoint instead of recomputing p2g + grid op -- unless the caller saw the forward flag a
   // pool overflow and asks for the recomputing backward (clip bit 1)
   const bool gck = ck.budget > 0 && !(clip & 2);
