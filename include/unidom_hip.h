@@ -246,6 +246,11 @@ typedef struct {
   int n_primitives;      /* 1 or 2 Spheres; only primitive 0 is actuated (3 action dims) */
   double radius[2];
   double lower_bound[3], upper_bound[3];   /* primitive xyz_limit */
+  int grid_ckpt_cells;   /* 0: ud_plb_step_bwd runs p2g again for every substep (substep_grad recomputes the whole substep,
+                            mpm_simulator.py:271-289).  K > 0: a forward with a checkpoint also keeps the touched grid cells
+                            (index, m, mv: 36 B each; up to min(27, K) * n_particles per substep, inside the caller's checkpoint:
+                            ud_plb_ckpt_bytes grows accordingly) and the backward restores them; a substep that touched more
+                            cells than that falls back to recomputing, per env, on the device.  K >= 27 can never fall back */
 } ud_plb_conf;
 
 int ud_plb_create(const ud_plb_conf* conf, ud_plb** out);

@@ -237,11 +237,13 @@ def test_loss_twin_known_answers():
     assert abs(float(total) - d0 ** 2) < 1e-15
 
 
-def _hip_sim(N, B, quality=0.5):
+def _hip_sim(N, B, quality=0.5, grid_ckpt_cells=None):
     from unidom_amd.engine.plb_simulator import PlbConf as HipConf, PlbSimulator
     cfg = HipConf()
     cfg.quality = quality
     cfg.n_particles = N
+    if grid_ckpt_cells is not None:
+        cfg.grid_ckpt_cells = grid_ckpt_cells
     return PlbSimulator(cfg, batch_size=B)
 
 
@@ -286,6 +288,39 @@ def test_hip_step_adjoint_matches_torch_twin(low):
     if low:
         assert np.abs(ref).max() > 0          # the friction branch really ran
     assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()[1]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [0, 1, 2])
+def test_hip_adjoint_with_and_without_the_grid_checkpoint(K):
+    """ud_plb_conf.grid_ckpt_cells: by default (27 cells per particle: every cell a substep can touch) the adjoint restores each
+    substep's (m, mv) cells from the checkpoint and never launches p2g again -- that is the configuration the twin comparison above
+    ran.  Here the other modes against it: K = 0 (no grid checkpoint: p2g recomputed every substep), K = 1 and 2 (a pool that the
+    substeps of this body overflow, some or all: those fall back to recomputing on the device, env by env).  The restored cells are
+    the forward's own sums, the recomputed ones a second run of the same atomics: 1e-8 relative."""
+    import torch
+    B, N = 3, 300
+    case = _small_case(B, N, 1, low=True)
+    x, v, Cm, F, prim, soft, act, E, nu, ys = case
+    rng = np.random.default_rng(9)
+    w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
+
+    def run(k):
+        sim = _hip_sim(N, B, grid_ckpt_cells=k)
+        assert sim.grid_ckpt_cells == k
+        T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+        hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
+        s = sim.reset()._replace(x=hl["x"], v=hl["v"], C=hl["C"], F=hl["F"], prim_pos=hl["prim"], softness=T(soft, False), E=hl["E"],
+                                 nu=hl["nu"], yield_stress=hl["ys"])
+        s1 = sim.step(sim.step(s, hl["act"]), hl["act"])                 # two env.steps chained
+        sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w)).backward()
+        return {k2: t.grad.cpu().numpy() for k2, t in hl.items()}, sim.ground_friction_grad.cpu().numpy()
+
+    ref, ref_f = run(27)
+    got, got_f = run(K)
+    for name in ref:
+        assert np.isfinite(got[name]).all() and _rel(got[name], ref[name]) < 1e-8, (name, _rel(got[name], ref[name]))
+    assert _rel(got_f, ref_f) < 1e-8
 
 
 @pytest.mark.gpu

@@ -44,7 +44,8 @@ class ud_mpm_conf(C.Structure):
 class ud_plb_conf(C.Structure):
     _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("substeps", C.c_int), ("dt", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double), ("n_primitives", C.c_int),
-                ("radius", C.c_double * 2), ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3)]
+                ("radius", C.c_double * 2), ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3),
+                ("grid_ckpt_cells", C.c_int)]
 
 
 def build(force: bool = False) -> str:

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   __shared__ double s_val[PLB_H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
+  if (a.ck_skip && a.w.gck_cnt[b * c.S + a.f] <= c.gck) return;   // adjoint: this env's substep is in the grid checkpoint (block-uniform)
   for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
   __syncthreads();
   double* val = plb_buf(a, a.lb, b);
@@ -86,6 +87,13 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
     for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
     dm_mul(IC, F, Ft);
     dsvd3(Ft, U, sig, Vh);
+    if (a.w.svd && qi == 0) {      // checkpointing forward: the factors of this substep's F, for the adjoint's pre-pass
+      double* o = a.w.svd + (((long)b * c.S + a.f) * 21) * c.Np + p;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { o[i * c.Np] = U[i]; o[(12 + i) * c.Np] = Vh[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) o[(9 + i) * c.Np] = sig[i];
+    }
     double eps[3], sum = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
@@ -209,9 +217,17 @@ __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
     double* old = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
     old[0] = 0.0; old[1] = 0.0; old[2] = 0.0; old[3] = 0.0;
   }
-  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
+  const int n = min(a.w.count[cur * a.B + b], a.cap);
+  if (a.w.gck_cnt && t == 0) a.w.gck_cnt[b * c.S + a.f] = n;
+  if (t >= n) return;
   const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
   double* cell = plb_buf(a, cur, b) + lin * 4;
+  if (a.w.gck_cnt && t < c.gck) {      // grid checkpoint: (index, m, mv) before the grid op overwrites mv
+    const long r = ((long)b * c.S + a.f) * c.gck + t;
+    a.w.gck_lin[r] = (int)lin;
+    double* o = a.w.gck_val + r * 4;
+    o[0] = cell[0]; o[1] = cell[1]; o[2] = cell[2]; o[3] = cell[3];
+  }
   double vv[3];
   plb_grid_cell(c, lin, cell[0], cell + 1, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, vv);
   cell[1] = vv[0]; cell[2] = vv[1]; cell[3] = vv[2];
@@ -393,14 +409,29 @@ int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
   return UD_OK;
 }
 
-// caller-owned checkpoint of one step call: hist[B][S+1][24][Np] | pos[B][S+1][np][3] | perm[B][Np] (int)
-void plb_ckpt_layout(const ud::PlbConst& c, int B, size_t* o_hist, size_t* o_pos, size_t* o_perm, size_t* total) {
+// caller-owned checkpoint of one step call: hist[B][S+1][24][Np] | pos[B][S+1][np][3] | perm[B][Np] (int) | grid checkpoint
+PlbCkOff plb_ckpt_layout(const ud::PlbConst& c, int B) {
+  PlbCkOff k;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  *o_hist = take((size_t)B * (c.S + 1) * 24 * c.Np * 8);
-  *o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8);
-  *o_perm = take((size_t)B * c.Np * 4);
-  *total = off;
+  k.hist = take((size_t)B * (c.S + 1) * 24 * c.Np * 8);
+  k.pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8);
+  k.perm = take((size_t)B * c.Np * 4);
+  k.gck_cnt = take(c.gck ? (size_t)B * c.S * 4 : 0);
+  k.gck_lin = take((size_t)B * c.S * c.gck * 4);
+  k.gck_val = take((size_t)B * c.S * c.gck * 32);
+  k.svd = take((size_t)B * c.S * 21 * c.Np * 8);
+  k.total = off;
+  return k;
+}
+void plb_bind_ckpt(ud::PlbArgs& a, const ud::PlbConst& c, int B, void* ckpt) {
+  const PlbCkOff k = plb_ckpt_layout(c, B);
+  char* base = (char*)ckpt;
+  a.w.hist = (double*)(base + k.hist); a.w.pos = (double*)(base + k.pos); a.w.perm = (int*)(base + k.perm);
+  a.w.gck_cnt = c.gck ? (int*)(base + k.gck_cnt) : nullptr;
+  a.w.gck_lin = c.gck ? (int*)(base + k.gck_lin) : nullptr;
+  a.w.gck_val = c.gck ? (double*)(base + k.gck_val) : nullptr;
+  a.w.svd = (double*)(base + k.svd);
 }
 
 extern "C" {
@@ -420,6 +451,7 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
   c.radius[0] = conf->radius[0]; c.radius[1] = conf->radius[1];
   h->G = (long)c.n_grid * c.n_grid * c.n_grid;
   h->cap = (int)std::min<long>(h->G, (long)27 * c.N);
+  c.gck = conf->grid_ckpt_cells > 0 ? (int)std::min<long>(h->cap, (long)conf->grid_ckpt_cells * c.N) : 0;
   (void)hipFuncSetAttribute((const void*)ud::plb_sort, hipFuncAttributeMaxDynamicSharedMemorySize, ud::PLB_SORT_MAX * 8);
   *out = h;
   return UD_OK;
@@ -433,9 +465,7 @@ void ud_plb_destroy(ud_plb* h) {
 
 size_t ud_plb_ckpt_bytes(const ud_plb* h, int B) {
   if (!h || B < 1) return 0;
-  size_t a, b, c, total;
-  plb_ckpt_layout(h->c, B, &a, &b, &c, &total);
-  return total;
+  return plb_ckpt_layout(h->c, B).total;
 }
 
 int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
@@ -453,10 +483,9 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0;
-  if (ckpt) {   // keep every substep's particle state, the primitive trajectory and the spatial order for ud_plb_step_bwd
-    size_t o_hist, o_pos, o_perm, total;
-    plb_ckpt_layout(h->c, B, &o_hist, &o_pos, &o_perm, &total);
-    a.w.hist = (double*)((char*)ckpt + o_hist); a.w.pos = (double*)((char*)ckpt + o_pos); a.w.perm = (int*)((char*)ckpt + o_perm);
+  a.ck_skip = 0; a.w.gck_cnt = nullptr; a.w.gck_lin = nullptr; a.w.gck_val = nullptr; a.w.svd = nullptr;
+  if (ckpt) {   // keep every substep's particle state, the primitive trajectory, the spatial order (and the touched grid cells) for ud_plb_step_bwd
+    plb_bind_ckpt(a, h->c, B, ckpt);
     a.slots = h->c.S + 1;
   }
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;

@@ -53,9 +53,26 @@ __global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { old[k] = 0.0; g[k] = 0.0; }
   }
-  if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
-  const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
-  const double* cell = plb_buf(a, cur, b) + lin * 4;
+  // this substep's cells: from the grid checkpoint when the forward kept them all (the recompute launch of plb_p2g then left at
+  // once for this env), else the list plb_p2g has just rebuilt
+  const int n_ck = a.w.gck_cnt ? a.w.gck_cnt[b * c.S + a.f] : 0x7fffffff;
+  const bool ck = n_ck <= c.gck;
+  const int n = ck ? n_ck : min(a.w.count[cur * a.B + b], a.cap);
+  if (ck && t == 0) a.w.count[cur * a.B + b] = n;      // the later launches of this substep read it; nobody in this one does
+  if (t >= n) return;
+  long lin;
+  double* cell = nullptr;
+  if (ck) {
+    const long r = ((long)b * c.S + a.f) * c.gck + t;
+    lin = a.w.gck_lin[r];
+    a.w.list[((long)cur * a.B + b) * a.cap + t] = (int)lin;
+    const double* rec = a.w.gck_val + r * 4;
+    cell = plb_buf(a, cur, b) + lin * 4;
+    cell[0] = rec[0]; cell[1] = rec[1]; cell[2] = rec[2]; cell[3] = rec[3];
+  } else {
+    lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
+    cell = plb_buf(a, cur, b) + lin * 4;
+  }
   double vv[3];
   plb_grid_cell(c, lin, cell[0], cell + 1, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, vv);
   double* out = plb_vout(a, b) + lin * 4;   // never cleared: read only at cells this launch has just written
@@ -313,7 +330,15 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
     dm_mul(IC, F, Ft);
-    dsvd3(Ft, U, sig, Vh);
+    if (a.w.svd) {                  // the forward's factors of this substep's F (same code, same inputs: the same bits)
+      const double* o = a.w.svd + (((long)b * c.S + a.f) * 21) * c.Np + p;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { U[i] = o[i * c.Np]; Vh[i] = o[(12 + i) * c.Np]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sig[i] = o[(9 + i) * c.Np];
+    } else {
+      dsvd3(Ft, U, sig, Vh);
+    }
     double eps[3], sum = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
@@ -728,10 +753,10 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
-  size_t o_hist, o_pos, o_perm, total;
-  plb_ckpt_layout(h->c, B, &o_hist, &o_pos, &o_perm, &total);
-  a.w.hist = (double*)((char*)ckpt + o_hist); a.w.pos = (double*)((char*)ckpt + o_pos); a.w.perm = (int*)((char*)ckpt + o_perm);
+  plb_bind_ckpt(a, h->c, B, const_cast<void*>(ckpt));
   a.slots = h->c.S + 1; a.lb = 0;
+  a.ck_skip = h->c.gck > 0 ? 1 : 0;
+  const bool never_recompute = h->c.gck >= h->cap;          // every substep of every env is in the grid checkpoint: no recompute launch at all
   const int S = h->c.S;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B), gpa((h->c.N + 127) / 128, B);
   const dim3 gq((4 * h->c.N + 255) / 256, B), gqa((4 * h->c.N + 127) / 128, B);
@@ -745,7 +770,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   // count -- the separate clear and count-reset launches of every substep are gone; one clear after the loop for substep 0.
   for (int f = S - 1; f >= 0; --f) {
     a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1; a.lb = f & 1;
-    ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);              // recompute (m, mv) (rewrites F[f + 1] with the same values)
+    if (!never_recompute) ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);   // recompute (m, mv) (rewrites F[f + 1] with the same values); envs with a checkpointed substep leave at once
     hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_g2p_adj<1>, gp, blk, 0, st, a, (f + 1) & 1);

@@ -7,6 +7,7 @@ namespace ud {
 
 struct PlbConst {
   int N, Np, n_grid, S, np;
+  int gck;        // grid checkpoint: cells kept per env and substep (0 = off; == cap: a substep can never overflow it)
   double dt, dx, inv_dx, p_mass, p_vol, g30dt[3], fric, radius[2], lo[3], hi[3];
 };
 
@@ -18,6 +19,11 @@ struct PlbBuf {
   double* pos;    // [B][S+1][np][3] primitive positions of this step (handle arena, or the caller's checkpoint)
   double* hist;   // [B][slots][24][Np] particle state per substep: slots = 2 (ping-pong) or S + 1 (checkpoint: all of them)
   int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
+  // grid checkpoint (caller's checkpoint; ud_plb_conf.grid_ckpt_cells): the touched cells of every substep before the grid op
+  int* gck_cnt;   // [B][S]        cells substep f touched (may exceed c.gck: then nothing usable was kept for it)
+  int* gck_lin;   // [B][S][gck]   their linear indices, in the order of the forward's active list
+  double* gck_val;// [B][S][gck][4] (m, mv)
+  double* svd;    // [B][S][21][Np] U, S, Vh of every substep's F (caller's checkpoint): the adjoint's pre-pass reads them instead of iterating again
   // adjoint only (plb_adj.hip)
   double* gacc;   // [B][G][4] cotangent of the cell's v_out (xyz), then of (mv xyz, m)
   double* vout;   // [B][G][4] the cell's v_out of the substep being reversed (xyz; never cleared: read only where just written)
@@ -34,6 +40,7 @@ struct PlbArgs {
   int Bcall;                  // envs of this call (<= B): the bound of every per-env guard that touches caller-owned arrays
   int slots, hs_in, hs_out;   // hist slots per env; slot of this substep's input state / output state
   int lb;                     // active list and grid buffer of this substep (forward: f & 1, the other one is being retired)
+  int ck_skip;                // adjoint's recompute launch of plb_p2g: envs whose substep f is in the grid checkpoint leave at once
   long G;
   const double *softness, *E, *nu, *ys;
 };
@@ -63,7 +70,7 @@ __device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, doub
     double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
     double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
     double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
-    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
+    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0; any_rot |= rot;                                 \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
       double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
       a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
@@ -87,9 +94,11 @@ __device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, dou
   for (int i = 0; i < 9; ++i) a[i] = A[i];
 #pragma unroll 1
   for (int sweep = 0; sweep < 6; ++sweep) {
+    bool any_rot = false;
     UD_DJROT(0, 1)
     UD_DJROT(0, 2)
     UD_DJROT(1, 2)
+    if (!__any(any_rot)) break;   // a sweep that rotates nothing is the identity, and so is every later one: same bits (cf. svd3, mpm_device.h)
   }
   double sv[3];
 #pragma unroll
@@ -208,4 +217,6 @@ struct ud_plb {
 // (re)size the handle's arena: forward buffers always, adjoint / loss buffers on first use (hipStreamSynchronize + hipFree +
 // hipMalloc when it has to grow: see the header's note on host synchronisation)
 int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss);
-void plb_ckpt_layout(const ud::PlbConst& c, int B, size_t* o_hist, size_t* o_pos, size_t* o_perm, size_t* total);
+struct PlbCkOff { size_t hist, pos, perm, gck_cnt, gck_lin, gck_val, svd, total; };
+PlbCkOff plb_ckpt_layout(const ud::PlbConst& c, int B);
+void plb_bind_ckpt(ud::PlbArgs& a, const ud::PlbConst& c, int B, void* ckpt);

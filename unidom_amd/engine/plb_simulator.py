@@ -140,11 +140,15 @@ class PlbSimulator:
         self.p_vol = (self.dx * 0.5) ** 2
         self.p_mass = self.p_vol * 1
         self.n_primitive = len(cfg.prim_radius)
+        # include/unidom_hip.h: the checkpoint also keeps the touched grid cells and the adjoint restores them instead of running p2g
+        # again (27 = every cell a substep can touch: never falls back; 36 B x 27 n_particles per env and substep of checkpoint)
+        self.grid_ckpt_cells = int(getattr(cfg, "grid_ckpt_cells", 27))
         cc = _lib.ud_plb_conf(
             n_particles=self.n_particles, n_grid=self.n_grid, substeps=self.substeps, dt=self.dt,
             gravity=(C.c_double * 3)(*cfg.gravity), ground_friction=float(cfg.ground_friction), n_primitives=self.n_primitive,
             radius=(C.c_double * 2)(*(list(cfg.prim_radius) + [0.0])[:2]),
-            lower_bound=(C.c_double * 3)(*cfg.lower_bound), upper_bound=(C.c_double * 3)(*cfg.upper_bound))
+            lower_bound=(C.c_double * 3)(*cfg.lower_bound), upper_bound=(C.c_double * 3)(*cfg.upper_bound),
+            grid_ckpt_cells=int(self.grid_ckpt_cells))
         self._h = C.c_void_p()
         self.ground_friction_grad = None   # [B], accumulated by backward() (optimize_ground_friction.grad); reset it by hand
         _lib.check(_lib.lib().ud_plb_create(C.byref(cc), C.byref(self._h)), "ud_plb_create")
