@@ -66,11 +66,13 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
     float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
     float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
     float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
-    const bool rot = fabsf(ga) > 1.5e-8f * UD_FSQRT(al * be);                                                \
+    const float nrm_ = UD_FSQRT(al * be);                                                                    \
+    const bool rot = !done && fabsf(ga) > 1.5e-8f * nrm_;                                                    \
+    any_rot |= fabsf(ga) > 1e-4f * nrm_;                                                                     \
     float zeta = (be - al) * UD_FRCP(2.f * (rot ? ga : 1.f));                                                \
     float t = copysignf(1.f, zeta) * UD_FRCP(fabsf(zeta) + UD_FSQRT(1.f + zeta * zeta));                     \
     float cs = UD_FRSQ(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */            \
-    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f; any_rot |= rot;                                                \
+    cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
       float ap = a[i * 3 + p], aq = a[i * 3 + q];                                                            \
       a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                                    \
@@ -98,17 +100,20 @@ __device__ __forceinline__ void svd3(const float* A, float* U, float* S, float* 
   float a[9], vv[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
 #pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = A[i];
-  // A sweep in which no pair rotates (all three off-diagonal products below the threshold) is the identity, and so is every sweep
-  // after it: leave then -- same bits as running them.  Per WAVE on the device (the wave leaves when none of its lanes rotated): a rope's
-  // F is near a rotation and its particles converge in two or three sweeps; the chain of dependent rotations is the longest serial
-  // stretch of the pre-pass, which at one or two waves per SIMD is what a launch waits for (lanes probe).
+  // Cyclic Jacobi converges quadratically: a sweep whose three normalised off-diagonal products were all below 1e-4 leaves them below
+  // 1e-8 -- under the rotation threshold, so every later sweep would be the identity.  Leave after such a sweep, per WAVE on the device
+  // (when none of its lanes had a larger product): a rope's F is near a rotation and its particles are done in two sweeps; the chain of
+  // dependent rotations is the longest serial stretch of the pre-pass, which at one or two waves per SIMD is what a launch waits for
+  // (lanes probe).
+  bool done = false;
 #pragma unroll 1
   for (int sweep = 0; sweep < UD_SVD_SWEEPS; ++sweep) {   // 4 sweeps reach f32 round-off for |F - I| up to O(1) (measured)
     bool any_rot = false;
     UD_JROT(0, 1)
     UD_JROT(0, 2)
     UD_JROT(1, 2)
-    if (!UD_WAVE_ANY(any_rot)) break;
+    done = done || !any_rot;              // this matrix rotates no more, whatever its wave goes on to do: the result depends on the matrix alone
+    if (!UD_WAVE_ANY(!done)) break;
   }
   float sv[3];
 #pragma unroll

@@ -1953,11 +1953,17 @@ void mpm_large_destroy(MpmLarge* L) {
 
 // checkpoint layout per env (floats): particle history [(S+1)][24][Np] | primitive tail [P][S*10] | grid checkpoint:
 // record index [S+1] (ints, padded to 4) and the record pool [budget][8] | spatial order [Np] (ints)
+static int lg_lanes(int B, int N);
+// The SVD factors ride in the history records where a launch waits for one wave's serial chain (the four-lane regime); where the chip
+// is full (one lane per particle: B N >= 100 000) they cost 84 B of traffic per particle-substep each way and save nothing
+// (rope at n_grid 256: 250 k -> 225-246 k substeps/s with them) -- so the record layout depends on the envs of the call, which
+// ud_mpm_ckpt_bytes, the forward and the backward all know.
+static bool lg_svd_rows(const MpmConst& c, int B) { return !c.det && lg_lanes(B, c.N) == 4; }
 struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int budget; };
-static CkLayout ck_layout(const MpmConst& c) {
+static CkLayout ck_layout(const MpmConst& c, int B) {
   CkLayout k;
   const long S = c.steps;
-  k.rec = (long)(24 + (c.det ? 0 : UD_SVD_ROWS)) * c.Np;      // state rows + (not in deterministic mode) the SVD factors of the substep's F
+  k.rec = (long)(24 + (lg_svd_rows(c, B) ? UD_SVD_ROWS : 0)) * c.Np;      // state rows + (four-lane regime) the SVD factors of the substep's F
   k.off_tail = (S + 1) * k.rec;
   k.off_idx = k.off_tail + (long)c.n_prim * S * 10;
   k.off_idx = (k.off_idx + 3) / 4 * 4;                         // float4 alignment of the pool behind it
@@ -1971,7 +1977,7 @@ static CkLayout ck_layout(const MpmConst& c) {
 }
 
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B) {
-  return (size_t)B * (size_t)ck_layout(L->c).stride * sizeof(float);
+  return (size_t)B * (size_t)ck_layout(L->c, B).stride * sizeof(float);
 }
 
 static int reserve(MpmLarge* L, int B, hipStream_t stream) {
@@ -1987,7 +1993,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_ppos = take(BP * S * 3 * 4), o_prot = take(BP * S * 4 * 4), o_ppin = take(BP * S * 3 * 4);
   const size_t o_trq = take((size_t)B * S * 4), o_gppos = take(BP * S * 3 * 4), o_gpv = take(BP * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 3 * 4);
-  const size_t o_hist = take((size_t)B * 2 * ck_layout(c).rec * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
+  const size_t o_hist = take((size_t)B * 2 * (24 + UD_SVD_ROWS) * c.Np * 4), o_gstate = take((size_t)B * 24 * c.Np * 4);
   const size_t o_grot = take(BP * S * 4 * 4), o_gpw = take(BP * S * 3 * 4), o_gpsz = take(BP * 4 * 4);
   const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&L->arena, off);
@@ -2114,7 +2120,7 @@ int mpm_large_plan(MpmLarge* L, int B) {
   const MpmConst& c = L->c;
   int plan = 1;
   if (clm_envs_per_launch(L, B, clm_lanes())) plan |= 2;
-  if (ck_layout(c).budget > 0 && lg_two_launch_bwd(c, lg_lanes(B, c.N))) plan |= 4;
+  if (ck_layout(c, B).budget > 0 && lg_two_launch_bwd(c, lg_lanes(B, c.N))) plan |= 4;
   return plan;
 }
 
@@ -2132,11 +2138,11 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
   float* hist = ckpt ? ckpt : L->w.hist;
-  const CkLayout ck = ck_layout(c);
+  const CkLayout ck = ck_layout(c, B);
   const long rec = ck.rec;
   const long stride_b = ckpt ? ck.stride : 2 * rec;
   a.hist_stride_b = stride_b;
-  a.svd_rows = (ckpt && !c.det) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
+  a.svd_rows = (ckpt && lg_svd_rows(c, B)) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
   // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
@@ -2258,11 +2264,11 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const dim3 blk(256), blks(LG_SCATTER_T);
   const int lanes = lg_lanes(B, N);                      // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
-  const CkLayout ck = ck_layout(c);
+  const CkLayout ck = ck_layout(c, B);
   const long rec = ck.rec;
   const long stride_b = ck.stride;
   a.hist_stride_b = stride_b;
-  { const char* e = getenv("UD_LG_SVD_ROWS"); a.svd_rows = (c.det || (e && e[0] == '0')) ? 0 : 1; }   // diagnostic: 0 = iterate again instead of reading the checkpointed factors
+  { const char* e = getenv("UD_LG_SVD_ROWS"); a.svd_rows = (!lg_svd_rows(c, B) || (e && e[0] == '0')) ? 0 : 1; }   // diagnostic: 0 = iterate again instead of reading the checkpointed factors
   // restore the grid from the checkpoint instead of recomputing p2g + grid op -- unless the caller saw the forward flag a
   // pool overflow and asks for the recomputing backward (clip bit 1)
   const bool gck = ck.budget > 0 && !(clip & 2);

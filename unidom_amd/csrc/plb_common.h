@@ -66,11 +66,13 @@ __device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, doub
     double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                      \
     double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                      \
     double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                      \
-    const bool rot = fabs(ga) > 1e-17 * sqrt(al * be);                                        \
+    const double nrm_ = sqrt(al * be);                                                        \
+    const bool rot = !done && fabs(ga) > 1e-17 * nrm_;                                        \
+    big_rot |= fabs(ga) > 3e-9 * nrm_;                                                        \
     double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
     double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
     double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
-    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0; any_rot |= rot;                                 \
+    cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
       double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
       a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
@@ -92,13 +94,18 @@ __device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, dou
   double a[9], vv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 #pragma unroll
   for (int i = 0; i < 9; ++i) a[i] = A[i];
+  bool done = false;
 #pragma unroll 1
   for (int sweep = 0; sweep < 6; ++sweep) {
-    bool any_rot = false;
+    // Cyclic Jacobi converges quadratically: a sweep whose three normalised off-diagonal products were all below 3e-9 leaves them
+    // below 1e-17 -- under the rotation threshold, so every later sweep would be the identity.  Leave after such a sweep (per wave):
+    // four sweeps instead of six on a typical Torus state, and the Jacobi iteration is most of plb_p2g's serial chain.
+    bool big_rot = false;
     UD_DJROT(0, 1)
     UD_DJROT(0, 2)
     UD_DJROT(1, 2)
-    if (!__any(any_rot)) break;   // a sweep that rotates nothing is the identity, and so is every later one: same bits (cf. svd3, mpm_device.h)
+    done = done || !big_rot;      // per matrix, so that the result does not depend on what else is in the wave
+    if (!__any(!done)) break;
   }
   double sv[3];
 #pragma unroll
