@@ -172,7 +172,7 @@ typedef struct {
                                 IEEE arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same
                                 inputs return the same bits, and x, v, C, F equal the CPU build of the same source bit for bit
                                 (tests/test_mpm_det.py).  A test mode: one thread per touched cell walks all particles -- 13x the
-                                default forward at 67 particles, 335x at 798 (profiles/r03b_det_cost.txt).  Position control with one box primitive only
+                                default forward at 67 particles, 307x at 798 (profiles/r03c_det_cost.txt).  Position control with one box primitive only
                                 (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the backward is
                                 the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
 } ud_mpm_conf;
@@ -180,6 +180,10 @@ typedef struct {
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */
 int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* hardness, ud_mpm** out);
 void ud_mpm_destroy(ud_mpm* h);
+/* bytes of the checkpoint one ud_mpm_step_fwd call with B envs writes for its backward: the particle state of every substep; on
+ * the many-workgroup path also the primitive rows, the spatial order, the grid-checkpoint pool and -- while B * n_particles is
+ * below 100 000 (the regime where a launch waits for one wave's serial chain) -- the SVD factors of every substep's F, which
+ * the backward reads instead of iterating again.  The layout is the library's; the same B must be passed to the backward */
 size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B);
 /* Which kernels a call with B envs runs (the choice is the library's, by measurement: DESIGN.md 3.2); for logs and benchmark
  * labels, nothing at this boundary depends on it.  0: one workgroup per env (bodies up to 128 particles, one box primitive).
