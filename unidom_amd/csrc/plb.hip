@@ -25,27 +25,31 @@ __global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* ac
   if (b >= a.Bcall) return;   // the caller's arrays (and a checkpoint laid out for this call) hold Bcall envs, the arena may hold more
   const PlbConst& c = a.c;
   double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
-  for (int i = 0; i < c.np * 3; ++i) P[i] = prim_pos[(long)b * c.np * 3 + i];
-  for (int s = 0; s < c.S; ++s)
-    for (int pi = 0; pi < c.np; ++pi)
-      for (int d = 0; d < 3; ++d) {
-        const double pv = (pi == 0) ? fmin(fmax(action[b * 3 + d], -1.0), 1.0) * 1.0 / (double)c.S : 0.0;
-        P[((s + 1) * c.np + pi) * 3 + d] = fmax(fmin(P[(s * c.np + pi) * 3 + d] + pv, c.hi[d]), c.lo[d]);
+  for (int pi = 0; pi < c.np; ++pi)
+    for (int d = 0; d < 3; ++d) {         // the recurrence runs in a register (reading each row back from memory made this launch 20 us of store-to-load round trips)
+      const double pv = (pi == 0) ? fmin(fmax(action[b * 3 + d], -1.0), 1.0) * 1.0 / (double)c.S : 0.0;
+      double cur = prim_pos[(long)b * c.np * 3 + pi * 3 + d];
+      P[pi * 3 + d] = cur;
+      for (int s = 0; s < c.S; ++s) {
+        cur = fmax(fmin(cur + pv, c.hi[d]), c.lo[d]);
+        P[((s + 1) * c.np + pi) * 3 + d] = cur;
       }
+    }
   a.w.count[0 * a.B + b] = 0;
   a.w.count[1 * a.B + b] = 0;
+  a.w.count[2 * a.B + b] = 0;
 }
 
 
 // end of a step only: zero the cells of the last substep (list / buffer `prev`), back to the all-zero grid invariant
 __global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int prev = a.lb ^ 1, cur = a.lb;
-  if (t < min(a.w.count[prev * a.B + b], a.cap)) {
-    double* cell = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
+  const int prev = a.lb ^ 1;
+  if (t < min(a.w.count[a.lprev * a.B + b], a.cap)) {
+    double* cell = plb_buf(a, prev, b) + (long)a.w.list[((long)a.lprev * a.B + b) * a.cap + t] * 4;
     cell[0] = 0.0; cell[1] = 0.0; cell[2] = 0.0; cell[3] = 0.0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[cur * a.B + b] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[a.ls * a.B + b] = 0;
 }
 
 
@@ -53,24 +57,20 @@ __global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
 // LANES lanes per particle (as in mpm_large.hip): 4 while the launch is too small to fill the chip -- the quad splits the 27
 // stencil cells 7/7/7/6 (every lane repeats the particle pre-pass on otherwise idle SIMDs) -- 1 once it is full.
 
+// What a p2g pass targets: the (m, mv) buffer and list slot it fills, the substep it belongs to (SVD rows), the history slot that receives
+// F of the NEXT state, the stamp epoch of its first-seen test.  plb_p2g fills it from the launch arguments; the fused forward kernel
+// (plb_g2p_p2g) runs the pass of substep f + 1 behind the g2p of substep f.
+struct P2gTarget { int buf, ls, f, hs_out, epoch; };
+
+// compute_F_tmp + svd + von Mises + p2g (:91-99, :133-195) of one particle's lane, then the block's flush.  Every thread of the block
+// calls it (the flush has barriers); `livep`: this lane has a particle, whose state is in x, v, Cm, F.  s_key / s_val: cleared, barrier passed.
 template <int LANES>
-__global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
-  __shared__ int s_key[PLB_H];
-  __shared__ double s_val[PLB_H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
-  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+__device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& tg, int b, int p, int qi, bool livep, const double* x, const double* v,
+                                             const double* Cm, const double* F, int* s_key, double* s_val) {
   const PlbConst& c = a.c;
-  if (a.ck_skip && a.w.gck_cnt[b * c.S + a.f] <= c.gck) return;   // adjoint: this env's substep is in the grid checkpoint (block-uniform)
-  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
-  __syncthreads();
-  double* val = plb_buf(a, a.lb, b);
-  if (p < c.N) {
-    const double* hi_ = plb_hist(a, b, a.hs_in);
-    double* ho = plb_hist(a, b, a.hs_out);
-    double x[3], v[3], Cm[9], F[9];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; v[d] = hi_[(3 + d) * c.Np + p]; }
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { Cm[d] = hi_[(6 + d) * c.Np + p]; F[d] = hi_[(15 + d) * c.Np + p]; }
+  double* val = plb_buf(a, tg.buf, b);
+  if (livep) {
+    double* ho = plb_hist(a, b, tg.hs_out);
     const double E = a.E[b], nu = a.nu[b];
     const double mu = E / (2 * (1 + nu)), lam = E * nu / ((1 + nu) * (1 - 2 * nu));
     int base[3];
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
     dm_mul(IC, F, Ft);
     dsvd3(Ft, U, sig, Vh);
     if (a.w.svd && qi == 0) {      // checkpointing forward: the factors of this substep's F, for the adjoint's pre-pass
-      double* o = a.w.svd + (((long)b * c.S + a.f) * 21) * c.Np + p;
+      double* o = a.w.svd + (((long)b * c.S + tg.f) * 21) * c.Np + p;
 #pragma unroll
       for (int i = 0; i < 9; ++i) { o[i * c.Np] = U[i]; o[(12 + i) * c.Np] = Vh[i]; }
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) atomicAdd(val + lin * 4 + r, contrib[r]);
-        plb_touch(a, b, lin);
+        plb_touch(a, b, lin, tg.ls, tg.epoch);
       }
     }
   }
@@ -187,16 +187,16 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {   // the returning exchanges of a lane go out together
       key[u] = s_key[threadIdx.x + u * 256];
-      old[u] = a.epoch;
-      if (key[u] >= 0) old[u] = atomicExch(&a.w.stamp[(long)b * a.G + key[u]], a.epoch);
+      old[u] = tg.epoch;
+      if (key[u] >= 0) old[u] = atomicExch(&a.w.stamp[(long)b * a.G + key[u]], tg.epoch);
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u)
-      if (old[u] != a.epoch) { newmask |= 1u << u; ++nnew; }
+      if (old[u] != tg.epoch) { newmask |= 1u << u; ++nnew; }
   }
   const int mine = nnew ? atomicAdd(&s_new, nnew) : 0;
   __syncthreads();
-  const int cur = a.lb;
+  const int cur = tg.ls;
   if (threadIdx.x == 0) s_base = s_new ? atomicAdd(&a.w.count[cur * a.B + b], s_new) : 0;
   __syncthreads();
   int e = s_base + mine;
@@ -208,19 +208,41 @@ __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
   }
 }
 
+template <int LANES>
+__global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
+  __shared__ int s_key[PLB_H];
+  __shared__ double s_val[PLB_H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const PlbConst& c = a.c;
+  if (a.ck_skip && a.w.gck_cnt[b * c.S + a.f] <= c.gck) return;   // adjoint: this env's substep is in the grid checkpoint (block-uniform)
+  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
+  __syncthreads();
+  double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, Cm[9], F[9];
+  if (p < c.N) {
+    const double* hi_ = plb_hist(a, b, a.hs_in);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { x[d] = hi_[d * c.Np + p]; v[d] = hi_[(3 + d) * c.Np + p]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { Cm[d] = hi_[(6 + d) * c.Np + p]; F[d] = hi_[(15 + d) * c.Np + p]; }
+  }
+  const P2gTarget tg{a.lb, a.ls, a.f, a.hs_out, a.epoch};
+  plb_p2g_body<LANES>(a, tg, b, p, qi, p < c.N, x, v, Cm, F, s_key, s_val);
+}
+
 // grid_op (:200-232) over the touched cells
 __global__ void __launch_bounds__(256) plb_grid(PlbArgs a) {
   const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
   const int cur = a.lb, prev = cur ^ 1;
-  if (t < min(a.w.count[prev * a.B + b], a.cap)) {          // the previous substep's cells, in the other buffer: done with
-    double* old = plb_buf(a, prev, b) + (long)a.w.list[((long)prev * a.B + b) * a.cap + t] * 4;
+  if (t < min(a.w.count[a.lprev * a.B + b], a.cap)) {          // the previous substep's cells, in the other buffer: done with
+    double* old = plb_buf(a, prev, b) + (long)a.w.list[((long)a.lprev * a.B + b) * a.cap + t] * 4;
     old[0] = 0.0; old[1] = 0.0; old[2] = 0.0; old[3] = 0.0;
   }
-  const int n = min(a.w.count[cur * a.B + b], a.cap);
+  if (t == 0 && a.lnext != a.lprev) a.w.count[a.lnext * a.B + b] = 0;   // fused forward: the third list, which the next launch's p2g pass fills
+  const int n = min(a.w.count[a.ls * a.B + b], a.cap);
   if (a.w.gck_cnt && t == 0) a.w.gck_cnt[b * c.S + a.f] = n;
   if (t >= n) return;
-  const long lin = a.w.list[((long)cur * a.B + b) * a.cap + t];
+  const long lin = a.w.list[((long)a.ls * a.B + b) * a.cap + t];
   double* cell = plb_buf(a, cur, b) + lin * 4;
   if (a.w.gck_cnt && t < c.gck) {      // grid checkpoint: (index, m, mv) before the grid op overwrites mv
     const long r = ((long)b * c.S + a.f) * c.gck + t;
@@ -238,7 +260,7 @@ template <int LANES>
 __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  if (gid == 0) a.w.count[(a.lb ^ 1) * a.B + b] = 0;   // the other list: plb_grid has just retired it, p2g of the next substep refills it
+  if (gid == 0) a.w.count[a.lprev * a.B + b] = 0;   // the other list: plb_grid has just retired it, p2g of the next substep refills it
   if (p >= c.N) return;   // whole quads leave together
   const double* hi_ = plb_hist(a, b, a.hs_in);
   double* ho = plb_hist(a, b, a.hs_out);
@@ -295,6 +317,82 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   }
 #pragma unroll
   for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+}
+
+// g2p of substep f, then -- the particle's new state in registers -- the p2g pass of substep f + 1 (forward only).  One launch instead
+// of two per substep boundary and no state round trip.  What makes it legal: the (m, mv) buffers alternate already (the pass of f + 1
+// fills the buffer plb_grid(f) has just retired), and the active lists take a third slot -- while this launch fills the list of f + 1,
+// the list of f is still wanted (plb_grid(f + 1) retires it) and the one of f - 1 has just been retired: three in flight; plb_grid(f)
+// resets the count of the slot this launch fills.
+template <int LANES>
+__global__ void __launch_bounds__(256) plb_g2p_p2g(PlbArgs a) {
+  __shared__ int s_key[PLB_H];
+  __shared__ double s_val[PLB_H * 4];
+  const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const PlbConst& c = a.c;
+  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
+  const bool livep = p < c.N;
+  double x[3] = {0, 0, 0}, nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[9];
+  if (livep) {   // whole quads together
+    const double* hi_ = plb_hist(a, b, a.hs_in);
+    double* ho = plb_hist(a, b, a.hs_out);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = hi_[d * c.Np + p];
+#pragma unroll
+    for (int d = 0; d < 9; ++d) F[d] = ho[(15 + d) * c.Np + p];   // F of state f + 1: the p2g pass of substep f wrote it
+    int base[3];
+    double fx[3], w[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      base[d] = (int)(x[d] * c.inv_dx - 0.5);
+      const double f = x[d] * c.inv_dx - (double)base[d];
+      fx[d] = f;
+      w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
+    }
+    const double* val = plb_buf(a, a.lb, b);
+    constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;
+#pragma unroll 1
+    for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
+      double g7[BATCH][3];
+#pragma unroll
+      for (int t = 0; t < BATCH; ++t) {
+        const int cidx = min(qi + LANES * (t0 + t), 26);
+        const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+        const int ci = min(max(base[0] + i, 0), c.n_grid - 1), cj = min(max(base[1] + j, 0), c.n_grid - 1), ck = min(max(base[2] + k, 0), c.n_grid - 1);
+        const double* cell = val + plb_lin(c, ci, cj, ck) * 4;
+        g7[t][0] = cell[1]; g7[t][1] = cell[2]; g7[t][2] = cell[3];
+      }
+#pragma unroll
+      for (int t = 0; t < BATCH; ++t) {
+        const int cidx = qi + LANES * (t0 + t);
+        if (cidx >= 27) break;
+        const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+        const double weight = dsel3(w, 0, i) * dsel3(w, 1, j) * dsel3(w, 2, k);
+        const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * g7[t][r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4 * c.inv_dx * weight * g7[t][r] * dp[s2];
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nv[d] = plb_quad_sum<LANES>(nv[d]);     // every lane of the quad gets the sums: they all run the pre-pass below
+#pragma unroll
+    for (int d = 0; d < 9; ++d) nC[d] = plb_quad_sum<LANES>(nC[d]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = fmax(fmin(x[d] + c.dt * nv[d], 1.0 - 3 * c.dx), 0.0);
+    if (qi == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ho[(3 + d) * c.Np + p] = nv[d]; ho[d * c.Np + p] = x[d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+    }
+  }
+  __syncthreads();   // the table clear
+  const P2gTarget tg{a.lb ^ 1, a.lnext, a.f + 1, a.hs_out2, a.epoch2};
+  plb_p2g_body<LANES>(a, tg, b, p, qi, livep, x, nv, nC, F, s_key, s_val);
 }
 
 // Spatial order (as lg_sort in mpm_large.hip): the Torus body is sampled with np.random (shape_maker.py:21,57), consecutive
@@ -388,8 +486,8 @@ int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
   const ud::PlbConst& c = h->c;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)2 * B * h->cap * 4);
-  const size_t o_count = take((size_t)2 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
+  const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)3 * B * h->cap * 4);
+  const size_t o_count = take((size_t)3 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
   const size_t o_perm = take((size_t)B * c.Np * 4);
   const size_t o_gacc = adj ? take((size_t)B * h->G * 32) : 0, o_vout = adj ? take((size_t)B * h->G * 32) : 0, o_gstate = adj ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
   const size_t o_gxs = adj ? take((size_t)B * 3 * c.Np * 8) : 0, o_gpos = adj ? take((size_t)B * (c.S + 1) * c.np * 3 * 8 + 64) : 0, o_gpar = adj ? take((size_t)B * 4 * 8) : 0;
@@ -482,7 +580,7 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   if (rc) return rc;
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
-  a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0;
+  a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1; a.hs_out2 = 0; a.epoch2 = 0;
   a.ck_skip = 0; a.w.gck_cnt = nullptr; a.w.gck_lin = nullptr; a.w.gck_val = nullptr; a.w.svd = nullptr;
   if (ckpt) {   // keep every substep's particle state, the primitive trajectory, the spatial order (and the touched grid cells) for ud_plb_step_bwd
     plb_bind_ckpt(a, h->c, B, ckpt);
@@ -503,15 +601,36 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
     hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, a, x, npow2);
   }
   hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted);
-  for (int f = 0; f < h->c.S; ++f) {
-    a.f = f; a.epoch = h->epoch++;
-    a.hs_in = f % a.slots; a.hs_out = (f + 1) % a.slots; a.lb = f & 1;
-    if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
+  // Per substep: plb_grid(f), then ONE particle launch: g2p(f) -> p2g(f + 1) (plb_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it.
+  // UD_PLB_FUSED=0 (diagnostic, read per call): p2g, grid, g2p as three launches.
+  const char* fz = getenv("UD_PLB_FUSED");
+  const bool fused = !(fz && fz[0] == '0');
+  const int S = h->c.S;
+  const int ep0 = h->epoch; h->epoch += S + 1;
+  auto set = [&](int f) {
+    a.f = f; a.epoch = ep0 + f; a.epoch2 = ep0 + f + 1;
+    a.hs_in = f % a.slots; a.hs_out = (f + 1) % a.slots; a.hs_out2 = (f + 2) % a.slots; a.lb = f & 1;
+    if (fused) { a.ls = f % 3; a.lprev = (f + 2) % 3; a.lnext = (f + 1) % 3; }
+    else { a.ls = a.lb; a.lprev = a.lb ^ 1; a.lnext = a.lprev; }
+  };
+  set(0);
+  if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
+  for (int f = 0; f < S; ++f) {
+    set(f);
     hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
-    if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
+    if (fused && f + 1 < S) {
+      if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p_p2g<1>, gp, blk, 0, st, a);
+    } else {
+      if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
+      if (f + 1 < S) {
+        set(f + 1);
+        if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
+      }
+    }
   }
-  a.f = h->c.S; a.epoch = h->epoch++; a.lb = h->c.S & 1;
-  hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);   // back to the all-zero grid invariant
+  // back to the all-zero grid invariant: the cells of the last substep (its list is `lprev` of a substep S that never runs)
+  set(S);
+  hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
   hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S % a.slots, x_out, v_out, C_out, F_out, prim_pos_out, sorted);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ud::set_error("ud_plb_step_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }

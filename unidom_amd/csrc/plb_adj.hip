@@ -754,7 +754,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   plb_bind_ckpt(a, h->c, B, const_cast<void*>(ckpt));
-  a.slots = h->c.S + 1; a.lb = 0;
+  a.slots = h->c.S + 1; a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1; a.hs_out2 = 0; a.epoch2 = 0;
   a.ck_skip = h->c.gck > 0 ? 1 : 0;
   const bool never_recompute = h->c.gck >= h->cap;          // every substep of every env is in the grid checkpoint: no recompute launch at all
   const int S = h->c.S;
@@ -769,7 +769,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   // the cells of substep f + 1 (their buffer and cotangent cells back to zero) beside its own work, plb_g2p_adj resets that list's
   // count -- the separate clear and count-reset launches of every substep are gone; one clear after the loop for substep 0.
   for (int f = S - 1; f >= 0; --f) {
-    a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1; a.lb = f & 1;
+    a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1; a.lb = f & 1; a.ls = a.lb; a.lprev = a.lb ^ 1; a.lnext = a.lprev;
     if (!never_recompute) ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);   // recompute (m, mv) (rewrites F[f + 1] with the same values); envs with a checkpointed substep leave at once
     hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
@@ -778,7 +778,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
     if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g_adj<4>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_p2g_adj<1>, gpa, dim3(128), 0, st, a, (f + 1) & 1);
   }
-  a.lb = 0;
+  a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1;
   hipLaunchKernelGGL(ud::plb_adj_clear, gc, blk, 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_unpack, gp, blk, 0, st, a, 0, g_x0, g_v0, g_C0, g_F0);

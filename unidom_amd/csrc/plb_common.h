@@ -14,8 +14,8 @@ struct PlbConst {
 struct PlbBuf {
   double* val;    // [2][B][G][4] (m, mv) -> after the grid op (m, v)
   int* stamp;     // [B][G]
-  int* list;      // [2][B][cap]
-  int* count;     // [2][B]
+  int* list;      // [3][B][cap]
+  int* count;     // [3][B]
   double* pos;    // [B][S+1][np][3] primitive positions of this step (handle arena, or the caller's checkpoint)
   double* hist;   // [B][slots][24][Np] particle state per substep: slots = 2 (ping-pong) or S + 1 (checkpoint: all of them)
   int* perm;      // [B][Np] spatial order of this call: slot p of hist holds the caller's particle perm[p]
@@ -40,6 +40,9 @@ struct PlbArgs {
   int Bcall;                  // envs of this call (<= B): the bound of every per-env guard that touches caller-owned arrays
   int slots, hs_in, hs_out;   // hist slots per env; slot of this substep's input state / output state
   int lb;                     // active list and grid buffer of this substep (forward: f & 1, the other one is being retired)
+  int ls, lprev;              // active-list slots: this substep's cells, the list being retired.  Two slots alternating with lb everywhere
+                              // except the fused forward (plb_g2p_p2g), which fills substep f + 1's list (lnext) while f's is still read: three slots
+  int lnext, hs_out2, epoch2; // fused forward only: list slot / history slot for F / stamp epoch of the p2g pass of substep f + 1
   int ck_skip;                // adjoint's recompute launch of plb_p2g: envs whose substep f is in the grid checkpoint leave at once
   long G;
   const double *softness, *E, *nu, *ys;
@@ -126,10 +129,9 @@ __device__ __forceinline__ double dsel3(const double* w, int d, int i) { return 
 
 __device__ __forceinline__ long plb_lin(const PlbConst& c, int i, int j, int k) { return ((long)i * c.n_grid + j) * c.n_grid + k; }
 
-__device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin) {
-  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], a.epoch);
-  if (old != a.epoch) {
-    const int cur = a.lb;
+__device__ __forceinline__ void plb_touch(const PlbArgs& a, int b, long lin, int cur, int epoch) {   // cur: list slot, epoch: stamp of the pass
+  const int old = atomicExch(&a.w.stamp[(long)b * a.G + lin], epoch);
+  if (old != epoch) {
     const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
     if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = (int)lin;
   }
