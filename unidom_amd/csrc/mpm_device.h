@@ -292,7 +292,13 @@ struct PreB {                   // extras the adjoint needs
 // factors of this substep's F to the checkpoint right after the Jacobi iteration (no register lives longer for it), the backward
 // takes them from there instead of iterating again -- the same bits, the longest serial stretch of its pre-pass gone.
 #define UD_SVD_ROWS 21
-template <bool KEEP>
+// LIQ (many-workgroup path): a liquid particle (material 0: mu = 0, Q10) takes no SVD at all -- the stress is la J (J - 1) I, J = the
+// product of the singular values = |det Fu|, and its cotangent reaches Fu through the cofactor matrix (particle_adjoint) -- exact, and
+// a liquid's F is never reset: sheared without bound, it is the matrix that needs every Jacobi sweep (39 % of pour_water's lg_p2g).
+__device__ __forceinline__ float det3(const float* A) {
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+template <bool KEEP, bool LIQ = false>
 __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, const float* Cm, const float* F,
                                              float mu_s, float la_s, int material, float hard, Pre& q, PreB* kb,
                                              float* svd_out = nullptr, const float* svd_in = nullptr, long svd_stride = 0) {
@@ -313,6 +319,15 @@ __device__ __forceinline__ void particle_pre(const MpmConst& c, const float* x, 
   float mu = mu_s * h, la = la_s * h;
   if (material == 0) { mu = 0.f; la = 1.f; }                     // Q10
   float U[9], Vh[9], sr[3], sg[3];
+  if (LIQ && material == 0) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { q.Fn[i] = Fu[i]; q.affine[i] = c.p_mass * Cm[i]; }
+    const float Jd = fabsf(det3(Fu));
+    const float sdiag = c.stress_c * (la * Jd * (Jd - 1.f)) / c.dx2;
+    q.affine[0] += sdiag; q.affine[4] += sdiag; q.affine[8] += sdiag;
+    if (KEEP) { kb->Jd = Jd; kb->mu = 0.f; kb->la = la; }     // the rest of PreB is not read for a liquid (particle_adjoint<LIQ>)
+    return;
+  }
   if (UD_MPM_ABLATE & 1) {
     for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.f : 0.f; Vh[i] = U[i]; }
     sr[0] = Fu[0]; sr[1] = Fu[4]; sr[2] = Fu[8];
@@ -430,6 +445,7 @@ __device__ __forceinline__ void grid_head_adjoint(float m, const float* mvv, flo
 // Adjoint of the particle pre-pass (:233-268) given the gathered stencil cotangents:
 //   gw[k*3+d] (weights), gfx (fractional position), gaff (affine), gvp (momentum v) ; gx/gv/gC/gF in: cotangents of
 //   the substep outputs (gF = cotangent of F_out = Fn), out: cotangents of the substep inputs.
+template <bool LIQ = false>
 __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q, const PreB& kb, const float* Cm, const float* F,
                                                  int material, const float* gw, float* gfx, const float* gaff, const float* gvp,
                                                  float* gx, float* gv, float* gC, float* gF, float& gmu_p, float& gla_p) {
@@ -442,6 +458,25 @@ __device__ __forceinline__ void particle_adjoint(const MpmConst& c, const Pre& q
   float gS[9], gCn[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) { gCn[d] = gaff[d] * c.p_mass; gS[d] = gaff[d] / c.dx2 * c.stress_c; }
+  if (LIQ && material == 0) {
+    // stress = la J (J - 1) I with J = |det Fu|: dJ / dFu = sign(det) cof(Fu); Fn = Fu passes the next state's cotangent through
+    const float* A = q.Fn;
+    const float trg = gS[0] + gS[4] + gS[8];
+    const float gJ = kb.la * (2.f * kb.Jd - 1.f) * trg * ((det3(A) < 0.f) ? -1.f : 1.f);
+    gmu_p = 0.f; gla_p = kb.Jd * (kb.Jd - 1.f) * trg;
+    float gFu[9];
+    gFu[0] = gF[0] + gJ * (A[4] * A[8] - A[5] * A[7]); gFu[1] = gF[1] - gJ * (A[3] * A[8] - A[5] * A[6]); gFu[2] = gF[2] + gJ * (A[3] * A[7] - A[4] * A[6]);
+    gFu[3] = gF[3] - gJ * (A[1] * A[8] - A[2] * A[7]); gFu[4] = gF[4] + gJ * (A[0] * A[8] - A[2] * A[6]); gFu[5] = gF[5] - gJ * (A[0] * A[7] - A[1] * A[6]);
+    gFu[6] = gF[6] + gJ * (A[1] * A[5] - A[2] * A[4]); gFu[7] = gF[7] - gJ * (A[0] * A[5] - A[2] * A[3]); gFu[8] = gF[8] + gJ * (A[0] * A[4] - A[1] * A[3]);
+    float T1[9], IC[9];
+    m_mul_bt(gFu, F, T1);
+#pragma unroll
+    for (int d = 0; d < 9; ++d) { gC[d] = gCn[d] + c.dt * T1[d]; IC[d] = ((d % 4 == 0) ? 1.f : 0.f) + c.dt * Cm[d]; }
+    m_mul_at(IC, gFu, gF);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { gx[d] = gx[d] + gfx[d] * c.inv_dx; gv[d] = gvp[d]; }
+    return;
+  }
   // stress = 2 mu A Fn^T + la J (J-1) I
   float AFt[9], T1[9], gA[9], gFn[9];
   m_mul_bt(kb.A, q.Fn, AFt);

@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     LG_STAMP(0, 0);   // table clear + state loads
     // (store_F = the caller's checkpoint is being written: the SVD factors go into this substep's record, one lane of the quad)
     float* svd_o = (store_F && a.svd_rows && qi == 0) ? const_cast<float*>(a.hist_in) + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr;
-    particle_pre<false>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr, svd_o, nullptr, c.Np);
+    particle_pre<false, true>(c, x, Cm, F, a.mu[b], a.lamda[b], a.material[up], a.hard[up], q, nullptr, svd_o, nullptr, c.Np);
     if (store_F && qi == 0) {
       float* ho = a.hist_out + (long)b * a.hist_stride_b;
 #pragma unroll
@@ -1333,7 +1333,7 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   const int up = user_index(a, b, p);
   const int material = a.material[up];
   LG_STAMP(2, 0);     // state loads
-  particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
+  particle_pre<true, true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
                      a.svd_rows ? a.hist_in + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr, c.Np);
   LG_STAMP(2, 1);     // pre-pass with the adjoint's extras
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
@@ -1457,7 +1457,7 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
     }
   }
   float gmu_p, gla_p;
-  particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+  particle_adjoint<true>(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
     const float h = clipf(a.hard[up], 0.1f, 5.f);
     atomicAdd(&s_par[0], gmu_p * h);
@@ -1572,7 +1572,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_
     PreB kb;
     const int up = user_index(a, b, p);
     const int material = a.material[up];
-    particle_pre<true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
+    particle_pre<true, true>(c, x, Cm, F, a.mu[b], a.lamda[b], material, a.hard[up], q, &kb, nullptr,
                        a.svd_rows ? a.hist_in + (long)b * a.hist_stride_b + (long)24 * c.Np + p : nullptr, c.Np);
     const float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
     float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
@@ -1615,7 +1615,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_
 #pragma unroll
     for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<4>(gfx[d]); gvp[d] = lg_quad_sum<4>(gvp[d]); }
     float gmu_p, gla_p;     // every lane of the quad: the g2p adjoint below wants the result in all four
-    particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
+    particle_adjoint<true>(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
     if (qi == 0) {
       if (material != 0) {
         const float h = clipf(a.hard[up], 0.1f, 5.f);
