@@ -19,43 +19,14 @@
 namespace ud {
 
 // ---- kernels -------------------------------------------------------------------------------------------
-// primitive positions for the whole step: pos[s+1] = clamp(pos[s] + v), v = clip(action)*scale/substeps for primitive 0
-__global__ void plb_prologue(PlbArgs a, const double* prim_pos, const double* action) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.Bcall) return;   // the caller's arrays (and a checkpoint laid out for this call) hold Bcall envs, the arena may hold more
-  const PlbConst& c = a.c;
-  double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
-  for (int pi = 0; pi < c.np; ++pi)
-    for (int d = 0; d < 3; ++d) {         // the recurrence runs in a register (reading each row back from memory made this launch 20 us of store-to-load round trips)
-      const double pv = (pi == 0) ? fmin(fmax(action[b * 3 + d], -1.0), 1.0) * 1.0 / (double)c.S : 0.0;
-      double cur = prim_pos[(long)b * c.np * 3 + pi * 3 + d];
-      P[pi * 3 + d] = cur;
-      for (int s = 0; s < c.S; ++s) {
-        cur = fmax(fmin(cur + pv, c.hi[d]), c.lo[d]);
-        P[((s + 1) * c.np + pi) * 3 + d] = cur;
-      }
-    }
-  a.w.count[0 * a.B + b] = 0;
-  a.w.count[1 * a.B + b] = 0;
-  a.w.count[2 * a.B + b] = 0;
-}
-
-
-// end of a step only: zero the cells of the last substep (list / buffer `prev`), back to the all-zero grid invariant
-__global__ void __launch_bounds__(256) plb_clear(PlbArgs a) {
-  const int b = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+// end of a step only: zero the cells of the last substep (list `lprev`, the other buffer), back to the all-zero grid invariant
+__device__ __forceinline__ void plb_clear_body(const PlbArgs& a, int b, int t) {
   const int prev = a.lb ^ 1;
   if (t < min(a.w.count[a.lprev * a.B + b], a.cap)) {
     double* cell = plb_buf(a, prev, b) + (long)a.w.list[((long)a.lprev * a.B + b) * a.cap + t] * 4;
     cell[0] = 0.0; cell[1] = 0.0; cell[2] = 0.0; cell[3] = 0.0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.w.count[a.ls * a.B + b] = 0;
 }
-
-
-// compute_F_tmp + svd + von Mises + p2g (:91-99, :133-195)
-// LANES lanes per particle (as in mpm_large.hip): 4 while the launch is too small to fill the chip -- the quad splits the 27
-// stencil cells 7/7/7/6 (every lane repeats the particle pre-pass on otherwise idle SIMDs) -- 1 once it is full.
 
 // What a p2g pass targets: the (m, mv) buffer and list slot it fills, the substep it belongs to (SVD rows), the history slot that receives
 // F of the NEXT state, the stamp epoch of its first-seen test.  plb_p2g fills it from the launch arguments; the fused forward kernel
@@ -142,7 +113,7 @@ __device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& 
 #pragma unroll
       for (int r = 0; r < 3; ++r) contrib[1 + r] = weight * (c.p_mass * v[r] + aff[r * 3] * dp0 + aff[r * 3 + 1] * dp1 + aff[r * 3 + 2] * dp2);
       // block-level staging
-      unsigned s = plb_hash((int)lin);
+      unsigned s = plb_hash_t<PlbTab<LANES>::LOGH>((int)lin);
       int slot = -1;
       for (int probe = 0; probe < 64; ++probe) {
         const int cur = s_key[s];
@@ -151,11 +122,11 @@ __device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& 
           const int old = atomicCAS(&s_key[s], -1, (int)lin);
           if (old == -1 || old == (int)lin) { slot = (int)s; break; }
         }
-        s = (s + 1) & (PLB_H - 1);
+        s = (s + 1) & (PlbTab<LANES>::H - 1);
       }
       if (slot >= 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&s_val[r * PLB_H + slot], contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < 4; ++r) __hip_atomic_fetch_add(&s_val[r * PlbTab<LANES>::H + slot], contrib[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) atomicAdd(val + lin * 4 + r, contrib[r]);
@@ -168,16 +139,16 @@ __device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& 
   __shared__ int s_new, s_base;
   if (threadIdx.x == 0) s_new = 0;
   __syncthreads();
-  constexpr int PER = PLB_H / 256;
+  constexpr int PER = PlbTab<LANES>::H / 256;
   // value atomics: four lanes per cell, one per component -- a cell is 32 contiguous bytes (as in mpm_large.hip: one lane per cell
   // and component put the 64 lanes of an atomic on 64 different lines)
   {
     const int r = threadIdx.x & 3;
 #pragma unroll 4
-    for (int sl = threadIdx.x >> 2; sl < PLB_H; sl += 64) {
+    for (int sl = threadIdx.x >> 2; sl < PlbTab<LANES>::H; sl += 64) {
       const int key = s_key[sl];
       if (key < 0) continue;
-      atomicAdd(val + (long)key * 4 + r, s_val[r * PLB_H + sl]);
+      atomicAdd(val + (long)key * 4 + r, s_val[r * PlbTab<LANES>::H + sl]);
     }
   }
   unsigned newmask = 0;
@@ -210,12 +181,12 @@ __device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& 
 
 template <int LANES>
 __global__ void __launch_bounds__(256) plb_p2g(PlbArgs a) {
-  __shared__ int s_key[PLB_H];
-  __shared__ double s_val[PLB_H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
+  __shared__ int s_key[PlbTab<LANES>::H];
+  __shared__ double s_val[PlbTab<LANES>::H * 4];   // component-major [4][PLB_H]: slot-major rows of 32 B leave the lanes of a ds_add_f64 on 8 banks
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
   if (a.ck_skip && a.w.gck_cnt[b * c.S + a.f] <= c.gck) return;   // adjoint: this env's substep is in the grid checkpoint (block-uniform)
-  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
+  for (int s = threadIdx.x; s < PlbTab<LANES>::H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PlbTab<LANES>::H + s] = 0; s_val[2 * PlbTab<LANES>::H + s] = 0; s_val[3 * PlbTab<LANES>::H + s] = 0; }
   __syncthreads();
   double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, Cm[9], F[9];
   if (p < c.N) {
@@ -278,7 +249,7 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
   }
   const double* val = plb_buf(a, a.lb, b);
   double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;   // four lanes: the lane's seven cells requested together
+  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES > 1 ? TRIPS : 1;   // four / eight lanes: the lane's seven / four cells requested together
 #pragma unroll 1
   for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
     double g7[BATCH][3];
@@ -326,11 +297,11 @@ __global__ void __launch_bounds__(256) plb_g2p(PlbArgs a) {
 // resets the count of the slot this launch fills.
 template <int LANES>
 __global__ void __launch_bounds__(256) plb_g2p_p2g(PlbArgs a) {
-  __shared__ int s_key[PLB_H];
-  __shared__ double s_val[PLB_H * 4];
+  __shared__ int s_key[PlbTab<LANES>::H];
+  __shared__ double s_val[PlbTab<LANES>::H * 4];
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; s_val[3 * PLB_H + s] = 0; }
+  for (int s = threadIdx.x; s < PlbTab<LANES>::H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PlbTab<LANES>::H + s] = 0; s_val[2 * PlbTab<LANES>::H + s] = 0; s_val[3 * PlbTab<LANES>::H + s] = 0; }
   const bool livep = p < c.N;
   double x[3] = {0, 0, 0}, nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[9];
   if (livep) {   // whole quads together
@@ -350,7 +321,7 @@ __global__ void __launch_bounds__(256) plb_g2p_p2g(PlbArgs a) {
       w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
     }
     const double* val = plb_buf(a, a.lb, b);
-    constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;
+    constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES > 1 ? TRIPS : 1;
 #pragma unroll 1
     for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
       double g7[BATCH][3];
@@ -407,7 +378,7 @@ __device__ __forceinline__ unsigned plb_morton10(unsigned v) {
   return v;
 }
 constexpr int PLB_SORT_MAX = 8192;
-__global__ void __launch_bounds__(1024) plb_sort(PlbArgs a, const double* x, int npow2) {
+__global__ void __launch_bounds__(1024) plb_sort(PlbArgs a, const double* x, int npow2, int* perm_out) {
   extern __shared__ unsigned long long plb_sk[];
   const PlbConst& c = a.c;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -437,30 +408,51 @@ __global__ void __launch_bounds__(1024) plb_sort(PlbArgs a, const double* x, int
       }
       __syncthreads();
     }
-  for (int i = tid; i < c.N; i += blockDim.x) a.w.perm[(long)b * c.Np + i] = (int)(plb_sk[i] & 0xffffffffu);
+  for (int i = tid; i < c.N; i += blockDim.x) perm_out[(long)b * c.Np + i] = (int)(plb_sk[i] & 0xffffffffu);
 }
 
-__global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, const double* v, const double* Cm, const double* F, int sorted) {
+// state into the history's slot 0 in the call's spatial order; block 0 of each env also runs the prologue (primitive positions of the whole
+// step, both list counts).  order: the handle's current spatial order (arena), copied to this call's perm (the checkpoint's, for the adjoint).
+__global__ void __launch_bounds__(256) plb_pack(PlbArgs a, const double* x, const double* v, const double* Cm, const double* F, const int* order,
+                                                const double* prim_pos, const double* action) {
   const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
   const PlbConst& c = a.c;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < c.np * 3) {   // pos[s+1] = clamp(pos[s] + v), v = clip(action) * scale / substeps for primitive 0; one thread per coordinate
+      const int pi = threadIdx.x / 3, d = threadIdx.x % 3;
+      double* P = a.w.pos + (long)b * (c.S + 1) * c.np * 3;
+      const double pv = (pi == 0) ? fmin(fmax(action[b * 3 + d], -1.0), 1.0) * 1.0 / (double)c.S : 0.0;
+      double cur = prim_pos[(long)b * c.np * 3 + pi * 3 + d];
+      P[pi * 3 + d] = cur;
+      for (int s = 0; s < c.S; ++s) {
+        cur = fmax(fmin(cur + pv, c.hi[d]), c.lo[d]);
+        P[((s + 1) * c.np + pi) * 3 + d] = cur;
+      }
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 67) a.w.count[(threadIdx.x - 64) * a.B + b] = 0;
+  }
   if (p >= c.N) return;
   double* h = plb_hist(a, b, 0);
-  const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
+  const int up = order ? order[(long)b * c.Np + p] : p;
+  a.w.perm[(long)b * c.Np + p] = up;
   const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { h[d * c.Np + p] = x[o3 + d]; h[(3 + d) * c.Np + p] = v[o3 + d]; }
 #pragma unroll
   for (int d = 0; d < 9; ++d) { h[(6 + d) * c.Np + p] = Cm[o9 + d]; h[(15 + d) * c.Np + p] = F[o9 + d]; }
 }
-
-__global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x, double* v, double* Cm, double* F, double* prim_o, int sorted) {
-  const int b = blockIdx.y, p = blockIdx.x * blockDim.x + threadIdx.x;
+// end of a forward call in one launch: blocks [0, nb_unpack) write the last state back in the caller's order (+ the primitive positions),
+// the blocks behind them clear the last substep's cells
+__global__ void __launch_bounds__(256) plb_unpack_clear(PlbArgs a, int slot, double* x, double* v, double* Cm, double* F, double* prim_o, int nb_unpack) {
+  const int b = blockIdx.y;
   const PlbConst& c = a.c;
+  if ((int)blockIdx.x >= nb_unpack) { plb_clear_body(a, b, ((int)blockIdx.x - nb_unpack) * blockDim.x + threadIdx.x); return; }
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x < c.np * 3)
     prim_o[(long)b * c.np * 3 + threadIdx.x] = a.w.pos[((long)b * (c.S + 1) + c.S) * c.np * 3 + threadIdx.x];   // copyframe(cur, 0)
   if (p >= c.N) return;
   const double* h = plb_hist(a, b, slot);
-  const int up = sorted ? a.w.perm[(long)b * c.Np + p] : p;
+  const int up = a.w.perm[(long)b * c.Np + p];
   const long o3 = ((long)b * c.N + up) * 3, o9 = ((long)b * c.N + up) * 9;
 #pragma unroll
   for (int d = 0; d < 3; ++d) { x[o3 + d] = h[d * c.Np + p]; v[o3 + d] = h[(3 + d) * c.Np + p]; }
@@ -469,7 +461,8 @@ __global__ void __launch_bounds__(256) plb_unpack(PlbArgs a, int slot, double* x
 }
 
 void plb_launch_p2g(const PlbArgs& a, int lanes, dim3 grid, hipStream_t st) {
-  if (lanes == 4) hipLaunchKernelGGL(plb_p2g<4>, grid, dim3(256), 0, st, a);
+  if (lanes == 8) hipLaunchKernelGGL(plb_p2g<8>, grid, dim3(256), 0, st, a);
+  else if (lanes == 4) hipLaunchKernelGGL(plb_p2g<4>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(plb_p2g<1>, grid, dim3(256), 0, st, a);
 }
 
@@ -503,7 +496,7 @@ int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
   h->w.gacc = adj ? (double*)(base + o_gacc) : nullptr; h->w.vout = adj ? (double*)(base + o_vout) : nullptr; h->w.gstate = adj ? (double*)(base + o_gstate) : nullptr;
   h->w.gxs = adj ? (double*)(base + o_gxs) : nullptr; h->w.gpos = adj ? (double*)(base + o_gpos) : nullptr; h->w.gpar = adj ? (double*)(base + o_gpar) : nullptr;
   h->gm = loss ? (double*)(base + o_gm) : nullptr; h->lred = loss ? (double*)(base + o_lred) : nullptr;
-  h->B = B; h->epoch = 1; h->has_adj = adj; h->has_loss = loss;
+  h->B = B; h->epoch = 1; h->has_adj = adj; h->has_loss = loss; h->sort_B = 0;
   return UD_OK;
 }
 
@@ -590,17 +583,26 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
   const char* lanes_env = getenv("UD_PLB_LANES");          // diagnostic override, read per call (the tests reach both mappings with it)
   const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
-  const int lanes = (force_lanes == 1 || force_lanes == 4) ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);   // lanes per particle in p2g / g2p
-  const dim3 gq((4 * h->c.N + 255) / 256, B);
-  hipLaunchKernelGGL(ud::plb_prologue, dim3((B + 63) / 64), dim3(64), 0, st, a, prim_pos, action);
+  // lanes per particle in p2g / g2p: 8 while even four leave half of the SIMDs without a wave (B N <= 16 000: the walk's share of the
+  // one wave a launch waits for halves again -- Torus forward 268 k -> 287 k substeps/s; 16 lanes: 250 k, the repeated pre-pass then
+  // competes for issue), 4 while the launch does not fill the chip, 1 beyond
+  const int lanes = (force_lanes == 1 || force_lanes == 4 || force_lanes == 8) ? force_lanes
+                    : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));
+  const dim3 gq((lanes * h->c.N + 255) / 256, B);
+  // Spatial order: any permutation is valid, only its locality ages (a particle moves a fraction of a cell per step) -- computed on the
+  // first call, when more envs arrive than it covers, and every UD_PLB_SORT_EVERY-th call (default 8) after that; kept in the arena and
+  // copied into every call's own perm (the checkpoint's) by plb_pack.
   static const int no_sort = [] { const char* e = getenv("UD_PLB_NO_SORT"); return e ? atoi(e) : 0; }();   // diagnostic override
-  const int sorted = (!no_sort && h->c.N <= ud::PLB_SORT_MAX) ? 1 : 0;
-  if (sorted) {
+  const char* se = getenv("UD_PLB_SORT_EVERY");
+  const int sort_every = se ? std::max(1, atoi(se)) : 8;
+  const bool sorted = !no_sort && h->c.N <= ud::PLB_SORT_MAX;
+  if (sorted && (B > h->sort_B || ++h->sort_age >= sort_every)) {
     int npow2 = 64;
     while (npow2 < h->c.N) npow2 <<= 1;
-    hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, a, x, npow2);
+    hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, a, x, npow2, h->w.perm);
+    h->sort_B = std::max(h->sort_B, B); h->sort_age = 0;
   }
-  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted);
+  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted ? (const int*)h->w.perm : (const int*)nullptr, prim_pos, action);
   // Per substep: plb_grid(f), then ONE particle launch: g2p(f) -> p2g(f + 1) (plb_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it.
   // UD_PLB_FUSED=0 (diagnostic, read per call): p2g, grid, g2p as three launches.
   const char* fz = getenv("UD_PLB_FUSED");
@@ -614,24 +616,25 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
     else { a.ls = a.lb; a.lprev = a.lb ^ 1; a.lnext = a.lprev; }
   };
   set(0);
-  if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
+#define UD_PLB_LAUNCH(K) do { if (lanes == 8) hipLaunchKernelGGL(ud::K<8>, gq, blk, 0, st, a); else if (lanes == 4) hipLaunchKernelGGL(ud::K<4>, gq, blk, 0, st, a); \
+                               else hipLaunchKernelGGL(ud::K<1>, gp, blk, 0, st, a); } while (0)
+  UD_PLB_LAUNCH(plb_p2g);
   for (int f = 0; f < S; ++f) {
     set(f);
     hipLaunchKernelGGL(ud::plb_grid, gc, blk, 0, st, a);
     if (fused && f + 1 < S) {
-      if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p_p2g<1>, gp, blk, 0, st, a);
+      UD_PLB_LAUNCH(plb_g2p_p2g);
     } else {
-      if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_g2p<1>, gp, blk, 0, st, a);
+      UD_PLB_LAUNCH(plb_g2p);
       if (f + 1 < S) {
         set(f + 1);
-        if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g<4>, gq, blk, 0, st, a); else hipLaunchKernelGGL(ud::plb_p2g<1>, gp, blk, 0, st, a);
+        UD_PLB_LAUNCH(plb_p2g);
       }
     }
   }
   // back to the all-zero grid invariant: the cells of the last substep (its list is `lprev` of a substep S that never runs)
   set(S);
-  hipLaunchKernelGGL(ud::plb_clear, gc, blk, 0, st, a);
-  hipLaunchKernelGGL(ud::plb_unpack, gp, blk, 0, st, a, h->c.S % a.slots, x_out, v_out, C_out, F_out, prim_pos_out, sorted);
+  hipLaunchKernelGGL(ud::plb_unpack_clear, dim3(gp.x + gc.x, B), blk, 0, st, a, h->c.S % a.slots, x_out, v_out, C_out, F_out, prim_pos_out, (int)gp.x);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { ud::set_error("ud_plb_step_fwd: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;

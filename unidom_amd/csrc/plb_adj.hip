@@ -87,11 +87,11 @@ __global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
 // kernel (30-35 us of a 105 us reverse substep on Torus, profiles/r02j_kernel_stats_torus_grad_ngrid64.csv).
 template <int LANES>   // lanes per particle, as in plb_g2p: the quad splits the 27 cells 7/7/7/6 and adds its partial sums with DPP
 __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
-  __shared__ int s_key[PLB_H];
-  __shared__ double s_val[PLB_H * 3];   // component-major [3][PLB_H]
+  __shared__ int s_key[PlbTab<LANES>::H];
+  __shared__ double s_val[PlbTab<LANES>::H * 3];   // component-major [3][PLB_H]
   const int b = blockIdx.y, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const PlbConst& c = a.c;
-  for (int s = threadIdx.x; s < PLB_H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PLB_H + s] = 0; s_val[2 * PLB_H + s] = 0; }
+  for (int s = threadIdx.x; s < PlbTab<LANES>::H; s += blockDim.x) { s_key[s] = -1; s_val[s] = 0; s_val[PlbTab<LANES>::H + s] = 0; s_val[2 * PlbTab<LANES>::H + s] = 0; }
   if (gid == 0) a.w.count[(a.lb ^ 1) * a.B + b] = 0;   // the other list: plb_grid_keep has just retired it, p2g of substep f - 1 refills it
   __syncthreads();
   double* gacc = a.w.gacc + (long)b * a.G * 4;
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   double gfx[3] = {0, 0, 0};
   const double k4 = 4 * c.inv_dx;
   const int rot = (p * LANES) % 27;   // staggered stencil walk, as in plb_p2g: neighbours never on the same table slot at once
-  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES == 4 ? TRIPS : 1;   // four lanes: the lane's seven cells requested together
+  constexpr int TRIPS = (27 + LANES - 1) / LANES, BATCH = LANES > 1 ? TRIPS : 1;   // four / eight lanes: the lane's seven / four cells requested together
 #pragma unroll 1
   for (int t0 = 0; t0 < TRIPS; t0 += BATCH) {
   double g7[BATCH][3];
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
     const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
     const long lin = lin7[t];
     const double g[3] = {g7[t][0], g7[t][1], g7[t][2]};
-    unsigned s = plb_hash((int)lin);
+    unsigned s = plb_hash_t<PlbTab<LANES>::LOGH>((int)lin);
     int slot = -1;
     for (int probe = 0; probe < 64; ++probe) {
       const int cur = s_key[s];
@@ -153,14 +153,14 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
         const int old = atomicCAS(&s_key[s], -1, (int)lin);
         if (old == -1 || old == (int)lin) { slot = (int)s; break; }
       }
-      s = (s + 1) & (PLB_H - 1);
+      s = (s + 1) & (PlbTab<LANES>::H - 1);
     }
     double gw = 0, gdp[3] = {0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const double cd = gC1[r * 3] * dp[0] + gC1[r * 3 + 1] * dp[1] + gC1[r * 3 + 2] * dp[2];
       const double gcell = weight * (gv1[r] + k4 * cd);
-      if (slot >= 0) __hip_atomic_fetch_add(&s_val[r * PLB_H + slot], gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (slot >= 0) __hip_atomic_fetch_add(&s_val[r * PlbTab<LANES>::H + slot], gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else atomicAdd(gacc + lin * 4 + r, gcell);
       gw += g[r] * (gv1[r] + k4 * cd);
 #pragma unroll
@@ -183,10 +183,10 @@ __global__ void __launch_bounds__(256) plb_g2p_adj(PlbArgs a, int gs_in) {
   {                  // flush: four lanes per cell (a cell is 32 contiguous bytes), the fourth component is the grid-op adjoint's
     const int r = threadIdx.x & 3;
 #pragma unroll 4
-    for (int sl = threadIdx.x >> 2; sl < PLB_H; sl += 64) {
+    for (int sl = threadIdx.x >> 2; sl < PlbTab<LANES>::H; sl += 64) {
       const int key = s_key[sl];
       if (key < 0 || r == 3) continue;
-      atomicAdd(gacc + (long)key * 4 + r, s_val[r * PLB_H + sl]);
+      atomicAdd(gacc + (long)key * 4 + r, s_val[r * PlbTab<LANES>::H + sl]);
     }
   }
 }
@@ -759,10 +759,11 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   const bool never_recompute = h->c.gck >= h->cap;          // every substep of every env is in the grid checkpoint: no recompute launch at all
   const int S = h->c.S;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B), gpa((h->c.N + 127) / 128, B);
-  const dim3 gq((4 * h->c.N + 255) / 256, B), gqa((4 * h->c.N + 127) / 128, B);
   const char* lanes_env = getenv("UD_PLB_LANES");          // the forward's diagnostic override (read per call)
   const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
-  const int lanes = (force_lanes == 1 || force_lanes == 4) ? force_lanes : (((long)B * h->c.N < 100000) ? 4 : 1);
+  const int lanes = (force_lanes == 1 || force_lanes == 4 || force_lanes == 8) ? force_lanes
+                    : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));   // as the forward (plb.hip)
+  const dim3 gq((lanes * h->c.N + 255) / 256, B), gqa((lanes * h->c.N + 127) / 128, B);
   hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_pack, gp, blk, 0, st, a, S & 1, g_x, g_v, g_C, g_F, g_prim_pos);
   // Five launches per reverse substep.  List and (m, mv) buffer alternate with the substep like the forward's: plb_grid_keep retires
@@ -770,12 +771,14 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   // count -- the separate clear and count-reset launches of every substep are gone; one clear after the loop for substep 0.
   for (int f = S - 1; f >= 0; --f) {
     a.f = f; a.epoch = h->epoch++; a.hs_in = f; a.hs_out = f + 1; a.lb = f & 1; a.ls = a.lb; a.lprev = a.lb ^ 1; a.lnext = a.lprev;
-    if (!never_recompute) ud::plb_launch_p2g(a, lanes, lanes == 4 ? gq : gp, st);   // recompute (m, mv) (rewrites F[f + 1] with the same values); envs with a checkpointed substep leave at once
+    if (!never_recompute) ud::plb_launch_p2g(a, lanes, lanes > 1 ? gq : gp, st);   // recompute (m, mv) (rewrites F[f + 1] with the same values); envs with a checkpointed substep leave at once
     hipLaunchKernelGGL(ud::plb_grid_keep, gc, blk, 0, st, a);
-    if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
+    if (lanes == 8) hipLaunchKernelGGL(ud::plb_g2p_adj<8>, gq, blk, 0, st, a, (f + 1) & 1);
+    else if (lanes == 4) hipLaunchKernelGGL(ud::plb_g2p_adj<4>, gq, blk, 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_g2p_adj<1>, gp, blk, 0, st, a, (f + 1) & 1);
     hipLaunchKernelGGL(ud::plb_grid_adj, gc, blk, 0, st, a);
-    if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g_adj<4>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
+    if (lanes == 8) hipLaunchKernelGGL(ud::plb_p2g_adj<8>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
+    else if (lanes == 4) hipLaunchKernelGGL(ud::plb_p2g_adj<4>, gqa, dim3(128), 0, st, a, (f + 1) & 1);
     else hipLaunchKernelGGL(ud::plb_p2g_adj<1>, gpa, dim3(128), 0, st, a, (f + 1) & 1);
   }
   a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1;

@@ -150,6 +150,15 @@ __device__ __forceinline__ double plb_wave_sum(double v) {   // all 64 lanes get
 
 #define PLB_H 1024
 #define PLB_LOGH 10
+// block table size by lanes per particle: a block of 256 lanes holds 256 / LANES particles; at eight lanes (32 particles, 864 cells at the very
+// most, ~150 when sorted) 512 slots halve the clear and the three flush sweeps; a full table falls back to global atomics as ever
+template <int LANES> struct PlbTab { static constexpr int H = LANES == 8 ? 512 : PLB_H, LOGH = LANES == 8 ? 9 : PLB_LOGH; };
+template <int LOGH>
+__device__ __forceinline__ unsigned plb_hash_t(int cell) {
+  unsigned h = (unsigned)cell;
+  h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
+  return h >> (32 - LOGH);
+}
 __device__ __forceinline__ unsigned plb_hash(int cell) {
   unsigned h = (unsigned)cell;
   h ^= h >> 9; h *= 2654435761u; h ^= h >> 15;
@@ -165,10 +174,11 @@ __device__ __forceinline__ double dpp_d(double v) {
 }
 template <int LANES>
 __device__ __forceinline__ double plb_quad_sum(double v) {
-  if (LANES == 4) {
+  if (LANES >= 4) {
     v += dpp_d<0xB1>(v);  // quad_perm [1,0,3,2]
     v += dpp_d<0x4E>(v);  // quad_perm [2,3,0,1]
   }
+  if (LANES >= 8) v += dpp_d<0x141>(v);  // row_half_mirror: lane i <-> 7 - i of each group of eight = the other quad
   return v;
 }
 
@@ -222,6 +232,7 @@ struct ud_plb {
   double* lred = nullptr;   // [B][16] loss partial sums
   bool has_adj = false, has_loss = false;
   void* arena = nullptr;
+  int sort_B = 0, sort_age = 0;   // envs the arena's spatial order (w.perm) covers, forward calls since it was computed
 };
 // (re)size the handle's arena: forward buffers always, adjoint / loss buffers on first use (hipStreamSynchronize + hipFree +
 // hipMalloc when it has to grow: see the header's note on host synchronisation)
