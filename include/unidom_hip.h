@@ -166,6 +166,9 @@ typedef struct {
                                 sampled liquids, mpm_simulator.py:87-91); bodies above 8192 particles keep their order (the
                                 sort runs in the LDS of one workgroup per env).  Invisible at this boundary: inputs, outputs and
                                 gradients stay in the caller's order; only the summation order of the scatters changes */
+  float prim_friction_each[4], prim_softness_each[4];   /* soft contact with several primitives: friction / softness of primitive i where
+                                prim_softness_each[i] > 0 (create_primitive passes them per primitive, mpm_env.py:201-217); entries left
+                                at 0 take prim_friction / prim_softness (every reference env passes 0.1 / 666 to all of them) */
   int deterministic;         /* != 0: ud_mpm_step_fwd sums every grid cell over the particles in index order and each particle's
                                 27 offsets in (i, j, k) order, in f32 -- the order of the reference's scatter-add on XLA's CPU
                                 backend (mpm_simulator.py:178-194) -- and g2p adds its cells in (i, j, k) order; no float atomics,

@@ -187,6 +187,12 @@ void* oc_mpm_create(int N, int n_grid, const int* res, int steps, double dt, dou
   return h;
 }
 void oc_mpm_destroy(void* h) { delete (OcMpm*)h; }
+// per-primitive friction / softness (PrimitiveState.friction / .softness as create_primitive sets them, mpm_env.py:201-217)
+void oc_mpm_set_prim_each(void* hv, int n, const double* friction, const double* softness) {
+  OcMpm* h = (OcMpm*)hv;
+  h->pf.prim_friction_each.assign(friction, friction + n); h->pd.prim_friction_each.assign(friction, friction + n);
+  h->pf.prim_softness_each.assign(softness, softness + n); h->pd.prim_softness_each.assign(softness, softness + n);
+}
 
 void oc_svd3_f32(const float* A, float* U, float* S, float* Vh) {
   M3<float> a = load9(A), u, vh;

@@ -125,7 +125,8 @@ struct MpmParams {
   T dtg[3];        // T(dt)*T(gravity) (:285)
   int position_control;
   int n_prim = 1, sdf_kind = 0;                       // sdf_kind: 0 box (box.py), 1 container (container.py); one per process in the reference (set_sdf)
-  T prim_friction = T(0.1), prim_softness = T(666);   // PrimitiveState.friction / .softness (primitives.py:31-60), same for all primitives
+  T prim_friction = T(0.1), prim_softness = T(666);   // PrimitiveState.friction / .softness (primitives.py:31-60), same for all primitives ...
+  std::vector<T> prim_friction_each, prim_softness_each;   // ... unless set per primitive (create_primitive passes them per primitive, mpm_env.py:201-217)
   std::vector<int> material;  // [N]
   std::vector<T> h;           // [N] hardness, clipped to [0.1,5] at use (:241)
 };
@@ -452,12 +453,13 @@ template <class T> inline long cell_gather(const MpmParams<T>& pr, int i, int j,
 }
 
 template <class T>
-inline PrimCtx<T> prim_ctx(const MpmParams<T>& pr, const PrimS<T>& st, int f) {
+inline PrimCtx<T> prim_ctx(const MpmParams<T>& pr, const PrimS<T>& st, int f, int ip = 0) {
   const int f0 = clampi<T>(f, pr.steps), f1 = clampi<T>(f + 1, pr.steps);
   PrimCtx<T> pc;
   for (int a = 0; a < 3; ++a) { pc.p0[a] = st.ppos[f0 * 3 + a]; pc.p1[a] = st.ppos[f1 * 3 + a]; pc.size[a] = st.psize[a]; }
   for (int a = 0; a < 4; ++a) { pc.r0[a] = st.prot[f0 * 4 + a]; pc.r1[a] = st.prot[f1 * 4 + a]; }
-  pc.softness = pr.prim_softness; pc.friction = pr.prim_friction; pc.kind = pr.sdf_kind;
+  pc.softness = ip < (int)pr.prim_softness_each.size() ? pr.prim_softness_each[ip] : pr.prim_softness;
+  pc.friction = ip < (int)pr.prim_friction_each.size() ? pr.prim_friction_each[ip] : pr.prim_friction; pc.kind = pr.sdf_kind;
   return pc;
 }
 
@@ -488,7 +490,7 @@ inline void grid_cell_op(const MpmParams<T>& pr, const MpmState<T>& st, int f, i
   } else {                                                          // collide_batch (:154-182), primitive after primitive (:292-294)
     T gp[3] = {(T)ci * pr.dx, (T)cj * pr.dx, (T)ck * pr.dx};
     for (int i = 0; i < pr.n_prim; ++i) {
-      PrimCtx<T> pc = prim_ctx(pr, st.prims[i], f);
+      PrimCtx<T> pc = prim_ctx(pr, st.prims[i], f, i);
       CollideRec<T> cr;
       T vo[3];
       collide_cell(pc, pr.dt, gp, v, vo, cr);
@@ -659,7 +661,7 @@ void mpm_substep_bwd(const MpmParams<T>& pr, int f, const MpmState<T>& in, MpmGr
   const int fc = clampi<T>(f, pr.steps);
   T gpv_f[3] = {0, 0, 0};
   std::vector<PrimCtx<T>> pctx;
-  for (int i = 0; i < pr.n_prim; ++i) pctx.push_back(prim_ctx(pr, mid.prims[i], f));
+  for (int i = 0; i < pr.n_prim; ++i) pctx.push_back(prim_ctx(pr, mid.prims[i], f, i));
   std::vector<PrimGrad<T>> pgrad(pr.n_prim);
   for (int ci = 0; ci < pr.res[0]; ++ci) for (int cj = 0; cj < pr.res[1]; ++cj) for (int ck = 0; ck < pr.res[2]; ++ck) {
     size_t c = ((size_t)ci * pr.res[1] + cj) * pr.res[2] + ck;

@@ -149,9 +149,13 @@ class MpmOracle:
         g = np.ascontiguousarray(gravity, dtype=np.float64)
         self.h = C.c_void_p(lib().oc_mpm_create(
             C.c_int(N), C.c_int(n_grid), _p(r), C.c_int(steps), C.c_double(dt), C.c_double(p_mass), C.c_double(p_vol),
-            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd), C.c_double(prim_friction), C.c_double(prim_softness),
+            _p(g), C.c_int(int(position_control)), _p(mat), _p(hd), C.c_double(float(np.ravel(prim_friction)[0])), C.c_double(float(np.ravel(prim_softness)[0])),
             C.c_int(n_prim), C.c_int({"box": 0, "container": 1}[sdf])))
         assert self.h.value, "oc_mpm_create refused the configuration"
+        if not np.isscalar(prim_friction) or not np.isscalar(prim_softness):     # one value per primitive
+            fr = np.ascontiguousarray(np.broadcast_to(np.asarray(prim_friction, np.float64), (n_prim,)))
+            so = np.ascontiguousarray(np.broadcast_to(np.asarray(prim_softness, np.float64), (n_prim,)))
+            lib().oc_mpm_set_prim_each(self.h, C.c_int(n_prim), _p(fr), _p(so))
 
     def __del__(self):
         try:

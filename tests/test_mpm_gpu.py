@@ -666,6 +666,46 @@ def test_two_container_primitives_match_oracle(demo, clip, large_path):
     assert np.abs(ob["gaction"]).min() > 0 and np.abs(got["gprot"].cpu().numpy()[0, 1]).max() > 0
 
 
+def test_two_primitives_with_their_own_friction_and_softness(demo, multi_kernel_path):
+    """ud_mpm_conf.prim_friction_each / prim_softness_each: one pair per primitive (create_primitive passes them per primitive,
+    mpm_env.py:201-217).  Upright, translating bowls with friction 0.1 / 0.45 and softness 666 / 120 against the oracle with the same
+    pairs, forward (f32) and adjoint (f64); the uniform handle gives a different answer."""
+    from oracle.pyoracle import MpmOracle
+    from test_oracle_mpm import _two_bowl_case
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    S, N = 3, 67
+    st, g = _two_bowl_case(demo, S, 40, 0, np.float32, turning=False)
+    fr_each, so_each = [0.1, 0.45], [666.0, 120.0]
+
+    def make(each):
+        conf = LegacyConf()
+        conf.steps = S
+        sim = SimpleMPMSimulator(conf, 1, use_position_control=False)
+        sim.n_particles, sim.material, sim.h = N, np.zeros(N, np.int32), np.ones(N, np.float32)
+        sim.n_primitive, sim.sdf_kind = 2, "container"
+        if each:
+            sim.prim_friction_each, sim.prim_softness_each = fr_each, so_each
+        sim._make_handle()
+        return sim
+    orc = MpmOracle(N, steps=S, material=np.zeros(N), position_control=False, n_prim=2, sdf="container", prim_friction=fr_each, prim_softness=so_each)
+    st64, g64 = {k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()}
+    of, of64 = orc.step_fwd(st), orc.step_fwd(st64)
+    ob, ob32 = orc.step_bwd(st64, g64, clip=False), orc.step_bwd(st, g, clip=False)
+    got = run_hip_collide(make(True), st, g, False)
+    uni = run_hip_collide(make(False), st, g, False)
+    base = dict(x=5e-6, v=1e-4, C=1e-3, F=5e-5)
+    for key in ("x", "v", "C", "F"):
+        gap = _rel(of[key], of64[key])
+        assert _rel(got[key], of64[key]) < 3 * gap + base[key], (key, _rel(got[key], of64[key]), gap)
+    assert _rel(uni["v"], of64["v"]) > 10 * (_rel(got["v"], of64["v"]) + 1e-7)       # the pairs matter
+    lin = [0, 1, 2, 6, 7, 8]          # the bowls do not turn: d|w|/dw at w = 0 is NaN without the clip, here as in the reference (primitives.py:86)
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        a, b, b32 = (v[:, lin] if key == "gaction" else v for v in (got[key], ob[key], ob32[key]))
+        gap = _rel(b32, b)
+        assert np.isfinite(a).all() and _rel(a, b) < 3 * gap + 2e-3, (key, _rel(a, b), gap)
+    assert np.isnan(got["gaction"][:, [3, 4, 5, 9, 10, 11]]).all() and np.isnan(ob["gaction"][:, [3, 4, 5, 9, 10, 11]]).all()
+
+
 def test_two_upright_containers_forward_tracks_f32_oracle(demo):
     """Same two bowls, upright and only translating: no library sin / cos in the poses, so the SDF + finite-difference
     normal path is operation-for-operation the oracle's and the forward agrees at the usual tolerances."""

@@ -310,6 +310,48 @@ def test_two_container_primitives_adjoint_matches_autograd_f64(demo, clip):
     assert _rel(ob["gaction"][0], ac.grad.numpy()) < 2e-7 and np.abs(ob["gaction"][0]).min() > 0
 
 
+def test_two_primitives_with_their_own_friction_and_softness_f64(demo):
+    """create_primitive passes friction / softness PER primitive (mpm_env.py:201-217; every reference env gives all of them 0.1 /
+    666): the restatement with one pair per primitive == the twin whose two PrimitiveStates carry different values, forward and
+    adjoint; and it is not the uniform case (the second bowl's values matter)."""
+    S = 3
+    st, g = _two_bowl_case(demo, S, 40, 0)
+    fr_each, so_each = [0.1, 0.45], [666.0, 120.0]
+    orc = MpmOracle(67, steps=S, material=np.zeros(67), position_control=False, n_prim=2, sdf="container",
+                    prim_friction=fr_each, prim_softness=so_each)
+    of, ob = orc.step_fwd(st), orc.step_bwd(st, g, clip=False)
+    uni = MpmOracle(67, steps=S, material=np.zeros(67), position_control=False, n_prim=2, sdf="container").step_fwd(st)
+    assert _rel(of["v"], uni["v"]) > 1e-6
+    conf = tw.MPMConf(steps=S, n_primitive=2)
+    tw.set_sdf(tw.container_sdf)
+    try:
+        sim = tw.MPMTwin(conf, 67, material=0, dtype=torch.float64, clip_grads=False, use_position_control=False)
+        L = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+        xt, vt, Ct, Ft = L(st["x"][0]), L(st["v"][0]), L(st["C"][0]), L(st["F"][0])
+        fr, mu, la, ac = L(st["friction"]), L(st["mu"]), L(st["lamda"]), L(st["action"][0])
+        prims, pps = [], []
+        for i in range(2):
+            pp, pr = L(st["ppos"][0, i]), L(st["prot"][0, i])
+            p = tw.make_prim(conf, st["psize"][0, i], [0, 0, 0], torch.float64, friction=fr_each[i], softness=so_each[i])
+            prims.append(p._replace(position=pp, rotation=pr))
+            pps.append(pp)
+        s2 = sim.step(tw.MPMState(xt, vt, Ct, Ft, torch.tensor(st["J"][0]), prims, fr, mu, la), ac)
+    finally:
+        tw.set_sdf(tw.box_sdf)
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    loss = (s2.x * T(g["gx"][0])).sum() + (s2.v * T(g["gv"][0])).sum() + (s2.C * T(g["gC"][0])).sum() + (s2.F * T(g["gF"][0])).sum()
+    for i in range(2):
+        loss = loss + (s2.primitives[i].position * T(g["gppos"][0, i])).sum() + (s2.primitives[i].rotation * T(g["gprot"][0, i])).sum()
+    loss.backward()
+    for key, ref in (("x", s2.x), ("v", s2.v), ("C", s2.C), ("F", s2.F)):
+        assert _rel(of[key][0], ref.detach().numpy()) < 1e-11, key
+    for key, ref in (("gx", xt), ("gv", vt), ("gC", Ct), ("gF", Ft)):
+        assert _rel(ob[key][0], ref.grad.numpy()) < 2e-7, key
+    for i in range(2):
+        assert _rel(ob["gppos"][0, i], pps[i].grad.numpy()) < 2e-7, i
+    assert _rel(ob["gaction"][0], ac.grad.numpy()) < 2e-7
+
+
 @pytest.mark.parametrize("sdf,n_prim", [("box", 1), ("container", 2)])
 def test_collide_adjoint_vs_finite_differences_f64(demo, sdf, n_prim):
     """Soft contact, independent of autograd: central differences of the oracle's own f64 forward against its hand-derived

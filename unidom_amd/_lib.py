@@ -38,7 +38,8 @@ class ud_mpm_conf(C.Structure):
     _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("res", C.c_int * 3), ("steps", C.c_int),
                 ("dt", C.c_float), ("p_mass", C.c_float), ("p_vol", C.c_float), ("gravity", C.c_float * 3),
                 ("use_position_control", C.c_int), ("prim_friction", C.c_float), ("prim_softness", C.c_float),
-                ("n_primitive", C.c_int), ("sdf_kind", C.c_int), ("grid_ckpt_cells", C.c_int), ("sort_particles", C.c_int), ("deterministic", C.c_int)]
+                ("n_primitive", C.c_int), ("sdf_kind", C.c_int), ("grid_ckpt_cells", C.c_int), ("sort_particles", C.c_int),
+                ("prim_friction_each", C.c_float * 4), ("prim_softness_each", C.c_float * 4), ("deterministic", C.c_int)]
 
 
 class ud_plb_conf(C.Structure):

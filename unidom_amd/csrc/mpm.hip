@@ -1264,6 +1264,11 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   for (int d = 0; d < 3; ++d) c.dtg[d] = conf->dt * conf->gravity[d];    // :285
   c.position_control = conf->use_position_control ? 1 : 0;
   c.prim_friction = conf->prim_friction; c.prim_softness = conf->prim_softness;
+  for (int i = 0; i < 4; ++i) {
+    const bool each = conf->prim_softness_each[i] > 0.f;
+    c.prim_friction_each[i] = each ? conf->prim_friction_each[i] : conf->prim_friction;
+    c.prim_softness_each[i] = each ? conf->prim_softness_each[i] : conf->prim_softness;
+  }
   c.n_prim = conf->n_primitive > 0 ? conf->n_primitive : 1;   // 0 = unset = 1
   c.sdf_kind = conf->sdf_kind;
   c.gck = conf->grid_ckpt_cells > 0 ? conf->grid_ckpt_cells : 0;

@@ -17,6 +17,7 @@ struct MpmConst {
   int H, logH, nthreads;
   int position_control;            // 1: position_control_batch, 0: collide_batch (soft contact)
   float prim_friction, prim_softness;   // PrimitiveState.friction / .softness (collide_batch only)
+  float prim_friction_each[4], prim_softness_each[4];   // per primitive (filled from the scalars where the conf leaves them unset)
   int n_prim, sdf_kind;            // primitives per env (collide_batch: 1..UD_MAX_PRIM); 0 box SDF, 1 container SDF
   int gck;                         // many-workgroup path: grid-checkpoint records per particle and substep (0 = recompute in the backward)
   int sort;                        // many-workgroup path: re-order the particles by cell inside the handle at every step

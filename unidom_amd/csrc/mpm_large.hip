@@ -131,7 +131,7 @@ __device__ __forceinline__ void load_primc_f(const LargeArgs& a, int b, int ip, 
   for (int d = 0; d < 3; ++d) { pc.p0[d] = pp[f0 * 3 + d]; pc.p1[d] = pp[f1 * 3 + d]; pc.size[d] = a.psize[bp * 3 + d]; }
 #pragma unroll
   for (int d = 0; d < 4; ++d) { pc.r0[d] = pr[f0 * 4 + d]; pc.r1[d] = pr[f1 * 4 + d]; }
-  pc.soft = a.c.prim_softness; pc.mu = a.c.prim_friction; pc.kind = a.c.sdf_kind;
+  pc.soft = a.c.prim_softness_each[ip]; pc.mu = a.c.prim_friction_each[ip]; pc.kind = a.c.sdf_kind;
   primc_finish(pc);
 }
 __device__ __forceinline__ void load_primc(const LargeArgs& a, int b, int ip, PrimC& pc) { load_primc_f(a, b, ip, a.f, pc); }

@@ -135,6 +135,7 @@ class SimpleMPMSimulator:
         self.h = None
         self.clip_grad = True            # norm_grad_state / norm_grad (:375-411)
         self.prim_friction, self.prim_softness = 0.1, 666.0   # PrimitiveState.friction / .softness (collide_batch); set by create_primitive
+        self.prim_friction_each, self.prim_softness_each = [], []   # per primitive, filled by reset_jax
         self.n_primitive, self.sdf_kind = 1, "box"             # fixed at reset_jax (state.primitives, primitives.set_sdf)
         self.grid_ckpt_cells = int(getattr(conf, "grid_ckpt_cells", 0))   # include/unidom_hip.h: 0 = recompute the grid in the backward
         self.sort_particles = int(getattr(conf, "sort_particles", 0))     # include/unidom_hip.h: internal spatial order (liquids)
@@ -205,9 +206,11 @@ class SimpleMPMSimulator:
         if state.primitives:                   # constants of collide_batch (primitives.py:154-182), fixed per handle
             self.prim_friction = float(state.primitives[0].friction.reshape(-1)[0])
             self.prim_softness = float(state.primitives[0].softness.reshape(-1)[0])
-            for q in state.primitives[1:]:
-                if float(q.friction.reshape(-1)[0]) != self.prim_friction or float(q.softness.reshape(-1)[0]) != self.prim_softness:
-                    raise NotImplementedError("primitives with different friction / softness (every reference env uses 0.1 / 666)")
+            # create_primitive passes friction / softness per primitive (mpm_env.py:201-217): one pair per primitive in the handle
+            self.prim_friction_each = [float(q.friction.reshape(-1)[0]) for q in state.primitives]
+            self.prim_softness_each = [float(q.softness.reshape(-1)[0]) for q in state.primitives]
+            if len(state.primitives) > 4 or any(s <= 0 for s in self.prim_softness_each):
+                raise NotImplementedError("at most four primitives, softness > 0")
             self.n_primitive = len(state.primitives)
         from .primitives.primitives import get_sdf_kind
         self.sdf_kind = get_sdf_kind()
@@ -225,6 +228,8 @@ class SimpleMPMSimulator:
                               prim_friction=float(self.prim_friction), prim_softness=float(self.prim_softness),
                               n_primitive=int(self.n_primitive), sdf_kind={"box": 0, "container": 1}[self.sdf_kind],
                               grid_ckpt_cells=int(self.grid_ckpt_cells), sort_particles=int(self.sort_particles),
+                              prim_friction_each=(C.c_float * 4)(*(list(self.prim_friction_each) + [0.0] * 4)[:4]),
+                              prim_softness_each=(C.c_float * 4)(*(list(self.prim_softness_each) + [0.0] * 4)[:4]),
                               deterministic=int(self.deterministic))
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
