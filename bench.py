@@ -906,6 +906,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturation", action="store_true", help="skip the many-env probe of the same kernels")
     ap.add_argument("--no-graph", action="store_true", help="whip_rope: eager update instead of the captured HIP graph")
+    ap.add_argument("--graph", action="store_true", help="cloth workloads: also time the update replayed as one HIP graph (reported as `hip_graph`, beside the eager `value`)")
     ap.add_argument("--workload", default="fold_cloth1", choices=["fold_cloth1", "fold_cloth1_para", "fold_tshirt", "whip_rope", "torus", "shape_rope", "pour_water", "pour_soup", "selftest"],
                     help="fold_cloth1 = the headline metric (default); fold_cloth1_para = BASELINE config 3 (parameter-aware obs, "
                          "32 envs/GPU); whip_rope = the MPM path (BASELINE config 4 shape: 32 envs/GPU)")
@@ -954,6 +955,11 @@ def main():
                                                 eval_min_max_stiff=[10, 1800], device=device)
     else:
         env = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, conf=conf, seed=0, aux_reward=True, device=device)
+    want_graph = args.graph and world == 1      # opt-in: the headline `value` below stays the eager update; the graph replay is reported beside it
+    if want_graph:                               # APG.capture: the learner's whole life on one non-default stream
+        work = torch.cuda.Stream(device)
+        work.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(work)
     learner = APG(env, EP_LEN, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
     key_env = prng.split(prng.PRNGKey(0), world)[rank]
     _, state = env.reset(key_env)
@@ -976,6 +982,22 @@ def main():
     dt = time.perf_counter() - t0
     prof = env.simulator.profile
     env.simulator.profile = None
+
+    graph_line = None
+    if want_graph:
+        try:
+            learner.capture(state)
+            learner.minimize_captured()
+            sync()
+            tg0 = time.perf_counter()
+            for _ in range(args.steps):
+                learner.minimize_captured()
+            sync()
+            dtg = time.perf_counter() - tg0
+            graph_line = {"value": NUM_ENVS_PER_GPU * EP_LEN * MACRO * SUBSTEPS * args.steps / dtg, "ms_per_step": dtg / args.steps * 1e3,
+                          "note": "the same update replayed as one HIP graph (APG.capture); not the headline value"}
+        except Exception as e:
+            graph_line = {"error": f"{type(e).__name__}: {e}"}
 
     # forward-only rate (BASELINE config 2), untimed region of the main metric
     with torch.no_grad():
@@ -1022,6 +1044,8 @@ def main():
                                  "about this kernel -- see `issue` (instruction issue on the busy CUs) and `saturation`",
                          "issue": issue_roof(kname, k_ms[dom], 8 * NUM_ENVS_PER_GPU, NUM_ENVS_PER_GPU, MACRO * SUBSTEPS)},
         }
+        if graph_line is not None:
+            out["hip_graph"] = graph_line
         if not args.no_saturation:
             out["saturation"] = saturation_probe(env, device)
         if not args.no_cpu_baseline:
