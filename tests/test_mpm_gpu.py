@@ -951,6 +951,24 @@ def test_backward_reads_the_svd_factors_the_forward_checkpointed(forward, materi
         assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
 
 
+def test_launch_plan_reports_the_kernels_a_call_runs(monkeypatch):
+    """ud_mpm_launch_plan (for logs and bench labels): 0 = one workgroup per env; bit 0 many-workgroup path, bit 1 persistent forward,
+    bit 2 two-launch backward -- following the library's own rules and their diagnostic switches."""
+    for var in ("UD_MPM_CLUSTER", "UD_LG_FUSED_BWD", "UD_LG_LANES"):
+        monkeypatch.delenv(var, raising=False)
+    assert make_sim(5, 2).launch_plan(2) == 0                               # whip_rope's 67 particles
+    sim, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=2)               # rope at n_grid 128: solid, one primitive, four lanes
+    assert sim.launch_plan(2) == 1 | 2 | 4
+    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+    assert sim.launch_plan(2) == 1 | 4
+    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
+    assert sim.launch_plan(2) == 1
+    monkeypatch.delenv("UD_LG_FUSED_BWD")
+    sim0, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=0)              # no grid checkpoint: the backward recomputes (six kernels)
+    assert sim0.launch_plan(2) == 1
+    assert sim.launch_plan(200) == 1                                         # 200 x 798 particles: one lane per particle, neither rule applies
+
+
 def test_cluster_part_table_overflow_is_flagged(monkeypatch):
     """Parts of 32 particles (UD_MPM_CLUSTER_T=128, the default for solids) hold 512 cells: particles thrown uniformly through the
     volume touch more, the part sets status[] bit 1 and check_status raises -- loud, not a wrong step."""
