@@ -62,7 +62,7 @@ class _Step(torch.autograd.Function):
         ckpt = None
         if any(ctx.needs_input_grad):
             ckpt = torch.empty((L.ud_mpm_ckpt_bytes(sim._h, C.c_int(B)) // 4,), dtype=torch.float32, device=dev)
-        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)   # every entry is written by the call (include/unidom_hip.h)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ev = sim._prof_begin("fwd")
         _lib.check(L.ud_mpm_step_fwd(
@@ -100,7 +100,7 @@ class _Step(torch.autograd.Function):
         ox, ov, oC, oF, opp, opr = (torch.empty_like(t) for t in (gx, gv, gC, gF, gppos, gprot))
         ofr, omu, ola = (torch.empty((B,), device=dev) for _ in range(3))
         oa = torch.empty((B, 6 * sim.n_primitive), device=dev)
-        status = torch.zeros((B,), dtype=torch.int32, device=dev)
+        status = torch.empty((B,), dtype=torch.int32, device=dev)   # every entry is written by the call (include/unidom_hip.h)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         ev = sim._prof_begin("bwd")
         _lib.check(L.ud_mpm_step_bwd(
