@@ -136,10 +136,14 @@ def test_hip_matches_restatement_quality_2():
 
 
 @pytest.mark.gpu
-def test_hip_one_lane_kernels_match_restatement(monkeypatch):
-    """plb_p2g / plb_g2p come in two lane mappings (4 lanes per particle below 100 k particles per launch, 1 beyond); UD_PLB_LANES,
-    read at every step call, forces one lane per particle so that mapping meets the restatement too."""
-    monkeypatch.setenv("UD_PLB_LANES", "1")
+@pytest.mark.parametrize("lanes", ["1", "4"])
+def test_hip_other_lane_mappings_match_restatement(lanes, monkeypatch):
+    """The particle kernels come in three lane mappings: 8 lanes per particle up to 16 k particles per launch (what the tests' sizes get
+    by default), 4 below 100 k, 1 beyond; UD_PLB_LANES, read at every step call, puts the other two in front of the restatement too.
+    UD_PLB_FUSED=0 does the same for the three-launch substep (p2g, grid, g2p) behind the fused one."""
+    monkeypatch.setenv("UD_PLB_LANES", lanes)
+    test_hip_matches_restatement_full_torus_state()
+    monkeypatch.setenv("UD_PLB_FUSED", "0")
     test_hip_matches_restatement_full_torus_state()
 
 
@@ -391,11 +395,37 @@ def test_hip_losses_match_torch_twin(soft_contact):
 
 
 @pytest.mark.gpu
-def test_hip_step_adjoint_one_lane_kernels(monkeypatch):
-    """The adjoint kernels have the forward's two lane mappings (4 lanes per particle below 100 k particles per launch, 1
-    beyond); UD_PLB_LANES=1 puts the one-lane instantiations in front of the twin too."""
-    monkeypatch.setenv("UD_PLB_LANES", "1")
+@pytest.mark.parametrize("lanes", ["1", "4"])
+def test_hip_step_adjoint_other_lane_mappings(lanes, monkeypatch):
+    """The adjoint kernels have the forward's lane mappings (8 / 4 / 1 lanes per particle by launch size); UD_PLB_LANES puts the
+    instantiations the tests' sizes do not get by default in front of the twin too."""
+    monkeypatch.setenv("UD_PLB_LANES", lanes)
     test_hip_step_adjoint_matches_torch_twin(True)
+
+
+@pytest.mark.gpu
+def test_hip_spatial_order_is_reused_and_still_valid_after_the_state_changes(monkeypatch):
+    """The spatial order is computed on the first call and every eighth after it (UD_PLB_SORT_EVERY); in between a call runs on
+    the previous order -- any permutation is valid, only its locality ages.  A handle that sorted for one state and is then given a
+    completely different one (the body mirrored and shuffled) still matches the restatement."""
+    from oracle.pyoracle import PlbOracle
+    from unidom_amd.engine.plb_simulator import PlbSimulator
+    import torch
+    sim = PlbSimulator(batch_size=2)
+    st = sim.reset()
+    act = torch.tensor([[0.3, -0.2, 0.1]] * 2, dtype=torch.float64, device=sim.device)
+    s1 = sim.step(st, act)                                  # sorts for this state
+    rng = np.random.default_rng(5)
+    perm = torch.tensor(rng.permutation(sim.n_particles), device=sim.device)
+    x2 = st.x[:, perm].clone()
+    x2[..., 0] = 1.0 - x2[..., 0]                           # elsewhere in the grid, in another particle order
+    st2 = st._replace(x=x2)
+    got = sim.step(st2, act)                                # reuses the order computed for `st`
+    monkeypatch.setenv("UD_PLB_SORT_EVERY", "1")
+    ref = sim.step(st2, act)                                # sorts again
+    for a, b, name in ((got.x, ref.x, "x"), (got.v, ref.v, "v"), (got.C, ref.C, "C"), (got.F, ref.F, "F")):
+        assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-9, name
+    assert torch.isfinite(s1.x).all()
 
 
 @pytest.mark.gpu
