@@ -951,6 +951,30 @@ def test_backward_reads_the_svd_factors_the_forward_checkpointed(forward, materi
         assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
 
 
+@pytest.mark.parametrize("lanes", ["4", "1"])
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
+def test_multi_kernel_forward_two_three_and_four_launches_per_substep(lanes, grid_ckpt_cells, multi_kernel_path, monkeypatch):
+    """The multi-kernel forward runs two launches per substep: lg_grid (which also retires the previous substep's cells in the other
+    (m, mv) grid and clears its own list's bits) and lg_g2p_p2g (g2p of substep f, then the p2g pass of f + 1 with the state in
+    registers); UD_LG_FUSED_FWD=0 keeps p2g / grid / g2p apart, UD_LG_CLEAR_LAUNCH=1 is the four-launch substep of rounds 1-2 with
+    lg_clear_fk in front.  Same arithmetic per particle and cell (only the atomics' order differs), with and without the grid
+    checkpoint, four lanes per particle and one; the modes alternate on ONE handle, each followed by its backward, so every mode must
+    leave grids, bitmap and counters the way the others (and both backwards) expect them."""
+    monkeypatch.setenv("UD_LG_LANES", lanes)
+    sim, st, g, N = _scaled_case(5, 7, B=3, grid_ckpt_cells=grid_ckpt_cells)
+    runs = {}
+    for name, env in (("four", {"UD_LG_CLEAR_LAUNCH": "1"}), ("two", {}), ("three", {"UD_LG_FUSED_FWD": "0"}), ("two again", {}), ("four again", {"UD_LG_CLEAR_LAUNCH": "1"})):
+        for k in ("UD_LG_CLEAR_LAUNCH", "UD_LG_FUSED_FWD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs[name] = run_hip(sim, st, g=g, clip=True)
+    ref = runs["four"]
+    for name, r in runs.items():
+        for key in ("x", "v", "C", "F", "J", "gx", "gv", "gC", "gF", "gppos", "gaction"):
+            assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (name, key, _rel(r[key], ref[key]))
+
+
 def test_launch_plan_reports_the_kernels_a_call_runs(monkeypatch):
     """ud_mpm_launch_plan (for logs and bench labels): 0 = one workgroup per env; bit 0 many-workgroup path, bit 1 persistent forward,
     bit 2 two-launch backward -- following the library's own rules and their diagnostic switches."""

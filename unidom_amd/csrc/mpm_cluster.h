@@ -261,6 +261,10 @@ __device__ __forceinline__ void clm_grid_op(const LargeArgs& a, int b, int f, in
 // substep f reads them -- exactly what lg_clear_fk's per-substep update gives it.  One block per (env, primitive).
 __global__ void __launch_bounds__(64) lg_fk_all(LargeArgs a) {
   const int b = blockIdx.x + a.b0, ip = blockIdx.y, S = a.c.steps, tid = threadIdx.x;
+  if (a.ls3 && ip == 0 && tid >= 48 && tid < 52) {   // multi-kernel forward without a clear launch: the three list counts, the first record index
+    if (tid < 51) a.w.count[(tid - 48) * a.B + b] = 0;
+    else if (a.gck_base) gck_idx(a, b)[0] = 0;
+  }
   const long bp = (long)b * a.c.n_prim + ip;
   float* pp = a.w.ppos + bp * S * 3;
   float* pr = a.w.prot + bp * S * 4;

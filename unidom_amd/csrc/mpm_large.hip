@@ -23,11 +23,12 @@ namespace ud {
 
 struct LargeBuf {
   float4* val;      // [B][G]  (m, mvx, mvy, mvz); after the grid op (fwd): (m, vx, vy, vz)
+  float4* val2;     // [B][G]  the forward's second (m, mv) grid: odd substeps (ls3 mode: see LargeArgs)
   float4* vel;      // [B][G]  bwd: grid velocity after the grid op
   float4* gacc;     // [B][G]  bwd: cotangent of grid velocity -> (g_mv xyz, g_m)
   unsigned* bits;   // [B][W32]  one bit per cell: in the active list of the substep in flight (cleared with the list)
-  int* list;        // [2][B][cap]
-  int* count;       // [2][B]
+  int* list;        // [3][B][cap]
+  int* count;       // [3][B]
   // primitive arrays carry a primitive axis: [B][P][...], P = c.n_prim (1 in position-control mode)
   float* ppos;      // [B][P][S*3]  primitive position (evolving)
   float* prot;      // [B][P][S*4]
@@ -51,6 +52,11 @@ struct LargeArgs {
   const int* material;
   const float* hard;
   int B, f, cap;
+  // Forward without a clear launch (ls3 != 0): the (m, mv) grid alternates between val and val2 with the substep (vb), lg_grid(f) retires
+  // the cells of substep f - 1 in the OTHER buffer and clears its own list's bits beside its work, and the active lists take three
+  // slots (ls: this substep's; lprev: the one being retired; lnext: the one the next substep's p2g fills, its count reset by lg_grid).
+  // ls3 == 0 (every backward launch): one grid, two lists alternating with f, lg_clear_fk in front of every substep.
+  int ls3, vb, ls, lprev, lnext;
   int gpar;               // backward with the grid checkpoint, fused kernels: the cotangent grid of substep f is w.gacc for even f and
                           // w.val (untouched by that backward otherwise) for odd f, so that substep f - 1's scatter can run beside f's gather
   long W32;               // bitmap words per env
@@ -87,6 +93,8 @@ __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
   return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
 }
 
+__device__ __forceinline__ int lg_ls(const LargeArgs& a) { return a.ls3 ? a.ls : (a.f & 1); }
+__device__ __forceinline__ float4* lg_val(const LargeArgs& a) { return (a.ls3 && a.vb) ? a.w.val2 : a.w.val; }
 __device__ __forceinline__ float4* lg_gacc(const LargeArgs& a, int f) { return (a.gpar && (f & 1)) ? a.w.val : a.w.gacc; }
 
 // caller's index of the particle in slot p
@@ -99,7 +107,7 @@ __device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long l
   const unsigned bit = 1u << (lin & 31);
   const unsigned old = atomicOr(&a.w.bits[(long)b * a.W32 + (lin >> 5)], bit);
   if (!(old & bit)) {
-    const int cur = a.f & 1;
+    const int cur = lg_ls(a);
     const int e = atomicAdd(&a.w.count[cur * a.B + b], 1);
     if (e < a.cap) a.w.list[((long)cur * a.B + b) * a.cap + e] = key;
   }
@@ -351,22 +359,32 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 }
 
 // particle pre-pass + scatter (:233-274).  store_F: write F_out into the next history record (forward only)
+// `reg`: nullptr = the particle's state comes from the history record hist_in; else x[3], v[3], C[9] in registers (the fused forward kernel:
+// g2p of the previous substep has just produced them) and only F is read from hist_in.  Every thread of the block calls it (barriers inside).
 template <int LANES>
-__global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) {
+__device__ __forceinline__ void lg_p2g_body(const LargeArgs& a, int store_F, const float* reg) {
   constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
   const BlockTable bt = bt_make<TH>();
   const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   LG_STAMP_BEGIN
   bt_clear<TH>(bt);
-  float4* val = a.w.val + (long)b * a.G;
+  float4* val = lg_val(a) + (long)b * a.G;
   const bool live = p < c.N;
   Pre q;
   float v[3] = {0.f, 0.f, 0.f};
   q.base[0] = q.base[1] = q.base[2] = 0;
   if (live) {
     float x[3], Cm[9], F[9];
-    load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+    if (reg) {
+      const float* hi = a.hist_in + (long)b * a.hist_stride_b;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = reg[d]; v[d] = reg[3 + d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) { Cm[d] = reg[6 + d]; F[d] = hi[(15 + d) * c.Np + p]; }
+    } else {
+      load_state(a.hist_in + (long)b * a.hist_stride_b, c.Np, p, x, v, Cm, F);
+    }
     const int up = user_index(a, b, p);
     LG_STAMP(0, 0);   // table clear + state loads
     // (store_F = the caller's checkpoint is being written: the SVD factors go into this substep's record, one lane of the quad)
@@ -490,7 +508,7 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
     }
   }
   unsigned* bits = a.w.bits + (long)b * a.W32;
-  const int cur = a.f & 1;
+  const int cur = lg_ls(a);
   int* list = a.w.list + ((long)cur * a.B + b) * a.cap;
   if (win.on) {             // block-uniform.  64 rows of eight slots: wave 0 alone, no barrier
     if (threadIdx.x >= 64) return;
@@ -563,15 +581,23 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F)
   LG_STAMP(0, 6);     // list append
 }
 
+template <int LANES>
+__global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) { lg_p2g_body<LANES>(a, store_F, nullptr); }
+
 // grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
 __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, int to_vel) {
-  const int cur = a.f & 1;
+  const int cur = lg_ls(a);
+  if (a.ls3 && t < min(a.w.count[a.lprev * a.B + b], a.cap)) {      // the previous substep's cells, in the other grid: g2p has read them
+    const long lp = cell_lin(a.c, a.w.list[((long)a.lprev * a.B + b) * a.cap + t]);
+    (a.vb ? a.w.val : a.w.val2)[(long)b * a.G + lp] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   if (t >= min(a.w.count[cur * a.B + b], a.cap)) return;
   const int key = a.w.list[((long)cur * a.B + b) * a.cap + t];
   int ci, cj, ck;
   decode_cell(a.c, key, ci, cj, ck);
   const long lin = ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck;
-  const float4 mv = a.w.val[(long)b * a.G + lin];
+  if (a.ls3) a.w.bits[(long)b * a.W32 + (lin >> 5)] = 0u;            // this substep's p2g is done with the bitmap (every bit of the word is this list's)
+  const float4 mv = lg_val(a)[(long)b * a.G + lin];
   const float mvv[3] = {mv.y, mv.z, mv.w};
   float vo[3];
   if (a.c.position_control) {
@@ -596,7 +622,7 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
     grid_tail<false>(a.c, a.friction[b], ci, cj, ck, v1, vo, nullptr);
   }
   if (to_vel) a.w.vel[(long)b * a.G + lin] = make_float4(vo[0], vo[1], vo[2], 0.f);
-  else a.w.val[(long)b * a.G + lin] = make_float4(mv.x, vo[0], vo[1], vo[2]);
+  else lg_val(a)[(long)b * a.G + lin] = make_float4(mv.x, vo[0], vo[1], vo[2]);
   if (!to_vel && a.gck_base) {
     const int pos = gck_idx(a, b)[a.f] + t;
     if (pos < a.gck_budget) {
@@ -609,7 +635,24 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
   }
 }
 __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
-  const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+  const int b = blockIdx.y + a.b0;
+  int n = min(a.w.count[lg_ls(a) * a.B + b], a.cap);
+  if (a.ls3) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.w.count[a.lnext * a.B + b] = 0;                              // the list the next substep's p2g fills (nobody reads it in this launch)
+      if (a.gck_base && a.f < a.c.steps) gck_idx(a, b)[a.f + 1] = gck_idx(a, b)[a.f] + n;   // records of substep f + 1 start where these end
+    }
+    n = max(n, min(a.w.count[a.lprev * a.B + b], a.cap));
+    if (a.f >= a.c.steps) {                                           // the launch after the last substep: only the retiring
+      for (int u = 0;; ++u) {
+        const int t = (u * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (t - (int)threadIdx.x >= n) break;
+        if (t < min(a.w.count[a.lprev * a.B + b], a.cap))
+          (a.vb ? a.w.val : a.w.val2)[(long)b * a.G + cell_lin(a.c, a.w.list[((long)a.lprev * a.B + b) * a.cap + t])] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      return;
+    }
+  }
   for (int u = 0;; ++u) {
     const int base = (u * gridDim.x + blockIdx.x) * 256;
     if (base >= n) break;
@@ -637,7 +680,7 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
     fx[d] = f;
     w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
   }
-  const float4* val = a.w.val + (long)b * a.G;
+  const float4* val = lg_val(a) + (long)b * a.G;
   float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (LANES == 1) {   // nine (i, j) columns, the three k cells of a column (neighbours in memory) in flight together -- see lg_g2p_adj
 #pragma unroll 1
@@ -697,6 +740,103 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
     const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
     atomicAdd(&a.w.trq[(long)b * c.steps + a.f], (up == 0) ? r0 : ((up == 1) ? r1 : r2));
   }
+}
+
+// Forward, ls3 mode: g2p of substep f and -- the particle's new x, v, C in registers -- the p2g pass of substep f + 1 in ONE launch
+// (hist_out2: where that pass stores F of state f + 2).  The pass fills the other (m, mv) grid and the list slot lnext, both made
+// ready by lg_grid(f); its bitmap is clean because lg_grid(f) cleared the bits of substep f's list.
+template <int LANES>
+__global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_p2g(LargeArgs a, float* hist_out2) {
+  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const MpmConst& c = a.c;
+  float reg[15];
+#pragma unroll
+  for (int d = 0; d < 15; ++d) reg[d] = 0.f;
+  if (p < c.N) {   // whole quads together
+    const float* hi = a.hist_in + (long)b * a.hist_stride_b;
+    float* ho = a.hist_out + (long)b * a.hist_stride_b;
+    float x[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = hi[d * c.Np + p];
+    int base[3];
+    float fx[3], w[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      base[d] = (int)(x[d] * c.inv_dx - 0.5f);
+      const float f = x[d] * c.inv_dx - (float)base[d];
+      fx[d] = f;
+      w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+    }
+    const float4* val = lg_val(a) + (long)b * a.G;
+    float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (LANES == 1) {
+#pragma unroll 1
+      for (int col = 0; col < 9; ++col) {
+        const int i = col / 3, j = col - 3 * i;
+        const float wij = sel3(w, 0, i) * sel3(w, 1, j);
+        float4 g4[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g4[k] = val[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float weight = wij * w[k * 3 + 2];
+          const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+          const float g[3] = {g4[k].y, g4[k].z, g4[k].w};
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            nv[r] += weight * g[r];
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+          }
+        }
+      }
+    } else {
+      float4 g7[7];
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int cidx = min(qi + 4 * t, 26);
+        g7[t] = val[cell_lin(c, cell_gather(c, base[0] + cidx / 9, base[1] + (cidx / 3) % 3, base[2] + cidx % 3))];
+      }
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const int cidx = qi + 4 * t;
+        if (cidx >= 27) break;
+        const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+        const float weight = sel3(w, 0, i) * sel3(w, 1, j) * sel3(w, 2, k);
+        const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+        const float g[3] = {g7[t].y, g7[t].z, g7[t].w};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          nv[r] += weight * g[r];
+#pragma unroll
+          for (int s2 = 0; s2 < 3; ++s2) nC[r * 3 + s2] += 4.f * weight * (g[r] * dp[s2]) * c.inv_dx;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nv[d] = lg_quad_sum<LANES>(nv[d]);     // every lane of the quad holds the sums: they all run the pre-pass
+#pragma unroll
+    for (int d = 0; d < 9; ++d) nC[d] = lg_quad_sum<LANES>(nC[d]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { reg[d] = x[d] + c.dt * nv[d]; reg[3 + d] = nv[d]; }
+#pragma unroll
+    for (int d = 0; d < 9; ++d) reg[6 + d] = nC[d];
+    if (qi == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { ho[d * c.Np + p] = reg[d]; ho[(3 + d) * c.Np + p] = nv[d]; }
+#pragma unroll
+      for (int d = 0; d < 9; ++d) ho[(6 + d) * c.Np + p] = nC[d];
+      const int up = user_index(a, b, p);
+      if (up < 3) {   // Q6, as lg_g2p
+        const float r0 = nC[0] + nC[1] + nC[2], r1 = nC[3] + nC[4] + nC[5], r2 = nC[6] + nC[7] + nC[8];
+        atomicAdd(&a.w.trq[(long)b * c.steps + a.f], (up == 0) ? r0 : ((up == 1) ? r1 : r2));
+      }
+    }
+  }
+  LargeArgs n = a;                    // the p2g pass of substep f + 1
+  n.f = a.f + 1; n.vb = a.vb ^ 1; n.ls = a.lnext;
+  n.hist_in = a.hist_out; n.hist_out = hist_out2;
+  lg_p2g_body<LANES>(n, 1, reg);
 }
 
 // Spatial order for bodies whose particles arrive in no particular order (the uniformly sampled liquid of pour_water: the
@@ -1914,6 +2054,8 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   // dynamic LDS of the staging kernels (set explicitly so that a table above the 64 KB default keeps working)
   (void)hipFuncSetAttribute((const void*)lg_p2g<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)lg_g2p_p2g<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
+  (void)hipFuncSetAttribute((const void*)lg_g2p_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_sort, hipFuncAttributeMaxDynamicSharedMemorySize, LG_SORT_MAX * 8);
@@ -1988,8 +2130,8 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t BP = (size_t)B * c.n_prim;   // rows of the primitive arrays
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_val = take((size_t)B * G * 16), o_vel = take((size_t)B * G * 16), o_gacc = take((size_t)B * G * 16);
-  const size_t o_bits = take((size_t)B * L->W32 * 4), o_list = take((size_t)2 * B * L->cap * 4), o_count = take((size_t)2 * B * 4);
+  const size_t o_val = take((size_t)B * G * 16), o_val2 = take((size_t)B * G * 16), o_vel = take((size_t)B * G * 16), o_gacc = take((size_t)B * G * 16);
+  const size_t o_bits = take((size_t)B * L->W32 * 4), o_list = take((size_t)3 * B * L->cap * 4), o_count = take((size_t)3 * B * 4);
   const size_t o_ppos = take(BP * S * 3 * 4), o_prot = take(BP * S * 4 * 4), o_ppin = take(BP * S * 3 * 4);
   const size_t o_trq = take((size_t)B * S * 4), o_gppos = take(BP * S * 3 * 4), o_gpv = take(BP * S * 3 * 4);
   const size_t o_acc = take((size_t)B * 4 * 4), o_pscr = take((size_t)B * c.Np * 3 * 4);
@@ -2001,7 +2143,7 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, bitmap and counters start at zero
   if (e != hipSuccess) { set_error("ud_mpm (large path): memset failed"); return UD_ERR_HIP; }
   char* base = (char*)L->arena;
-  L->w.val = (float4*)(base + o_val); L->w.vel = (float4*)(base + o_vel); L->w.gacc = (float4*)(base + o_gacc);
+  L->w.val = (float4*)(base + o_val); L->w.val2 = (float4*)(base + o_val2); L->w.vel = (float4*)(base + o_vel); L->w.gacc = (float4*)(base + o_gacc);
   L->w.bits = (unsigned*)(base + o_bits); L->w.list = (int*)(base + o_list); L->w.count = (int*)(base + o_count);
   L->w.ppos = (float*)(base + o_ppos); L->w.prot = (float*)(base + o_prot); L->w.ppin = (float*)(base + o_ppin);
   L->w.trq = (float*)(base + o_trq); L->w.gppos = (float*)(base + o_gppos); L->w.gpv = (float*)(base + o_gpv);
@@ -2019,6 +2161,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.cap = L->cap; a.G = L->G; a.W32 = L->W32;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr; a.gpar = 0;
+  a.svd_rows = 0; a.ls3 = 0; a.vb = 0; a.ls = 0; a.lprev = 0; a.lnext = 0;
   a.perm = nullptr; a.perm_stride = 0;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
@@ -2223,22 +2366,49 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     if (sort) hipLaunchKernelGGL(lg_sort, dim3(grp[g].Bg), dim3(1024), (size_t)npow2 * 8, grp[g].s, c, a.b0, x, perm, perm_stride, npow2);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
   }
+  // Two launches per substep: the grid op (which also retires the previous substep's cells and its own list's bits: no clear launch)
+  // and ONE particle launch, g2p(f) -> p2g(f + 1) (lg_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it -- the (m, mv) grid alternates between two arrays, the active lists between three (LargeArgs, ls3); forward
+  // kinematics of the whole step once (lg_fk_all).  UD_LG_CLEAR_LAUNCH=1 (diagnostic, read per call): the four-launch substep with
+  // lg_clear_fk in front.
+  const char* cle = getenv("UD_LG_CLEAR_LAUNCH");
+  const bool ls3 = !(cle && cle[0] == '1');
+  const char* fze = getenv("UD_LG_FUSED_FWD");          // diagnostic: 0 = p2g, grid op, g2p as three launches (ls3 only)
+  const bool fuse = ls3 && !(fze && fze[0] == '0');
+  if (ls3)
+    for (int g = 0; g < G; ++g) {
+      a.b0 = grp[g].b0; a.f = 0; a.ls3 = 1;
+      hipLaunchKernelGGL(lg_fk_all, dim3(grp[g].Bg, c.n_prim), dim3(64), 0, grp[g].s, a);
+    }
   for (int f = 0; f <= S; ++f) {
     a.f = f;
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
+    a.ls3 = ls3 ? 1 : 0; a.vb = f & 1; a.ls = f % 3; a.lprev = (f + 2) % 3; a.lnext = (f + 1) % 3;
     for (int g = 0; g < G; ++g) {
       const int Bg = grp[g].Bg;
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
       const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      if (f == S) { hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 0); continue; }   // restore the all-zero grid invariant
-      hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 1, 0);
-      if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
+      if (ls3) {
+        if (f == S) { hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0); continue; }   // retires the last substep's cells: both grids all-zero again
+      } else {
+        if (f == S) { hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 0); continue; }   // restore the all-zero grid invariant
+        hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 1, 0);
+      }
+      // ls3: the p2g pass of substep f >= 1 rode behind g2p(f - 1) in lg_g2p_p2g -- two launches per substep
+      if (!fuse || f == 0) {
+        if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
+      }
       hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0);
-      if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, s, a);
+      if (fuse && f + 1 < S) {
+        float* ho2 = hist + (ckpt ? (long)(f + 2) * rec : (long)(f & 1) * rec);
+        if (lanes == 4) hipLaunchKernelGGL(lg_g2p_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, ho2); else hipLaunchKernelGGL(lg_g2p_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, ho2);
+      } else {
+        if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, s, a);
+      }
     }
   }
+  a.ls3 = 0;
   a.f = S;
   const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
   float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
