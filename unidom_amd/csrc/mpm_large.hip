@@ -2,9 +2,12 @@
 // n_grid 128 / 256 -> N = 798 / 6675): many workgroups per env, the `res` grid dense in HBM, a handful of small
 // kernels per substep.  Same arithmetic (shared device functions, mpm_device.h) and the same C ABI as mpm.hip.
 //
-// Per substep the forward runs  clear+FK -> p2g -> grid op -> g2p  and the backward either
+// Per substep the forward runs  grid op (+ retiring the previous substep's cells) -> [g2p -> p2g of the next substep] (two launches:
+// lg_grid, lg_g2p_p2g; round 3 -- rounds 1-2: clear+FK -> p2g -> grid op -> g2p, still there behind UD_LG_CLEAR_LAUNCH=1), or, for
+// solids with one primitive below the chip-filling size, ONE persistent launch per step call (mpm_cluster.h); the backward either
 // clear -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint in extra blocks)
-// or, with the grid checkpoint,  restore -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint):
+// or, with the grid checkpoint,  restore -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint), which for four lanes per
+// particle and one primitive is two launches (lg_gadj_restore, lg_padj_gadj); ud_mpm_conf.deterministic: mpm_det.hip:
 //   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells in a bitmap
 //     (one bit per cell); the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
 //     the next substep visit only touched cells (never the 32^3..128^3 dense volume the reference sweeps ~10x);
