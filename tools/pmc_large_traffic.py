@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import src_hash
 
-FWD = ("lg_clear_fk", "lg_p2g<", "lg_grid", "lg_g2p<", "lg_sort", "lg_pack", "lg_unpack", "lg_fwd_out", "lg_prim_in", "lg_fk_all", "clm_fwd_kernel")
+FWD = ("lg_clear_fk", "lg_p2g<", "lg_grid", "lg_g2p<", "lg_g2p_p2g", "lg_sort", "lg_pack", "lg_unpack", "lg_fwd_out", "lg_prim_in", "lg_fk_all", "clm_fwd_kernel")
 BWD = ("lg_restore", "lg_g2p_adj", "lg_grid_adj", "lg_p2g_adj", "lg_gadj_restore", "lg_padj_gadj", "lg_bwd_in", "lg_bwd_norm", "lg_bwd_out", "clm_bwd_kernel")
 rows = list(csv.DictReader(open(sys.argv[1])))
 name = sys.argv[2]
