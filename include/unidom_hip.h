@@ -175,7 +175,7 @@ typedef struct {
                                 IEEE arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same
                                 inputs return the same bits, and x, v, C, F equal the CPU build of the same source bit for bit
                                 (tests/test_mpm_det.py).  A test mode: one thread per touched cell walks all particles -- 13x the
-                                default forward at 67 particles, 336x at 798 (profiles/r03f_det_cost.txt).  Position control with one box primitive only
+                                default forward at 67 particles, 332x at 798 (profiles/r03g_det_cost.txt).  Position control with one box primitive only
                                 (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the backward is
                                 the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
 } ud_mpm_conf;
