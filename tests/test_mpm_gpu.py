@@ -910,24 +910,24 @@ def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkey
 
 @pytest.mark.parametrize("S", [1, 2, 5, 8])
 @pytest.mark.parametrize("forward", ["cluster", "multi_kernel"])
-def test_two_launch_backward_is_the_four_kernel_backward(S, forward, monkeypatch):
-    """With the grid checkpoint and four lanes per particle the backward runs two launches per reverse substep (lg_gadj_restore,
-    lg_padj_gadj: the cotangent grids of odd and even substeps in two arrays); UD_LG_FUSED_BWD=0 keeps the four-kernel sequence.
-    Same arithmetic per particle and per cell -- the float atomics' order is the only difference -- for odd and even numbers of
-    substeps, a single one included, behind either forward.  The third step on the same handle recomputes the grid (clip bit 1
-    through an overflowing pool is test_cluster_forward_grid_checkpoint_overflow...; here grid_ckpt_cells = 0 on a second handle)
-    and must see all-zero grids, so the two-launch sequence has cleaned both of its cotangent arrays."""
+def test_two_and_three_launch_backwards_are_the_four_kernel_backward(S, forward, monkeypatch):
+    """With the grid checkpoint the backward runs two launches per reverse substep where four lanes work on a particle and one primitive
+    touches the grid (lg_gadj_restore, lg_padj_gadj), three elsewhere (lg_gadj_restore, lg_p2g_adj, lg_g2p_adj) -- the cotangent grids
+    of odd and even substeps in two arrays; UD_LG_FUSED_BWD=0 / UD_LG_BWD3=0 step down to the three-launch form and to the
+    four-kernel sequence of rounds 1-2.  Same arithmetic per particle and per cell -- the float atomics' order is the only
+    difference -- for odd and even numbers of substeps, a single one included, behind either forward; the forms alternate on ONE handle,
+    so each must hand both cotangent arrays back all-zero."""
     monkeypatch.setenv("UD_MPM_CLUSTER", "1" if forward == "cluster" else "0")
     sim, st, g, N = _scaled_case(S, 4, B=3, grid_ckpt_cells=6)
-    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
-    ref = run_hip(sim, st, g=g, clip=True)
-    monkeypatch.setenv("UD_LG_FUSED_BWD", "1")
-    got = run_hip(sim, st, g=g, clip=True)
-    again = run_hip(sim, st, g=g, clip=True)
-    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
-    after = run_hip(sim, st, g=g, clip=True)
+    runs = []
+    for name, fused, three in (("four-kernel", "0", "0"), ("two-launch", "1", "1"), ("three-launch", "0", "1"), ("two-launch again", "1", "1"),
+                               ("four-kernel after", "0", "0"), ("three-launch after", "0", "1")):
+        monkeypatch.setenv("UD_LG_FUSED_BWD", fused)
+        monkeypatch.setenv("UD_LG_BWD3", three)
+        runs.append((name, run_hip(sim, st, g=g, clip=True)))
+    ref = runs[0][1]
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gfriction", "gmu", "glamda"):
-        for name, r in (("two-launch", got), ("two-launch again", again), ("four-kernel after", after)):
+        for name, r in runs[1:]:
             assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (key, name, _rel(r[key], ref[key]))
 
 

@@ -2483,6 +2483,8 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   // shape_rope (soft contact: the grid-op adjoint is the long launch and overlaps the other groups' particle launches)
   // 6.08 / 6.00 in one, 5.98 / 5.65 in two, 7.24 / 5.25 in four; pour_water (two container primitives) 1.35 / 1.61: kept on four.
   const bool fused = gck && lg_two_launch_bwd(c, lanes);
+  const char* b3 = getenv("UD_LG_BWD3");                          // 1 = three launches where the two-launch form does not apply (measured slower: below)
+  const bool three = !fused && b3 && b3[0] == '1';
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp, fused ? (c.position_control ? 1 : 4) : 0);
   for (int g = 0; g < G; ++g) {
@@ -2514,6 +2516,36 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       // the grid-op adjoint of substep 0) -- both grids all-zero again
       a.f = -1;
       hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
+    }
+  } else if (gck && three) {
+    // Three launches per reverse substep where the two-launch form does not apply (one lane per particle, several primitives): the
+    // restore of substep f - 1 rides beside the grid-op adjoint of f (lg_gadj_restore), the two particle kernels stay apart; the
+    // cotangent grids alternate by parity exactly as above.  Correct (tests) and NOT the default: backward ms per step, four / three
+    // launches: pour_water 1.23 / 1.59, pour_soup 3.34 / 3.46, rope at n_grid 256 5.38 / 6.44 (32 envs, 1x MI355X) -- the restore is
+    // cheaper as a launch of its own than as a block range of the grid-op adjoint's register-heavy kernel.
+    a.gpar = 1;
+    for (int g = 0; g < G; ++g) {
+      const int Bg = grp[g].Bg;
+      hipStream_t s = grp[g].s;
+      a.b0 = grp[g].b0;
+      const int nb = lg_cell_blocks(L->cap);
+      const dim3 gc2(2 * nb, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
+      const dim3 gqf(gq.x + c.n_prim, Bg);
+      auto g2p_adj = [&](int f) {
+        a.f = f; a.hist_in = ckpt + (long)f * rec;
+        if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
+      };
+      a.f = S; a.hist_in = ckpt;
+      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);          // restore of substep S - 1
+      g2p_adj(S - 1);
+      for (int f = S - 1; f >= 0; --f) {
+        a.f = f; a.hist_in = ckpt + (long)f * rec;
+        hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);        // grid-op adjoint of f || restore of f - 1
+        if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gqf, blk, 0, s, a, (int)gq.x); else hipLaunchKernelGGL(lg_p2g_adj<1>, gqf, blk, 0, s, a, (int)gq.x);
+        if (f > 0) g2p_adj(f - 1);
+      }
+      a.f = -1;
+      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);          // zeroes substep 0's cotangent cells: both grids all-zero again
     }
   } else
   for (int f = S - 1; f >= -1; --f) {
