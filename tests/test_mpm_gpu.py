@@ -573,15 +573,15 @@ def test_collide_zero_rotation_action_laundered(demo):
     assert (lau["gaction"][0, 3:] == 0).all() and np.isfinite(lau["gaction"]).all()
 
 
-def test_collide_shape_rope_geometry_fwd_bwd(large_path):
-    """shape_rope's sizes (582 plastic particles, 64x6x64 grid, dt 0.5e-4, ground friction 0.9; 4 lanes per particle on
-    the many-workgroup path): a pusher overlapping the rope -- forward vs the f32 oracle, adjoint vs the f64 oracle."""
-    from oracle.pyoracle import MpmOracle
+def _shape_rope_case(S, B):
+    """shape_rope's sizes (shape_rope_env.py: 582 plastic particles seeded like the goal lattice, 64x6x64 grid, dt 0.5e-4, ground
+    friction 0.9, soft contact) with a pusher overlapping the rope; env b > 1 repeats env b % 2's geometry moved by a fraction of a
+    cell, with its own v / C / F / action."""
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
     from unidom_amd.envs.shape_rope_env import DefaultConf
     conf = DefaultConf()
-    conf.steps = S = 4
-    B, N = 2, 582
+    conf.steps = S
+    N = 582
     sim = SimpleMPMSimulator(conf, B, use_position_control=False)
     sim.n_particles, sim.material, sim.h = N, np.full(N, 2, np.int32), np.ones(N, np.float32)
     assert sim.grid_ckpt_cells == conf.grid_ckpt_cells == 2          # the env runs with the grid checkpoint
@@ -590,20 +590,37 @@ def test_collide_shape_rope_geometry_fwd_bwd(large_path):
     x0 = np.load(conf.goal_path).astype(np.float32)
     x = np.stack([x0, x0 + np.float32(0.003)]).astype(np.float32)
     x[..., 1] = x0[:, 1]
-    ppos = np.zeros((B, S, 3), np.float32)
+    ppos = np.zeros((2, S, 3), np.float32)
     ppos[:, 0] = x[:, 291] + np.array([[0.002, 0.0, -0.012], [-0.003, 0.001, 0.011]], np.float32)
-    prot = np.zeros((B, S, 4), np.float32)
+    prot = np.zeros((2, S, 4), np.float32)
     q = np.array([[0.95, 0.05, 0.3, -0.02], [1, 0, 0, 0]], np.float32)
     prot[:] = (q / np.linalg.norm(q, axis=1, keepdims=True))[:, None]
+    action = np.array([[0.002, 0, 0.012, 0.2, -0.1, 0.3], [-0.004, 0, -0.01, 0.1, 0.2, -0.2]], np.float32)
+    if B > 2:
+        rep = lambda a: np.ascontiguousarray(np.concatenate([a] * ((B + 1) // 2), 0)[:B])
+        x, ppos, prot, action = rep(x), rep(ppos), rep(prot), rep(action)
+        off = np.zeros((B, 1, 3), np.float32)
+        off[2:, 0, 0] = rng.uniform(-0.004, 0.004, size=B - 2)      # up to half a cell (dx = 1/128) in x and z: other base cells,
+        off[2:, 0, 2] = rng.uniform(-0.004, 0.004, size=B - 2)      # other weights, the same contact geometry
+        x = x + off
+        ppos[:, :1] += off
+        action[2:] *= rng.uniform(0.5, 1.5, size=(B - 2, 6)).astype(np.float32)
     mu0, la0 = conf.E / (2 * (1 + conf.nu)), conf.E * conf.nu / ((1 + conf.nu) * (1 - 2 * conf.nu))
     st = dict(x=x, v=rng.normal(size=(B, N, 3)).astype(np.float32) * 0.05, C=rng.normal(size=(B, N, 3, 3)).astype(np.float32) * 2,
               F=(np.eye(3) + rng.normal(size=(B, N, 3, 3)) * 0.05).astype(np.float32), J=np.ones((B, N), np.float32), ppos=ppos, prot=prot,
               psize=np.tile(np.array([0.015, 0.06, 0.015], np.float32), (B, 1)), friction=np.full(B, 0.9, np.float32),
-              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32),
-              action=np.array([[0.002, 0, 0.012, 0.2, -0.1, 0.3], [-0.004, 0, -0.01, 0.1, 0.2, -0.2]], np.float32))
+              mu=np.full(B, mu0, np.float32), lamda=np.full(B, la0, np.float32), action=action)
     g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)) * 1e-3, gC=rng.normal(size=(B, N, 3, 3)) * 1e-6,
              gF=rng.normal(size=(B, N, 3, 3)) * 1e-2, gppos=rng.normal(size=(B, S, 3)), gprot=rng.normal(size=(B, S, 4)))
-    g = {k: v.astype(np.float32) for k, v in g.items()}
+    return sim, conf, st, {k: v.astype(np.float32) for k, v in g.items()}, N
+
+
+def test_collide_shape_rope_geometry_fwd_bwd(large_path):
+    """shape_rope's sizes (582 plastic particles, 64x6x64 grid, dt 0.5e-4, ground friction 0.9; 4 lanes per particle on
+    the many-workgroup path): a pusher overlapping the rope -- forward vs the f32 oracle, adjoint vs the f64 oracle."""
+    from oracle.pyoracle import MpmOracle
+    S, B = 4, 2
+    sim, conf, st, g, N = _shape_rope_case(S, B)
     orc = MpmOracle(N, n_grid=128, res=(64, 6, 64), steps=S, dt=conf.dt, position_control=False, material=np.full(N, 2))
     of = orc.step_fwd(st, nthreads=2)
     ob = orc.step_bwd({k: v.astype(np.float64) for k, v in st.items()}, {k: v.astype(np.float64) for k, v in g.items()},
@@ -615,6 +632,76 @@ def test_collide_shape_rope_geometry_fwd_bwd(large_path):
         assert np.isfinite(oh[key]).all(), key
         assert _rel(oh[key], ob[key]) < 5e-3, (key, _rel(oh[key], ob[key]))
     assert np.abs(ob["gprot"]).max() > 0 and np.abs(ob["gaction"][:, 3:]).min() > 0
+
+
+def _no_path_override():
+    return not any(k in os.environ for k in ("UD_MPM_CLUSTER", "UD_MPM_CLUSTER_T", "UD_MPM_CLUSTER_BWD", "UD_MPM_CLUSTER_ENVS",
+                                             "UD_LG_LANES", "UD_LG_GROUPS", "UD_LG_FUSED_FWD", "UD_LG_FUSED_BWD", "UD_LG_BWD3"))
+
+
+def test_bench_launch_shape_rope_n_grid_128_32_envs_default_kernels_match_oracle():
+    """The launch bench.py --workload whip_rope --n-grid 128 times: 32 envs x 798 particles in ONE step call, no switch set -- the
+    persistent cluster forward (32 envs x 25 parts of 32 particles = 800 workgroups that must all be resident and meet at the
+    inter-workgroup barrier every substep: what a 2-env launch cannot exercise) writing the grid checkpoint, and the two-launch
+    backward restoring from it.  Every env has its own v / C / F and a position moved by a fraction of a cell; two of them are
+    followed by the CPU oracle (forward f32, adjoint f64) over 5 substeps; check_status() clean."""
+    from oracle.pyoracle import MpmOracle
+    assert _no_path_override()
+    S, B, pick = 5, 32, [5, 30]
+    sim, st, g, N = _scaled_case(S, 17, B=B, grid_ckpt_cells=2)       # bench.py's --grid-ckpt default
+    assert N == 798 and sim.launch_plan(B) == 7                         # many-workgroup, persistent forward, two-launch backward
+    rng = np.random.default_rng(3)
+    off = np.zeros((B, 1, 3), np.float32)
+    off[:, 0, 0], off[:, 0, 2] = rng.uniform(-0.004, 0.004, size=B), rng.uniform(-0.004, 0.004, size=B)
+    st["x"] = st["x"] + off
+    st["ppos"][:, :1] += off
+    st["action"] = (st["action"] * rng.uniform(-1.5, 1.5, size=(B, 6))).astype(np.float32)
+    sub = lambda d: {k: np.ascontiguousarray(v[pick]) for k, v in d.items()}
+    orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
+    of = orc.step_fwd(sub(st), nthreads=2)
+    assert all(np.isfinite(of[k]).all() for k in ("x", "v", "C", "F"))
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in sub(st).items()},
+                      {k: v.astype(np.float64) for k, v in sub(g).items()}, clip=True, nthreads=2)
+    oh = run_hip(sim, st, g=g, clip=True)
+    sim.check_status()
+    assert sim.grid_ckpt_overflows == 0
+    assert _rel(oh["x"][pick], of["x"]) < 5e-6 and _rel(oh["v"][pick], of["v"]) < 1e-4     # north_star: 1e-4 relative
+    assert _rel(oh["C"][pick], of["C"]) < 1e-3 and _rel(oh["F"][pick], of["F"]) < 5e-5
+    for key in ("ppos", "prot", "pv", "pw"):
+        np.testing.assert_allclose(oh[key][pick], of[key], rtol=0, atol=1e-7)
+    for key in ("x", "v", "C", "F", "gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert np.isfinite(oh[key]).all(), key
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+        assert _rel(oh[key][pick], ob[key]) < 5e-3, (key, _rel(oh[key][pick], ob[key]))   # tolerance of the 2-env test
+    for key in ("gfriction", "gmu", "glamda"):
+        assert _rel(oh[key].reshape(-1)[pick], ob[key]) < 2e-2, (key, oh[key].reshape(-1)[pick], ob[key])
+    # the same handle again: rotating grids, owner stamps and barrier words must be back in their initial state
+    oh2 = run_hip(sim, st)
+    assert _rel(oh2["x"][pick], of["x"]) < 5e-6 and _rel(oh2["v"][pick], of["v"]) < 1e-4
+
+
+def test_bench_launch_shape_shape_rope_32_envs_default_kernels_match_oracle():
+    """The launch bench.py --workload shape_rope times: 32 envs x 582 plastic particles, soft contact, grid checkpoint 2, no switch
+    set -- cluster forward (32 x 19 parts) + two-launch backward in four env groups.  Two envs followed by the CPU oracle."""
+    from oracle.pyoracle import MpmOracle
+    assert _no_path_override()
+    S, B, pick = 5, 32, [3, 28]
+    sim, conf, st, g, N = _shape_rope_case(S, B)
+    assert sim.launch_plan(B) == 7
+    sub = lambda d: {k: np.ascontiguousarray(v[pick]) for k, v in d.items()}
+    orc = MpmOracle(N, n_grid=128, res=(64, 6, 64), steps=S, dt=conf.dt, position_control=False, material=np.full(N, 2))
+    of = orc.step_fwd(sub(st), nthreads=2)
+    ob = orc.step_bwd({k: v.astype(np.float64) for k, v in sub(st).items()}, {k: v.astype(np.float64) for k, v in sub(g).items()},
+                      clip=False, nthreads=2)
+    oh = run_hip_collide(sim, st, g, clip=False)
+    sim.check_status()
+    assert sim.grid_ckpt_overflows == 0
+    assert _rel(oh["x"][pick], of["x"]) < 5e-6 and _rel(oh["v"][pick], of["v"]) < 1e-4
+    assert _rel(oh["C"][pick], of["C"]) < 1e-3 and _rel(oh["F"][pick], of["F"]) < 5e-5
+    for key in ("x", "v", "C", "F", "gx", "gv", "gC", "gF", "gppos", "gprot"):
+        assert np.isfinite(oh[key]).all(), key
+    for key in ("gx", "gv", "gC", "gF", "gppos", "gprot", "gaction"):
+        assert _rel(oh[key][pick], ob[key]) < 5e-3, (key, _rel(oh[key][pick], ob[key]))
 
 
 @pytest.mark.parametrize("clip", [False, True])

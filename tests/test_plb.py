@@ -295,6 +295,56 @@ def test_hip_step_adjoint_matches_torch_twin(low):
 
 
 @pytest.mark.gpu
+def test_hip_step_adjoint_at_the_benched_configuration():
+    """bench.py --workload torus --plb-grad as it is measured: N = 1000, n_grid 64 (quality 1, 19 substeps per env.step), 8 envs in
+    one launch, the default lane mapping for that launch size, the grid checkpoint on (27 cells per particle) -- the body of the
+    Torus task (shape_maker.py:49-58) with sphere 0 on it (sticky contact: action and primitive-position cotangents), every env with
+    its own v / C / F, action, E, nu and yield stress.  Two of the eight envs are followed by torch.autograd through the twin over
+    the whole env.step: forward 1e-9, every leaf 1e-6 relative (the tolerances of the n_grid-32 test above)."""
+    import os
+    import torch
+    torch.set_num_threads(8)
+    assert "UD_PLB_LANES" not in os.environ
+    B, N, pick = 8, 1000, [2, 7]
+    sim = _hip_sim(N, B, quality=1.0)
+    assert (sim.n_grid, sim.substeps, sim.grid_ckpt_cells) == (64, 19, 27)
+    conf = PlbConf(quality=1.0, n_particles=N)
+    rng = np.random.default_rng(21)
+    x = torus_particles(1000)[None].repeat(B, 0) + rng.normal(size=(B, N, 3)) * 1e-4
+    v = rng.normal(size=(B, N, 3)) * 0.05
+    Cm = rng.normal(size=(B, N, 3, 3)) * 0.5
+    F = np.eye(3)[None, None] + rng.normal(size=(B, N, 3, 3)) * 0.02
+    prim = np.stack([x[:, 7], np.repeat(np.array([[0.5, 0.55, 0.5]]), B, 0)], 1)
+    soft = np.full((B, 2), 666.0)
+    # the sphere moves action / substeps / dt per substep: 0.01 per env.step is 5 m/s, the scripted rollout's order of magnitude
+    # (solver.py:299-302: 0.0015 per step); 0.5 would be 1.6 cells per substep and the forward itself blows up
+    act = rng.uniform(-0.01, 0.01, size=(B, 3)) * np.array([1.0, 0.3, 1.0])
+    E = rng.uniform(3e3, 6e3, size=B)
+    nu = rng.uniform(0.25, 0.4, size=B)
+    ys = np.array([1762.2, 30.0, 1762.2, 200.0, 1762.2, 50.0, 1762.2, 30.0])      # env 7 yields almost everywhere, env 2 hardly
+    w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
+    sub = lambda a: np.ascontiguousarray(np.asarray(a)[pick])
+    case = tuple(sub(a) for a in (x, v, Cm, F, prim, soft, act, E, nu, ys))
+    leaves, out, loss = _twin_step(conf, case, conf.ground_friction, [sub(wi) for wi in w])
+    loss.backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
+    s = sim.reset()._replace(x=hl["x"], v=hl["v"], C=hl["C"], F=hl["F"], prim_pos=hl["prim"], softness=T(soft, False), E=hl["E"],
+                             nu=hl["nu"], yield_stress=hl["ys"])
+    s1 = sim.step(s, hl["act"])
+    for o, t, name in zip(out, (s1.x, s1.v, s1.C, s1.F, s1.prim_pos), "xvCFp"):
+        assert torch.isfinite(t).all(), name
+        assert _rel(t.detach().cpu().numpy()[pick], o.detach().numpy()) < 1e-9, name
+    sim.ground_friction_grad = None
+    sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w)).backward()
+    for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
+        got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
+        assert np.isfinite(got).all(), name
+        assert _rel(got[pick], ref) < 1e-6, (name, _rel(got[pick], ref))
+    assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()[1]) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [0, 1, 2])
 def test_hip_adjoint_with_and_without_the_grid_checkpoint(K):
     """ud_plb_conf.grid_ckpt_cells: by default (27 cells per particle: every cell a substep can touch) the adjoint restores each
