@@ -88,14 +88,17 @@ def bench_selftest(args, rank, world, device):
 
     for _ in range(args.warmup):
         one()
+    sync.profile = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one()
     barrier()
-    tm = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    dt_rank = time.perf_counter() - t0
+    tm = torch.tensor([dt_rank], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ranks = rank_report(world, device, dt_rank, None, sync)
     flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
     same = torch.ones((), device=device)
     if world > 1:
@@ -110,10 +113,30 @@ def bench_selftest(args, rank, world, device):
                           "config": {"workload": "selftest (no simulator): policy gradient all-reduce + Adam"},
                           "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                           "allreduce_bytes_per_update": sync.n_params * 4 if world > 1 else 0,
-                          "replicas_identical": bool(same.item())}), flush=True)
+                          "replicas_identical": bool(same.item()), **ranks}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rank_report(world, device, dt, k_ms=None, sync=None):
+    """What makes an N-rank line explain itself (the first hardware run happens at round end, on a node this session never sees): per rank
+    the wall time of the timed region, the mean kernel time of the simulator's forward / adjoint launches (HIP events on the launch stream)
+    and the mean time of the one collective per update (events / perf_counter around dist.all_reduce in GradSync.step) -- gathered with ONE
+    all_gather after the timed region.  `value` is still units / max-over-ranks time; a spread between max and min rank time, or an
+    all-reduce time far above 3.7 MB / link bandwidth, says where a poor scaling figure comes from."""
+    if world <= 1:
+        return {}
+    ar = sync.allreduce_ms() if sync is not None else []
+    mine = torch.tensor([dt, (k_ms or {}).get("fwd", float("nan")), (k_ms or {}).get("bwd", float("nan")),
+                         float(np.mean(ar)) if ar else float("nan"), float(np.max(ar)) if ar else float("nan")], device=device, dtype=torch.float64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = torch.stack(allr).cpu().numpy()
+    fin = lambda col: [None if not np.isfinite(v) else float(v) for v in rows[:, col]]
+    return {"ranks": {"time_s": {"max": float(rows[:, 0].max()), "min": float(rows[:, 0].min()), "per_rank": fin(0)},
+                      "kernel_ms": {"fwd": fin(1), "bwd": fin(2)}, "allreduce_ms": {"mean": fin(3), "max": fin(4)},
+                      "note": "per rank, in rank order; value = units / time_s.max"}}
 
 
 def dist_info(world, allreduce_params=0):
@@ -144,6 +167,16 @@ def lg_issue(key, kernel_ms):
     return r
 
 
+def plb_issue(key, step_ms):
+    """instruction-issue roof of the PlasticineLab lines: VALU + SALU wave-instructions of every plb_* launch of one bench step (PMC pass,
+    tools/pmc_plb.sh) / the step's wall time / what 256 CUs can issue.  8 envs x 1000 particles occupy a fraction of the chip's wave slots, so
+    this fraction is small by construction; what it says is that neither HBM nor issue binds these lines -- latency of one wave's chain does."""
+    r = issue_roof(key, step_ms, None, 256, None)
+    if r:
+        r["note"] = "all plb_* launches of one bench step over the step's wall time; 256 CUs x 4 SIMDs x 0.6 G wave-instr/s"
+    return r
+
+
 def pmc_traffic(key):
     """HBM bytes per launch from the committed counter passes (profiles/pmc_traffic.json), or None when there is no
     entry or the kernel sources have changed since the passes were taken (the entry carries their hash)."""
@@ -159,36 +192,47 @@ def pmc_traffic(key):
 
 
 VALU_CLOCK_HZ = 2.4e9     # MI355X_MICROARCH.md: a SIMD issues one wave64 VALU instruction per 4 clocks -> 0.6e9 per SIMD and second at the peak clock
-# static VALU + SALU wave-instructions per lane-substep of the one-workgroup cloth kernels (tools/asm_loop_stats.py on the inner loops,
-# DESIGN.md 3.1) -- used when profiles/pmc_traffic.json holds no SQ_INSTS_* pass for the current sources
+# static VALU + SALU wave-instructions per wave-substep of the one-workgroup cloth kernels (tools/asm_loop_stats.py on the inner loops,
+# DESIGN.md 3.1) -- used ONLY when profiles/pmc_traffic.json holds no SQ_INSTS_* pass for the current sources (see issue_roof)
 STATIC_INSTR_PER_SUBSTEP = {"cloth_rollout_fwd_v2_kernel": 392, "cloth_rollout_bwd_fast_kernel": 707}
 
 
-def issue_roof(kname, kernel_ms, waves, busy_cus, substeps, static_only=False):
+def issue_roof(kname, kernel_ms, waves, busy_cus, substeps):
     """What bounds a one-workgroup-per-env kernel is instruction issue on the few CUs it occupies, not HBM: `frac` = wave-instructions
-    the launch executes per second / what the busy SIMDs can issue (busy CUs x 4 SIMDs x clock / 4).  Counts from the SQ_INSTS_VALU
-    (+ SALU: they share the issue port with VALU at 2 waves per SIMD) PMC pass when profiles/pmc_traffic.json has one
-    for the current sources, else the static per-substep count of the inner loop."""
+    the launch executes per second / what the busy SIMDs can issue (busy CUs x 4 SIMDs x clock / 4).  ONE count for every launch shape:
+    the EXECUTED VALU + SALU wave-instructions of the SQ_INSTS_* counter pass (SALU shares the issue port with VALU at 2 waves per SIMD,
+    DESIGN.md 3.1) in profiles/pmc_traffic.json, taken on the headline shape and scaled by waves of this launch / SQ_WAVES of the pass
+    (every env runs the same substeps: the count per wave does not depend on how many envs a launch holds).  Only when there is no pass
+    for the current sources: the static count of the inner loop, which also counts the blocks a wave-uniform branch skips at run time
+    (no lane on the ground, no lane grasped) and therefore overstates the executed count (707 static vs 541 executed per wave-substep in
+    the cloth adjoint) -- `source` says which one a line carries."""
     tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     src, per_launch = None, None
-    if os.path.exists(tj) and not static_only:   # the counter pass belongs to the headline launch shape
+    if os.path.exists(tj):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import src_hash
         e = json.load(open(tj)).get(kname) or {}
         if e.get("insts") and e.get("src_sha16") == src_hash.sha16(kname):
             per_launch = e["insts"].get("SQ_INSTS_VALU", 0.0) + e["insts"].get("SQ_INSTS_SALU", 0.0)
-            waves = int(e["insts"].get("SQ_WAVES", 0)) or waves
+            pass_waves = int(e["insts"].get("SQ_WAVES", 0))
             src = "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU (profiles/pmc_traffic.json)"
-    if per_launch is None and kname in STATIC_INSTR_PER_SUBSTEP:
+            if waves and pass_waves and waves != pass_waves:
+                per_launch *= waves / pass_waves
+                src += f", scaled from the pass's {pass_waves} waves to this launch's {waves}"
+            waves = waves or pass_waves
+    if per_launch is None and kname in STATIC_INSTR_PER_SUBSTEP and waves and substeps:
         per_launch = STATIC_INSTR_PER_SUBSTEP[kname] * waves * substeps
-        src = "static count of the inner loop (tools/asm_loop_stats.py) x waves x substeps"
+        src = "static count of the inner loop (tools/asm_loop_stats.py) x waves x substeps: an upper bound of the executed count"
     if per_launch is None:
         return None
     rate = per_launch / (kernel_ms * 1e-3)
     peak = busy_cus * 4 * VALU_CLOCK_HZ / 4
-    return {"bound": "valu_issue", "wave_instructions_per_launch": per_launch, "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
-            "frac": rate / peak, "busy_cus": busy_cus, "waves": waves, "source": src,
-            "note": "the binding roof of this kernel: one workgroup per env, the substeps of a launch are sequential (see roofline.note)"}
+    out = {"bound": "valu_issue", "wave_instructions_per_launch": per_launch, "achieved": rate / 1e9, "peak": peak / 1e9, "unit": "G wave-instr/s",
+           "frac": rate / peak, "busy_cus": busy_cus, "waves": waves, "source": src,
+           "note": "the binding roof of this kernel: one workgroup per env, the substeps of a launch are sequential (see roofline.note)"}
+    if waves and substeps:
+        out["per_wave_substep"] = per_launch / waves / substeps
+    return out
 
 
 def host_cores():
@@ -259,6 +303,38 @@ def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
                                     f"the box shows {os.cpu_count()} logical CPUs); more envs than the headline workload has"}}
 
 
+def cpu_baseline_tshirt(env, st, sample_envs=4, macro=4):
+    """Oracle (CPU restatement, NOT JAX-CPU) beside the fold_tshirt line: the env's own reset state (3573 particles on the 180x180
+    lattice, k = 5000, dt = 0.5e-3), `macro` of the 40 macro actions of a step_diff (a lifting sequence; the work per substep does not
+    depend on the data), forward + adjoint, OpenMP over envs.  Checker only, never the product path."""
+    pyoracle, build = _oracle_native()
+    conf = env.conf
+    mask = env.cloth_mask.cpu().numpy() if hasattr(env.cloth_mask, "cpu") else np.asarray(env.cloth_mask)
+    orc = pyoracle.ClothOracle(mask, N=int(conf.N), gravity=float(conf.gravity), damping=float(conf.damping), dt=float(conf.dt),
+                               max_v=float(conf.max_v), small_num=float(conf.small_num), substeps=SUBSTEPS)
+    npy = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy()[:sample_envs])
+    x, v = npy(st.x), npy(st.v)
+    prim = np.stack([npy(st.primitive0), npy(st.primitive1)], 1)
+    k, mu = npy(st.stiffness.float()), npy(st.mu)
+    acts = np.zeros((macro, sample_envs, 8), np.float32)
+    acts[:, :, 1] = 0.006 * 50
+    acts[:, :, 3] = 1
+    prim[:, 0, :3] = x[:, x.shape[1] // 2] + np.float32([0, 0.002, 0])
+    rng = np.random.default_rng(0)
+    g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
+    threads = min(sample_envs, host_cores())
+    t0 = time.time()
+    orc.rollout_fwd(x, v, prim, k, mu, acts, nthreads=threads)
+    t_f = time.time() - t0
+    t0 = time.time()
+    orc.rollout_bwd(x, v, prim, k, mu, acts, g[0], g[1], g[2], normalize=True, nthreads=threads)
+    t_b = time.time() - t0
+    n = sample_envs * macro * SUBSTEPS
+    return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port", "fwd_only_value": n / t_f,
+            "sample": f"CPU restatement (C++ {build}, f32, reference op order; not JAX-CPU): {sample_envs} envs x {macro} macro actions x {SUBSTEPS} substeps of the env's "
+                      f"reset state (P={x.shape[1]}), forward {t_f:.2f}s + adjoint (with its own forward recompute) {t_b:.2f}s, OpenMP over envs ({threads} threads)"}
+
+
 def saturation_probe(env, device, num_envs=1024, reps=3):
     """NOT the headline metric: the same two kernels with enough environments to fill the chip (the headline
     workload has 4 envs = 4 workgroups on 256 CUs, so its HBM fraction is fixed by the workload, not the kernel).
@@ -301,7 +377,7 @@ def saturation_probe(env, device, num_envs=1024, reps=3):
             "hbm_frac_algorithmic": {"fwd": n * BYTES_FWD / (ms["fwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "bwd": n * BYTES_BWD / (ms["bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "issue": {k: issue_roof({"fwd": "cloth_rollout_fwd_v2_kernel", "bwd": "cloth_rollout_bwd_fast_kernel"}[k], ms[k], 8 * num_envs,
-                                    min(256, num_envs), MACRO * SUBSTEPS, static_only=True) for k in ("fwd", "bwd")} if sim.mode == 0 else None}
+                                    min(256, num_envs), MACRO * SUBSTEPS) for k in ("fwd", "bwd")} if sim.mode == 0 else None}
 
 
 def touched_cells(x, n_grid=64):
@@ -361,6 +437,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             print(f"[bench] graph capture failed, eager update instead: {type(e).__name__}: {e}", file=sys.stderr)
     if not graphed:
         env.simulator.profile = {"fwd": [], "bwd": []}
+    learner.sync.profile = []
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -373,6 +450,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
     if not graphed:
         prof, env.simulator.profile = env.simulator.profile, None
     env.simulator.check_status()
+    ranks = rank_report(world, device, dt, {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}, learner.sync)
     tm = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -413,7 +491,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
                             if N <= 128 and env.simulator.n_primitive == 1 else {"issue": lg_issue(f"large_path:{name}:{dom}", k_ms[dom]) if B == 32 else None}),
                          "note": f"one workgroup per env ({min(B, 256)} of 256 CUs busy), latency bound: LDS atomics + barriers" if N <= 128 and env.simulator.n_primitive == 1
                          else f"latency / issue bound: small launches on {B} x {N} particles"},
-            **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
+            **ranks, **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -508,11 +586,12 @@ def bench_torus(args, rank, world, device):
         loss, _ = sim.compute_loss(s, target_density, target_sdf, (1.0, 1.0, 1.0), True)
         loss.sum().backward()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup):           # a warm-up step is a whole bench step in both modes (inner env.steps)
         if grad:
             one_grad()
         else:
-            st = sim.step(st, action)
+            for _ in range(inner):
+                st = sim.step(st, action)
     sync()
     t0 = time.perf_counter()
     if grad:
@@ -548,6 +627,7 @@ def bench_torus(args, rank, world, device):
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(f"plb:{'grad' if grad else 'fwd'}:ngrid{sim.n_grid}") if B == 8 else None,
                          "algorithmic_bytes_per_launch": units / world / args.steps * per_sub,
                          "launch": "one bench step: all plb_* kernels of " + f"{inner} env.steps" + (" + loss + adjoint" if grad else ""),
+                         "issue": plb_issue(f"plb:{'grad' if grad else 'fwd'}:ngrid{sim.n_grid}", dt / args.steps * 1e3) if B == 8 else None,
                          "note": "launch/latency bound: 8 envs x 1000 particles per substep"},
             **({"cpu_baseline": cpu} if cpu else {})}), flush=True)
     if world > 1:
@@ -818,9 +898,12 @@ def bench_fold_tshirt(args, rank, world, device):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("cloth_cluster_bwd_kernel" if dom == "bwd" else "cloth_cluster_fwd_kernel") if cluster and B == 4 else None,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": per_launch,
+                         "issue": issue_roof("cloth_cluster_bwd_kernel" if dom == "bwd" else "cloth_cluster_fwd_kernel", k_ms[dom], B * -(-P // 512) * 8,
+                                             min(256, B * -(-P // 512)), MACRO * SUBSTEPS) if cluster else None,
                          "note": (f"{-(-P // 512)} workgroups of 512 lanes per env (one particle per lane), halo positions / force cotangents / "
                                   "block sums exchanged through HBM every substep; 2000 sequential substeps per launch") if cluster else
-                                 "one workgroup of 1024 lanes per env, 4 particles per lane, 2000 sequential substeps per launch"}}), flush=True)
+                                 "one workgroup of 1024 lanes per env, 4 particles per lane, 2000 sequential substeps per launch"},
+            **({"cpu_baseline": cpu_baseline_tshirt(env, st, min(B, 4))} if not (args.no_cpu_baseline or world > 1) else {})}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -974,6 +1057,7 @@ def main():
     for _ in range(args.warmup):
         learner.minimize(state)
     env.simulator.profile = {"fwd": [], "bwd": []}   # HIP events around every kernel launch, on its stream
+    learner.sync.profile = []                        # ... and around the gradient all-reduce (N > 1)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -982,6 +1066,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = env.simulator.profile
     env.simulator.profile = None
+    ranks = rank_report(world, device, dt, {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}, learner.sync)
+    learner.sync.profile = None
 
     graph_line = None
     if want_graph:
@@ -1044,12 +1130,13 @@ def main():
                                  "about this kernel -- see `issue` (instruction issue on the busy CUs) and `saturation`",
                          "issue": issue_roof(kname, k_ms[dom], 8 * NUM_ENVS_PER_GPU, NUM_ENVS_PER_GPU, MACRO * SUBSTEPS)},
         }
+        out.update(ranks)
         if graph_line is not None:
             out["hip_graph"] = graph_line
         if not args.no_saturation:
             out["saturation"] = saturation_probe(env, device)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(sample_envs=min(NUM_ENVS_PER_GPU, max(4, host_cores())))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -51,6 +51,13 @@ def test_bench_gpus_2_launches_its_own_ranks_gloo():
     assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["allreduce_bytes_per_update"] == 4 * (32 * 64 + 64 + 64 * 32 + 32 + 32 * 12 + 12)
     assert line["replicas_identical"] is True and line["value"] > 0
+    # the N-rank line explains itself: per-rank wall time (max = the time `value` is computed from), per-rank kernel times (none here: the
+    # selftest has no simulator) and the per-rank time of the one collective per update, measured around dist.all_reduce in GradSync.step
+    r = line["ranks"]
+    assert len(r["time_s"]["per_rank"]) == 2 and r["time_s"]["max"] >= r["time_s"]["min"] > 0
+    assert abs(r["time_s"]["max"] - line["ms_per_step"] * 3 / 1e3) < 1e-6
+    assert r["kernel_ms"] == {"fwd": [None, None], "bwd": [None, None]}
+    assert len(r["allreduce_ms"]["mean"]) == 2 and all(v is not None and v > 0 for v in r["allreduce_ms"]["mean"] + r["allreduce_ms"]["max"])
 
 
 def test_bench_self_launch_propagates_a_failing_rank():

@@ -1,8 +1,8 @@
 #!/bin/bash
 # end-of-round regression on the GPU box: the GPU test suite, then every bench line of profiles/README.md, then (KS=1) one
-# rocprofv3 kernel-stats CSV per bench workload.   usage: TAG=r03 KS=1 bash tools/final_regression.sh
+# rocprofv3 kernel-stats CSV per bench workload.   usage: TAG=r04 KS=1 bash tools/final_regression.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r03}; O=gpurun_out/final; rm -rf $O; mkdir -p $O
+TAG=${TAG:-r04}; O=gpurun_out/final; rm -rf $O; mkdir -p $O
 timeout -k 10 1100 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/${TAG}_gpu_tests.log; tail -2 $O/${TAG}_gpu_tests.log
 timeout -k 10 300 python tools/det_cost.py > $O/${TAG}_det_cost.txt 2>$O/det_cost.err; cat $O/${TAG}_det_cost.txt
 run() { name=$1; shift; timeout -k 10 300 python bench.py "$@" 2>$O/$name.err | tail -n 1 > $O/${TAG}_bench_line_$name.json
@@ -19,13 +19,13 @@ PY
   fi
 }
 run fold_cloth1
-run fold_cloth1_para_32envs --workload fold_cloth1_para --no-cpu-baseline
-run fold_tshirt --workload fold_tshirt --no-cpu-baseline
+run fold_cloth1_para_32envs --workload fold_cloth1_para
+run fold_tshirt --workload fold_tshirt
 run whip_rope --workload whip_rope
 run whip_rope_eager --workload whip_rope --no-graph --no-cpu-baseline
 run whip_rope_256envs --workload whip_rope --envs 256 --no-cpu-baseline
-run whip_rope_ngrid128 --workload whip_rope --n-grid 128 --no-cpu-baseline
-run whip_rope_ngrid256 --workload whip_rope --n-grid 256 --no-cpu-baseline
+run whip_rope_ngrid128 --workload whip_rope --n-grid 128
+run whip_rope_ngrid256 --workload whip_rope --n-grid 256
 run shape_rope --workload shape_rope
 run pour_water --workload pour_water
 run pour_soup --workload pour_soup

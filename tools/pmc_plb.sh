@@ -7,28 +7,30 @@ O=gpurun_out/pmc_plb; rm -rf $O; mkdir -p $O
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 for NG in 64 128; do for MODE in fwd grad; do
   FL=""; [ $MODE = grad ] && FL="--plb-grad"
-  for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace -d $O/${MODE}_${NG}_$C -o p -f csv -- python3 bench.py --workload torus --n-grid $NG $FL --steps 2 --warmup 1 --no-cpu-baseline > $O/${MODE}_${NG}_$C.log 2>&1 || echo "pass $MODE $NG $C failed"
+  for C in FETCH_SIZE WRITE_SIZE INSTS; do
+    CN=$C; [ $C = INSTS ] && CN="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU"
+    timeout -k 10 300 rocprofv3 --pmc $CN --kernel-trace -d $O/${MODE}_${NG}_$C -o p -f csv -- python3 bench.py --workload torus --n-grid $NG $FL --steps 2 --warmup 1 --no-cpu-baseline > $O/${MODE}_${NG}_$C.log 2>&1 || echo "pass $MODE $NG $C failed"
   done
   python3 - <<PY
 import csv, json, sys
 sys.path.insert(0, "tools")
 import src_hash
 tot = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
+for c, f in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("SQ_WAVES", "INSTS"), ("SQ_INSTS_VALU", "INSTS"), ("SQ_INSTS_SALU", "INSTS")):
     s = 0.0
-    for r in csv.DictReader(open("$O/${MODE}_${NG}_%s/p_counter_collection.csv" % c)):
-        if r["Counter_Name"] == c and "plb_" in r["Kernel_Name"]:
+    for r in csv.DictReader(open("$O/${MODE}_${NG}_%s/p_counter_collection.csv" % f)):
+        if r["Counter_Name"] == c and "plb" in r["Kernel_Name"]:
             s += float(r["Counter_Value"])
     tot[c] = s
-steps = 3   # --warmup 1 --steps 2
+steps = 3.0   # --warmup 1 --steps 2: a warm-up step is a whole bench step in both modes (bench.py::bench_torus)
 per_step = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
 d = json.load(open("$O/pmc_traffic.json"))
 d["plb:$MODE:ngrid$NG"] = {"hbm_bytes_per_launch": per_step, "src_sha16": src_hash.sha16("plb"),
+    "insts": {k: tot[k] / steps for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
     "note": "all plb_* kernels of one bench step (8 envs x 10 env.steps x 19 substeps" + (", + loss + adjoint" if "$MODE" == "grad" else "") +
-            "): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 summed over the pass / 3 steps; separate --pmc passes (tools/pmc_plb.sh)"}
+            "): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 summed over the pass / its 3 bench steps; separate --pmc passes (tools/pmc_plb.sh)"}
 json.dump(d, open("$O/pmc_traffic.json", "w"), indent=1)
 print("plb:$MODE:ngrid$NG  %.3f GB per bench step" % (per_step / 1e9))
 PY
-  rm -rf $O/${MODE}_${NG}_FETCH_SIZE $O/${MODE}_${NG}_WRITE_SIZE
+  rm -rf $O/${MODE}_${NG}_FETCH_SIZE $O/${MODE}_${NG}_WRITE_SIZE $O/${MODE}_${NG}_INSTS
 done; done

@@ -86,6 +86,15 @@ class GradSync:
         self._bind()
         self.max_gradient_norm = max_gradient_norm
         self.optimizer = torch.optim.Adam(self.params, lr=learning_rate, betas=(0.9, 0.999), eps=1e-8)
+        self.profile = None    # a list: step() appends (start, end) around the all-reduce -- torch.cuda.Event pairs recorded on the current
+                               # stream when the gradient lives on a GPU, perf_counter() seconds otherwise (bench.py: `allreduce_ms` per rank)
+
+    def allreduce_ms(self):
+        """milliseconds per all-reduce from `profile` (synchronise the device first), [] when nothing was recorded"""
+        out = []
+        for a, b in self.profile or []:
+            out.append(a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3)
+        return out
 
     def _bind(self):
         off = 0
@@ -112,7 +121,17 @@ class GradSync:
                             self.max_gradient_norm / g_norm)                 # apg.py:260-267 (per device, BEFORE the mean)
         g.mul_(scale)
         if dist.is_initialized() and dist.get_world_size() > 1:              # apg.py:235 lax.pmean
+            if self.profile is not None:
+                cuda = g.device.type == "cuda"
+                t0 = torch.cuda.Event(enable_timing=True) if cuda else time.perf_counter()
+                if cuda:
+                    t0.record(torch.cuda.current_stream(g.device))
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            if self.profile is not None:
+                t1 = torch.cuda.Event(enable_timing=True) if cuda else time.perf_counter()
+                if cuda:
+                    t1.record(torch.cuda.current_stream(g.device))
+                self.profile.append((t0, t1))
             g.div_(dist.get_world_size())
         self.optimizer.step()
         return raw_norm
@@ -238,24 +257,32 @@ class APG:
         cur = torch.cuda.current_stream(dev)
         if cur == torch.cuda.default_stream(dev):
             raise RuntimeError("APG.capture: run the learner under a non-default stream (with torch.cuda.stream(s): ...), eager updates included")
+        # The many-workgroup MPM path with a grid checkpoint hands a per-step overflow flag from the forward to the backward THROUGH THE
+        # HOST (SimpleMPMSimulator._stage_flags: a side stream, pinned memory, an event the backward synchronises on): none of that can be
+        # recorded into a graph -- the capture would fail, or bake in the flag of the capturing run.
+        if sim is not None and getattr(sim, "_h_large", False) and getattr(sim, "grid_ckpt_cells", 0) > 0:
+            raise RuntimeError("APG.capture: this env's simulator stages grid-checkpoint flags through the host per step "
+                               "(many-workgroup MPM path with grid_ckpt_cells > 0); run it eagerly")
         # the warm-up updates below are real updates (with zero noise): parameters and Adam moments are put back afterwards, IN PLACE --
         # the graph holds the addresses of these very tensors
         saved_p = [p.detach().clone() for p in self.params]
         saved_s = [{k: v.detach().clone() for k, v in self.optimizer.state.get(p, {}).items() if torch.is_tensor(v)} for p in self.params]
-        for _ in range(warmup):                      # eager warm-up: lazy initialisations, arenas, Adam state
-            self._update(state, self._cap_noise)
-        torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, stream=cur):
-            self._cap_out = self._update(state, self._cap_noise)
-        with torch.no_grad():
-            for p, sp, ss in zip(self.params, saved_p, saved_s):
-                p.copy_(sp)
-                for k, v in self.optimizer.state[p].items():
-                    if torch.is_tensor(v):
-                        v.copy_(ss[k]) if k in ss else v.zero_()     # no earlier state: a fresh Adam (zero moments, step 0)
-        if had:
-            sim.profile = prof
+        try:
+            for _ in range(warmup):                  # eager warm-up: lazy initialisations, Adam state
+                self._update(state, self._cap_noise)
+            torch.cuda.synchronize(dev)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=cur):
+                self._cap_out = self._update(state, self._cap_noise)
+        finally:                                     # also when the capture raises: the learner keeps the parameters it came with
+            with torch.no_grad():
+                for p, sp, ss in zip(self.params, saved_p, saved_s):
+                    p.copy_(sp)
+                    for k, v in self.optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            v.copy_(ss[k]) if k in ss else v.zero_()     # no earlier state: a fresh Adam (zero moments, step 0)
+            if had:
+                sim.profile = prof
         return self
 
     def _update(self, state, noise):
