@@ -13,12 +13,11 @@
  *   - purely functional like the reference (NamedTuple._replace): inputs are never written, the caller owns
  *     every state / gradient / checkpoint buffer; a handle owns constant tables and, for the many-workgroup MPM and
  *     PLB paths, a scratch arena (HBM grid + active-cell lists) that is (re)allocated when a larger batch arrives.
- *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync inside, with ONE
- *     exception: handle-owned scratch is sized for the largest batch seen so far.  The first call with a given handle,
- *     and any later call whose B exceeds every earlier one, allocates it with hipMalloc (itself a device-wide
- *     synchronising runtime call) after hipStreamSynchronize(stream) + hipFree of the smaller arena.  That concerns
- *     ud_cloth_rollout_bwd for bodies above 1024 particles (cotangent parking arena), ud_mpm_step_fwd/bwd on the
- *     many-workgroup path (grid + active lists) and ud_plb_step.  In steady state (same or smaller B) nothing syncs.
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no allocation and no host synchronisation
+ *     inside any rollout / step / loss call: handle-owned scratch is allocated in ud_*_create for conf.max_envs envs
+ *     (the reference's per-handle constants, mpm_simulator.py:117-122,154: the batch size is known when the simulator
+ *     is built) and a call with more envs than that returns UD_ERR_INVALID.  The only entry points that synchronise
+ *     are the ud_*_poll_* / ud_*_reset calls, which say so.
  *   - return value: 0 = ok, negative = ud_status; ud_last_error() gives the text (thread-local).
  *   - a handle is bound to the device current at create time; not thread-safe per handle.
  */
@@ -257,11 +256,34 @@ typedef struct {
                             mpm_simulator.py:271-289).  K > 0: a forward with a checkpoint also keeps the touched grid cells
                             (index, m, mv: 36 B each; up to min(27, K) * n_particles per substep, inside the caller's checkpoint:
                             ud_plb_ckpt_bytes grows accordingly) and the backward restores them; a substep that touched more
-                            cells than that falls back to recomputing, per env, on the device.  K >= 27 can never fall back */
+                            cells than that falls back to recomputing, per env, on the device.  K >= 27 can never fall back.
+                            Multi-kernel path only (the persistent path always keeps its parts' cells: ud_plb_ckpt_bytes says what a
+                            checkpoint takes) */
+  int max_envs;          /* the largest B any call on this handle will pass (>= 1).  Every arena -- exchange grids, active lists, adjoint
+                            and loss scratch -- is allocated in ud_plb_create for this many envs; no step or loss call allocates or
+                            synchronises the host; a call with B > max_envs returns UD_ERR_INVALID */
+  int path;              /* which kernels the handle runs, fixed at create (ud_plb_launch_plan reports it).  0: the library's choice --
+                            ONE persistent launch per step call and direction (csrc/plb_cluster.hip: parts of 32 particles, one
+                            workgroup each, the particle state in registers, the grid exchanged through HBM once per substep) where
+                            every workgroup of a launch can be resident and the exchange grids fit (bodies up to ~8 000 particles per
+                            env), else the multi-kernel path (2 launches per forward substep, 5 per reverse one).  1: the multi-kernel
+                            path.  2: the persistent path (UD_ERR_UNSUPPORTED where it cannot run) */
+  int lanes;             /* multi-kernel path: lanes per particle in the particle kernels.  0: by launch size (8 up to 16 000 particles
+                            per launch, 4 below 100 000, 1 beyond); 1 / 4 / 8 force one mapping (how the tests put all three before
+                            the restatement at their sizes) */
+  int sort_every;        /* the handle orders each env's particles by grid cell internally (invisible at this boundary) on the first
+                            call and every sort_every-th forward call after it; 0 = 8; negative = never */
 } ud_plb_conf;
 
 int ud_plb_create(const ud_plb_conf* conf, ud_plb** out);
 void ud_plb_destroy(ud_plb* h);
+/* 1: the multi-kernel path, 2: the persistent path (one launch per step call and direction); negative: bad arguments (B > max_envs) */
+int ud_plb_launch_plan(const ud_plb* h, int B);
+/* Persistent path only: a workgroup that waits for a sibling longer than ~seconds gives up, its env's outputs are NaN and a device-side
+ * counter is raised.  This call SYNCHRONISES `stream`, returns the number of such workgroups since the previous call (0 = none, also on
+ * the multi-kernel path; ud_last_error() holds the text otherwise) and, when it is not 0, puts the handle's exchange arena back into its
+ * rest state so that later calls are valid again.  The step calls themselves stay asynchronous and return UD_OK. */
+int ud_plb_poll_timeouts(ud_plb* h, void* stream);
 /* One env.step for B independent envs (float64 device arrays): x, v [B,N,3]; C, F [B,N,3,3]; prim_pos
  * [B,n_primitives,3]; softness [B,n_primitives]; action [B,3]; E, nu, yield_stress [B]. */
 int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,

@@ -70,10 +70,16 @@ def test_sticky_sphere_moves_material_with_it():
 
 
 @pytest.mark.gpu
-def test_hip_matches_restatement_full_torus_state():
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_matches_restatement_full_torus_state(path, lanes=0):
+    """path 2: ONE persistent launch per step call (csrc/plb_cluster.hip; what ud_plb_create picks for the Torus sizes); path 1: the
+    multi-kernel path (2 launches per substep)."""
     import torch
-    from unidom_amd.engine.plb_simulator import PlbSimulator
-    sim = PlbSimulator(batch_size=3)
+    from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
+    cfg = PlbConf()
+    cfg.path, cfg.lanes = path, lanes
+    sim = PlbSimulator(cfg, batch_size=3)
+    assert sim.launch_plan() == path
     st = sim.reset()
     assert st.x.shape == (3, 1000, 3) and (sim.n_grid, sim.substeps) == (64, 19)
     rng = np.random.default_rng(1)
@@ -101,19 +107,22 @@ def test_hip_matches_restatement_full_torus_state():
     s2 = sim.step(s, act * 0)
     cur2 = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act * 0, E, nu, ys, nthreads=3)
     assert _rel(s2.x.cpu().numpy(), cur2["x"]) < 1e-9 and _rel(s2.v.cpu().numpy(), cur2["v"]) < 1e-8
+    sim.check_status()
 
 
 @pytest.mark.gpu
-def test_hip_matches_restatement_quality_2():
-    """The same path at quality 2 (n_grid 128, dt 0.5e-4 / 1 -> 39 substeps per step (int(2e-3 // 5e-5), float floor division), bench.py --workload torus --n-grid 128):
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_matches_restatement_quality_2(path):
+    """The same paths at quality 2 (n_grid 128, dt 0.5e-4 / 1 -> 39 substeps per step (int(2e-3 // 5e-5), float floor division), bench.py --workload torus --n-grid 128):
     ~1 particle per cell, the regime where the internal spatial order and the four-lane mapping matter most."""
     import torch
     from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
     cfg = PlbConf()
     cfg.quality = 2
+    cfg.path = path
     sim = PlbSimulator(cfg, batch_size=2)
     st = sim.reset()
-    assert sim.n_grid == 128
+    assert sim.n_grid == 128 and sim.launch_plan() == path
     rng = np.random.default_rng(3)
     x0 = st.x.cpu().numpy()
     v0 = rng.normal(size=x0.shape) * 0.01
@@ -136,15 +145,44 @@ def test_hip_matches_restatement_quality_2():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", ["1", "4"])
-def test_hip_other_lane_mappings_match_restatement(lanes, monkeypatch):
-    """The particle kernels come in three lane mappings: 8 lanes per particle up to 16 k particles per launch (what the tests' sizes get
-    by default), 4 below 100 k, 1 beyond; UD_PLB_LANES, read at every step call, puts the other two in front of the restatement too.
-    UD_PLB_FUSED=0 does the same for the three-launch substep (p2g, grid, g2p) behind the fused one."""
-    monkeypatch.setenv("UD_PLB_LANES", lanes)
-    test_hip_matches_restatement_full_torus_state()
-    monkeypatch.setenv("UD_PLB_FUSED", "0")
-    test_hip_matches_restatement_full_torus_state()
+@pytest.mark.parametrize("lanes", [1, 4, 8])
+def test_hip_other_lane_mappings_match_restatement(lanes):
+    """The multi-kernel path's particle kernels come in three lane mappings: 8 lanes per particle up to 16 k particles per launch, 4 below
+    100 k, 1 beyond; ud_plb_conf.lanes (fixed at create) puts each of them in front of the restatement at the tests' sizes."""
+    test_hip_matches_restatement_full_torus_state(1, lanes)
+
+
+@pytest.mark.gpu
+def test_hip_persistent_path_several_launches_per_call_and_odd_part_sizes():
+    """The persistent path cuts a call into launches whose workgroups are all resident at once (envs per launch = CUs x occupancy / parts per
+    env: 8 envs of 32 parts on 256 CUs): 11 envs = a launch of 8 and one of 3 on the same exchange arena; N = 1000 leaves a last part of 8
+    particles, N = 37 a second part of 5, N = 5 a single part.  Forward with checkpoint vs the restatement, twice on the same handle."""
+    import torch
+    from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
+    for N, B in ((1000, 11), (37, 3), (5, 2)):
+        cfg = PlbConf()
+        cfg.n_particles, cfg.path = N, 2
+        sim = PlbSimulator(cfg, batch_size=B)
+        rng = np.random.default_rng(N)
+        x0 = sim.reset().x.cpu().numpy() + rng.normal(size=(B, N, 3)) * 1e-3
+        v0 = rng.normal(size=x0.shape) * 0.01
+        C0 = rng.normal(size=(B, N, 3, 3)) * 0.1
+        F0 = np.eye(3)[None, None] + rng.normal(size=(B, N, 3, 3)) * 0.002
+        prim = np.stack([x0[:, 3], np.repeat(np.array([[0.5, 0.75, 0.5]]), B, 0)], 1)
+        soft = np.full((B, 2), 666.0)
+        E, nu, ys = rng.uniform(3e3, 5e3, size=B), rng.uniform(0.3, 0.35, size=B), np.where(np.arange(B) % 2 == 0, 1762.2, 5.0)
+        act = rng.uniform(-0.004, 0.004, size=(B, 3))
+        T = lambda a, r=False: torch.tensor(a, dtype=torch.float64, device=sim.device, requires_grad=r)
+        s = sim.reset()._replace(x=T(x0, True), v=T(v0), C=T(C0), F=T(F0), prim_pos=T(prim), softness=T(soft), E=T(E), nu=T(nu), yield_stress=T(ys))
+        cur = dict(x=x0, v=v0, C=C0, F=F0, prim_pos=prim)
+        orc = PlbOracle(N=N)
+        for step in range(2):
+            s = sim.step(s, act)
+            cur = orc.step(cur["x"], cur["v"], cur["C"], cur["F"], cur["prim_pos"], soft, act, E, nu, ys, nthreads=4)
+        sim.check_status()
+        for key, t in (("x", s.x), ("v", s.v), ("C", s.C), ("F", s.F)):
+            assert _rel(t.detach().cpu().numpy(), cur[key]) < 1e-9, (N, key, _rel(t.detach().cpu().numpy(), cur[key]))
+        np.testing.assert_allclose(s.prim_pos.detach().cpu().numpy(), cur["prim_pos"], rtol=0, atol=1e-14)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -241,20 +279,22 @@ def test_loss_twin_known_answers():
     assert abs(float(total) - d0 ** 2) < 1e-15
 
 
-def _hip_sim(N, B, quality=0.5, grid_ckpt_cells=None):
+def _hip_sim(N, B, quality=0.5, grid_ckpt_cells=None, path=0, lanes=0, sort_every=0):
     from unidom_amd.engine.plb_simulator import PlbConf as HipConf, PlbSimulator
     cfg = HipConf()
     cfg.quality = quality
     cfg.n_particles = N
+    cfg.path, cfg.lanes, cfg.sort_every = path, lanes, sort_every
     if grid_ckpt_cells is not None:
         cfg.grid_ckpt_cells = grid_ckpt_cells
     return PlbSimulator(cfg, batch_size=B)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", [2, 1])
 @pytest.mark.parametrize("low", [True, False])
-def test_hip_step_adjoint_matches_torch_twin(low):
-    """ud_plb_step_fwd (with checkpoint) + ud_plb_step_bwd against torch.autograd through the twin: three envs with different
+def test_hip_step_adjoint_matches_torch_twin(low, path, lanes=0):
+    """ud_plb_step_fwd (with checkpoint) + ud_plb_step_bwd (path 2: one persistent launch each; path 1: the multi-kernel path) against torch.autograd through the twin: three envs with different
     E / nu / yield stress (one yields almost everywhere: the return-mapping adjoint; one hardly: the SVD adjoint alone), a body
     on the floor (ground-friction branch and the boundary zeroing) or in the air, sphere 0 inside it (sticky contact -> action
     and primitive-position cotangents).  n_grid 32, 9 substeps.  f64 on both sides; what differs is summation order (atomics)
@@ -262,8 +302,8 @@ def test_hip_step_adjoint_matches_torch_twin(low):
     import torch
     torch.set_num_threads(8)
     B, N = 3, 300
-    sim = _hip_sim(N, B)
-    assert (sim.n_grid, sim.substeps) == (32, 9)
+    sim = _hip_sim(N, B, path=path, lanes=lanes)
+    assert (sim.n_grid, sim.substeps) == (32, 9) and sim.launch_plan() == path
     conf = PlbConf(quality=0.5, n_particles=N)
     case = _small_case(B, N, 1, low=low)
     x, v, Cm, F, prim, soft, act, E, nu, ys = case
@@ -297,17 +337,16 @@ def test_hip_step_adjoint_matches_torch_twin(low):
 @pytest.mark.gpu
 def test_hip_step_adjoint_at_the_benched_configuration():
     """bench.py --workload torus --plb-grad as it is measured: N = 1000, n_grid 64 (quality 1, 19 substeps per env.step), 8 envs in
-    one launch, the default lane mapping for that launch size, the grid checkpoint on (27 cells per particle) -- the body of the
+    one launch, the kernels ud_plb_create picks by itself (the persistent path: 8 x 32 workgroups that must all be resident and meet
+    at an inter-workgroup barrier every substep) -- the body of the
     Torus task (shape_maker.py:49-58) with sphere 0 on it (sticky contact: action and primitive-position cotangents), every env with
     its own v / C / F, action, E, nu and yield stress.  Two of the eight envs are followed by torch.autograd through the twin over
     the whole env.step: forward 1e-9, every leaf 1e-6 relative (the tolerances of the n_grid-32 test above)."""
-    import os
     import torch
     torch.set_num_threads(8)
-    assert "UD_PLB_LANES" not in os.environ
     B, N, pick = 8, 1000, [2, 7]
     sim = _hip_sim(N, B, quality=1.0)
-    assert (sim.n_grid, sim.substeps, sim.grid_ckpt_cells) == (64, 19, 27)
+    assert (sim.n_grid, sim.substeps) == (64, 19) and sim.launch_plan() == 2     # the library's choice at this shape: the persistent path
     conf = PlbConf(quality=1.0, n_particles=N)
     rng = np.random.default_rng(21)
     x = torus_particles(1000)[None].repeat(B, 0) + rng.normal(size=(B, N, 3)) * 1e-4
@@ -337,6 +376,7 @@ def test_hip_step_adjoint_at_the_benched_configuration():
         assert _rel(t.detach().cpu().numpy()[pick], o.detach().numpy()) < 1e-9, name
     sim.ground_friction_grad = None
     sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w)).backward()
+    sim.check_status()
     for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
         got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
         assert np.isfinite(got).all(), name
@@ -360,7 +400,7 @@ def test_hip_adjoint_with_and_without_the_grid_checkpoint(K):
     w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
 
     def run(k):
-        sim = _hip_sim(N, B, grid_ckpt_cells=k)
+        sim = _hip_sim(N, B, grid_ckpt_cells=k, path=1)     # the multi-kernel path's own machinery
         assert sim.grid_ckpt_cells == k
         T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
         hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
@@ -378,13 +418,14 @@ def test_hip_adjoint_with_and_without_the_grid_checkpoint(K):
 
 
 @pytest.mark.gpu
-def test_hip_two_steps_chain_and_forward_without_checkpoint():
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_two_steps_chain_and_forward_without_checkpoint(path):
     """Two env.steps chained through autograd (the tape of solver.py:41-54) equal the twin's; a forward under no_grad (no
     checkpoint) gives the same state as the checkpointing forward."""
     import torch
     torch.set_num_threads(8)
     B, N = 2, 200
-    sim = _hip_sim(N, B)
+    sim = _hip_sim(N, B, path=path)
     conf = PlbConf(quality=0.5, n_particles=N)
     case = _small_case(B, N, 4)
     x, v, Cm, F, prim, soft, act, E, nu, ys = case
@@ -445,23 +486,27 @@ def test_hip_losses_match_torch_twin(soft_contact):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", ["1", "4"])
-def test_hip_step_adjoint_other_lane_mappings(lanes, monkeypatch):
-    """The adjoint kernels have the forward's lane mappings (8 / 4 / 1 lanes per particle by launch size); UD_PLB_LANES puts the
-    instantiations the tests' sizes do not get by default in front of the twin too."""
-    monkeypatch.setenv("UD_PLB_LANES", lanes)
-    test_hip_step_adjoint_matches_torch_twin(True)
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_hip_step_adjoint_other_lane_mappings(lanes):
+    """The multi-kernel adjoint kernels have the forward's lane mappings (8 / 4 / 1 lanes per particle by launch size); ud_plb_conf.lanes
+    puts the instantiations the tests' sizes do not get by default in front of the twin too."""
+    test_hip_step_adjoint_matches_torch_twin(True, 1, lanes)
 
 
 @pytest.mark.gpu
-def test_hip_spatial_order_is_reused_and_still_valid_after_the_state_changes(monkeypatch):
-    """The spatial order is computed on the first call and every eighth after it (UD_PLB_SORT_EVERY); in between a call runs on
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_spatial_order_is_reused_and_still_valid_after_the_state_changes(path):
+    """The spatial order is computed on the first call and every eighth after it (ud_plb_conf.sort_every); in between a call runs on
     the previous order -- any permutation is valid, only its locality ages.  A handle that sorted for one state and is then given a
-    completely different one (the body mirrored and shuffled) still matches the restatement."""
-    from oracle.pyoracle import PlbOracle
-    from unidom_amd.engine.plb_simulator import PlbSimulator
+    completely different one (the body mirrored and shuffled) still matches a handle that sorts at every call."""
+    from unidom_amd.engine.plb_simulator import PlbConf, PlbSimulator
     import torch
-    sim = PlbSimulator(batch_size=2)
+    cfg = PlbConf()
+    cfg.path = path
+    sim = PlbSimulator(cfg, batch_size=2)
+    cfg1 = PlbConf()
+    cfg1.path, cfg1.sort_every = path, 1
+    sim1 = PlbSimulator(cfg1, batch_size=2)
     st = sim.reset()
     act = torch.tensor([[0.3, -0.2, 0.1]] * 2, dtype=torch.float64, device=sim.device)
     s1 = sim.step(st, act)                                  # sorts for this state
@@ -471,17 +516,17 @@ def test_hip_spatial_order_is_reused_and_still_valid_after_the_state_changes(mon
     x2[..., 0] = 1.0 - x2[..., 0]                           # elsewhere in the grid, in another particle order
     st2 = st._replace(x=x2)
     got = sim.step(st2, act)                                # reuses the order computed for `st`
-    monkeypatch.setenv("UD_PLB_SORT_EVERY", "1")
-    ref = sim.step(st2, act)                                # sorts again
+    ref = sim1.step(st2, act)                               # sorts for st2
     for a, b, name in ((got.x, ref.x, "x"), (got.v, ref.v, "v"), (got.C, ref.C, "C"), (got.F, ref.F, "F")):
         assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-9, name
     assert torch.isfinite(s1.x).all()
 
 
 @pytest.mark.gpu
-def test_hip_smaller_batch_after_larger_stays_inside_the_callers_arrays():
-    """One handle, a call with B = 8 and then one with B = 3 (ud_plb_step_fwd / _bwd take B per call; the handle's arena keeps
-    the larger size): every [B] / [B, ...] array of the second call sits between canaries, and its results equal those of a
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_smaller_batch_after_larger_stays_inside_the_callers_arrays(path):
+    """One handle, a call with B = 8 and then one with B = 3 (ud_plb_step_fwd / _bwd take B per call; the handle's arenas are sized
+    for max_envs = 8 at create): every [B] / [B, ...] array of the second call sits between canaries, and its results equal those of a
     fresh handle that has only ever seen B = 3.  (The per-env guards of plb_prologue / plb_adj_epilogue once used the arena's
     B: envs 3..7 of the epilogue's 64-thread block then wrote g_action, g_E, ... past the caller's arrays.)"""
     import ctypes as C
@@ -524,9 +569,11 @@ def test_hip_smaller_batch_after_larger_stays_inside_the_callers_arrays():
             assert (buf[:PAD] == CANARY).all() and (buf[PAD + n:] == CANARY).all(), "a kernel wrote outside the caller's array"
         return [t.cpu().numpy().copy() for t in (xo, vo, Co, Fo, po, *og)]
 
-    big = _hip_sim(N, 8)
-    run(big, 8, 2)                       # the arena now holds 8 envs
+    big = _hip_sim(N, 8, path=path)
+    run(big, 8, 2)
     got = run(big, 3, 3)
-    ref = run(_hip_sim(N, 3), 3, 3)
+    ref = run(_hip_sim(N, 3, path=path), 3, 3)
+    with pytest.raises(_lib.UnidomError):                      # more envs than the handle was created for: refused, nothing allocated
+        run(_hip_sim(N, 2, path=path), 3, 3)
     for g, r in zip(got, ref):
         assert np.isfinite(g).all() and _rel(g, r) < 1e-9

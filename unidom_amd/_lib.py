@@ -19,7 +19,7 @@ SYMBOLS = [
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes", "ud_cloth_launch_envs", "ud_cloth_poll_timeouts",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
     "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_launch_plan", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
-    "ud_plb_create", "ud_plb_destroy", "ud_plb_step_fwd", "ud_plb_ckpt_bytes", "ud_plb_step_bwd", "ud_plb_loss_fwd", "ud_plb_loss_bwd",
+    "ud_plb_create", "ud_plb_destroy", "ud_plb_launch_plan", "ud_plb_poll_timeouts", "ud_plb_step_fwd", "ud_plb_ckpt_bytes", "ud_plb_step_bwd", "ud_plb_loss_fwd", "ud_plb_loss_bwd",
     "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
     "ud_mpm_focus_fwd", "ud_mpm_focus_bwd", "ud_mpm_finish_fwd", "ud_mpm_finish_bwd",
 ]
@@ -46,7 +46,7 @@ class ud_plb_conf(C.Structure):
     _fields_ = [("n_particles", C.c_int), ("n_grid", C.c_int), ("substeps", C.c_int), ("dt", C.c_double),
                 ("gravity", C.c_double * 3), ("ground_friction", C.c_double), ("n_primitives", C.c_int),
                 ("radius", C.c_double * 2), ("lower_bound", C.c_double * 3), ("upper_bound", C.c_double * 3),
-                ("grid_ckpt_cells", C.c_int)]
+                ("grid_ckpt_cells", C.c_int), ("max_envs", C.c_int), ("path", C.c_int), ("lanes", C.c_int), ("sort_every", C.c_int)]
 
 
 def build(force: bool = False) -> str:

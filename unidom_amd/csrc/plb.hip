@@ -12,7 +12,7 @@
 // but only cells on the per-env active list are ever read, written or cleared.  No MFMA (scatter / stencil work).
 // ti.svd (third party) is replaced by a one-sided Jacobi SVD in registers.  Parity: UNPINNED (see the header).
 #include <cstdlib>
-#include "plb_common.h"
+#include "plb_device.h"
 
 #include <vector>
 
@@ -42,63 +42,23 @@ __device__ __forceinline__ void plb_p2g_body(const PlbArgs& a, const P2gTarget& 
   double* val = plb_buf(a, tg.buf, b);
   if (livep) {
     double* ho = plb_hist(a, b, tg.hs_out);
-    const double E = a.E[b], nu = a.nu[b];
-    const double mu = E / (2 * (1 + nu)), lam = E * nu / ((1 + nu) * (1 - 2 * nu));
     int base[3];
     double fx[3], w[9];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      base[d] = (int)(x[d] * c.inv_dx - 0.5);
-      const double f = x[d] * c.inv_dx - (double)base[d];
-      fx[d] = f;
-      w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
-    }
-    double IC[9], Ft[9], U[9], Vh[9], sig[3];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
-    dm_mul(IC, F, Ft);
-    dsvd3(Ft, U, sig, Vh);
+    plb_weights_fwd(c, x, base, fx, w);
+    PlbPre q;
+    plb_prepass(c, a.E[b], a.nu[b], a.ys[b], Cm, F, q, false);
+    const double* aff = q.aff;
     if (a.w.svd && qi == 0) {      // checkpointing forward: the factors of this substep's F, for the adjoint's pre-pass
       double* o = a.w.svd + (((long)b * c.S + tg.f) * 21) * c.Np + p;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { o[i * c.Np] = U[i]; o[(12 + i) * c.Np] = Vh[i]; }
+      for (int i = 0; i < 9; ++i) { o[i * c.Np] = q.U[i]; o[(12 + i) * c.Np] = q.Vh[i]; }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) o[(9 + i) * c.Np] = sig[i];
-    }
-    double eps[3], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
-    double eh[3], nn = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { eh[i] = eps[i] - sum / 3; nn += eh[i] * eh[i]; }
-    const double ehn = sqrt(nn + 1e-8);
-    const double dg = ehn - a.ys[b] / (2 * mu);
-    double nF[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) nF[i] = Ft[i];
-    if (dg > 0) {
-      double US[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double s = exp(eps[i] - (dg / ehn) * eh[i]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) US[r * 3 + i] = U[r * 3 + i] * s;
-      }
-      dm_mul(US, Vh, nF);
+      for (int i = 0; i < 3; ++i) o[(9 + i) * c.Np] = q.sig[i];
     }
     if (qi == 0) {
 #pragma unroll
-      for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = nF[d];
+      for (int d = 0; d < 9; ++d) ho[(15 + d) * c.Np + p] = q.nF[d];
     }
-    const double J = nF[0] * (nF[4] * nF[8] - nF[5] * nF[7]) - nF[1] * (nF[3] * nF[8] - nF[5] * nF[6]) + nF[2] * (nF[3] * nF[7] - nF[4] * nF[6]);
-    double R[9], A[9], St[9], aff[9];
-    dm_mul(U, Vh, R);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) A[i] = nF[i] - R[i];
-    dm_mul_bt(A, nF, St);
-    const double sc = -c.dt * c.p_vol * 4 * c.inv_dx * c.inv_dx;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
     const int rot = (p * LANES) % 27;   // staggered stencil walk (see lg_p2g, mpm_large.hip): neighbours never on the same slot at once
 #pragma unroll 1
     for (int it = qi; it < 27; it += LANES) {
@@ -471,32 +431,33 @@ void plb_launch_p2g(const PlbArgs& a, int lanes, dim3 grid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss) {
-  if (B <= h->B && (!adj || h->has_adj) && (!loss || h->has_loss)) return UD_OK;
-  adj = adj || h->has_adj; loss = loss || h->has_loss;
-  B = std::max(B, h->B);
-  if (h->arena) { (void)hipStreamSynchronize(st); (void)hipFree(h->arena); h->arena = nullptr; }
+int plb_reserve(ud_plb* h, int B, bool multi_kernel) {
   const ud::PlbConst& c = h->c;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t o_val = take((size_t)2 * B * h->G * 32), o_stamp = take((size_t)B * h->G * 4), o_list = take((size_t)3 * B * h->cap * 4);
-  const size_t o_count = take((size_t)3 * B * 4), o_pos = take((size_t)B * (c.S + 1) * c.np * 3 * 8), o_hist = take((size_t)B * 2 * 24 * c.Np * 8);
-  const size_t o_perm = take((size_t)B * c.Np * 4);
-  const size_t o_gacc = adj ? take((size_t)B * h->G * 32) : 0, o_vout = adj ? take((size_t)B * h->G * 32) : 0, o_gstate = adj ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
-  const size_t o_gxs = adj ? take((size_t)B * 3 * c.Np * 8) : 0, o_gpos = adj ? take((size_t)B * (c.S + 1) * c.np * 3 * 8 + 64) : 0, o_gpar = adj ? take((size_t)B * 4 * 8) : 0;
-  const size_t o_gm = loss ? take((size_t)B * h->G * 8) : 0, o_lred = loss ? take((size_t)B * 16 * 8) : 0;
+  const bool mk = multi_kernel;
+  // multi-kernel path: dense double-buffered (m, mv) grid, stamps, active lists, ping-pong history, the adjoint's grids and cotangent state
+  const size_t o_val = mk ? take((size_t)2 * B * h->G * 32) : 0, o_stamp = mk ? take((size_t)B * h->G * 4) : 0, o_list = mk ? take((size_t)3 * B * h->cap * 4) : 0;
+  const size_t o_count = mk ? take((size_t)3 * B * 4) : 0, o_pos = mk ? take((size_t)B * (c.S + 1) * c.np * 3 * 8) : 0, o_hist = mk ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
+  const size_t o_perm = mk ? take((size_t)B * c.Np * 4) : 0;
+  const size_t o_gacc = mk ? take((size_t)B * h->G * 32) : 0, o_vout = mk ? take((size_t)B * h->G * 32) : 0, o_gstate = mk ? take((size_t)B * 2 * 24 * c.Np * 8) : 0;
+  const size_t o_gxs = mk ? take((size_t)B * 3 * c.Np * 8) : 0, o_gpos = mk ? take((size_t)B * (c.S + 1) * c.np * 3 * 8 + 64) : 0, o_gpar = mk ? take((size_t)B * 4 * 8) : 0;
+  // both paths: the spatial order, the loss kernels' grid mass and partial sums
+  const size_t o_order = take((size_t)B * c.Np * 4), o_gm = take((size_t)B * h->G * 8), o_lred = take((size_t)B * 16 * 8);
   hipError_t e = hipMalloc(&h->arena, off);
-  if (e != hipSuccess) { ud::set_error("ud_plb: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); h->B = 0; h->has_adj = h->has_loss = false; return UD_ERR_HIP; }
-  e = hipMemsetAsync(h->arena, 0, off, st);
-  if (e != hipSuccess) { ud::set_error("ud_plb: memset failed"); return UD_ERR_HIP; }
+  if (e != hipSuccess) { ud::set_error("ud_plb_create: hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); return UD_ERR_HIP; }
+  e = hipMemset(h->arena, 0, off);
+  if (e != hipSuccess) { ud::set_error("ud_plb_create: memset failed"); return UD_ERR_HIP; }
   char* base = (char*)h->arena;
-  h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
-  h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
-  h->w.perm = (int*)(base + o_perm);
-  h->w.gacc = adj ? (double*)(base + o_gacc) : nullptr; h->w.vout = adj ? (double*)(base + o_vout) : nullptr; h->w.gstate = adj ? (double*)(base + o_gstate) : nullptr;
-  h->w.gxs = adj ? (double*)(base + o_gxs) : nullptr; h->w.gpos = adj ? (double*)(base + o_gpos) : nullptr; h->w.gpar = adj ? (double*)(base + o_gpar) : nullptr;
-  h->gm = loss ? (double*)(base + o_gm) : nullptr; h->lred = loss ? (double*)(base + o_lred) : nullptr;
-  h->B = B; h->epoch = 1; h->has_adj = adj; h->has_loss = loss; h->sort_B = 0;
+  if (mk) {
+    h->w.val = (double*)(base + o_val); h->w.stamp = (int*)(base + o_stamp); h->w.list = (int*)(base + o_list);
+    h->w.count = (int*)(base + o_count); h->w.pos = (double*)(base + o_pos); h->w.hist = (double*)(base + o_hist);
+    h->w.perm = (int*)(base + o_perm);
+    h->w.gacc = (double*)(base + o_gacc); h->w.vout = (double*)(base + o_vout); h->w.gstate = (double*)(base + o_gstate);
+    h->w.gxs = (double*)(base + o_gxs); h->w.gpos = (double*)(base + o_gpos); h->w.gpar = (double*)(base + o_gpar);
+  }
+  h->order = (int*)(base + o_order); h->gm = (double*)(base + o_gm); h->lred = (double*)(base + o_lred);
+  h->B = B; h->epoch = 1; h->sort_B = 0;
   return UD_OK;
 }
 
@@ -532,6 +493,10 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
   if (conf->n_particles < 1 || conf->n_grid < 8 || conf->n_grid > 512 || conf->substeps < 1 || conf->n_primitives < 0 || conf->n_primitives > 2) {
     ud::set_error("ud_plb_create: bad sizes"); return UD_ERR_INVALID;
   }
+  if (conf->max_envs < 1) { ud::set_error("ud_plb_create: max_envs = %d (every arena is sized at create: give the largest B any call will pass)", conf->max_envs); return UD_ERR_INVALID; }
+  if (conf->path < 0 || conf->path > 2 || !(conf->lanes == 0 || conf->lanes == 1 || conf->lanes == 4 || conf->lanes == 8)) {
+    ud::set_error("ud_plb_create: path = %d (0 auto, 1 multi-kernel, 2 persistent), lanes = %d (0 auto, 1, 4, 8)", conf->path, conf->lanes); return UD_ERR_INVALID;
+  }
   auto* h = new ud_plb;
   ud::PlbConst& c = h->c;
   c.N = conf->n_particles; c.Np = (c.N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.S = conf->substeps; c.np = conf->n_primitives;
@@ -543,7 +508,20 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
   h->G = (long)c.n_grid * c.n_grid * c.n_grid;
   h->cap = (int)std::min<long>(h->G, (long)27 * c.N);
   c.gck = conf->grid_ckpt_cells > 0 ? (int)std::min<long>(h->cap, (long)conf->grid_ckpt_cells * c.N) : 0;
+  h->lanes = conf->lanes;
+  h->sort_every = conf->sort_every == 0 ? 8 : conf->sort_every;
   (void)hipFuncSetAttribute((const void*)ud::plb_sort, hipFuncAttributeMaxDynamicSharedMemorySize, ud::PLB_SORT_MAX * 8);
+  // Which kernels this handle runs is decided here, once: the persistent launch per step call (plb_cluster.hip) where all parts of a
+  // launch can be resident and the exchange grids fit, else the multi-kernel path.  path = 1 / 2 force one (2: an error if it cannot run).
+  int per = conf->path == 1 ? 0 : plb_cluster_plan(h, conf->max_envs);
+  if (conf->path == 2 && per < 1) {
+    ud::set_error("ud_plb_create: path = 2 (persistent) does not fit this configuration (parts per env %d, substeps %d)", h->cl.W, c.S);
+    delete h; return UD_ERR_UNSUPPORTED;
+  }
+  int rc = plb_reserve(h, conf->max_envs, per < 1);
+  if (rc == UD_OK && per >= 1) rc = plb_cluster_reserve(h, per);
+  if (rc != UD_OK) { ud_plb_destroy(h); return rc; }
+  if (hipDeviceSynchronize() != hipSuccess) { ud::set_error("ud_plb_create: device synchronisation failed"); ud_plb_destroy(h); return UD_ERR_HIP; }
   *out = h;
   return UD_OK;
 }
@@ -551,12 +529,37 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
 void ud_plb_destroy(ud_plb* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
+  if (h->cl.arena) (void)hipFree(h->cl.arena);
   delete h;
 }
 
 size_t ud_plb_ckpt_bytes(const ud_plb* h, int B) {
   if (!h || B < 1) return 0;
-  return plb_ckpt_layout(h->c, B).total;
+  return h->cl.per > 0 ? plb_cluster_ckpt_bytes(h, B) : plb_ckpt_layout(h->c, B).total;
+}
+
+int ud_plb_launch_plan(const ud_plb* h, int B) {
+  if (!h || B < 1 || B > h->B) return -1;
+  return h->cl.per > 0 ? 2 : 1;
+}
+
+int ud_plb_poll_timeouts(ud_plb* h, void* stream) {
+  if (!h) { ud::set_error("ud_plb_poll_timeouts: null handle"); return UD_ERR_INVALID; }
+  if (h->cl.per < 1) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int n = 0;
+  if (hipMemcpyAsync(&n, h->cl.timeouts, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    ud::set_error("ud_plb_poll_timeouts: copy failed"); return UD_ERR_HIP;
+  }
+  if (n > 0) {
+    // a part that gave up leaves its env's exchange grids, barrier words and accumulators dirty: back to the rest state before anything else runs
+    (void)hipMemsetAsync(h->cl.arena, 0, h->cl.bytes, st);
+    (void)hipStreamSynchronize(st);
+    ud::set_error("ud_plb: %d workgroup(s) of the persistent kernels gave up waiting for a sibling (outputs of those envs are NaN); the handle's "
+                  "exchange arena has been reset.  The persistent path needs every workgroup of a launch resident at once: other kernels "
+                  "occupying the device for seconds can cause this", n);
+  }
+  return n;
 }
 
 int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F,
@@ -568,9 +571,23 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
     ud::set_error("ud_plb_step_fwd: null argument"); return UD_ERR_INVALID;
   }
   if (B < 1) { ud::set_error("ud_plb_step_fwd: B=%d", B); return UD_ERR_INVALID; }
+  if (B > h->B) { ud::set_error("ud_plb_step_fwd: B=%d exceeds the handle's max_envs=%d (arenas are sized at create)", B, h->B); return UD_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  int rc = plb_reserve(h, B, st, false, false);
-  if (rc) return rc;
+  // Spatial order: any permutation is valid, only its locality ages (a particle moves a fraction of a cell per step) -- computed on the
+  // first call, when more envs arrive than it covers, and every sort_every-th call (conf; default 8) after that; kept in the handle and
+  // copied into every call's own perm (the checkpoint's).
+  const bool sorted = h->sort_every > 0 && h->c.N <= ud::PLB_SORT_MAX;
+  if (sorted && (B > h->sort_B || ++h->sort_age >= h->sort_every)) {
+    int npow2 = 64;
+    while (npow2 < h->c.N) npow2 <<= 1;
+    ud::PlbArgs sa{};
+    sa.c = h->c;
+    hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, sa, x, npow2, h->order);
+    h->sort_B = std::max(h->sort_B, B); h->sort_age = 0;
+  }
+  if (h->cl.per > 0)
+    return plb_cluster_step_fwd(h, B, x, v, C, F, prim_pos, softness, action, E, nu, yield_stress, x_out, v_out, C_out, F_out, prim_pos_out,
+                                sorted ? (const int*)h->order : (const int*)nullptr, ckpt, st);
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1; a.hs_out2 = 0; a.epoch2 = 0;
@@ -581,32 +598,13 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   }
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B);
-  const char* lanes_env = getenv("UD_PLB_LANES");          // diagnostic override, read per call (the tests reach both mappings with it)
-  const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
-  // lanes per particle in p2g / g2p: 8 while even four leave half of the SIMDs without a wave (B N <= 16 000: the walk's share of the
-  // one wave a launch waits for halves again -- Torus forward 268 k -> 287 k substeps/s; 16 lanes: 250 k, the repeated pre-pass then
-  // competes for issue), 4 while the launch does not fill the chip, 1 beyond
-  const int lanes = (force_lanes == 1 || force_lanes == 4 || force_lanes == 8) ? force_lanes
-                    : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));
+  // lanes per particle in p2g / g2p: 8 while even four leave half of the SIMDs without a wave (B N <= 16 000), 4 while the launch does
+  // not fill the chip, 1 beyond; ud_plb_conf.lanes forces one mapping (how the tests reach all three at their sizes)
+  const int lanes = h->lanes ? h->lanes : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));
   const dim3 gq((lanes * h->c.N + 255) / 256, B);
-  // Spatial order: any permutation is valid, only its locality ages (a particle moves a fraction of a cell per step) -- computed on the
-  // first call, when more envs arrive than it covers, and every UD_PLB_SORT_EVERY-th call (default 8) after that; kept in the arena and
-  // copied into every call's own perm (the checkpoint's) by plb_pack.
-  static const int no_sort = [] { const char* e = getenv("UD_PLB_NO_SORT"); return e ? atoi(e) : 0; }();   // diagnostic override
-  const char* se = getenv("UD_PLB_SORT_EVERY");
-  const int sort_every = se ? std::max(1, atoi(se)) : 8;
-  const bool sorted = !no_sort && h->c.N <= ud::PLB_SORT_MAX;
-  if (sorted && (B > h->sort_B || ++h->sort_age >= sort_every)) {
-    int npow2 = 64;
-    while (npow2 < h->c.N) npow2 <<= 1;
-    hipLaunchKernelGGL(ud::plb_sort, dim3(B), dim3(1024), (size_t)npow2 * 8, st, a, x, npow2, h->w.perm);
-    h->sort_B = std::max(h->sort_B, B); h->sort_age = 0;
-  }
-  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted ? (const int*)h->w.perm : (const int*)nullptr, prim_pos, action);
+  hipLaunchKernelGGL(ud::plb_pack, gp, blk, 0, st, a, x, v, C, F, sorted ? (const int*)h->order : (const int*)nullptr, prim_pos, action);
   // Per substep: plb_grid(f), then ONE particle launch: g2p(f) -> p2g(f + 1) (plb_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it.
-  // UD_PLB_FUSED=0 (diagnostic, read per call): p2g, grid, g2p as three launches.
-  const char* fz = getenv("UD_PLB_FUSED");
-  const bool fused = !(fz && fz[0] == '0');
+  const bool fused = true;
   const int S = h->c.S;
   const int ep0 = h->epoch; h->epoch += S + 1;
   auto set = [&](int f) {

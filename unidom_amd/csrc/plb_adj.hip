@@ -19,27 +19,9 @@
 // ships no gradient of this path; the checker is torch.autograd through oracle/twin/plb_twin_torch.py (tests/test_plb.py).
 #include <cstdlib>
 
-#include "plb_common.h"
+#include "plb_device.h"
 
 namespace ud {
-
-__device__ __forceinline__ void dm_mul_at(const double* A, const double* B, double* R) {   // A^T B
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
-}
-
-__device__ __forceinline__ void plb_weights(const PlbConst& c, const double* x, int* base, double* fx, double* w, double* dw) {
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    base[d] = (int)(x[d] * c.inv_dx - 0.5);
-    const double f = x[d] * c.inv_dx - (double)base[d];
-    fx[d] = f;
-    w[d] = 0.5 * (1.5 - f) * (1.5 - f); w[3 + d] = 0.75 - (f - 1) * (f - 1); w[6 + d] = 0.5 * (f - 0.5) * (f - 0.5);
-    dw[d] = -(1.5 - f); dw[3 + d] = -2 * (f - 1); dw[6 + d] = f - 0.5;
-  }
-}
 
 // ---- grid op, kept: v_out of every touched cell into buffer 1 (buffer 0 keeps (m, mv)) ---------------------------------
 __global__ void __launch_bounds__(256) plb_grid_keep(PlbArgs a) {
@@ -202,86 +184,11 @@ __global__ void __launch_bounds__(256) plb_grid_adj(PlbArgs a) {
   const long lin = inlist ? a.w.list[((long)a.lb * a.B + b) * a.cap + t] : 0;
   const double* cell = plb_buf(a, a.lb, b) + lin * 4;
   double* ga = a.w.gacc + ((long)b * a.G + lin) * 4;
-  const double m = inlist ? cell[0] : 0.0;
-  if (inlist && !(m > 1e-12)) { ga[0] = 0; ga[1] = 0; ga[2] = 0; ga[3] = 0; }
-  if (inlist && m > 1e-12) {
-  double g[3] = {ga[0], ga[1], ga[2]};
-  const int n = c.n_grid;
-  const int I[3] = {(int)(lin / ((long)n * n)), (int)((lin / n) % n), (int)(lin % n)};
-  const double* P0 = a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
-  const double* P1 = P0 + c.np * 3;
-  // forward, keeping the velocity that entered each boundary stage
-  double vv[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) vv[k] = (1.0 / m) * cell[1 + k] + c.g30dt[k];
-  bool stick[2] = {false, false};
-  const double gp[3] = {I[0] * c.dx, I[1] * c.dx, I[2] * c.dx};
-  for (int pi = 0; pi < c.np; ++pi) {
-    const double d0 = gp[0] - P0[pi * 3], d1 = gp[1] - P0[pi * 3 + 1], d2 = gp[2] - P0[pi * 3 + 2];
-    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2 + 1e-14) - c.radius[pi];
-    const double sf = a.softness[b * c.np + pi];
-    const double infl = fmin(exp(-dist * sf), 1.0);
-    if (((sf > 0 && infl > 0.1) || dist <= 0.001) && sf > 0) {
-      stick[pi] = true;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) vv[k] = (P1[pi * 3 + k] - P0[pi * 3 + k]) / c.dt;
-    }
-  }
-  double vin[3][3];        // velocity entering stage d
-  int kind[3];             // 0 nothing, 1 component zeroed, 2 friction, 3 all zeroed
-  bool hiz[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) vin[d][k] = vv[k];
-    kind[d] = 0;
-    if (I[d] < 3 && vv[d] < 0) {
-      if (d != 1 || c.fric == 0) { vv[d] = 0; kind[d] = 1; }
-      else if (c.fric < 10) {
-        const double lin_ = vv[1] + 1e-30;
-        const double vit[3] = {vv[0] - I[0] * 1e-30, vv[1] - lin_ - I[1] * 1e-30, vv[2] - I[2] * 1e-30};
-        const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
-        const double s = fmax(1.0 + c.fric * lin_ / lit, 0.0);
-        vv[0] = s * (vit[0] + I[0] * 1e-30); vv[2] = s * (vit[2] + I[2] * 1e-30); vv[1] = 0;
-        kind[d] = 2;
-      } else { vv[0] = 0; vv[1] = 0; vv[2] = 0; kind[d] = 3; }
-    }
-    hiz[d] = (I[d] > n - 3 && vv[d] > 0);
-    if (hiz[d]) vv[d] = 0;
-  }
-  // reverse
-#pragma unroll
-  for (int d = 2; d >= 0; --d) {
-    if (hiz[d]) g[d] = 0;
-    if (kind[d] == 1) g[d] = 0;
-    else if (kind[d] == 3) { g[0] = 0; g[1] = 0; g[2] = 0; }
-    else if (kind[d] == 2) {
-      const double* u = vin[d];
-      const double lin_ = u[1] + 1e-30;
-      const double vit[3] = {u[0] - I[0] * 1e-30, u[1] - lin_ - I[1] * 1e-30, u[2] - I[2] * 1e-30};
-      const double lit = sqrt(vit[0] * vit[0] + vit[1] * vit[1] + vit[2] * vit[2] + 1e-8);
-      const double arg = 1.0 + c.fric * lin_ / lit;
-      const double s = fmax(arg, 0.0);
-      const double gs = g[0] * (vit[0] + I[0] * 1e-30) + g[2] * (vit[2] + I[2] * 1e-30);
-      double gvit[3] = {g[0] * s, 0.0, g[2] * s};
-      double glin = 0, glit = 0;
-      if (arg > 0) { glin = gs * c.fric / lit; glit = -gs * c.fric * lin_ / (lit * lit); gfric += gs * lin_ / lit; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) gvit[k] += glit * vit[k] / lit;
-      glin -= gvit[1];                       // vit_y = v_y - lin - I_y 1e-30
-      g[0] = gvit[0]; g[2] = gvit[2]; g[1] = gvit[1] + glin;
-    }
-  }
-#pragma unroll
-  for (int pi = 1; pi >= 0; --pi) {
-    if (pi < c.np && stick[pi]) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { qs[pi][k] = g[k] / c.dt; g[k] = 0; }
-    }
-  }
-  const double im = 1.0 / m;
-  ga[0] = g[0] * im; ga[1] = g[1] * im; ga[2] = g[2] * im;
-  ga[3] = -(g[0] * cell[1] + g[1] * cell[2] + g[2] * cell[3]) * im * im;
+  if (inlist) {
+    const double g[3] = {ga[0], ga[1], ga[2]};
+    double gout[4];
+    plb_grid_cell_adj(c, lin, cell[0], cell + 1, g, a.w.pos + ((long)b * (c.S + 1) + a.f) * c.np * 3, a.softness + b * c.np, gout, qs, gfric);
+    ga[0] = gout[0]; ga[1] = gout[1]; ga[2] = gout[2]; ga[3] = gout[3];
   }
   double* gpos = a.w.gpos + ((long)b * (c.S + 1) + a.f) * c.np * 3;
   const bool lead = (threadIdx.x & 63) == 0;
@@ -321,55 +228,20 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
 #pragma unroll
     for (int d = 0; d < 9; ++d) { Cm[d] = hi_[(6 + d) * c.Np + p]; F[d] = hi_[(15 + d) * c.Np + p]; }
     const double E = a.E[b], nu = a.nu[b], ys = a.ys[b];
-    const double mu = E / (2 * (1 + nu)), lam = E * nu / ((1 + nu) * (1 - 2 * nu));
     int base[3];
     double fx[3], w[9], dw[9];
     plb_weights(c, x, base, fx, w, dw);
     // ---- forward pre-pass, as plb_p2g
-    double IC[9], Ft[9], U[9], Vh[9], sig[3];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
-    dm_mul(IC, F, Ft);
+    PlbPre q;
     if (a.w.svd) {                  // the forward's factors of this substep's F (same code, same inputs: the same bits)
       const double* o = a.w.svd + (((long)b * c.S + a.f) * 21) * c.Np + p;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { U[i] = o[i * c.Np]; Vh[i] = o[(12 + i) * c.Np]; }
+      for (int i = 0; i < 9; ++i) { q.U[i] = o[i * c.Np]; q.Vh[i] = o[(12 + i) * c.Np]; }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) sig[i] = o[(9 + i) * c.Np];
-    } else {
-      dsvd3(Ft, U, sig, Vh);
+      for (int i = 0; i < 3; ++i) q.sig[i] = o[(9 + i) * c.Np];
     }
-    double eps[3], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { eps[i] = log(fmax(sig[i], 0.05)); sum += eps[i]; }
-    double eh[3], nn = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { eh[i] = eps[i] - sum / 3; nn += eh[i] * eh[i]; }
-    const double ehn = sqrt(nn + 1e-8);
-    const double dg = ehn - ys / (2 * mu);
-    const bool yields = dg > 0;
-    double nF[9], ex[3] = {1, 1, 1};
-#pragma unroll
-    for (int i = 0; i < 9; ++i) nF[i] = Ft[i];
-    if (yields) {
-      double US[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        ex[i] = exp(eps[i] - (dg / ehn) * eh[i]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) US[r * 3 + i] = U[r * 3 + i] * ex[i];
-      }
-      dm_mul(US, Vh, nF);
-    }
-    const double J = nF[0] * (nF[4] * nF[8] - nF[5] * nF[7]) - nF[1] * (nF[3] * nF[8] - nF[5] * nF[6]) + nF[2] * (nF[3] * nF[7] - nF[4] * nF[6]);
-    double R[9], A[9], St[9], aff[9];
-    dm_mul(U, Vh, R);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) A[i] = nF[i] - R[i];
-    dm_mul_bt(A, nF, St);
-    const double sc = -c.dt * c.p_vol * 4 * c.inv_dx * c.inv_dx;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) aff[i] = sc * (2 * mu * St[i] + ((i % 4 == 0) ? lam * J * (J - 1) : 0.0)) + c.p_mass * Cm[i];
+    plb_prepass(c, E, nu, ys, Cm, F, q, a.w.svd != nullptr);
+    const double* aff = q.aff;
     // ---- gather the cell cotangents (p2g in reverse)
     const double* gacc = a.w.gacc + (long)b * a.G * 4;
     double gv[3] = {0, 0, 0}, gaff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gfx[3] = {0, 0, 0};
@@ -402,106 +274,12 @@ __global__ void __launch_bounds__(128) plb_p2g_adj(PlbArgs a, int gs_in) {
     const double* gxs = a.w.gxs + (long)b * 3 * c.Np;
 #pragma unroll
     for (int d = 0; d < 3; ++d) { g0[d * c.Np + p] = gxs[d * c.Np + p] + c.inv_dx * gfx[d]; g0[(3 + d) * c.Np + p] = gv[d]; }
-    // ---- affine = sc * stress + p_mass * C ; stress = 2 mu (nF - R) nF^T + lam J (J - 1) I
-    double gC[9], Gs[9];
+    double g1F[9], gC[9], gF0[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { gC[i] = c.p_mass * gaff[i]; Gs[i] = sc * gaff[i]; }
-    const double trG = Gs[0] + Gs[4] + Gs[8];
-    double gmu = 0, glam = J * (J - 1) * trG;
+    for (int i = 0; i < 9; ++i) g1F[i] = g1[(15 + i) * c.Np + p];
+    plb_particle_adjoint(c, E, nu, ys, q, F, gaff, g1F, gC, gF0, accE, accNu, accYs);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) gmu += 2 * Gs[i] * St[i];
-    const double gJ = lam * (2 * J - 1) * trG;
-    double gM[9], gA[9], gnF[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gM[i] = 2 * mu * Gs[i];
-    dm_mul(gM, nF, gA);            // M = A nF^T: gA = gM nF
-    dm_mul_at(gM, A, gnF);         // g(nF) = gM^T A
-    const double cof[9] = {nF[4] * nF[8] - nF[5] * nF[7], nF[5] * nF[6] - nF[3] * nF[8], nF[3] * nF[7] - nF[4] * nF[6],
-                           nF[2] * nF[7] - nF[1] * nF[8], nF[0] * nF[8] - nF[2] * nF[6], nF[1] * nF[6] - nF[0] * nF[7],
-                           nF[1] * nF[5] - nF[2] * nF[4], nF[2] * nF[3] - nF[0] * nF[5], nF[0] * nF[4] - nF[1] * nF[3]};
-#pragma unroll
-    for (int i = 0; i < 9; ++i) gnF[i] += gA[i] + gJ * cof[i] + g1[(15 + i) * c.Np + p];   // + the cotangent of F[f + 1]
-    // R = U V^T (Vh = V^T):  gU = gR V = gR Vh^T,  gV = gR^T U  with gR = -gA
-    double gU[9], gV[9], V[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) V[i * 3 + j] = Vh[j * 3 + i];
-    double ngA[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ngA[i] = -gA[i];
-    dm_mul(ngA, V, gU);
-    dm_mul_at(ngA, U, gV);
-    double gsig[3] = {0, 0, 0}, gFt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double gys = 0;
-    if (yields) {   // nF = U diag(ex) V^T
-      double T1[9], T2[9];
-      dm_mul(gnF, V, T1);          // gnF V
-      dm_mul_at(gnF, U, T2);       // gnF^T U
-      double ge[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        ge[i] = U[i] * T1[i] + U[3 + i] * T1[3 + i] + U[6 + i] * T1[6 + i];   // (U^T gnF V)_ii
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { gU[r * 3 + i] += T1[r * 3 + i] * ex[i]; gV[r * 3 + i] += T2[r * 3 + i] * ex[i]; }
-      }
-      double gey[3], geps[3], geh[3];
-      const double q = dg / ehn;
-      double gq = 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { gey[i] = ge[i] * ex[i]; geps[i] = gey[i]; gq -= gey[i] * eh[i]; geh[i] = -q * gey[i]; }
-      // q = 1 - ys / (2 mu ehn)
-      gys = -gq / (2 * mu * ehn);
-      gmu += gq * ys / (2 * mu * mu * ehn);
-      const double gehn = gq * ys / (2 * mu * ehn * ehn);
-      double gsum = 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { geh[i] += gehn * eh[i] / ehn; gsum += geh[i]; }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) { geps[i] += geh[i] - gsum / 3; gsig[i] = (sig[i] > 0.05) ? geps[i] / sig[i] : 0.0; }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) gFt[i] = gnF[i];
-    }
-    // ---- backward_svd (:107-124): gFt += U ((Fm * (U^T gU - gU^T U)) sig) V^T + U (sig ((Fm * (V^T gV - gV^T V)) V^T)) + U gsig V^T
-    {
-      double UtgU[9], VtgV[9];
-      dm_mul_at(U, gU, UtgU);
-      dm_mul_at(V, gV, VtgV);
-      const double s2[3] = {sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2]};
-      double Mm[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          double val = 0.0;
-          if (i != j) {
-            double df = s2[j] - s2[i];
-            df = (df >= 0) ? fmax(df, 1e-6) : fmin(df, -1e-6);   // clamp :152-161
-            const double Fm = 1.0 / df;
-            val = Fm * (UtgU[i * 3 + j] - UtgU[j * 3 + i]) * sig[j] + sig[i] * Fm * (VtgV[i * 3 + j] - VtgV[j * 3 + i]);
-          } else {
-            val = gsig[i];
-          }
-          Mm[i * 3 + j] = val;
-        }
-      double UM[9], add[9];
-      dm_mul(U, Mm, UM);
-      dm_mul(UM, Vh, add);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) gFt[i] += add[i];
-    }
-    // ---- F_tmp = (I + dt C) F
-    double gCF[9], gF0[9];
-    dm_mul_bt(gFt, F, gCF);        // gFt F^T
-    dm_mul_at(IC, gFt, gF0);       // (I + dt C)^T gFt
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { g0[(6 + i) * c.Np + p] = gC[i] + c.dt * gCF[i]; g0[(15 + i) * c.Np + p] = gF0[i]; }
-    // ---- mu, lam -> E, nu
-    const double a1 = 1 + nu, a2 = 1 - 2 * nu;
-    accE = gmu / (2 * a1) + glam * nu / (a1 * a2);
-    accNu = gmu * (-E / (2 * a1 * a1)) + glam * E * (1 + 2 * nu * nu) / (a1 * a1 * a2 * a2);
-    accYs = gys;
+    for (int i = 0; i < 9; ++i) { g0[(6 + i) * c.Np + p] = gC[i]; g0[(15 + i) * c.Np + p] = gF0[i]; }
     }
   }
   // block sums -> one atomic per block and parameter
@@ -747,9 +525,11 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
     ud::set_error("ud_plb_step_bwd: null argument"); return UD_ERR_INVALID;
   }
   if (B < 1) { ud::set_error("ud_plb_step_bwd: B=%d", B); return UD_ERR_INVALID; }
+  if (B > h->B) { ud::set_error("ud_plb_step_bwd: B=%d exceeds the handle's max_envs=%d", B, h->B); return UD_ERR_INVALID; }
   hipStream_t st = (hipStream_t)stream;
-  int rc = plb_reserve(h, B, st, true, false);
-  if (rc) return rc;
+  if (h->cl.per > 0)
+    return plb_cluster_step_bwd(h, B, ckpt, softness, action, E, nu, yield_stress, g_x, g_v, g_C, g_F, g_prim_pos, g_x0, g_v0, g_C0, g_F0,
+                                g_prim_pos0, g_action, g_E, g_nu, g_yield_stress, g_ground_friction, st);
   ud::PlbArgs a;
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
@@ -759,10 +539,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   const bool never_recompute = h->c.gck >= h->cap;          // every substep of every env is in the grid checkpoint: no recompute launch at all
   const int S = h->c.S;
   const dim3 blk(256), gp((h->c.N + 255) / 256, B), gc((h->cap + 255) / 256, B), gpa((h->c.N + 127) / 128, B);
-  const char* lanes_env = getenv("UD_PLB_LANES");          // the forward's diagnostic override (read per call)
-  const int force_lanes = lanes_env ? atoi(lanes_env) : 0;
-  const int lanes = (force_lanes == 1 || force_lanes == 4 || force_lanes == 8) ? force_lanes
-                    : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));   // as the forward (plb.hip)
+  const int lanes = h->lanes ? h->lanes : (((long)B * h->c.N <= 16000) ? 8 : (((long)B * h->c.N < 100000) ? 4 : 1));   // as the forward (plb.hip)
   const dim3 gq((lanes * h->c.N + 255) / 256, B), gqa((lanes * h->c.N + 127) / 128, B);
   hipLaunchKernelGGL(ud::plb_adj_reset_counts, dim3((B + 63) / 64), dim3(64), 0, st, a);
   hipLaunchKernelGGL(ud::plb_adj_pack, gp, blk, 0, st, a, S & 1, g_x, g_v, g_C, g_F, g_prim_pos);
@@ -793,8 +570,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
 
 static int plb_loss_common(ud_plb* h, int B, const double* x, const double* prim_pos, const double* target_density, const double* target_sdf,
                            const double* weights, int soft_contact, hipStream_t st) {
-  int rc = plb_reserve(h, B, st, false, true);
-  if (rc) return rc;
+  if (B > h->B) { ud::set_error("ud_plb_loss: B=%d exceeds the handle's max_envs=%d", B, h->B); return UD_ERR_INVALID; }
   const ud::PlbConst& c = h->c;
   hipError_t e = hipMemsetAsync(h->gm, 0, (size_t)B * h->G * 8, st);
   if (e != hipSuccess) { ud::set_error("ud_plb_loss: memset failed"); return UD_ERR_HIP; }

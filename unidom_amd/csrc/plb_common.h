@@ -222,21 +222,44 @@ void plb_launch_p2g(const PlbArgs& a, int lanes, dim3 grid, hipStream_t st);   /
 
 }  // namespace ud
 
-// ---- host side, shared by plb.hip and plb_adj.hip -----------------------------------------------------------
+// ---- host side, shared by plb.hip, plb_adj.hip and plb_cluster.hip ------------------------------------------
+struct PlbCluster {     // persistent path (plb_cluster.hip): exchange grids for `per` envs per launch, allocated at create
+  void* arena = nullptr;
+  size_t bytes = 0;
+  double* cg[3] = {nullptr, nullptr, nullptr};
+  unsigned* bar = nullptr;
+  double* gposacc = nullptr;
+  double* gpar = nullptr;
+  int* timeouts = nullptr;
+  int W = 0, per = 0;   // parts per env; envs per launch (0 = this handle runs the multi-kernel path)
+};
 struct ud_plb {
   ud::PlbConst c;
-  int B = 0, cap = 0, epoch = 1;
+  int B = 0, cap = 0, epoch = 1;   // B = envs every arena is sized for (ud_plb_conf.max_envs): fixed at create
   long G = 0;
   ud::PlbBuf w{};
   double* gm = nullptr;     // [B][G] grid mass of the loss kernels
   double* lred = nullptr;   // [B][16] loss partial sums
-  bool has_adj = false, has_loss = false;
   void* arena = nullptr;
-  int sort_B = 0, sort_age = 0;   // envs the arena's spatial order (w.perm) covers, forward calls since it was computed
+  int* order = nullptr;     // [B][Np] the handle's current spatial order (both paths)
+  int sort_B = 0, sort_age = 0;   // envs the spatial order covers, forward calls since it was computed
+  int lanes = 0;            // multi-kernel path: lanes per particle forced by the conf (0 = by launch size)
+  int sort_every = 8;       // forward calls between two sorts (<= 0: never sort)
+  PlbCluster cl;
 };
-// (re)size the handle's arena: forward buffers always, adjoint / loss buffers on first use (hipStreamSynchronize + hipFree +
-// hipMalloc when it has to grow: see the header's note on host synchronisation)
-int plb_reserve(ud_plb* h, int B, hipStream_t st, bool adj, bool loss);
+// every arena of the handle, once, at create (no allocation and no host synchronisation in any step call)
+int plb_reserve(ud_plb* h, int B, bool multi_kernel);
 struct PlbCkOff { size_t hist, pos, perm, gck_cnt, gck_lin, gck_val, svd, total; };
 PlbCkOff plb_ckpt_layout(const ud::PlbConst& c, int B);
 void plb_bind_ckpt(ud::PlbArgs& a, const ud::PlbConst& c, int B, void* ckpt);
+// persistent path (plb_cluster.hip)
+int plb_cluster_plan(ud_plb* h, int max_envs);
+int plb_cluster_reserve(ud_plb* h, int per);
+size_t plb_cluster_ckpt_bytes(const ud_plb* h, int B);
+int plb_cluster_step_fwd(ud_plb* h, int B, const double* x, const double* v, const double* C, const double* F, const double* prim_pos,
+                         const double* softness, const double* action, const double* E, const double* nu, const double* ys, double* xo,
+                         double* vo, double* Co, double* Fo, double* prim_o, const int* order, void* ckpt, hipStream_t st);
+int plb_cluster_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, const double* action, const double* E, const double* nu,
+                         const double* ys, const double* g_x, const double* g_v, const double* g_C, const double* g_F, const double* g_prim_pos,
+                         double* g_x0, double* g_v0, double* g_C0, double* g_F0, double* g_prim_pos0, double* g_action, double* g_E, double* g_nu,
+                         double* g_ys, double* g_fric, hipStream_t st);

@@ -143,12 +143,15 @@ class PlbSimulator:
         # include/unidom_hip.h: the checkpoint also keeps the touched grid cells and the adjoint restores them instead of running p2g
         # again (27 = every cell a substep can touch: never falls back; 36 B x 27 n_particles per env and substep of checkpoint)
         self.grid_ckpt_cells = int(getattr(cfg, "grid_ckpt_cells", 27))
+        # kernel selection, fixed at create (include/unidom_hip.h): path 0 = the library's choice (one persistent launch per step call
+        # where it fits), 1 = multi-kernel, 2 = persistent; lanes / sort_every: diagnostics of the multi-kernel path / the spatial order
+        self.path, self.lanes, self.sort_every = (int(getattr(cfg, k, 0)) for k in ("path", "lanes", "sort_every"))
         cc = _lib.ud_plb_conf(
             n_particles=self.n_particles, n_grid=self.n_grid, substeps=self.substeps, dt=self.dt,
             gravity=(C.c_double * 3)(*cfg.gravity), ground_friction=float(cfg.ground_friction), n_primitives=self.n_primitive,
             radius=(C.c_double * 2)(*(list(cfg.prim_radius) + [0.0])[:2]),
             lower_bound=(C.c_double * 3)(*cfg.lower_bound), upper_bound=(C.c_double * 3)(*cfg.upper_bound),
-            grid_ckpt_cells=int(self.grid_ckpt_cells))
+            grid_ckpt_cells=int(self.grid_ckpt_cells), max_envs=int(batch_size), path=self.path, lanes=self.lanes, sort_every=self.sort_every)
         self._h = C.c_void_p()
         self.ground_friction_grad = None   # [B], accumulated by backward() (optimize_ground_friction.grad); reset it by hand
         _lib.check(_lib.lib().ud_plb_create(C.byref(cc), C.byref(self._h)), "ud_plb_create")
@@ -159,6 +162,18 @@ class PlbSimulator:
                 _lib.lib().ud_plb_destroy(self._h)
         except Exception:
             pass
+
+    def launch_plan(self, B=None):
+        """ud_plb_launch_plan: 1 = multi-kernel path, 2 = one persistent launch per step call and direction"""
+        return int(_lib.lib().ud_plb_launch_plan(self._h, C.c_int(self.batch_size if B is None else B)))
+
+    def check_status(self):
+        """Synchronises the current stream; raises if a workgroup of the persistent kernels gave up waiting (outputs NaN); the handle is usable
+        again afterwards (ud_plb_poll_timeouts resets its exchange arena)."""
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        n = int(_lib.lib().ud_plb_poll_timeouts(self._h, stream))
+        if n != 0:
+            raise _lib.UnidomError(_lib.lib().ud_last_error().decode())
 
     def reset(self) -> PlbState:
         """Shapes.add_box with np.random.seed(0) (shape_maker.py:21-31,49-58) + primitive init (torus.yml)."""
