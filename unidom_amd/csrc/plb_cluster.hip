@@ -38,6 +38,22 @@ constexpr int PCL_SMAX = 128;                   // substeps per step call the pr
 constexpr int PCL_BAR_STRIDE = 64, PCL_BAR_GEN = 32, PCL_BAR_EXIT = 48;
 constexpr unsigned PCL_SPIN = 1u << 22;         // polls (~1 us each) before a part gives up
 
+// Diagnostic build only (-DUD_PCL_STAMPS, tools/pcl_stamps.sh): s_memtime at the phase boundaries of the two kernels, summed over thread 0
+// of every part into ud_pcl_stamps[kernel][phase] ([..][15] = parts); memory waits are forced at the stamps so that a load's latency is
+// billed to the phase that issued it.
+#ifdef UD_PCL_STAMPS
+__device__ unsigned long long ud_pcl_stamps[2][16];
+// the sums stay in thread 0's registers until the end of the kernel (an atomic per stamp would put its own round trip into the next phase)
+#define PCL_STAMP_BEGIN unsigned long long pcl_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pcl_t0_ = __builtin_amdgcn_s_memtime();
+#define PCL_STAMP(K, PH) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pcl_acc_[PH] += t_ - pcl_t0_; pcl_t0_ = t_; } } while (0)
+#define PCL_STAMP_END(K) do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&ud_pcl_stamps[K][i_], pcl_acc_[i_]); atomicAdd(&ud_pcl_stamps[K][15], 1ull); } } while (0)
+#else
+#define PCL_STAMP_BEGIN
+#define PCL_STAMP(K, PH) do {} while (0)
+#define PCL_STAMP_END(K) do {} while (0)
+#endif
+
 struct PclCk {          // the caller's checkpoint of one step call, bound to pointers (plb_cluster_ckpt_layout)
   double* hist;         // [B][S+1][24][Np]  particle state at the start of every substep (+ the final one), in the call's spatial order
   double* pos;          // [B][S+1][np][3]   primitive trajectory
@@ -82,23 +98,31 @@ __device__ __forceinline__ void pcl_decode(int W, int& bl, int& w) {   // ids co
 }
 __host__ inline int pcl_grid(int Bl, int W) { return 8 * W * ((Bl + 7) / 8); }
 
-// The parts of an env meet (mpm_cluster.h::clm_barrier): returns false once the env is dead (a part gave up).
-__device__ __forceinline__ bool pcl_barrier(unsigned* bar, unsigned phase, unsigned W, int* s_dead) {
+// The parts of an env meet (mpm_cluster.h::clm_barrier), in two halves so that work which needs nothing from the siblings can run between
+// them: pcl_arrive -- every wave has drained its global traffic, one lane adds to the env's counter, the part whose add completes the count
+// publishes the phase; pcl_wait -- that lane polls the generation word, the others join it at a workgroup barrier.  pcl_wait returns false
+// once the env is dead (a part gave up).
+__device__ __forceinline__ void pcl_arrive(unsigned* bar, unsigned phase, unsigned W) {
   pcl_drain();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == phase * W) {
-      __hip_atomic_store(bar + PCL_BAR_GEN, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      for (unsigned spins = 0; __hip_atomic_load(bar + PCL_BAR_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase; ++spins) {
-        if (spins > PCL_SPIN) { *s_dead = 1; break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
+    if (old + 1u == phase * W) __hip_atomic_store(bar + PCL_BAR_GEN, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__device__ __forceinline__ bool pcl_wait(unsigned* bar, unsigned phase, int* s_dead) {
+  if (threadIdx.x == 0) {
+    for (unsigned spins = 0; __hip_atomic_load(bar + PCL_BAR_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase; ++spins) {
+      if (spins > PCL_SPIN) { *s_dead = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
     }
   }
   __syncthreads();
   return *s_dead == 0;
+}
+__device__ __forceinline__ bool pcl_barrier(unsigned* bar, unsigned phase, unsigned W, int* s_dead) {
+  pcl_arrive(bar, phase, W);
+  return pcl_wait(bar, phase, s_dead);
 }
 // End of a launch: the last part of the env to leave puts the barrier words back to their rest state (no memset between launches).
 __device__ __forceinline__ void pcl_exit(unsigned* bar, unsigned W) {
@@ -205,20 +229,31 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
   int nprev = 0;
   bool alive = true;
   __syncthreads();
+  PCL_STAMP_BEGIN
+  PCL_STAMP(0, 0);                                              // prologue: trajectory, state loads
   for (int f = 0; f < S && alive; ++f) {
     int* klist = s_klist[f & 1];
     const int* kprev = s_klist[(f + 1) & 1];
     double* gcur = a.cg[f % 3] + (long)bl * a.G * 4;
     double* gold = a.cg[(f + 2) % 3] + (long)bl * a.G * 4;    // substep f - 1's buffer
-    // ---- table clear, pre-pass ----
-    for (int s = tid; s < PCL_H; s += PCL_T) { s_key[s] = -1; s_val[s] = 0.0; s_val[PCL_H + s] = 0.0; s_val[2 * PCL_H + s] = 0.0; s_val[3 * PCL_H + s] = 0.0; }
+    // ---- table clear (after the first substep: only the slots the previous substep used -- s_slist still lists them), pre-pass ----
+    if (f == 0) {
+      for (int s = tid; s < PCL_H; s += PCL_T) { s_key[s] = -1; s_val[s] = 0.0; s_val[PCL_H + s] = 0.0; s_val[2 * PCL_H + s] = 0.0; s_val[3 * PCL_H + s] = 0.0; }
+    } else {
+      for (int e = tid; e < nprev; e += PCL_T) {
+        const int s = s_slist[e];
+        s_key[s] = -1; s_val[s] = 0.0; s_val[PCL_H + s] = 0.0; s_val[2 * PCL_H + s] = 0.0; s_val[3 * PCL_H + s] = 0.0;
+      }
+    }
     if (tid == 0) s_n = 0;
+    PCL_STAMP(0, 9);                                            // (diagnostic split of phase 1) table clear
     int base[3] = {0, 0, 0};
     double fx[3], wgt[9];
     PlbPre q;
     if (live) {
       plb_weights_fwd(c, x, base, fx, wgt);
       plb_prepass(c, E, nu, ys, Cm, F, q, false);
+      PCL_STAMP(0, 10);                                         // (diagnostic split) weights + pre-pass
       if (a.keep && qi == 0) {      // record f: the state this substep starts from, and the factors of its F_tmp
         double* ho = pcl_hist(a, b, f);
 #pragma unroll
@@ -233,16 +268,21 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
       }
     }
     __syncthreads();
-    // ---- p2g into the table ----
+    PCL_STAMP(0, 1);                                            // table clear, pre-pass, record stores
+    // ---- p2g into the table (the lane's four cells keep their slots for the gather below) ----
+    const int rot = (p * PCL_LANES) % 27;     // staggered stencil walk: neighbouring particles never on the same slot at once
+    int slot4[4] = {0, 0, 0, 0};
     if (live) {
-      const int rot = (p * PCL_LANES) % 27;   // staggered stencil walk: neighbouring particles never on the same slot at once
-#pragma unroll 1
-      for (int it = qi; it < 27; it += PCL_LANES) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int it = qi + PCL_LANES * t;
+        if (it >= 27) break;
         const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
         const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
         const double weight = dsel3(wgt, 0, i) * dsel3(wgt, 1, j) * dsel3(wgt, 2, k);
         const double dp0 = ((double)i - fx[0]) * c.dx, dp1 = ((double)j - fx[1]) * c.dx, dp2 = ((double)k - fx[2]) * c.dx;
         const int sl = pcl_find(s_key, (int)plb_stencil_lin(c, base, cidx));
+        slot4[t] = sl;
         __hip_atomic_fetch_add(&s_val[sl], weight * c.p_mass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int r = 0; r < 3; ++r)
@@ -251,15 +291,19 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
       }
     }
     __syncthreads();
+    PCL_STAMP(0, 2);                                            // p2g walk
     const int n = pcl_compact(s_key, klist, s_slist, &s_n);
+    PCL_STAMP(0, 3);                                            // compaction
     // ---- flush: four lanes per cell, one per component (a cell is 32 contiguous bytes) ----
     {
       const int r = tid & 3;
       for (int e = tid >> 2; e < n; e += PCL_T / 4)
         __hip_atomic_fetch_add(gcur + (long)klist[e] * 4 + r, s_val[r * PCL_H + s_slist[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PCL_STAMP(0, 4);                                            // flush atomics (drained)
     alive = pcl_barrier(bar, (unsigned)(f + 1), (unsigned)a.W, &s_dead);
     if (!alive) break;
+    PCL_STAMP(0, 5);                                            // barrier
     // ---- read the summed cells back, (record,) grid op; zero the cells of substep f - 1 ----
     for (int e0 = 0; e0 < n; e0 += PCL_T) {
       const int e = e0 + tid;
@@ -286,15 +330,17 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
     }
     nprev = n;
     __syncthreads();
+    PCL_STAMP(0, 6);                                            // read-back, records, grid op, zeroing
     // ---- g2p + advect ----
     if (live) {
       double nv[3] = {0, 0, 0}, nC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int cidx = qi + PCL_LANES * t;
-        if (cidx >= 27) break;
+        const int it = qi + PCL_LANES * t;
+        if (it >= 27) break;
+        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
         const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
-        const int sl = pcl_lookup(s_key, (int)plb_stencil_lin(c, base, cidx));
+        const int sl = slot4[t];
         const double g3[3] = {s_val[PCL_H + sl], s_val[2 * PCL_H + sl], s_val[3 * PCL_H + sl]};
         const double weight = dsel3(wgt, 0, i) * dsel3(wgt, 1, j) * dsel3(wgt, 2, k);
         const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
@@ -315,6 +361,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
       for (int d = 0; d < 9; ++d) { Cm[d] = nC[d]; F[d] = q.nF[d]; }
     }
     __syncthreads();   // s_key / s_val are rewritten by the next substep
+    PCL_STAMP(0, 7);                                            // g2p
   }
   // the buffers go back all-zero: the cells of the last substep, once every part has read them
   if (alive) alive = pcl_barrier(bar, (unsigned)(S + 1), (unsigned)a.W, &s_dead);
@@ -346,6 +393,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
   }
   if (w == 0 && tid < c.np * 3) a.prim_o[(long)b * c.np * 3 + tid] = s_pos[S * c.np * 3 + tid];   // copyframe(cur, 0)
   if (tid == 0 && s_dead) atomicAdd(a.timeouts, 1);
+  PCL_STAMP(0, 8);                                              // last meeting, zeroing, outputs
+  PCL_STAMP_END(0);
 }
 
 // ---- backward -----------------------------------------------------------------------------------------------------------------------
@@ -390,6 +439,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
   bool alive = true;
   unsigned phase = 0;
   __syncthreads();
+  PCL_STAMP_BEGIN
+  PCL_STAMP(1, 0);
   for (int f = S - 1; f >= 0 && alive; --f) {
     const int ring = (S - 1 - f) % 3;                          // buffers rotate in the order the substeps are reversed
     int* klist = s_klist[ring];
@@ -397,7 +448,14 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
     double* gcur = a.cg[ring] + (long)bl * a.G * 4;
     double* gold = a.cg[(ring + 2) % 3] + (long)bl * a.G * 4;
     // ---- the part's cells of substep f from its records; particle state f and the SVD factors from the checkpoint ----
-    for (int s = tid; s < PCL_H; s += PCL_T) { s_key[s] = -1; s_gv[s] = 0.0; s_gv[PCL_H + s] = 0.0; s_gv[2 * PCL_H + s] = 0.0; }
+    if (f == S - 1) {
+      for (int s = tid; s < PCL_H; s += PCL_T) { s_key[s] = -1; s_gv[s] = 0.0; s_gv[PCL_H + s] = 0.0; s_gv[2 * PCL_H + s] = 0.0; }
+    } else {                                                   // only the slots substep f + 1 used (s_slist still lists them)
+      for (int e = tid; e < nprev; e += PCL_T) {
+        const int s = s_slist[e];
+        s_key[s] = -1; s_gv[s] = 0.0; s_gv[PCL_H + s] = 0.0; s_gv[2 * PCL_H + s] = 0.0;
+      }
+    }
     const int n = a.ck.rec_cnt[((long)b * S + f) * a.W + w];
     __syncthreads();
     for (int e = tid; e < n; e += PCL_T) {
@@ -428,9 +486,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) q.sig[i] = o[(9 + i) * c.Np];
       plb_weights(c, x, base, fx, wgt, dw);
-      plb_prepass(c, E, nu, ys, Cm, F, q, true);
     }
     __syncthreads();
+    PCL_STAMP(1, 1);                                            // restore records, state + SVD loads
     // ---- grid op on the part's cells: v_out ----
     for (int e = tid; e < n; e += PCL_T) {
       const int sl = s_slist[e];
@@ -440,8 +498,11 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
       s_vout[sl] = vv[0]; s_vout[PCL_H + sl] = vv[1]; s_vout[2 * PCL_H + sl] = vv[2];
     }
     __syncthreads();
+    PCL_STAMP(1, 2);                                            // grid op
     // ---- g2p adjoint (:234-253 in reverse): v_out cotangents into the table, the x cotangent that flows through g2p ----
     double gxs[3] = {0, 0, 0};
+    const int rot = (p * PCL_LANES) % 27;
+    int slot4[4] = {0, 0, 0, 0};
     if (live) {
       double gxp[3];
 #pragma unroll
@@ -453,15 +514,17 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
       }
       double gfx[3] = {0, 0, 0};
       const double k4 = 4 * c.inv_dx;
-      const int rot = (p * PCL_LANES) % 27;
-#pragma unroll 1
-      for (int it = qi; it < 27; it += PCL_LANES) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int it = qi + PCL_LANES * t;
+        if (it >= 27) break;
         const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
         const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
         const double wi = dsel3(wgt, 0, i), wj = dsel3(wgt, 1, j), wk = dsel3(wgt, 2, k);
         const double weight = wi * wj * wk;
         const double dp[3] = {(double)i - fx[0], (double)j - fx[1], (double)k - fx[2]};
         const int sl = pcl_lookup(s_key, (int)plb_stencil_lin(c, base, cidx));
+        slot4[t] = sl;
         const double g[3] = {s_vout[sl], s_vout[PCL_H + sl], s_vout[2 * PCL_H + sl]};
         double gw = 0, gdp[3] = {0, 0, 0};
 #pragma unroll
@@ -480,6 +543,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
       for (int d = 0; d < 3; ++d) gxs[d] = gxp[d] + c.inv_dx * plb_quad_sum<PCL_LANES>(gfx[d]);
     }
     __syncthreads();
+    PCL_STAMP(1, 3);                                            // g2p adjoint walk
     // ---- flush the v_out cotangents, meet, read the env's sums back; zero the cells of substep f + 1 ----
     {
       const int r = tid & 3;
@@ -487,8 +551,15 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
         for (int e = tid >> 2; e < n; e += PCL_T / 4)
           __hip_atomic_fetch_add(gcur + (long)klist[e] * 4 + r, s_gv[r * PCL_H + s_slist[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    alive = pcl_barrier(bar, ++phase, (unsigned)a.W, &s_dead);
+    PCL_STAMP(1, 4);                                            // flush atomics (drained)
+    // the particle pre-pass (stress, return mapping: what the p2g adjoint needs) asks nothing of the siblings: it runs while the arrivals
+    // and the generation word travel
+    pcl_arrive(bar, ++phase, (unsigned)a.W);
+    if (live) plb_prepass(c, E, nu, ys, Cm, F, q, true);
+    PCL_STAMP(1, 9);                                            // arrive + pre-pass
+    alive = pcl_wait(bar, phase, &s_dead);
     if (!alive) break;
+    PCL_STAMP(1, 5);                                            // wait
     // ---- grid-op adjoint per cell (every part that holds the cell: same inputs, same result); its per-env cotangents weighted with the
     // part's share of the cell's mass ----
     for (int e0 = 0; e0 < n; e0 += PCL_T) {
@@ -534,16 +605,20 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
     }
     nprev = n;
     __syncthreads();
+    PCL_STAMP(1, 6);                                            // read-back, grid-op adjoint, per-env atomics, zeroing
     // ---- p2g adjoint (gather from LDS) + particle adjoint: the cotangent of state f replaces that of f + 1 ----
     if (live) {
       double gv[3] = {0, 0, 0}, gaff[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gfx[3] = {0, 0, 0};
-#pragma unroll 1
-      for (int cidx = qi; cidx < 27; cidx += PCL_LANES) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int it = qi + PCL_LANES * t;
+        if (it >= 27) break;
+        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
         const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
         const double wi = dsel3(wgt, 0, i), wj = dsel3(wgt, 1, j), wk = dsel3(wgt, 2, k);
         const double weight = wi * wj * wk;
         const double dp[3] = {((double)i - fx[0]) * c.dx, ((double)j - fx[1]) * c.dx, ((double)k - fx[2]) * c.dx};
-        const int sl = pcl_lookup(s_key, (int)plb_stencil_lin(c, base, cidx));
+        const int sl = slot4[t];
         const double gm = s_mmv[sl], gmv[3] = {s_mmv[PCL_H + sl], s_mmv[2 * PCL_H + sl], s_mmv[3 * PCL_H + sl]};
         double gw = c.p_mass * gm, gdp[3] = {0, 0, 0};
 #pragma unroll
@@ -570,6 +645,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
       for (int d = 0; d < 9; ++d) { gC1[d] = gC0[d]; gF1[d] = gF0[d]; }
     }
     __syncthreads();   // the tables are rewritten by the next substep
+    PCL_STAMP(1, 7);                                            // p2g adjoint gather + particle adjoint
   }
   // E / nu / yield-stress cotangents: one atomic per part and parameter, before the last meeting
   {
@@ -635,6 +711,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
     for (int d = 0; d < 9; ++d) { a.Co[o9 + d] = gC1[d] + bad; a.Fo[o9 + d] = gF1[d] + bad; }
   }
   if (tid == 0 && s_dead) atomicAdd(a.timeouts, 1);
+  PCL_STAMP(1, 8);
+  PCL_STAMP_END(1);
 }
 
 }  // namespace ud
@@ -752,3 +830,11 @@ int plb_cluster_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softn
   if (e != hipSuccess) { ud::set_error("ud_plb_step_bwd (persistent path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
   return UD_OK;
 }
+
+#ifdef UD_PCL_STAMPS
+extern "C" int ud_debug_pcl_stamps(unsigned long long* out32, int reset) {   // diagnostic builds only: [2][16] counters
+  if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(ud::ud_pcl_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ud::ud_pcl_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif

@@ -64,23 +64,59 @@ __device__ __forceinline__ void dm_mul_bt(const double* A, const double* B, doub
     for (int j = 0; j < 3; ++j) R[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
 }
 
+// f64 reciprocal / square root / reciprocal square root from the hardware seeds (v_rcp_f64 / v_rsq_f64) and Newton / Goldschmidt steps on FMAs,
+// for operands in the normal range (no scaling, no special-case fix-up: the compiler's IEEE sequences carry both, v_div_scale / v_div_fmas /
+// v_div_fixup and two v_ldexp, and are 11-14 dependent instructions each).  Two quadratic steps from the seed (>= 14 good bits) reach the last
+// one or two bits; the Jacobi rotations below need no more -- their angle only has to shrink the off-diagonal product, the factors are re-
+// normalised at the end.
+__device__ __forceinline__ double ud_rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double ud_sqrt_nr(double x) {      // x > 0
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  return fma(d, h, g);
+}
+__device__ __forceinline__ double ud_rsqrt_nr(double x) {     // x > 0
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);                                           // 0.5 / sqrt(x)
+  return h + h;
+}
+
+// One-sided Jacobi rotation of columns p, q.  With al = |a_p|^2, be = |a_q|^2, ga = a_p . a_q the textbook angle is zeta = (be - al) / (2 ga),
+// t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), c = 1 / sqrt(1 + t^2): three square roots and three divisions in one dependent chain (with the
+// threshold's sqrt(al be)).  The same t without forming zeta: t = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)) with d = be - al, g = 2 ga -- ONE square
+// root, ONE reciprocal, ONE reciprocal square root; the thresholds compare squares.  The rotation was 60-70 % of the particle pre-pass, which was
+// 5.7 of the persistent forward's 19 us per substep (tools/pcl_stamps.py).
 #define UD_DJROT(p, q)                                                                       \
   {                                                                                          \
-    double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                      \
-    double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                      \
-    double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                      \
-    const double nrm_ = sqrt(al * be);                                                        \
-    const bool rot = !done && fabs(ga) > 1e-17 * nrm_;                                        \
-    big_rot |= fabs(ga) > 3e-9 * nrm_;                                                        \
-    double zeta = (be - al) / (2.0 * (rot ? ga : 1.0));                                       \
-    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                  \
-    double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;                                         \
+    const double al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                \
+    const double be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                \
+    const double ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                \
+    const double ab_ = al * be, gg_ = ga * ga;                                                \
+    const bool rot = !done && gg_ > 1e-34 * ab_;            /* |ga| > 1e-17 sqrt(al be) */    \
+    big_rot |= gg_ > 9e-18 * ab_;                           /* |ga| > 3e-9 sqrt(al be) */     \
+    const double g2_ = rot ? ga + ga : 1.0, d_ = be - al;                                     \
+    const double h_ = ud_sqrt_nr(fma(d_, d_, g2_ * g2_));                                     \
+    double t = fabs(g2_) * ud_rcp_nr(fabs(d_) + h_);                                          \
+    t = ((d_ < 0.0) != (g2_ < 0.0)) ? -t : t;                                                 \
+    double cs = ud_rsqrt_nr(fma(t, t, 1.0)), sn = cs * t;                                     \
     cs = rot ? cs : 1.0; sn = rot ? sn : 0.0;                                                 \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                           \
       double ap = a[i * 3 + p], aq = a[i * 3 + q];                                            \
       a[i * 3 + p] = cs * ap - sn * aq; a[i * 3 + q] = sn * ap + cs * aq;                     \
       double vp = vv[i * 3 + p], vq = vv[i * 3 + q];                                          \
-      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                   \
+      vv[i * 3 + p] = cs * vp - sn * vq; vv[i * 3 + q] = sn * vp + cs * vq;                     \
     }                                                                                         \
   }
 #define UD_DCSWAP(p, q)                                                              \
@@ -110,18 +146,24 @@ __device__ __forceinline__ void dsvd3(const double* A, double* U, double* S, dou
     done = done || !big_rot;      // per matrix, so that the result does not depend on what else is in the wave
     if (!__any(!done)) break;
   }
-  double sv[3];
+  double sv[3], isv[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) sv[j] = sqrt(a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j]);
-  UD_DCSWAP(0, 1)
-  UD_DCSWAP(1, 2)
-  UD_DCSWAP(0, 1)
+  for (int j = 0; j < 3; ++j) {
+    const double n2 = a[j] * a[j] + a[3 + j] * a[3 + j] + a[6 + j] * a[6 + j];
+    const bool pos = n2 > 1e-280;
+    isv[j] = pos ? ud_rsqrt_nr(pos ? n2 : 1.0) : 0.0;
+    sv[j] = pos ? n2 * isv[j] : 0.0;
+  }
+#define UD_DISWAP(p, q) { const bool sw_ = sv[p] < sv[q]; const double ti_ = isv[p]; isv[p] = sw_ ? isv[q] : isv[p]; isv[q] = sw_ ? ti_ : isv[q]; }
+  UD_DISWAP(0, 1) UD_DCSWAP(0, 1)
+  UD_DISWAP(1, 2) UD_DCSWAP(1, 2)
+  UD_DISWAP(0, 1) UD_DCSWAP(0, 1)
+#undef UD_DISWAP
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     S[j] = sv[j];
-    const double inv = sv[j] > 1e-300 ? 1.0 / sv[j] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * inv; Vh[j * 3 + i] = vv[i * 3 + j]; }
+    for (int i = 0; i < 3; ++i) { U[i * 3 + j] = a[i * 3 + j] * isv[j]; Vh[j * 3 + i] = vv[i * 3 + j]; }
   }
 }
 

@@ -172,7 +172,7 @@ __device__ __forceinline__ void plb_particle_adjoint(const PlbConst& c, double E
         if (i != j) {
           double df = s2[j] - s2[i];
           df = (df >= 0) ? fmax(df, 1e-6) : fmin(df, -1e-6);   // clamp :152-161
-          const double Fm = 1.0 / df;
+          const double Fm = ud_rcp_nr(df);
           val = Fm * (UtgU[i * 3 + j] - UtgU[j * 3 + i]) * sig[j] + sig[i] * Fm * (VtgV[i * 3 + j] - VtgV[j * 3 + i]);
         } else {
           val = gsig[i];
