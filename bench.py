@@ -882,7 +882,7 @@ def bench_fold_tshirt(args, rank, world, device):
     dt = float(tm[0])
     if rank == 0:
         P = st.x.shape[1]
-        cluster = os.environ.get("UD_CLOTH_CLUSTER", "1") != "0"     # csrc/cloth.hip::cloth_use_cluster; launches of <= n_cu // parts envs
+        cluster = not getattr(env.conf, "one_workgroup_per_env", False)   # csrc/cloth.hip::cloth_use_cluster; launches of <= n_cu // parts envs
         units = world * B * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
@@ -1000,6 +1000,9 @@ def main():
     ap.add_argument("--grid-ckpt", type=int, default=2, help="scaled whip_rope only: ud_mpm_conf.grid_ckpt_cells (0 = the backward "
                     "recomputes p2g + grid op instead of restoring the checkpointed grid)")
     ap.add_argument("--plb-grad", action="store_true", help="torus only: forward with checkpoints + loss + adjoint instead of the forward rollout")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="MPM workloads, diagnostics only: ud_mpm_conf.tune_* of every simulator this run builds (lanes, cluster, cluster_part_lanes, "
+                         "cluster_envs, env_groups, bwd_two_launch), e.g. --tune env_groups=1 for counter passes that attribute per kernel")
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
     args = ap.parse_args()
@@ -1012,6 +1015,9 @@ def main():
 
     rank, world, device = init_distributed(args.gpus)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.tune:
+        from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+        SimpleMPMSimulator.default_tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune}
     if args.workload == "selftest":
         return bench_selftest(args, rank, world, device)
     if args.workload == "torus":

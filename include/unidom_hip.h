@@ -72,6 +72,11 @@ typedef struct {
                     *    SEVERAL workgroups per env (512 particles each, halo positions / force cotangents / block sums handed
                     *    over through HBM every substep; forward still bit-identical to the v2 restatement); mode 1 runs the
                     *    reference-order kernels on one 1024-lane workgroup per env. */
+  int max_envs;    /* the largest B any call on this handle will pass (>= 1): handle-owned scratch (bodies above 1024 particles: the
+                    * several-workgroup kernels' hand-off arena, or the one-workgroup adjoint's parking area) is allocated in
+                    * ud_cloth_create for this many envs; a call with more returns UD_ERR_INVALID */
+  int one_workgroup_per_env;   /* bodies above 1024 particles only.  != 0: keep the one-workgroup-per-env kernels where the library would
+                    * run several workgroups per env (diagnostics and tests; fixed at create) */
 } ud_cloth_conf;
 
 /* mask: host pointer, N*N bytes, row-major, non-zero = cloth particle (create_cloth_mask,
@@ -177,6 +182,22 @@ typedef struct {
                                 default forward at 67 particles, 332x at 798 (profiles/r03g_det_cost.txt).  Position control with one box primitive only
                                 (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the backward is
                                 the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
+  int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
+                                grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's
+                                scratch) is allocated in ud_mpm_create for this many envs: no step call allocates or synchronises the
+                                host; a call with B > max_envs returns UD_ERR_INVALID.  (SimpleMPMSimulator's batch size,
+                                mpm_simulator.py:27-63: known when the simulator is built) */
+  /* Kernel selection of the many-workgroup path, fixed at create; 0 everywhere = the library's choice by measurement,
+     which ud_mpm_launch_plan reports.  The other values exist for diagnostics and so that the tests can put every kernel before the
+     oracle at sizes the oracle can follow: */
+  int tune_lanes;            /* lanes per particle of the particle kernels: 0 = 4 below 100 000 particles per launch, 1 beyond; 1 / 4 force */
+  int tune_cluster;          /* the persistent forward (one launch per step call): 0 = solids with one primitive in the four-lane regime;
+                                1 = wherever its parts fit the chip; -1 = never (the multi-kernel forward) */
+  int tune_cluster_part_lanes; /* its lanes per part: 0 = 128 (32 particles), 64 (16 particles: a part can never outgrow its cell table) */
+  int tune_cluster_envs;     /* > 0: at most this many envs per persistent launch (several launches per call) */
+  int tune_env_groups;       /* > 0: this many stream groups on the multi-kernel path (1 = everything on the caller's stream) */
+  int tune_bwd_two_launch;   /* backward with the grid checkpoint: 0 = two launches per reverse substep where they apply (four lanes, one
+                                primitive); -1 = always the four-kernel sequence */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */
@@ -194,15 +215,23 @@ size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B);
  * the grid from the checkpoint (grid_ckpt_cells > 0), takes two launches per substep, else four (six when it recomputes).
  * Negative: bad arguments. */
 int ud_mpm_launch_plan(const ud_mpm* h, int B);
+/* Puts every handle-owned arena back into its rest state, asynchronously on `stream` (no host synchronisation).  For the one case in which
+ * a step call can leave them dirty: status bit 4 of the persistent forward (a workgroup gave up waiting for its siblings and skipped
+ * the zeroing of its cells).  Until then later calls on the handle would sum into stale cells.  The Python mirror calls it when its
+ * status check sees that bit.  The persistent forward needs every workgroup of a launch resident at once (launch size = occupancy x CUs
+ * of an otherwise idle device): kernels of other streams or processes that occupy CUs for seconds are what can cause such a time-out. */
+int ud_mpm_reset(ud_mpm* h, void* stream);
 
 /* Forward `step`: state (x,v [B,N,3]; C,F [B,N,3,3]; J [B,N]), primitive 0 (position [B,steps,3], rotation
  * [B,steps,4] (w,x,y,z), size [B,3]), friction/mu/lamda [B], action [B,6] -> new state, primitive position /
  * rotation after copy_frame(steps,0) and the v,w [B,steps,3] written by set_action.
  * ckpt (may be NULL = no backward): ud_mpm_ckpt_bytes() bytes. status [B] int32, written asynchronously, the caller reads
  * it when it next synchronises: 0 ok.  One-workgroup path: 1 = LDS cell table overflow in that env (outputs invalid).
- * Many-workgroup path, a bit mask: 1 = the grid-checkpoint pool ran out in that env (outputs valid; that step's backward
- * must recompute: clip bit 1 of ud_mpm_step_bwd), 2 = a workgroup's cell table overflowed (persistent forward: a part of 32
- * particles touched more than 512 cells; outputs invalid), 4 = a workgroup gave up waiting for a sibling (outputs invalid). */
+ * Many-workgroup path, a bit mask: 1 = the grid checkpoint of that env is incomplete -- its pool ran out, or (persistent forward) a
+ * part of 32 particles touched more cells than its 512-slot table holds and sent the rest to the HBM grid directly (outputs valid; that
+ * step's backward must recompute the grid: clip bit 1 of ud_mpm_step_bwd); 2 = a part's spill list overflowed as well (more than 896
+ * cells for 32 particles: cannot happen with a 27-cell stencil; outputs invalid); 4 = a workgroup gave up waiting for a sibling
+ * (outputs invalid; call ud_mpm_reset before the next step). */
 int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                     const float* prim_position, const float* prim_rotation, const float* prim_size,
                     const float* friction, const float* mu, const float* lamda, const float* action, float* x_out,

@@ -394,13 +394,11 @@ def test_big_body_kernels_match_oracle(which, path, monkeypatch):
     """Bodies above 1024 particles (fold_tshirt: 3573).  Default: the env is cut into parts of 512 particles, one workgroup
     each, exchanging halo positions / force cotangents / the nine block sums through HBM (csrc/cloth_cluster.h) -- the
     per-particle code of the 512-particle kernels, so the forward is bit-exact against the oracle in operation order "v2".
-    UD_CLOTH_CLUSTER=0: one workgroup per env, four particles per lane, reference operation order (the path a launch takes
-    when its parts would not all fit on the chip at once) -- bit-exact against the reference-order oracle.  Grasp sets
+    ud_cloth_conf.one_workgroup_per_env: one workgroup per env, four particles per lane, reference operation order (the path a launch
+    takes when its parts would not all fit on the chip at once) -- bit-exact against the reference-order oracle.  Grasp sets
     included; adjoint within the usual tolerance on both paths."""
     from oracle.pyoracle import ClothOracle
     from unidom_amd.engine.cloth_simulator import ClothSimulator
-    if path == "one_workgroup":
-        monkeypatch.setenv("UD_CLOTH_CLUSTER", "0")
     N = 180
     if which == "disk":
         ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
@@ -412,7 +410,9 @@ def test_big_body_kernels_match_oracle(which, path, monkeypatch):
     P = int(mask.sum())
     assert 1024 < P <= 4096 and P % 64 != 0
     B, T = 2, 2
-    sim = ClothSimulator(BigConf(), B, lambda x, v, i, j: v, mask)
+    conf = BigConf()
+    conf.one_workgroup_per_env = path == "one_workgroup"
+    sim = ClothSimulator(conf, B, lambda x, v, i, j: v, mask)
     orc = ClothOracle(mask, N=N, order=2 if path == "several_workgroups" else 1,
                       **{k: getattr(BigConf, k) for k in ("gravity", "damping", "dt", "max_v", "small_num")})
     assert sim.n_particles == orc.P == P

@@ -607,9 +607,11 @@ def test_mpm_step_diff_fused_matches_op_by_op(name):
     assert name == "shape_rope" or not ({"grad a", "grad x", "grad v", "grad pos0"} & set(skipped)), skipped
 
 
-SHAPE_ROPE_WIRING_STEPS = 8   # scanned simulator.steps (133 substeps each) of the gradient wiring check below: the longest horizon at
-                              # which the measured noise of the adjoint (one-ulp nudge, run-to-run) stays under 5 % for the action, x, v
-                              # and C cotangents -- 1e-3 ... 1e-2 up to 8 steps, O(1) from 12 on (profiles/r03_shape_rope_grad_noise.txt).
+SHAPE_ROPE_WIRING_STEPS = 6   # scanned simulator.steps (133 substeps each) of the gradient wiring check below: a horizon at which the
+                              # measured noise of the adjoint (one-ulp nudge, run-to-run) stays under 5 % for the action, x, v and C
+                              # cotangents -- 1e-3 ... 1e-2 up to 8 steps, O(1) from 12 on (profiles/r03_shape_rope_grad_noise.txt); the
+                              # onset moves with the float atomics' order from build to build: at 8 a round-4 build (same per-cell
+                              # arithmetic, another schedule) measured 5 % on the action and x cotangents, so two steps of margin.
                               # The F cotangent is the exception: 0.3 ... 1 at EVERY horizon, one step included (a plastic body's F enters
                               # only through the SVD of (I + dt C) F, with 1 / (s_j^2 - s_i^2) factors on an almost isotropic F); it is
                               # compared wherever its noise allows and reported otherwise.
@@ -825,7 +827,8 @@ def test_pour_soup_reset_step_matches_oracle_and_grad():
 @pytest.mark.gpu
 def test_pour_soup_step_matches_oracle_with_one_lane_kernels(monkeypatch):
     """bench.py's pour_soup workload (32 envs x 7631 particles) runs the one-lane-per-particle kernels of the many-workgroup path;
-    at the two envs the oracle can follow the four-lane ones would run.  UD_LG_LANES=1 (read per step call) puts the same env.step
-    through the one-lane kernels: internal spatial order, block window / hash staging, soft contact, mixed materials."""
-    monkeypatch.setenv("UD_LG_LANES", "1")
+    at the two envs the oracle can follow the four-lane ones would run.  tune_lanes = 1 (ud_mpm_conf, fixed at create) puts the same
+    env.step through the one-lane kernels: internal spatial order, block window / hash staging, soft contact, mixed materials."""
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    monkeypatch.setattr(SimpleMPMSimulator, "default_tuning", {"lanes": 1})
     test_pour_soup_reset_step_matches_oracle_and_grad()

@@ -339,34 +339,37 @@ def _scaled_case(S, seed, B=1, grid_ckpt_cells=0, conf_cls=ScaledConf):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
-@pytest.fixture(params=["cluster_128", "cluster_64", "cluster_128_both", "cluster_64_both", "multi_kernel"])
+def _tune(monkeypatch, **kw):
+    """Kernel selection of every SimpleMPMSimulator built from here on in this test (ud_mpm_conf.tune_*, fixed at ud_mpm_create)."""
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    monkeypatch.setattr(SimpleMPMSimulator, "default_tuning", dict(kw))
+
+
+@pytest.fixture(params=["cluster_128", "cluster_64", "multi_kernel"])
 def large_path(request, monkeypatch):
-    """The many-workgroup path below 100 k particles per launch has two implementations: the persistent cluster kernels
-    (csrc/mpm_cluster.h; one launch per step call, parts of 32 or 16 particles -- UD_MPM_CLUSTER_T) and the multi-kernel path
-    (UD_MPM_CLUSTER=0; a few launches per substep).  By default the FORWARD of a one-primitive solid takes the cluster kernel and
-    writes the grid checkpoint the multi-kernel backward restores from; *_both also runs the cluster backward
-    (UD_MPM_CLUSTER_BWD=1).  All switches are read at every step call, so a test can put each combination in front of the oracle."""
+    """The many-workgroup path below 100 k particles per launch has two forwards: the persistent cluster kernel (csrc/mpm_cluster.h; one
+    launch per step call, parts of 32 or 16 particles -- tune_cluster_part_lanes) and the multi-kernel forward (tune_cluster = -1; two
+    launches per substep).  By default a one-primitive solid takes the cluster forward, which writes the grid checkpoint the
+    multi-kernel backward restores from.  The choice is fixed when a handle is created; the fixture sets it for the handles of a test."""
     if request.param == "multi_kernel":
-        monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+        _tune(monkeypatch, cluster=-1)
     else:
-        monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-        monkeypatch.setenv("UD_MPM_CLUSTER_T", request.param.split("_")[1])
-        monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1" if request.param.endswith("both") else "0")
+        _tune(monkeypatch, cluster=1, cluster_part_lanes=int(request.param.split("_")[1]))
     return request.param
 
 
 @pytest.fixture
 def multi_kernel_path(monkeypatch):
     """for the tests of the multi-kernel path's own machinery (active list, bitmap, grid checkpoint)"""
-    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
+    _tune(monkeypatch, cluster=-1)
 
 
 @pytest.fixture
 def one_lane_per_particle(monkeypatch):
     """The many-workgroup kernels come in two lane mappings: 4 lanes per particle below 100 k particles per launch, 1 beyond --
-    sizes the CPU oracle cannot follow.  UD_LG_LANES (read at every step call) forces the mapping, so the one-lane kernels
-    (the ones bench.py's n_grid-256 and pour_soup workloads run) meet the oracle at test sizes."""
-    monkeypatch.setenv("UD_LG_LANES", "1")
+    sizes the CPU oracle cannot follow.  tune_lanes = 1 (fixed at create) puts the one-lane kernels (the ones bench.py's n_grid-256 and
+    pour_soup workloads run) before the oracle at test sizes."""
+    _tune(monkeypatch, lanes=1)
 
 
 @pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
@@ -414,7 +417,7 @@ def test_baseline_config4_size_n_grid_256_matches_oracle(grid_ckpt_cells):
     from oracle.pyoracle import MpmOracle
     S, B, pick = 3, 16, [0, 9]
     sim, st, g, N = _scaled_case(S, 11, B=B, grid_ckpt_cells=grid_ckpt_cells, conf_cls=ScaledConf256)
-    assert N == 6675 and B * N >= 100000 and "UD_LG_LANES" not in os.environ
+    assert N == 6675 and B * N >= 100000 and _no_path_override()
     st["action"][9] = np.float32([-0.3, 0.2, 0.1, 0, 0, 0]) / 50
     sub = lambda d: {k: np.ascontiguousarray(v[pick]) for k, v in d.items()}
     orc = MpmOracle(N, n_grid=256, res=(128, 128, 128), steps=S)
@@ -468,13 +471,13 @@ def test_large_path_matches_oracle_n798(grid_ckpt_cells, large_path):
 
 
 @pytest.mark.parametrize("lanes", ["4", "1"])
-def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch, multi_kernel_path):
+def test_active_list_bitmap_rows_at_every_word_offset(lanes, monkeypatch):
     """First toucher of a cell = whoever sets its bit in the env's bitmap; a block window marks a row of eight z-consecutive cells
     with one OR, or two when the row straddles a 32-bit word (z offset of the window & 31 > 24).  The rope is moved cell by cell
     in z so that the windows start at z = 25 ... 32: forward vs the oracle each time, twice on the same handle (a cell left
     marked, or a list entry lost, shows in the second call: the grid would not be all-zero again)."""
     from oracle.pyoracle import MpmOracle
-    monkeypatch.setenv("UD_LG_LANES", lanes)
+    _tune(monkeypatch, cluster=-1, lanes=int(lanes))
     S = 3
     sim, st, _, N = _scaled_case(S, 3, B=2)
     orc = MpmOracle(N, n_grid=128, res=(64, 64, 64), steps=S)
@@ -635,8 +638,8 @@ def test_collide_shape_rope_geometry_fwd_bwd(large_path):
 
 
 def _no_path_override():
-    return not any(k in os.environ for k in ("UD_MPM_CLUSTER", "UD_MPM_CLUSTER_T", "UD_MPM_CLUSTER_BWD", "UD_MPM_CLUSTER_ENVS",
-                                             "UD_LG_LANES", "UD_LG_GROUPS", "UD_LG_FUSED_FWD", "UD_LG_FUSED_BWD", "UD_LG_BWD3"))
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    return SimpleMPMSimulator.default_tuning == {}
 
 
 def test_bench_launch_shape_rope_n_grid_128_32_envs_default_kernels_match_oracle():
@@ -939,40 +942,49 @@ def test_internal_spatial_order_is_invisible(demo, grid_ckpt_cells):
 
 def test_cluster_call_cut_into_several_launches(monkeypatch):
     """The parts of a cluster launch wait for each other, so a call with more envs than fit on the chip at once is cut into
-    launches on the caller's stream (csrc/mpm_large.hip: clm_envs_per_launch).  UD_MPM_CLUSTER_ENVS caps the envs per launch:
+    launches on the caller's stream (csrc/mpm_large.hip: clm_envs_per_launch).  tune_cluster_envs caps the envs per launch:
     5 envs as 2 + 2 + 1 must give what one launch gives, forward and adjoint, whichever launch an env was in, and a second call
     on the same handle must find the rotating grids at rest."""
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-    monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1")
+    _tune(monkeypatch, cluster=1)
     sim, st, g, N = _scaled_case(4, 7, B=5, grid_ckpt_cells=2)
     for b in range(5):
         st["action"][b] = np.float32([0.1 * b - 0.2, 0.05 * b, 0.3 - 0.1 * b, 0, 0, 0]) / 50
     one = run_hip(sim, st, g=g, clip=True)
-    monkeypatch.setenv("UD_MPM_CLUSTER_ENVS", "2")
+    _tune(monkeypatch, cluster=1, cluster_envs=2)
+    sim2, _, _, _ = _scaled_case(4, 7, B=5, grid_ckpt_cells=2)
+    assert sim.launch_plan(5) == sim2.launch_plan(5) == 7
     for _ in range(2):
-        cut = run_hip(sim, st, g=g, clip=True)
+        cut = run_hip(sim2, st, g=g, clip=True)
         for key in ("x", "v", "C", "F", "J"):
             assert _rel(cut[key], one[key]) < 2e-6, (key, _rel(cut[key], one[key]))
         for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
             assert np.isfinite(cut[key]).all() and _rel(cut[key], one[key]) < 1e-4, (key, _rel(cut[key], one[key]))
 
 
-def test_cluster_scattered_cloud_cannot_overflow_its_tables(monkeypatch):
-    monkeypatch.setenv("UD_MPM_CLUSTER_BWD", "1")
-    """Parts of 16 particles touch at most 16 x 27 = 432 cells: the 512-slot table of a part cannot overflow however the cloud is
-    scattered (the same particles thrown uniformly through the volume: every part falls back from its window to open addressing).
-    Result = the multi-kernel path's, which sends what does not fit its tables to HBM atomics."""
-    sim, st, g, N = _scaled_case(3, 0, B=2)
+@pytest.mark.parametrize("part_lanes", [64, 128])
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 2])
+def test_cluster_scattered_cloud_outgrows_no_table_or_spills_and_stays_right(part_lanes, grid_ckpt_cells, monkeypatch):
+    """A rope whose particles are thrown uniformly through the volume (a plastic body that tears, a whip that scatters).  Parts of 16
+    particles (64 lanes) touch at most 16 x 27 = 432 cells: their 512-slot tables cannot overflow.  Parts of 32 particles (128 lanes,
+    the default for solids) can touch 864: what finds no slot goes to the env's HBM grid directly, is read back and put through the grid
+    op in the gather, and is zeroed from the part's spill list (csrc/mpm_cluster.h::clm_scatter) -- the step stays VALID; with a grid
+    checkpoint the env is flagged (its checkpoint misses cells) and that step's backward recomputes the grid.  Result = the multi-kernel
+    path's, which sends what does not fit its tables to HBM atomics too; twice on the same handle (everything back at rest)."""
+    _tune(monkeypatch, cluster=-1)
+    ref_sim, st, g, N = _scaled_case(3, 0, B=2, grid_ckpt_cells=grid_ckpt_cells)
     st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)   # env 1 scattered
-    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
-    ref = run_hip(sim, st, g=g, clip=True)
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-    monkeypatch.setenv("UD_MPM_CLUSTER_T", "64")
-    got = run_hip(sim, st, g=g, clip=True)          # run_hip ends with check_status(): no overflow flag
-    for key in ("x", "v", "C", "F"):
-        assert _rel(got[key], ref[key]) < 2e-6, (key, _rel(got[key], ref[key]))
-    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
-        assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 1e-4, (key, _rel(got[key], ref[key]))
+    ref = run_hip(ref_sim, st, g=g, clip=True)
+    _tune(monkeypatch, cluster=1, cluster_part_lanes=part_lanes)
+    sim, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=grid_ckpt_cells)
+    assert sim.launch_plan(2) & 2
+    for rep in range(2):
+        got = run_hip(sim, st, g=g, clip=True)          # run_hip ends with check_status(): no failure flag
+        for key in ("x", "v", "C", "F"):
+            assert _rel(got[key], ref[key]) < 2e-6, (rep, key, _rel(got[key], ref[key]))
+        for key in ("gx", "gv", "gC", "gF", "gppos", "gaction"):
+            assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 1e-4, (rep, key, _rel(got[key], ref[key]))
+    if grid_ckpt_cells and part_lanes == 128:
+        assert sim.grid_ckpt_overflows == 2               # both calls: env 1 spilled, its backward recomputed the grid
 
 
 def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkeypatch):
@@ -980,9 +992,8 @@ def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkey
     part that owns the cell, at a position drawn from the env's record counter).  A pool of 1 record per particle and substep
     holds the compact rope but not the same particles scattered through the volume: the env is flagged in status[] (bit 0), the
     host mirror sees it without a sync and asks that step's backward to recompute the grid (clip bit 1) -- same gradients as a
-    handle that never checkpoints the grid.  (Parts of 16 particles: a scattered cloud cannot overflow their cell tables.)"""
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-    monkeypatch.setenv("UD_MPM_CLUSTER_T", "64")
+    handle that never checkpoints the grid.  (Parts of 16 particles: a scattered cloud cannot outgrow their cell tables.)"""
+    _tune(monkeypatch, cluster=1, cluster_part_lanes=64)
     sim, st, g, N = _scaled_case(3, 0, B=2, grid_ckpt_cells=1)
     run_hip(sim, st, g=g, clip=True)                                   # the rope fits
     assert sim.grid_ckpt_overflows == 0
@@ -997,96 +1008,72 @@ def test_cluster_forward_grid_checkpoint_overflow_falls_back_to_recompute(monkey
 
 @pytest.mark.parametrize("S", [1, 2, 5, 8])
 @pytest.mark.parametrize("forward", ["cluster", "multi_kernel"])
-def test_two_and_three_launch_backwards_are_the_four_kernel_backward(S, forward, monkeypatch):
+def test_two_launch_backward_is_the_four_kernel_backward(S, forward, monkeypatch):
     """With the grid checkpoint the backward runs two launches per reverse substep where four lanes work on a particle and one primitive
-    touches the grid (lg_gadj_restore, lg_padj_gadj), three elsewhere (lg_gadj_restore, lg_p2g_adj, lg_g2p_adj) -- the cotangent grids
-    of odd and even substeps in two arrays; UD_LG_FUSED_BWD=0 / UD_LG_BWD3=0 step down to the three-launch form and to the
-    four-kernel sequence of rounds 1-2.  Same arithmetic per particle and per cell -- the float atomics' order is the only
-    difference -- for odd and even numbers of substeps, a single one included, behind either forward; the forms alternate on ONE handle,
-    so each must hand both cotangent arrays back all-zero."""
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1" if forward == "cluster" else "0")
-    sim, st, g, N = _scaled_case(S, 4, B=3, grid_ckpt_cells=6)
-    runs = []
-    for name, fused, three in (("four-kernel", "0", "0"), ("two-launch", "1", "1"), ("three-launch", "0", "1"), ("two-launch again", "1", "1"),
-                               ("four-kernel after", "0", "0"), ("three-launch after", "0", "1")):
-        monkeypatch.setenv("UD_LG_FUSED_BWD", fused)
-        monkeypatch.setenv("UD_LG_BWD3", three)
-        runs.append((name, run_hip(sim, st, g=g, clip=True)))
-    ref = runs[0][1]
-    for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gfriction", "gmu", "glamda"):
-        for name, r in runs[1:]:
+    touches the grid (lg_gadj_restore, lg_padj_gadj; the cotangent grids of odd and even substeps in two arrays), the four-kernel
+    sequence elsewhere (tune_bwd_two_launch = -1 forces it).  Same arithmetic per particle and per cell -- the float atomics' order is
+    the only difference -- for odd and even numbers of substeps, a single one included, behind either forward; each handle runs twice,
+    so each form must hand both cotangent arrays back all-zero."""
+    cl = 1 if forward == "cluster" else -1
+    _tune(monkeypatch, cluster=cl, bwd_two_launch=-1)
+    sim4, st, g, N = _scaled_case(S, 4, B=3, grid_ckpt_cells=6)
+    _tune(monkeypatch, cluster=cl)
+    sim2, _, _, _ = _scaled_case(S, 4, B=3, grid_ckpt_cells=6)
+    assert sim4.launch_plan(3) & 4 == 0 and sim2.launch_plan(3) & 4 == 4
+    ref = run_hip(sim4, st, g=g, clip=True)
+    for name, sim in (("two-launch", sim2), ("two-launch again", sim2), ("four-kernel again", sim4)):
+        r = run_hip(sim, st, g=g, clip=True)
+        for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gfriction", "gmu", "glamda"):
             assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (key, name, _rel(r[key], ref[key]))
 
 
 @pytest.mark.parametrize("forward", ["cluster", "multi_kernel"])
 @pytest.mark.parametrize("material", [1, 2])
 def test_backward_reads_the_svd_factors_the_forward_checkpointed(forward, material, monkeypatch):
-    """Every history record of the many-workgroup path carries the SVD factors (U, S, Vh) of its substep's F beside the state; the
-    backward's pre-pass reads them instead of running the Jacobi iteration again (UD_LG_SVD_ROWS=0: iterate).  Same code on the same
-    inputs produced them, so the per-particle arithmetic is unchanged; only the float atomics' order separates the two runs.  Plastic
-    material too (the clamp uses the raw singular values), behind either forward."""
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1" if forward == "cluster" else "0")
-    sim, st, g, N = _scaled_case(6, 5, B=2, grid_ckpt_cells=6)
-    if material == 2:
-        sim.material = np.full(N, 2, np.int32)
-        sim._make_handle()
-    monkeypatch.setenv("UD_LG_SVD_ROWS", "0")
-    ref = run_hip(sim, st, g=g, clip=True)
-    monkeypatch.setenv("UD_LG_SVD_ROWS", "1")
-    got = run_hip(sim, st, g=g, clip=True)
+    """In the four-lane regime every history record of the many-workgroup path carries the SVD factors (U, S, Vh) of its substep's F beside
+    the state, and the backward's pre-pass reads them instead of running the Jacobi iteration again; the one-lane kernels (tune_lanes = 1:
+    the regime of full launches) keep no factors and iterate.  Same code on the same inputs produced the factors, so the per-particle
+    arithmetic is the same; only the lane mapping and the float atomics' order separate the two runs.  Plastic material too (the clamp
+    uses the raw singular values), behind either forward."""
+    def build(**kw):
+        _tune(monkeypatch, **kw)
+        sim, st, g, N = _scaled_case(6, 5, B=2, grid_ckpt_cells=6)
+        if material == 2:
+            sim.material = np.full(N, 2, np.int32)
+            sim._make_handle()
+        return sim, st, g
+    sim1, st, g = build(cluster=-1, lanes=1)
+    ref = run_hip(sim1, st, g=g, clip=True)
+    sim4, _, _ = build(cluster=1 if forward == "cluster" else -1)
+    got = run_hip(sim4, st, g=g, clip=True)
     for key in ("gx", "gv", "gC", "gF", "gppos", "gaction", "gmu", "glamda"):
         assert np.isfinite(got[key]).all() and _rel(got[key], ref[key]) < 2e-5, (key, _rel(got[key], ref[key]))
 
 
-@pytest.mark.parametrize("lanes", ["4", "1"])
-@pytest.mark.parametrize("grid_ckpt_cells", [0, 6])
-def test_multi_kernel_forward_two_three_and_four_launches_per_substep(lanes, grid_ckpt_cells, multi_kernel_path, monkeypatch):
-    """The multi-kernel forward runs two launches per substep: lg_grid (which also retires the previous substep's cells in the other
-    (m, mv) grid and clears its own list's bits) and lg_g2p_p2g (g2p of substep f, then the p2g pass of f + 1 with the state in
-    registers); UD_LG_FUSED_FWD=0 keeps p2g / grid / g2p apart, UD_LG_CLEAR_LAUNCH=1 is the four-launch substep of rounds 1-2 with
-    lg_clear_fk in front.  Same arithmetic per particle and cell (only the atomics' order differs), with and without the grid
-    checkpoint, four lanes per particle and one; the modes alternate on ONE handle, each followed by its backward, so every mode must
-    leave grids, bitmap and counters the way the others (and both backwards) expect them."""
-    monkeypatch.setenv("UD_LG_LANES", lanes)
-    sim, st, g, N = _scaled_case(5, 7, B=3, grid_ckpt_cells=grid_ckpt_cells)
-    runs = {}
-    for name, env in (("four", {"UD_LG_CLEAR_LAUNCH": "1"}), ("two", {}), ("three", {"UD_LG_FUSED_FWD": "0"}), ("two again", {}), ("four again", {"UD_LG_CLEAR_LAUNCH": "1"})):
-        for k in ("UD_LG_CLEAR_LAUNCH", "UD_LG_FUSED_FWD"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        runs[name] = run_hip(sim, st, g=g, clip=True)
-    ref = runs["four"]
-    for name, r in runs.items():
-        for key in ("x", "v", "C", "F", "J", "gx", "gv", "gC", "gF", "gppos", "gaction"):
-            assert np.isfinite(r[key]).all() and _rel(r[key], ref[key]) < 2e-5, (name, key, _rel(r[key], ref[key]))
-
-
 def test_launch_plan_reports_the_kernels_a_call_runs(monkeypatch):
     """ud_mpm_launch_plan (for logs and bench labels): 0 = one workgroup per env; bit 0 many-workgroup path, bit 1 persistent forward,
-    bit 2 two-launch backward -- following the library's own rules and their diagnostic switches."""
-    for var in ("UD_MPM_CLUSTER", "UD_LG_FUSED_BWD", "UD_LG_LANES"):
-        monkeypatch.delenv(var, raising=False)
+    bit 2 two-launch backward -- the library's own rules, or what ud_mpm_conf.tune_* fixed at create."""
+    assert _no_path_override()
     assert make_sim(5, 2).launch_plan(2) == 0                               # whip_rope's 67 particles
     sim, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=2)               # rope at n_grid 128: solid, one primitive, four lanes
     assert sim.launch_plan(2) == 1 | 2 | 4
-    monkeypatch.setenv("UD_MPM_CLUSTER", "0")
-    assert sim.launch_plan(2) == 1 | 4
-    monkeypatch.setenv("UD_LG_FUSED_BWD", "0")
-    assert sim.launch_plan(2) == 1
-    monkeypatch.delenv("UD_LG_FUSED_BWD")
+    assert sim.launch_plan(3) == -1                                          # more envs than the handle was created for
+    _tune(monkeypatch, cluster=-1)
+    assert _scaled_case(3, 0, B=2, grid_ckpt_cells=2)[0].launch_plan(2) == 1 | 4
+    _tune(monkeypatch, cluster=-1, bwd_two_launch=-1)
+    assert _scaled_case(3, 0, B=2, grid_ckpt_cells=2)[0].launch_plan(2) == 1
+    _tune(monkeypatch)
     sim0, _, _, _ = _scaled_case(3, 0, B=2, grid_ckpt_cells=0)              # no grid checkpoint: the backward recomputes (six kernels)
-    assert sim0.launch_plan(2) == 1
-    assert sim.launch_plan(200) == 1                                         # 200 x 798 particles: one lane per particle, neither rule applies
+    assert sim0.launch_plan(2) == 1 | 2
+    big, _, _, _ = _scaled_case(3, 0, B=200, grid_ckpt_cells=2)
+    assert big.launch_plan(200) == 1                                         # 200 x 798 particles: one lane per particle, neither rule applies
 
 
-def test_cluster_part_table_overflow_is_flagged(monkeypatch):
-    """Parts of 32 particles (UD_MPM_CLUSTER_T=128, the default for solids) hold 512 cells: particles thrown uniformly through the
-    volume touch more, the part sets status[] bit 1 and check_status raises -- loud, not a wrong step."""
+def test_more_envs_than_the_handle_was_created_for_is_refused():
+    """Every arena is sized at ud_mpm_create (max_envs): a call with more envs returns UD_ERR_INVALID instead of growing anything."""
     from unidom_amd._lib import UnidomError
-    monkeypatch.setenv("UD_MPM_CLUSTER", "1")
-    monkeypatch.setenv("UD_MPM_CLUSTER_T", "128")
     sim, st, g, N = _scaled_case(2, 0, B=2)
-    st["x"][1] = np.random.default_rng(2).uniform(0.1, 0.4, size=st["x"][1].shape).astype(np.float32)
+    big = {k: np.concatenate([v, v[:1]]) for k, v in st.items()}
     with pytest.raises(UnidomError):
-        run_hip(sim, st)
+        run_hip(sim, big)
+    run_hip(sim, st)                                                         # the handle is still good

@@ -4,7 +4,7 @@
 # then: python3 tools/pmc_large_traffic.py gpurun_out/pmc_large_summary.csv $NAME   (per-step-call HBM bytes -> profiles/pmc_traffic.json)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 W=${W:-pour_soup}; NAME=${NAME:-$W}
-export UD_LG_GROUPS=1   # one launch per kernel and substep for the whole batch (env groups split it; the bytes are the same)
+ARGS="$ARGS --tune env_groups=1"   # one launch per kernel and substep for the whole batch (env groups split it; the bytes are the same)
 i=0
 PASSES=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE")
 [ -n "$QUICK" ] && PASSES=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE")   # QUICK=1: what pmc_traffic.json needs

@@ -18,7 +18,7 @@ SYMBOLS = [
     "ud_last_error", "ud_version",
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes", "ud_cloth_launch_envs", "ud_cloth_poll_timeouts",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
-    "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_launch_plan", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
+    "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_launch_plan", "ud_mpm_reset", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
     "ud_plb_create", "ud_plb_destroy", "ud_plb_launch_plan", "ud_plb_poll_timeouts", "ud_plb_step_fwd", "ud_plb_ckpt_bytes", "ud_plb_step_bwd", "ud_plb_loss_fwd", "ud_plb_loss_bwd",
     "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
     "ud_mpm_focus_fwd", "ud_mpm_focus_bwd", "ud_mpm_finish_fwd", "ud_mpm_finish_bwd",
@@ -31,7 +31,8 @@ class UnidomError(RuntimeError):
 
 class ud_cloth_conf(C.Structure):
     _fields_ = [("N", C.c_int), ("gravity", C.c_float), ("damping", C.c_float), ("dt", C.c_float),
-                ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int), ("mode", C.c_int)]
+                ("max_v", C.c_float), ("small_num", C.c_float), ("substeps", C.c_int), ("mode", C.c_int), ("max_envs", C.c_int),
+                ("one_workgroup_per_env", C.c_int)]
 
 
 class ud_mpm_conf(C.Structure):
@@ -39,7 +40,9 @@ class ud_mpm_conf(C.Structure):
                 ("dt", C.c_float), ("p_mass", C.c_float), ("p_vol", C.c_float), ("gravity", C.c_float * 3),
                 ("use_position_control", C.c_int), ("prim_friction", C.c_float), ("prim_softness", C.c_float),
                 ("n_primitive", C.c_int), ("sdf_kind", C.c_int), ("grid_ckpt_cells", C.c_int), ("sort_particles", C.c_int),
-                ("prim_friction_each", C.c_float * 4), ("prim_softness_each", C.c_float * 4), ("deterministic", C.c_int)]
+                ("prim_friction_each", C.c_float * 4), ("prim_softness_each", C.c_float * 4), ("deterministic", C.c_int),
+                ("max_envs", C.c_int), ("tune_lanes", C.c_int), ("tune_cluster", C.c_int), ("tune_cluster_part_lanes", C.c_int),
+                ("tune_cluster_envs", C.c_int), ("tune_env_groups", C.c_int), ("tune_bwd_two_launch", C.c_int)]
 
 
 class ud_plb_conf(C.Structure):

@@ -835,16 +835,17 @@ struct ud_cloth {
   ud::cl_granule* d_arena = nullptr;
   int arena_B = 0;
   int* d_timeouts = nullptr;   // parts of the several-workgroup kernels that gave up a poll (ud_cloth_poll_timeouts)
+  int max_envs = 0;            // ud_cloth_conf.max_envs: what d_arena / d_park were sized for at create
+  bool one_wg = false;         // ud_cloth_conf.one_workgroup_per_env
 };
 
 // Several workgroups per env when the body qualifies (halo <= CL_HMAX, the parts of one env fit on the chip) and the caller
 // did not ask for the reference-order kernels (mode 1).  A call is cut into launches of cloth_cluster_envs() envs so that
 // every workgroup of a launch is resident at once (cloth_cluster.h, "Progress").
-// UD_CLOTH_CLUSTER=0 (read at every call; diagnostics and tests) keeps the one-workgroup kernels.
+// ud_cloth_conf.one_workgroup_per_env != 0 (fixed at create; diagnostics and tests) keeps the one-workgroup kernels.
 static bool cloth_use_cluster(const ud_cloth* h, int B) {
   if (h->c.Pp <= 1024 || h->cl_H == 0 || h->mode == 1 || h->cl_W > h->n_cu / 8) return false;   // the parts of an env share an XCD (cl_decode)
-  const char* e = getenv("UD_CLOTH_CLUSTER");
-  return !(e && e[0] == '0');
+  return !h->one_wg;
 }
 // Envs per launch.  cl_decode deals the envs of a launch round-robin over the 8 XCDs and keeps the W parts of an env on one, and
 // the adjoint kernel (256 VGPRs, 512 lanes) fits once per CU: an XCD (n_cu / 8 CUs) holds floor((n_cu / 8) / W) whole envs.
@@ -852,15 +853,11 @@ static bool cloth_use_cluster(const ud_cloth* h, int B) {
 // 5 x 7 = 35 workgroups for 32 CUs, three parts waited for a CU while their siblings spun: ~2x the time, no deadlock.)
 static int cloth_cluster_envs(const ud_cloth* h, int B) { return std::min(B, std::max(1, 8 * ((h->n_cu / 8) / h->cl_W))); }
 
-// (re)size and zero the hand-off arena: tags start at 1, so a zeroed arena matches nothing.  Growing it is the one place
-// that synchronises (see the header: first call / larger B than ever before).
+// zero the hand-off arena (allocated at create for the largest launch: cloth_cluster_envs(max_envs)): tags start at 1, so a zeroed arena
+// matches nothing
 static int cloth_cluster_arena(ud_cloth* h, int B, hipStream_t stream, ud::ClusterArgs* q) {   // B: envs per launch
   const size_t per = ud::cl_env_granules(h->c.Pp, h->cl_W) * sizeof(ud::cl_granule);
-  if (h->arena_B < B) {
-    if (h->d_arena) { (void)hipStreamSynchronize(stream); (void)hipFree(h->d_arena); h->d_arena = nullptr; h->arena_B = 0; }
-    if (hipMalloc((void**)&h->d_arena, per * B) != hipSuccess) { ud::set_error("ud_cloth: hand-off arena allocation failed"); return UD_ERR_HIP; }
-    h->arena_B = B;
-  }
+  if (h->arena_B < B) { ud::set_error("ud_cloth: hand-off arena holds %d envs per launch, %d asked", h->arena_B, B); return UD_ERR_INVALID; }
   UD_HIP_CHECK(hipMemsetAsync(h->d_arena, 0, per * B, stream));
   q->W = h->cl_W; q->H = h->cl_H; q->arena = h->d_arena; q->b0 = 0; q->Bl = B; q->timeouts = h->d_timeouts;
   return UD_OK;
@@ -918,6 +915,9 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
   }
   h->mode = conf->mode;
   if (h->mode < 0 || h->mode > 2) { ud::set_error("ud_cloth_create: mode must be 0, 1 or 2"); delete h; return UD_ERR_INVALID; }
+  if (conf->max_envs < 1) { ud::set_error("ud_cloth_create: max_envs = %d (handle-owned scratch is sized at create: give the largest B any call will pass)", conf->max_envs); delete h; return UD_ERR_INVALID; }
+  h->max_envs = conf->max_envs;
+  h->one_wg = conf->one_workgroup_per_env != 0;
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) e = hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_nbr, nbr.size() * sizeof(int));
@@ -930,11 +930,25 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
     e = hipFuncSetAttribute((const void*)ud::cloth_big_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)9 * Pp * sizeof(float)));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ud::cloth_big_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)6 * Pp + 192 + 128) * sizeof(float)));
   }
+  // handle-owned scratch of bodies above 1024 particles, for max_envs envs: the several-workgroup kernels' hand-off arena (per launch) or the
+  // one-workgroup adjoint's cotangent parking area (per call) -- nothing is allocated in a rollout call
+  if (e == hipSuccess && Pp > 1024) {
+    if (cloth_use_cluster(h, h->max_envs)) {
+      const int per = cloth_cluster_envs(h, h->max_envs);
+      e = hipMalloc((void**)&h->d_arena, ud::cl_env_granules(h->c.Pp, h->cl_W) * sizeof(ud::cl_granule) * per);
+      if (e == hipSuccess) h->arena_B = per;
+    } else {
+      e = hipMalloc((void**)&h->d_park, (size_t)h->max_envs * UD_BIG_PARK * h->c.Pp * sizeof(float));
+      if (e == hipSuccess) h->park_B = h->max_envs;
+    }
+  }
   if (e != hipSuccess) {
     ud::set_error("ud_cloth_create: %s", hipGetErrorString(e));
     if (h->d_nbr) (void)hipFree(h->d_nbr);
     if (h->d_L0) (void)hipFree(h->d_L0);
     if (h->d_timeouts) (void)hipFree(h->d_timeouts);
+    if (h->d_arena) (void)hipFree(h->d_arena);
+    if (h->d_park) (void)hipFree(h->d_park);
     delete h;
     return UD_ERR_HIP;
   }
@@ -983,7 +997,7 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   if (!h || !x || !v || !prim || !stiffness || !mu || !actions || !x_out || !v_out || !prim_out) {
     ud::set_error("ud_cloth_rollout_fwd: null argument"); return UD_ERR_INVALID;
   }
-  if (B < 1 || T < 1) { ud::set_error("ud_cloth_rollout_fwd: B=%d T=%d", B, T); return UD_ERR_INVALID; }
+  if (B < 1 || T < 1 || B > h->max_envs) { ud::set_error("ud_cloth_rollout_fwd: B=%d T=%d (max_envs=%d)", B, T, h->max_envs); return UD_ERR_INVALID; }
   ud::ClothFwdArgs a;
   a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
   a.x = x; a.v = v; a.prim = prim; a.k = stiffness; a.mu = mu; a.actions = actions;
@@ -1022,7 +1036,7 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
       !g_actions || !g_stiffness || !g_mu) {
     ud::set_error("ud_cloth_rollout_bwd: null argument"); return UD_ERR_INVALID;
   }
-  if (B < 1 || T < 1) { ud::set_error("ud_cloth_rollout_bwd: B=%d T=%d", B, T); return UD_ERR_INVALID; }
+  if (B < 1 || T < 1 || B > h->max_envs) { ud::set_error("ud_cloth_rollout_bwd: B=%d T=%d (max_envs=%d)", B, T, h->max_envs); return UD_ERR_INVALID; }
   ud::ClothBwdArgs a;
   a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
   a.ckpt = (const float*)ckpt; a.k = stiffness; a.mu = mu; a.actions = actions;
@@ -1040,13 +1054,7 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
       ud::cloth_launch_bwd_cluster(a, q, (hipStream_t)stream);
     }
   } else if (h->c.Pp > 1024) {
-    if (h->park_B < B) {   // scratch of the big-body adjoint, grown on demand
-      if (h->d_park) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(h->d_park); h->d_park = nullptr; h->park_B = 0; }
-      if (hipMalloc((void**)&h->d_park, (size_t)B * UD_BIG_PARK * h->c.Pp * sizeof(float)) != hipSuccess) {
-        ud::set_error("ud_cloth_rollout_bwd: scratch allocation failed"); return UD_ERR_HIP;
-      }
-      h->park_B = B;
-    }
+    if (h->park_B < B) { ud::set_error("ud_cloth_rollout_bwd: the adjoint's scratch holds %d envs, %d asked", h->park_B, B); return UD_ERR_INVALID; }
     hipLaunchKernelGGL(ud::cloth_big_bwd_kernel, dim3(B), dim3(UD_BIG_T), shmem, (hipStream_t)stream, a, h->d_park);
   } else if (h->mode != 1 && h->c.Pp <= 512)
     ud::cloth_launch_bwd_fast(a, (hipStream_t)stream);

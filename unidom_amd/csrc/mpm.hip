@@ -1226,6 +1226,7 @@ struct ud_mpm {
   size_t lds_fwd = 0, lds_bwd = 0;
   int nthreads_bwd_ws = 0;         // > 0: the wave-specialised adjoint kernel (N <= 96) with this many threads
   ud::MpmLarge* large = nullptr;   // N > 128: many-workgroup path (mpm_large.hip)
+  int max_envs = 0;                // ud_mpm_conf.max_envs
 };
 
 extern "C" {
@@ -1235,6 +1236,10 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   const int N = conf->n_particles, S = conf->steps;
   if (N < 1 || S < 1 || conf->n_grid < 4 || conf->res[0] < 4 || conf->res[1] < 4 || conf->res[2] < 4) {
     ud::set_error("ud_mpm_create: bad sizes (N=%d steps=%d n_grid=%d)", N, S, conf->n_grid); return UD_ERR_INVALID;
+  }
+  if (conf->max_envs < 1) { ud::set_error("ud_mpm_create: max_envs = %d (every arena is sized at create: give the largest B any call will pass)", conf->max_envs); return UD_ERR_INVALID; }
+  if (!(conf->tune_lanes == 0 || conf->tune_lanes == 1 || conf->tune_lanes == 4) || !(conf->tune_cluster_part_lanes == 0 || conf->tune_cluster_part_lanes == 64 || conf->tune_cluster_part_lanes == 128)) {
+    ud::set_error("ud_mpm_create: tune_lanes = %d (0, 1, 4), tune_cluster_part_lanes = %d (0, 64, 128)", conf->tune_lanes, conf->tune_cluster_part_lanes); return UD_ERR_INVALID;
   }
   const int n_prim = conf->n_primitive > 0 ? conf->n_primitive : 1;
   if (n_prim > UD_MAX_PRIM || (conf->use_position_control && n_prim != 1) || conf->sdf_kind < 0 || conf->sdf_kind > 1 ||
@@ -1302,9 +1307,20 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   }
   bool has_liquid = false;
   for (int i = 0; i < N; ++i) has_liquid = has_liquid || material[i] == 0;
-  if (large) h->large = ud::mpm_large_create(h->c, h->d_material, h->d_hard, has_liquid);
+  h->max_envs = conf->max_envs;
+  if (large) {
+    const ud::LgTune tune{conf->max_envs, conf->tune_lanes, conf->tune_cluster, conf->tune_cluster_part_lanes, conf->tune_cluster_envs,
+                          conf->tune_env_groups, conf->tune_bwd_two_launch};
+    h->large = ud::mpm_large_create(h->c, h->d_material, h->d_hard, has_liquid, tune);
+    if (!h->large) { (void)hipFree(h->d_material); (void)hipFree(h->d_hard); delete h; return UD_ERR_HIP; }
+  }
   *out = h;
   return UD_OK;
+}
+
+int ud_mpm_reset(ud_mpm* h, void* stream) {
+  if (!h) { ud::set_error("ud_mpm_reset: null handle"); return UD_ERR_INVALID; }
+  return h->large ? ud::mpm_large_reset(h->large, (hipStream_t)stream) : UD_OK;   // the one-workgroup path owns no scratch
 }
 
 void ud_mpm_destroy(ud_mpm* h) {
@@ -1337,7 +1353,7 @@ int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const floa
       !prim_v_out || !prim_w_out) {
     ud::set_error("ud_mpm_step_fwd: null argument"); return UD_ERR_INVALID;
   }
-  if (B < 1) { ud::set_error("ud_mpm_step_fwd: B=%d", B); return UD_ERR_INVALID; }
+  if (B < 1 || B > h->max_envs) { ud::set_error("ud_mpm_step_fwd: B=%d (max_envs=%d)", B, h->max_envs); return UD_ERR_INVALID; }
   if (h->large)
     return ud::mpm_large_step_fwd(h->large, B, x, v, C, F, J, prim_position, prim_rotation, prim_size, friction, mu, lamda, action,
                                   x_out, v_out, C_out, F_out, J_out, prim_position_out, prim_rotation_out, prim_v_out, prim_w_out,
@@ -1363,7 +1379,7 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
       !g_action) {
     ud::set_error("ud_mpm_step_bwd: null argument"); return UD_ERR_INVALID;
   }
-  if (B < 1) { ud::set_error("ud_mpm_step_bwd: B=%d", B); return UD_ERR_INVALID; }
+  if (B < 1 || B > h->max_envs) { ud::set_error("ud_mpm_step_bwd: B=%d (max_envs=%d)", B, h->max_envs); return UD_ERR_INVALID; }
   if (h->large)
     return ud::mpm_large_step_bwd(h->large, B, (const float*)ckpt, prim_size, friction, mu, lamda, action, g_x, g_v, g_C, g_F,
                                   g_prim_position, g_prim_rotation, clip, g_x0, g_v0, g_C0, g_F0, g_prim_position0, g_prim_rotation0,

@@ -1,5 +1,7 @@
-// Persistent per-env CLUSTER kernels of the many-workgroup MPM path: all `steps` substeps of a simulator.step in ONE launch per
-// direction (included by mpm_large.hip, which holds the helpers it uses; same C ABI, same checkpoint layout).
+// Persistent per-env CLUSTER forward of the many-workgroup MPM path: all `steps` substeps of a simulator.step in ONE launch
+// (included by mpm_large.hip, which holds the helpers it uses; same C ABI, same checkpoint layout).  The backward of these bodies is
+// the multi-kernel one, restoring the grid from the checkpoint this kernel writes (a persistent backward was built in round 3 and
+// measured no faster; removed in round 4).
 //
 // What it replaces: the 4 (forward) / 4-6 (backward) launches per substep of mpm_large.hip for launches that do not fill the chip
 // (B x N < 100 k particles: shape_rope 582, the rope at n_grid 128 798, pour_water 702 particles per env, 32 envs).  Those
@@ -17,11 +19,13 @@
 // (m, mv) of ITS OWN cells back, runs the grid op on them (redundantly where parts share cells: same inputs, same result) and
 // gathers from LDS.  No active list, no bitmap, no counters: a part only ever asks for the cells in its own table.
 //   forward   p2g -> flush -> BARRIER -> read back + grid op -> g2p                                   1 barrier / substep
-//   backward  p2g (recompute) -> flush -> BARRIER -> read back + grid op -> g2p adjoint -> flush of the cotangent grid ->
-//             BARRIER -> read back + grid-op adjoint -> p2g adjoint + particle adjoint                  2 barriers / substep
-// Grid buffers rotate so that nobody adds into a buffer another part may still be zeroing: three for the forward (flush f,
-// read f after barrier f, zero f after barrier f + 1 with the keys kept from substep f, next flush f + 3), two for each grid of
-// the backward (its two barriers per substep already separate "everybody has read" from "the next flush").
+// Grid buffers rotate by three so that nobody adds into a buffer another part may still be zeroing (flush f, read f after barrier f,
+// zero f after barrier f + 1 with the keys kept from substep f, next flush f + 3).
+// A part whose particles touch more cells than its 512-slot table holds (32 particles can touch 864; a compact part touches 40-150)
+// does not fail: what does not fit goes to the env's HBM grid with atomics directly (clm_scatter), is read back and put through the
+// grid op cell by cell in the gather, and is zeroed from a per-part spill list two substeps later; such an env's grid checkpoint is
+// incomplete, so it is flagged (status bit 0) and that step's backward recomputes the grid.  Only a spill list that overflows too
+// (CLM_SPILL cells per part and substep) is an error (status bit 1).
 //
 // Hand-off rules (MI355X_MICROARCH.md, inter-workgroup visibility): per-XCD L2s are not coherent and a CU's L1 is never
 // refreshed, so EVERY access to data another part may have written inside this launch is an agent-scope operation: float /
@@ -40,14 +44,11 @@ namespace ud {
 // cells at most, so the 512-slot table can never overflow and the workgroup barriers are free) or 128 (32 particles: half the
 // parts per env and less duplicated grid work, but a part whose particles are spread over more than 512 cells is an error).
 constexpr int CLM_H = 512, CLM_LOGH = 9;   // staging-table slots per part (= LgTable<4>)
-#ifndef CLM_BWD_WPE
-#define CLM_BWD_WPE(T) ((T) / 64)   // waves per SIMD the backward kernel is compiled for (diagnostic builds override it)
-#endif
+constexpr int CLM_SPILL = 384;             // cells per part and substep that may go past the table (864 - 512 = 352 at the very most)
 constexpr unsigned CLM_SPIN = 1u << 22;    // polls (~1 us each) before a part gives up
 
 struct ClusterGrid {
-  float4* cg[3];      // [Bl][G] (m, mv): forward rotates three, the recomputing backward two
-  float4* gg[3];      // [Bl][G] backward: cotangent of the grid velocity (xyz); two rotate
+  float4* cg[3];      // [Bl][G] (m, mv), rotating
   int* own[3];        // [Bl][G] smallest part number that touched the cell this substep (the part that books its parameter cotangents)
   unsigned* bar;      // [Bl][CLM_BAR_STRIDE]: arrival counter (word 0) and generation word (word CLM_BAR_GEN) per env, zeroed before every launch
   int W, Bl;          // parts per env; envs of this launch (a.b0 = the first one)
@@ -128,21 +129,41 @@ __device__ __forceinline__ int clm_find(const BlockTable& t, const BlockWin& w, 
   }
   return -1;
 }
-// read-only slot of a cell that the walk of this substep has put into the table (-1 never happens for such a cell)
-__device__ __forceinline__ int clm_lookup(const int* key, const BlockWin& w, int cell) {
-  if (w.on) return bt_win_slot(w, cell);
+// read-only slot of a cell: clm_lookup_fast for a substep without spills (the walk has put every cell of the part into the table);
+// clm_lookup returns -1 for a cell that went past the table
+__device__ __forceinline__ int clm_lookup_fast(const int* key, const BlockWin& w, int cell) {
+  if (w.on) return max(bt_win_slot(w, cell), 0);
   unsigned s = lg_hash<CLM_LOGH>(cell);
   for (int probe = 0; probe < CLM_H; ++probe) {
     if (key[s] == cell) return (int)s;
     s = (s + 1) & (CLM_H - 1);
   }
+  return 0;
+}
+__device__ __forceinline__ int clm_lookup(const int* key, const BlockWin& w, int cell) {
+  if (w.on) return bt_win_slot(w, cell);
+  unsigned s = lg_hash<CLM_LOGH>(cell);
+  for (int probe = 0; probe < CLM_H; ++probe) {
+    const int k = key[s];
+    if (k == cell) return (int)s;
+    if (k == -1) return -1;
+    s = (s + 1) & (CLM_H - 1);
+  }
   return -1;
 }
 
-// p2g of one quad lane into the part's table (the walk of lg_p2g<4>, without its HBM fall-backs: a full table is an error here).
-// Returns false when a cell did not fit.
+// a cell the part's table has no room for: remembered (for the gather's direct read and for the zeroing two substeps later); false = the
+// spill list is full too
+__device__ __forceinline__ bool clm_spill_note(int* spill, int* s_nsp, int cell) {
+  const int e = atomicAdd(s_nsp, 1);
+  if (e < CLM_SPILL) { spill[e] = cell; return true; }
+  return false;
+}
+
+// p2g of one quad lane into the part's table (the walk of lg_p2g<4>).  A cell that finds no slot is added to the env's HBM grid directly
+// (gcur) and noted in the part's spill list.  Returns false when the spill list overflowed as well (the only failure left).
 __device__ __forceinline__ bool clm_scatter(const MpmConst& c, const BlockTable& bt, const BlockWin& win, const Pre& q, const float* v,
-                                            int p, int qi) {
+                                            int p, int qi, float4* gcur, int* spill, int* s_nsp) {
   constexpr int TH = CLM_H;
   bool ok = true;
   const bool interior = win.on && q.base[0] >= 0 && q.base[1] >= 0 && q.base[2] >= 0 &&
@@ -193,19 +214,24 @@ __device__ __forceinline__ bool clm_scatter(const MpmConst& c, const BlockTable&
     if (sc >= 0) {
       const float dp0 = ((float)i - q.fx[0]) * c.dx, dp1 = ((float)j - q.fx[1]) * c.dx, dp2 = ((float)k - q.fx[2]) * c.dx;
       const int sl = clm_find(bt, win, sc);
+      float ad[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) ad[r] = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
       if (sl >= 0) {
         __hip_atomic_fetch_add(&bt.val[sl], (double)(weight * c.p_mass), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const float ad = q.affine[r * 3] * dp0 + q.affine[r * 3 + 1] * dp1 + q.affine[r * 3 + 2] * dp2;
-          __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl], (double)(weight * (c.p_mass * v[r] + ad)), __ATOMIC_RELAXED,
+        for (int r = 0; r < 3; ++r)
+          __hip_atomic_fetch_add(&bt.val[(1 + r) * TH + sl], (double)(weight * (c.p_mass * v[r] + ad[r])), __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      } else {
-        ok = false;
+      } else {                                    // no room in the table: straight to the env's grid
+        float* cell = (float*)(gcur + cell_lin(c, sc));
+        atomicAdd(cell, weight * c.p_mass);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) atomicAdd(cell + 1 + r, weight * (c.p_mass * v[r] + ad[r]));
+        ok = clm_spill_note(spill, s_nsp, sc) && ok;
       }
     }
-    if (gc != sc) ok = (clm_find(bt, win, gc) >= 0) && ok;   // Q5: a clamped gather cell takes part with m = 0
+    if (gc != sc && clm_find(bt, win, gc) < 0) ok = clm_spill_note(spill, s_nsp, gc) && ok;   // Q5: a clamped gather cell takes part with m = 0
   }
   return ok;
 }
@@ -331,8 +357,9 @@ template <int T>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm_fwd_kernel(const LargeArgs a, const ClusterGrid g, float* hist, long rec, int keep, long last_off) {
   __shared__ int s_key[CLM_H], s_klist[2][CLM_H], s_slist[CLM_H];
   __shared__ double s_val[4 * CLM_H];
-  __shared__ int s_dead, s_ovf, s_hash, s_n, s_no, s_obase;
+  __shared__ int s_dead, s_ovf, s_hash, s_n, s_no, s_obase, s_nsp, s_spilled;
   __shared__ unsigned short s_olist[CLM_H];
+  __shared__ int s_spill[2][CLM_SPILL];            // cells past the table, of this and the previous substep (zeroed two substeps later)
   int bl, w;
   clm_decode(g.W, bl, w);
   if (bl >= g.Bl) return;
@@ -340,7 +367,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
   const MpmConst& c = a.c;
   const bool live = p < c.N;
   const int S = c.steps;
-  if (tid == 0) { s_dead = 0; s_ovf = 0; }
+  if (tid == 0) { s_dead = 0; s_ovf = 0; s_spilled = 0; }
   float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, Cm[9], F[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) { Cm[d] = 0.f; F[d] = (d % 4 == 0) ? 1.f : 0.f; }
@@ -360,12 +387,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
   float4* rpool = recs ? gck_pool(a, b) : nullptr;
   int* rcnt = a.w.count + b;                              // zeroed by lg_prim_in
   if (recs && w == 0 && tid == 0) ridx[0] = 0;
-  int nprev = 0;
+  int nprev = 0, nsp_prev = 0;
   bool alive = true;
   for (int f = 0; f < S && alive; ++f) {
     int* key = s_key;
     int* klist = s_klist[f & 1];
     const int* kprev = s_klist[(f + 1) & 1];
+    int* spill = s_spill[f & 1];
+    const int* spill_prev = s_spill[(f + 1) & 1];
     const BlockTable bt{key, s_val};
     float4* gcur = g.cg[f % 3] + (long)bl * a.G;
     float4* gold = g.cg[(f + 2) % 3] + (long)bl * a.G;    // substep f - 1's buffer
@@ -373,7 +402,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
     int* oold = g.own[(f + 2) % 3] + (long)bl * a.G;
     // ---- table clear, pre-pass, window ----
     for (int s = tid; s < CLM_H; s += T) { key[s] = -1; s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0; }
-    if (tid == 0) { s_hash = 0; s_n = 0; s_no = 0; }
+    if (tid == 0) { s_hash = 0; s_n = 0; s_no = 0; s_nsp = 0; }
     Pre q;
     q.base[0] = q.base[1] = q.base[2] = 0;
     if (live) {
@@ -390,7 +419,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
     __syncthreads();
     if (s_hash) win.on = 0;
     // ---- p2g into the table, the occupied cells as a list, flush to the env's grid ----
-    if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
+    if (live && !clm_scatter(c, bt, win, q, v, p, qi, gcur, spill, &s_nsp)) s_ovf = 1;
     __syncthreads();
     const int n = clm_compact<T>(key, klist, s_slist, &s_n);
     if (!(UD_MPM_ABLATE & 16384)) {   // (timing-only diagnostic builds, tools/build_abl.sh: 16384 no flush, 4096 no read-back, 8192 no zeroing, 32768 no barrier)
@@ -434,10 +463,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
         stc4_zero(gold + lin);
         if (recs) __hip_atomic_store(oold + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    for (int e = tid; e < nsp_prev; e += T) stc4_zero(gold + cell_lin(c, spill_prev[e]));   // (several parts may zero the same spilled cell)
     nprev = n;
+    nsp_prev = min(s_nsp, CLM_SPILL);
+    if (tid == 0 && s_nsp > 0) s_spilled = 1;
     __syncthreads();
     if (recs && tid == 0) s_obase = s_no ? atomicAdd(rcnt, s_no) : 0;    // where this part's records go (its latency runs beside g2p)
     // ---- g2p + advect ----
+    const bool nsp_prev_cur = nsp_prev > 0;                 // this substep spilled: a lookup may miss
     if (live) {
       float nv[3] = {0.f, 0.f, 0.f}, nC[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -445,8 +478,16 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
         const int cidx = qi + 4 * t;
         if (cidx >= 27) break;
         const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
-        const int sl = clm_lookup(key, win, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k));
-        const float4 g4 = vel[max(sl, 0)];
+        const int gcell = cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
+        const int sl = nsp_prev_cur ? clm_lookup(key, win, gcell) : clm_lookup_fast(key, win, gcell);
+        float4 g4;
+        if (sl >= 0) g4 = vel[sl];
+        else {                                              // a spilled cell: the env's sum from HBM, the grid op here
+          const float4 mvs = ldc4(gcur + cell_lin(c, gcell));
+          float vo[3];
+          clm_grid_op(a, b, f, gcell, mvs, vo);
+          g4 = make_float4(vo[0], vo[1], vo[2], mvs.x);
+        }
         const float weight = sel3(q.w, 0, i) * sel3(q.w, 1, j) * sel3(q.w, 2, k);
         const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)k - q.fx[2]};
         const float gv[3] = {g4.x, g4.y, g4.z};
@@ -490,7 +531,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
           r[0] = make_float4(__builtin_bit_cast(float, klist[e]), mv.x, mv.y, mv.z);
           r[1] = make_float4(mv.w, vv.x, vv.y, vv.z);
         } else if (a.status) {
-          a.status[b] = 1;     // pool exhausted: the backward of this env recomputes the grid (clip bit 1), as on the multi-kernel path
+          atomicOr(&a.status[b], 1);     // pool exhausted: the backward of this env recomputes the grid (clip bit 1), as on the multi-kernel path
         }
       }
       __syncthreads();  // vel / raw (= val), key and the cell list of substep f - 1 are rewritten by the next substep
@@ -507,6 +548,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
       stc4_zero(glast + lin);
       if (recs) __hip_atomic_store(olast + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    const int* sp = s_spill[(S - 1) & 1];
+    for (int e = tid; e < nsp_prev; e += T) stc4_zero(glast + cell_lin(c, sp[e]));
   }
   if (!keep && live && qi == 0) {
     float* ho = hw + last_off;
@@ -515,340 +558,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(2))) clm
 #pragma unroll
     for (int d = 0; d < 9; ++d) { ho[(6 + d) * c.Np + p] = Cm[d]; ho[(15 + d) * c.Np + p] = F[d]; }
   }
-  // status: 2 = a part's cell table overflowed, 4 = a part gave up waiting for its siblings (outputs invalid either way)
-  if (tid == 0 && a.status && (s_ovf || s_dead)) atomicOr(&a.status[b], s_dead ? 4 : 2);
-}
-
-// ---- backward -----------------------------------------------------------------------------------------------------
-// grid-op adjoint of one table slot (lg_grid_adj_tile, with the cell's data handed in instead of read from the env's list).
-// g: cotangent of the cell's output velocity (summed over the parts) -> cotangent of mv; gmm: cotangent of m.  `own`: this part
-// books the cell's contributions to the parameter / primitive cotangents (every part that holds the cell computes the same
-// numbers; exactly one may add them).  All lanes of the workgroup call this together (block reductions inside).
-template <int T>
-__device__ __forceinline__ void clm_grid_adj_cell(const LargeArgs& a, int b, int f, bool live, bool own, int key, const float4& mv,
-                                                  float* g, float& gmm, float (*red)[UD_PRIMC_NGRAD]) {
-  int ci = 0, cj = 0, ck = 0;
-  if (live) decode_cell(a.c, key, ci, cj, ck);
-  const float mvv[3] = {mv.y, mv.z, mv.w};
-  gmm = 0.f;
-  if (a.c.position_control) {
-    if (!live) return;
-    float dfric, pv[3], dpv[3];
-    PrimF pf;
-    load_prim_f(a, b, f, pf, pv);
-    const bool ctrl = grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dpv);
-    if (own) {
-      if (dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-      if (ctrl) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) atomicAdd(&a.w.gpv[(long)b * a.c.steps * 3 + f * 3 + d], dpv[d]);
-      }
-    }
-    return;
-  }
-  const int P = a.c.n_prim, S = a.c.steps, f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
-  const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
-  float v0[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
-#pragma unroll 1
-  for (int ip = P - 1; ip >= 0; --ip) {       // reverse walk over the primitives; primitive ip's input velocity by running 0..ip again
-    float pgv[UD_PRIMC_NGRAD];
-#pragma unroll
-    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) pgv[d] = 0.f;
-    if (live) {
-      PrimC pc;
-      CollideRec cr;
-      float vi[3] = {v0[0], v0[1], v0[2]}, v1[3];
-#pragma unroll 1
-      for (int j = 0; j <= ip; ++j) {
-        load_primc_f(a, b, j, f, pc);
-        collide_cell(pc, a.c.dt, gp, vi, v1, cr);
-        if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
-      }
-      if (ip == P - 1) {
-        CellRec rec;
-        float vo[3], dfric;
-        grid_tail<true>(a.c, a.friction[b], ci, cj, ck, v1, vo, &rec);
-        grid_tail_adjoint(a.friction[b], ci, cj, ck, rec, g, dfric);
-        if (own && dfric != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], dfric);
-      }
-      PrimCGrad pg;
-      float gin[3];
-      collide_cell_bwd(pc, a.c.dt, cr, g, gin, pg);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) g[d] = gin[d];
-      if (own) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { pgv[d] = pg.p0[d]; pgv[7 + d] = pg.p1[d]; pgv[14 + d] = pg.size[d]; }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { pgv[3 + d] = pg.r0[d]; pgv[10 + d] = pg.r1[d]; }
-        pgv[17] = pg.mu;
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
-      const float sum = wave_sum(pgv[d]);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
-    }
-    __syncthreads();
-    if (threadIdx.x < UD_PRIMC_NGRAD) {
-      const int d = threadIdx.x;
-      const long bp = (long)b * P + ip;
-      const float tot = T > 64 ? red[0][d] + red[1][d] : red[0][d];
-      float* dst = (d < 3)    ? a.w.gppos + bp * S * 3 + f0 * 3 + d
-                   : (d < 7)  ? a.w.grot + bp * S * 4 + f0 * 4 + (d - 3)
-                   : (d < 10) ? a.w.gppos + bp * S * 3 + f1 * 3 + (d - 7)
-                   : (d < 14) ? a.w.grot + bp * S * 4 + f1 * 4 + (d - 10)
-                              : a.w.gpsz + bp * 4 + (d - 14);
-      if (tot != 0.f) atomicAdd(dst, tot);
-    }
-    __syncthreads();
-  }
-  if (live) grid_head_adjoint(mv.x, mvv, g, gmm);
-}
-
-// LDS per part: key[512] | klist[2][512], slist[512] (the occupied cells of this / the previous substep) | val[4][512] doubles = the
-// p2g staging, after barrier 1 raw[512] float4 (m, mv) + vel[512] float4 (grid velocity, .w = 1 where this part owns the cell) |
-// gsc[3][512] doubles = the g2p adjoint's staging, after the barrier gres[512] float4 (cotangent of mv, of m).
-// Recomputes p2g + the grid op per substep (two barriers).  NOT the default backward: measured (profiles/r03f_cluster_paths.txt) it is
-// no faster than the multi-kernel backward restoring the grid from the checkpoint -- 256 VGPRs + 512 bytes of scratch per lane at two
-// waves per SIMD, and its long chains (pre-pass, particle adjoint) are single-wave latency either way -- so by default the cluster
-// FORWARD writes that checkpoint and the multi-kernel backward runs (UD_MPM_CLUSTER_BWD=1 selects this kernel; the tests do).
-// (A variant restoring the table from per-part records, one barrier per substep, was built and measured at the same speed: the
-// recompute is not what this kernel waits for.)
-template <int T>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(CLM_BWD_WPE(T)))) clm_bwd_kernel(const LargeArgs a, const ClusterGrid g, const float* ckpt, long rec) {
-  __shared__ int s_key[CLM_H], s_klist[2][CLM_H], s_slist[CLM_H];
-  __shared__ double s_val[4 * CLM_H];
-  __shared__ double s_gsc[3 * CLM_H];
-  __shared__ float s_red[2][UD_PRIMC_NGRAD];
-  __shared__ float s_par[2];
-  __shared__ int s_dead, s_ovf, s_hash, s_n;
-  int bl, w;
-  clm_decode(g.W, bl, w);
-  if (bl >= g.Bl) return;
-  const int b = a.b0 + bl, tid = threadIdx.x, p = w * (T / 4) + (tid >> 2), qi = tid & 3;
-  const MpmConst& c = a.c;
-  const bool live = p < c.N;
-  const int S = c.steps, P = c.n_prim;
-  constexpr int NB = 2, NG = 2;                       // barriers per substep, rotating cotangent grids
-  if (tid == 0) { s_dead = 0; s_ovf = 0; }
-  if (tid < 2) s_par[tid] = 0.f;
-  const float* hb = ckpt + (long)b * a.hist_stride_b;
-  float* gs = a.w.gstate + (long)b * 24 * c.Np;
-  float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9], gF[9];
-#pragma unroll
-  for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = 0.f; }
-  if (live) {                                         // cotangent of the step's outputs: lg_pack (an earlier launch)
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
-  }
-  const int up = live ? user_index(a, b, p) : 0;
-  const int material = a.material[up];
-  const float hard = a.hard[up], mu_s = a.mu[b], la_s = a.lamda[b];
-  float acc_mu = 0.f, acc_la = 0.f;
-  float4* raw = (float4*)s_val;
-  float4* vel = raw + CLM_H;
-  float4* gres = (float4*)s_gsc;
-  unsigned* bar = g.bar + (long)bl * CLM_BAR_STRIDE;
-  int nprev = 0;
-  bool alive = true;
-  for (int k = 0; k < S && alive; ++k) {
-    const int f = S - 1 - k;
-    int* key = s_key;
-    int* klist = s_klist[k & 1];
-    const int* kprev = s_klist[(k + 1) & 1];
-    const BlockTable bt{key, s_val};
-    float4* gcur = g.cg[k & 1] + (long)bl * a.G;
-    int* ocur = g.own[k & 1] + (long)bl * a.G;
-    float4* ggcur = g.gg[k % NG] + (long)bl * a.G;
-    float4* ggold = g.gg[(k + NG - 1) % NG] + (long)bl * a.G;   // the previous substep's cotangent grid
-    // ---- checkpointed state of substep f, pre-pass with the adjoint's extras ----
-    float x[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f}, Cm[9], F[9];
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { Cm[d] = 0.f; F[d] = (d % 4 == 0) ? 1.f : 0.f; }
-    if (live) load_state(hb + (long)f * rec, c.Np, p, x, v, Cm, F);
-    for (int s = tid; s < CLM_H; s += T) {
-      key[s] = -1;
-      s_val[s] = 0.0; s_val[CLM_H + s] = 0.0; s_val[2 * CLM_H + s] = 0.0; s_val[3 * CLM_H + s] = 0.0;
-      s_gsc[s] = 0.0; s_gsc[CLM_H + s] = 0.0; s_gsc[2 * CLM_H + s] = 0.0;
-    }
-    if (tid == 0) { s_hash = 0; s_n = 0; }
-    Pre q;
-    PreB kb;
-    q.base[0] = q.base[1] = q.base[2] = 0;
-    if (live) particle_pre<true>(c, x, Cm, F, mu_s, la_s, material, hard, q, &kb);
-    // ---- p2g again, flush, barrier, read back (m, mv) and the owner, grid op ----
-    BlockWin win = bt_window(c, live, q.base);
-    if (win.on && live && !clm_stencil_in_window(c, win, q.base)) s_hash = 1;
-    __syncthreads();
-    if (s_hash) win.on = 0;
-    if (live && !clm_scatter(c, bt, win, q, v, p, qi)) s_ovf = 1;
-    __syncthreads();
-    const int n = clm_compact<T>(key, klist, s_slist, &s_n);
-    {
-      const int r = tid & 3;
-      for (int e = tid >> 2; e < n; e += T / 4) {
-        const long lin = cell_lin(c, klist[e]);
-        atomicAdd((float*)(gcur + lin) + r, (float)s_val[r * CLM_H + s_slist[e]]);
-        if (r == 0) atomicMin(ocur + lin, w);
-      }
-    }
-    alive = clm_barrier(bar, (unsigned)(2 * k + 1), (unsigned)g.W, &s_dead);
-    if (!alive) break;
-    // FK adjoint of substep f + 1: every part's grid-op adjoint of that substep has landed (it preceded the barrier)
-    if (w == 0 && k > 0)
-      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<1>(a, (long)b * P + ip, f + 1);
-    for (int e = tid; e < n; e += T) {
-      const int kk = klist[e], sl = s_slist[e];
-      const long lin = cell_lin(c, kk);
-      const float4 mv = ldc4(gcur + lin);
-      const bool mine = ldci(ocur + lin) == w;
-      float vo[3];
-      clm_grid_op(a, b, f, kk, mv, vo);
-      raw[sl] = mv;
-      vel[sl] = make_float4(vo[0], vo[1], vo[2], mine ? 1.f : 0.f);
-    }
-    for (int e = tid; e < nprev; e += T) stc4_zero(ggold + cell_lin(c, kprev[e]));   // the previous substep's cotangent cells: everybody has read them
-    __syncthreads();
-    // ---- g2p adjoint: scatter the cotangent of the grid velocity, weight / fx partials ----
-    float gw[9], gfx[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < 9; ++d) gw[d] = 0.f;
-    if (live) {
-      float gnv[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) gnv[d] = gv[d] + c.dt * gx[d];
-      const int rot = (p * 4) % 27;
-#pragma unroll 1
-      for (int it = qi; it < 27; it += 4) {
-        const int cidx = it + rot >= 27 ? it + rot - 27 : it + rot;
-        const int i = cidx / 9, j = (cidx / 3) % 3, kq = cidx % 3;
-        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, kq);
-        const float weight = wi * wj * wk;
-        const float dp[3] = {(float)i - q.fx[0], (float)j - q.fx[1], (float)kq - q.fx[2]};
-        const int sl = max(clm_lookup(key, win, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + kq)), 0);
-        const float4 v4 = vel[sl];
-        const float vv[3] = {v4.x, v4.y, v4.z};
-        float gwt = 0.f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
-          const float gcell = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
-          __hip_atomic_fetch_add(&s_gsc[r * CLM_H + sl], (double)gcell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
-#pragma unroll
-          for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
-          gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
-          gw[kk * 3 + 2] += (kq == kk) ? gwt * wi * wj : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const int r = tid & 3;
-      if (r < 3)
-        for (int e = tid >> 2; e < n; e += T / 4)
-          atomicAdd((float*)(ggcur + cell_lin(c, klist[e])) + r, (float)s_gsc[r * CLM_H + s_slist[e]]);
-    }
-    alive = clm_barrier(bar, (unsigned)(NB * k + NB), (unsigned)g.W, &s_dead);
-    if (!alive) break;
-    nprev = n;
-    // ---- read the summed cotangent back, grid-op adjoint; (recompute) the (m, mv) cells and their owners go back to rest ----
-#pragma unroll 1
-    for (int e0 = 0; e0 < n; e0 += T) {                  // block-uniform trips: the cell adjoint holds workgroup barriers
-      const int e = e0 + tid;
-      const bool lv = e < n;
-      const int kk = lv ? klist[e] : 0, sl = lv ? s_slist[e] : 0;
-      float gg3[3] = {0.f, 0.f, 0.f}, gmm = 0.f;
-      float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
-      bool mine = false;
-      if (lv) {
-        const long lin = cell_lin(c, kk);
-        const float4 g4 = ldc4(ggcur + lin);
-        gg3[0] = g4.x; gg3[1] = g4.y; gg3[2] = g4.z;
-        mv = raw[sl];
-        mine = vel[sl].w != 0.f;
-        stc4_zero(gcur + lin);
-        __hip_atomic_store(ocur + lin, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      clm_grid_adj_cell<T>(a, b, f, lv, mine, kk, mv, gg3, gmm, s_red);
-      if (lv) gres[sl] = make_float4(gg3[0], gg3[1], gg3[2], gmm);
-    }
-    __syncthreads();
-    // ---- p2g adjoint (gather) + particle adjoint: cotangent of the state at substep f ----
-    if (live) {
-      float gaff[9], gvp[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-      for (int d = 0; d < 9; ++d) gaff[d] = 0.f;
-#pragma unroll 1
-      for (int cidx = qi; cidx < 27; cidx += 4) {
-        const int i = cidx / 9, j = (cidx / 3) % 3, kq = cidx % 3;
-        const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + kq);
-        if (sc < 0) continue;
-        const float wi = sel3(q.w, 0, i), wj = sel3(q.w, 1, j), wk = sel3(q.w, 2, kq);
-        const float weight = wi * wj * wk;
-        const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)kq - q.fx[2]) * c.dx};
-        const float4 g4 = gres[max(clm_lookup(key, win, sc), 0)];
-        const float gcv[3] = {g4.x, g4.y, g4.z};
-        float gwt = c.p_mass * g4.w;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const float ad = q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2];
-          gwt += gcv[r] * (c.p_mass * v[r] + ad);
-          gvp[r] += weight * c.p_mass * gcv[r];
-#pragma unroll
-          for (int s2 = 0; s2 < 3; ++s2) {
-            gaff[r * 3 + s2] += weight * gcv[r] * dpos[s2];
-            gfx[s2] -= c.dx * weight * gcv[r] * q.affine[r * 3 + s2];
-          }
-        }
-#pragma unroll
-        for (int kk2 = 0; kk2 < 3; ++kk2) {
-          gw[kk2 * 3 + 0] += (i == kk2) ? gwt * wj * wk : 0.f;
-          gw[kk2 * 3 + 1] += (j == kk2) ? gwt * wi * wk : 0.f;
-          gw[kk2 * 3 + 2] += (kq == kk2) ? gwt * wi * wj : 0.f;
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < 9; ++d) { gw[d] = lg_quad_sum<4>(gw[d]); gaff[d] = lg_quad_sum<4>(gaff[d]); }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { gfx[d] = lg_quad_sum<4>(gfx[d]); gvp[d] = lg_quad_sum<4>(gvp[d]); }
-      float gmu_p, gla_p;                      // every lane of the quad runs the particle adjoint: the cotangent state stays in registers
-      particle_adjoint(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
-      if (qi == 0 && material != 0) {
-        const float h = clipf(hard, 0.1f, 5.f);
-        acc_mu += gmu_p * h; acc_la += gla_p * h;
-      }
-    }
-    __syncthreads();
-  }
-  // the last substep's FK adjoint and cotangent cells, once every part is through its grid-op adjoint
-  if (alive) alive = clm_barrier(bar, (unsigned)(NB * S + 1), (unsigned)g.W, &s_dead);
-  if (alive) {
-    if (w == 0)
-      for (int ip = 0; ip < P; ++ip) fk_adj_block_f<1>(a, (long)b * P + ip, 0);
-    float4* gglast = g.gg[(S - 1) % NG] + (long)bl * a.G;
-    const int* kl = s_klist[(S - 1) & 1];
-    for (int e = tid; e < nprev; e += T) stc4_zero(gglast + cell_lin(c, kl[e]));
-  }
-  if (live && qi == 0) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
-#pragma unroll
-    for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
-    if (acc_mu != 0.f) atomicAdd(&s_par[0], acc_mu);
-    if (acc_la != 0.f) atomicAdd(&s_par[1], acc_la);
-  }
-  __syncthreads();
-  if (tid < 2 && s_par[tid] != 0.f) atomicAdd(&a.w.acc[b * 4 + 1 + tid], s_par[tid]);
+  // status: 1 = cells went past a part's table, so the grid checkpoint of this env is incomplete (outputs valid; the backward recomputes the
+  // grid: clip bit 1); 2 = a part's spill list overflowed too, 4 = a part gave up waiting for its siblings (outputs invalid either way)
+  if (tid == 0 && a.status && recs && s_spilled) atomicOr(&a.status[b], 1);
   if (tid == 0 && a.status && (s_ovf || s_dead)) atomicOr(&a.status[b], s_dead ? 4 : 2);
 }
 

@@ -2004,9 +2004,10 @@ namespace ud {
 
 struct MpmLarge {
   MpmConst c;
+  LgTune t{};
   const int* d_material;
   const float* d_hard;
-  int B = 0, cap = 0;
+  int B = 0, cap = 0;  // B = envs the arenas hold (LgTune::max_envs): fixed at create
   long W32 = 0;        // bitmap words per env
   long G = 0;
   LargeBuf w{};
@@ -2018,13 +2019,15 @@ struct MpmLarge {
   static constexpr int MAX_GROUPS = 4;   // (6 and 8 groups measured: shape_rope backward 5.0 -> 9.4 ms, profiles/r03c_fused_bwd_groups.txt)
   hipStream_t side[MAX_GROUPS - 1] = {};
   hipEvent_t ev_fork = nullptr, ev_join[MAX_GROUPS - 1] = {};
-  // persistent cluster kernels (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated on first use
+  // persistent cluster forward (mpm_cluster.h): rotating grids for `cl.Bl` envs per launch, allocated at create where the handle can take it
   ClusterGrid cl{};
   void* cl_arena = nullptr;
+  size_t cl_zero_bytes = 0, cl_own_off = 0, cl_own_words = 0, cl_bytes = 0;
   void* det_arena = nullptr; // deterministic forward (mpm_det.hip): flag [B][G] int, pre [B][27][Np], trq3 [B][S][3]
-  int det_B = 0, det_epoch = 0;
+  size_t det_bytes = 0;
+  int det_epoch = 0;
   bool has_liquid = false;   // some particle has material 0
-  int n_cu = 0, occ_fwd[2] = {0, 0}, occ_bwd[2] = {0, 0};   // CUs; resident parts per CU of the two kernels (occupancy query), [0] 64-lane, [1] 128-lane parts
+  int n_cu = 0, occ_fwd[2] = {0, 0};   // CUs; resident parts per CU of the persistent forward (occupancy query), [0] 64-lane, [1] 128-lane parts
 };
 
 #ifndef LG_GROUPS
@@ -2036,8 +2039,7 @@ struct MpmLarge {
 // four-lane launches are best at 2 (rope at n_grid 128 +6 %, shape_rope +3 %) and lose 5-20 % at 4 -- except pour_water (two container
 // primitives: the grid kernels, not the particle kernels, carry its substep): 231 k in one group, 199-227 k from run to run in two.
 static int lg_groups(const MpmLarge* L, int B) {
-  const char* ge = getenv("UD_LG_GROUPS");                        // diagnostic override, read at every call
-  const int forced = ge ? atoi(ge) : 0;
+  const int forced = L->t.env_groups;                             // ud_mpm_conf.tune_env_groups (diagnostics, counter passes)
   if (!L->ev_fork) return 1;
   const long particles = (long)B * L->c.N;
   int want = 1;
@@ -2048,9 +2050,14 @@ static int lg_groups(const MpmLarge* L, int B) {
   return want < MpmLarge::MAX_GROUPS ? want : MpmLarge::MAX_GROUPS;
 }
 
-MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid) {
+static int reserve(MpmLarge* L, int B);
+static int clm_lanes(const MpmLarge* L);
+static int clm_envs_per_launch(const MpmLarge* L, int B, int T);
+static int clm_reserve(MpmLarge* L, int Bl);
+
+MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid, const LgTune& tune) {
   auto* L = new MpmLarge;
-  L->c = c; L->d_material = d_material; L->d_hard = d_hard; L->has_liquid = has_liquid;
+  L->c = c; L->t = tune; L->d_material = d_material; L->d_hard = d_hard; L->has_liquid = has_liquid;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
   L->W32 = (L->G + 31) / 32 + 1;   // + 1: a row of eight cells may straddle into the word behind the last
@@ -2061,6 +2068,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
   (void)hipFuncSetAttribute((const void*)lg_g2p_p2g<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<1>());
   (void)hipFuncSetAttribute((const void*)lg_g2p_adj<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
+  (void)hipFuncSetAttribute((const void*)lg_padj_gadj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
   (void)hipFuncSetAttribute((const void*)lg_sort, hipFuncAttributeMaxDynamicSharedMemorySize, LG_SORT_MAX * 8);
   {
     int dev = 0;
@@ -2068,9 +2076,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
     (void)hipDeviceGetAttribute(&L->n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     for (int i = 0; i < 2; ++i) {   // i = 0: 64-lane parts, 1: 128-lane parts
       const void* kf = i ? (const void*)clm_fwd_kernel<128> : (const void*)clm_fwd_kernel<64>;
-      const void* kb = i ? (const void*)clm_bwd_kernel<128> : (const void*)clm_bwd_kernel<64>;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&L->occ_fwd[i], kf, i ? 128 : 64, 0) != hipSuccess) L->occ_fwd[i] = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&L->occ_bwd[i], kb, i ? 128 : 64, 0) != hipSuccess) L->occ_bwd[i] = 0;
     }
     (void)hipGetLastError();
   }
@@ -2080,12 +2086,25 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
     ok = ok && hipEventCreateWithFlags(&L->ev_join[g], hipEventDisableTiming) == hipSuccess;
   }
   if (!ok) { if (L->ev_fork) (void)hipEventDestroy(L->ev_fork); L->ev_fork = nullptr; (void)hipGetLastError(); }   // single-stream fallback
+  // every arena of the handle, once, for LgTune::max_envs envs: no step call allocates or synchronises the host
+  int rc = reserve(L, tune.max_envs);
+  if (rc == UD_OK) {
+    const int per = clm_envs_per_launch(L, tune.max_envs, clm_lanes(L));
+    if (per > 0) rc = clm_reserve(L, per);
+  }
+  if (rc == UD_OK && c.det) {
+    const size_t flag_b = ((size_t)tune.max_envs * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)tune.max_envs * 27 * c.Np * 4 + 255) / 256 * 256, trq_b = (size_t)tune.max_envs * c.steps * 3 * 4;
+    L->det_bytes = flag_b + pre_b + trq_b;
+    if (hipMalloc(&L->det_arena, L->det_bytes) != hipSuccess || hipMemset(L->det_arena, 0, L->det_bytes) != hipSuccess) { set_error("ud_mpm_create (deterministic): hipMalloc failed"); rc = UD_ERR_HIP; }
+  }
+  if (rc == UD_OK && hipDeviceSynchronize() != hipSuccess) { set_error("ud_mpm_create: device synchronisation failed"); rc = UD_ERR_HIP; }
+  if (rc != UD_OK) { mpm_large_destroy(L); return nullptr; }
   return L;
 }
 
 void mpm_large_destroy(MpmLarge* L) {
-  if (L && L->det_arena) (void)hipFree(L->det_arena);
   if (!L) return;
+  if (L->det_arena) (void)hipFree(L->det_arena);
   if (L->arena) (void)hipFree(L->arena);
   if (L->cl_arena) (void)hipFree(L->cl_arena);
   for (int g = 0; g < MpmLarge::MAX_GROUPS - 1; ++g) {
@@ -2098,17 +2117,18 @@ void mpm_large_destroy(MpmLarge* L) {
 
 // checkpoint layout per env (floats): particle history [(S+1)][24][Np] | primitive tail [P][S*10] | grid checkpoint:
 // record index [S+1] (ints, padded to 4) and the record pool [budget][8] | spatial order [Np] (ints)
-static int lg_lanes(int B, int N);
+static int lg_lanes(const MpmLarge* L, int B);
 // The SVD factors ride in the history records where a launch waits for one wave's serial chain (the four-lane regime); where the chip
 // is full (one lane per particle: B N >= 100 000) they cost 84 B of traffic per particle-substep each way and save nothing
 // (rope at n_grid 256: 250 k -> 225-246 k substeps/s with them) -- so the record layout depends on the envs of the call, which
 // ud_mpm_ckpt_bytes, the forward and the backward all know.
-static bool lg_svd_rows(const MpmConst& c, int B) { return !c.det && lg_lanes(B, c.N) == 4; }
+static bool lg_svd_rows(const MpmLarge* L, int B) { return !L->c.det && lg_lanes(L, B) == 4; }
 struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int budget; };
-static CkLayout ck_layout(const MpmConst& c, int B) {
+static CkLayout ck_layout(const MpmLarge* L, int B) {
+  const MpmConst& c = L->c;
   CkLayout k;
   const long S = c.steps;
-  k.rec = (long)(24 + (lg_svd_rows(c, B) ? UD_SVD_ROWS : 0)) * c.Np;      // state rows + (four-lane regime) the SVD factors of the substep's F
+  k.rec = (long)(24 + (lg_svd_rows(L, B) ? UD_SVD_ROWS : 0)) * c.Np;      // state rows + (four-lane regime) the SVD factors of the substep's F
   k.off_tail = (S + 1) * k.rec;
   k.off_idx = k.off_tail + (long)c.n_prim * S * 10;
   k.off_idx = (k.off_idx + 3) / 4 * 4;                         // float4 alignment of the pool behind it
@@ -2122,12 +2142,10 @@ static CkLayout ck_layout(const MpmConst& c, int B) {
 }
 
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B) {
-  return (size_t)B * (size_t)ck_layout(L->c, B).stride * sizeof(float);
+  return (size_t)B * (size_t)ck_layout(L, B).stride * sizeof(float);
 }
 
-static int reserve(MpmLarge* L, int B, hipStream_t stream) {
-  if (B <= L->B) return UD_OK;
-  if (L->arena) { (void)hipStreamSynchronize(stream); (void)hipFree(L->arena); L->arena = nullptr; }
+static int reserve(MpmLarge* L, int B) {
   const MpmConst& c = L->c;
   const long G = L->G, S = c.steps;
   const size_t BP = (size_t)B * c.n_prim;   // rows of the primitive arrays
@@ -2142,8 +2160,8 @@ static int reserve(MpmLarge* L, int B, hipStream_t stream) {
   const size_t o_grot = take(BP * S * 4 * 4), o_gpw = take(BP * S * 3 * 4), o_gpsz = take(BP * 4 * 4);
   const size_t o_perm = take((size_t)B * c.Np * 4);
   hipError_t e = hipMalloc(&L->arena, off);
-  if (e != hipSuccess) { set_error("ud_mpm (large path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
-  e = hipMemsetAsync(L->arena, 0, off, stream);   // grid cells, bitmap and counters start at zero
+  if (e != hipSuccess) { set_error("ud_mpm_create (many-workgroup path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); L->B = 0; return UD_ERR_HIP; }
+  e = hipMemset(L->arena, 0, off);   // grid cells, bitmap and counters start at zero
   if (e != hipSuccess) { set_error("ud_mpm (large path): memset failed"); return UD_ERR_HIP; }
   char* base = (char*)L->arena;
   L->w.val = (float4*)(base + o_val); L->w.val2 = (float4*)(base + o_val2); L->w.vel = (float4*)(base + o_vel); L->w.gacc = (float4*)(base + o_gacc);
@@ -2175,7 +2193,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
 struct LgGroup { int b0, Bg; hipStream_t s; };
 static int lg_fork(MpmLarge* L, int B, hipStream_t st, LgGroup* grp, int want = 0) {   // want > 0: that many groups where lg_groups allows any
   int G = lg_groups(L, B);
-  if (want > 0 && L->ev_fork && !getenv("UD_LG_GROUPS")) G = (B >= 2 * want) ? std::min(want, (int)MpmLarge::MAX_GROUPS) : 1;
+  if (want > 0 && L->ev_fork && L->t.env_groups <= 0) G = (B >= 2 * want) ? std::min(want, (int)MpmLarge::MAX_GROUPS) : 1;
   for (int g = 0; g < G; ++g) {
     const int b0 = (int)((long)B * g / G), b1 = (int)((long)B * (g + 1) / G);
     grp[g] = LgGroup{b0, b1 - b0, g == 0 ? st : L->side[g - 1]};
@@ -2193,80 +2211,82 @@ static void lg_join(MpmLarge* L, int G, hipStream_t st, const LgGroup* grp) {
   }
 }
 
-// lanes per particle: 4 while the launch is too small to fill the chip, 1 beyond (see LgTable).  UD_LG_LANES=1|4 overrides it --
-// a diagnostic, and how the tests reach the one-lane kernels at sizes their CPU oracle can follow.
-static int lg_lanes(int B, int N) {
-  const char* e = getenv("UD_LG_LANES");
-  const int forced = e ? atoi(e) : 0;
-  if (forced == 1 || forced == 4) return forced;
-  return ((long)B * N < 100000) ? 4 : 1;
+// lanes per particle: 4 while the launch is too small to fill the chip, 1 beyond (see LgTable).  ud_mpm_conf.tune_lanes = 1 | 4 fixes it at
+// create -- a diagnostic, and how the tests reach the one-lane kernels at sizes their CPU oracle can follow.
+static int lg_lanes(const MpmLarge* L, int B) {
+  if (L->t.lanes == 1 || L->t.lanes == 4) return L->t.lanes;
+  return ((long)B * L->c.N < 100000) ? 4 : 1;
 }
 
 // backward with the grid checkpoint: two launches per reverse substep (lg_gadj_restore, lg_padj_gadj) or four -- measurements at the call
-static bool lg_two_launch_bwd(const MpmConst& c, int lanes) {
-  const char* fe = getenv("UD_LG_FUSED_BWD");                     // diagnostic: 0 = the four-kernel sequence, 1 = two launches wherever possible
-  return lanes == 4 && (fe ? atoi(fe) != 0 : c.n_prim == 1);
-}
+static bool lg_two_launch_bwd(const MpmLarge* L, int lanes) { return lanes == 4 && L->c.n_prim == 1 && L->t.bwd_two_launch >= 0; }
 
-// ---- persistent cluster path (mpm_cluster.h) ----------------------------------------------------------------------
+// ---- persistent cluster forward (mpm_cluster.h) -------------------------------------------------------------------
 // Taken when the launch does not fill the chip (the four-lane regime) and the body's parts fit: envs per launch =
 // 8 * floor(resident parts per XCD / parts per env), the parts of an env sharing an XCD under round-robin placement.
-// UD_MPM_CLUSTER=0 (read at every call; diagnostics and the tests that compare the two paths) keeps the multi-kernel path.
-// lanes per part: 128 (default: 32 particles per part -- half the parts, less duplicated grid work; a part whose particles touch
-// more than 512 cells is flagged in status[]) or 64 (UD_MPM_CLUSTER_T=64, read at every call: 16 particles, cannot overflow)
-static int clm_lanes() {
-  const char* e = getenv("UD_MPM_CLUSTER_T");
-  return (e && atoi(e) == 64) ? 64 : 128;
-}
+// lanes per part: 128 (default: 32 particles per part -- half the parts, less duplicated grid work; what a part's 512-slot table
+// cannot hold goes to the env's HBM grid directly, clm_scatter) or 64 (tune_cluster_part_lanes = 64: 16 particles, never spills)
+static int clm_lanes(const MpmLarge* L) { return L->t.cluster_part_lanes == 64 ? 64 : 128; }
 static int clm_parts(const MpmConst& c, int T) { return (c.N + T / 4 - 1) / (T / 4); }
 // Which bodies: by default solids with one primitive -- lattice-seeded ropes, whose 32 consecutive particles stay within a few cells
-// of each other.  Liquids (material 0: sampled uniformly, they mix) could spread a part over more cells than its table holds, and
+// of each other.  Liquids (material 0: sampled uniformly, they mix) spread a part over more cells than its table holds, and
 // with several primitives every part repeats the collide chains of the cells it shares (measured, pour_water: the multi-kernel
-// path is faster): both keep the multi-kernel path.  UD_MPM_CLUSTER=1 forces the cluster path where it fits, 0 forbids it.
+// path is faster): both keep the multi-kernel path.  tune_cluster = 1 takes the cluster forward wherever it fits, -1 never.
 static int clm_envs_per_launch(const MpmLarge* L, int B, int T) {
-  const char* e = getenv("UD_MPM_CLUSTER");
-  if (e && e[0] == '0') return 0;
-  if (!(e && e[0] == '1') && (L->has_liquid || L->c.n_prim > 1)) return 0;
+  if (L->t.cluster < 0 || L->c.det) return 0;
+  if (L->t.cluster == 0 && (L->has_liquid || L->c.n_prim > 1)) return 0;
   const int i = T == 128 ? 1 : 0;
-  const int occ = std::min(L->occ_bwd[i], L->occ_fwd[i]);   // one answer for both directions of a step
-  if (occ <= 0 || L->n_cu < 8 || lg_lanes(B, L->c.N) != 4) return 0;
+  const int occ = L->occ_fwd[i];
+  if (occ <= 0 || L->n_cu < 8 || lg_lanes(L, B) != 4) return 0;
   const int W = clm_parts(L->c, T);
   const int per_xcd = ((L->n_cu / 8) * occ) / W;
   if (per_xcd < 1) return 0;
   int per = std::min(B, 8 * per_xcd);
-  if (const char* m = getenv("UD_MPM_CLUSTER_ENVS")) { const int cap = atoi(m); if (cap > 0) per = std::min(per, cap); }   // tests: several launches per call
+  if (L->t.cluster_envs > 0) per = std::min(per, L->t.cluster_envs);   // tests: several launches per call
   return per;
 }
 
-static int clm_reserve(MpmLarge* L, int Bl, hipStream_t stream) {
-  if (L->cl_arena && Bl <= L->cl.Bl) return UD_OK;
-  if (L->cl_arena) { (void)hipStreamSynchronize(stream); (void)hipFree(L->cl_arena); L->cl_arena = nullptr; L->cl.Bl = 0; }
+static int clm_reserve(MpmLarge* L, int Bl) {
   const size_t cells = (size_t)Bl * L->G;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  size_t o_cg[3], o_gg[3], o_own[3];
+  size_t o_cg[3], o_own[3];
   for (int i = 0; i < 3; ++i) o_cg[i] = take(cells * 16);
-  for (int i = 0; i < 3; ++i) o_gg[i] = take(cells * 16);
   const size_t zero_bytes = off;                         // grids rest at zero, the owner stamps at INT_MAX
   for (int i = 0; i < 3; ++i) o_own[i] = take(cells * 4);
   const size_t o_bar = take((size_t)Bl * CLM_BAR_STRIDE * 4);
   hipError_t e = hipMalloc(&L->cl_arena, off);
-  if (e != hipSuccess) { set_error("ud_mpm (cluster path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); return UD_ERR_HIP; }
+  if (e != hipSuccess) { set_error("ud_mpm_create (cluster path): hipMalloc(%zu MB) failed: %s", off >> 20, hipGetErrorString(e)); return UD_ERR_HIP; }
   char* base = (char*)L->cl_arena;
-  e = hipMemsetAsync(base, 0, zero_bytes, stream);
-  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(base + o_own[0]), 0x7fffffff, (o_bar - o_own[0]) / 4, stream);
-  if (e != hipSuccess) { set_error("ud_mpm (cluster path): memset failed"); (void)hipFree(L->cl_arena); L->cl_arena = nullptr; return UD_ERR_HIP; }
-  for (int i = 0; i < 3; ++i) { L->cl.cg[i] = (float4*)(base + o_cg[i]); L->cl.gg[i] = (float4*)(base + o_gg[i]); L->cl.own[i] = (int*)(base + o_own[i]); }
+  L->cl_zero_bytes = zero_bytes; L->cl_own_off = o_own[0]; L->cl_own_words = (o_bar - o_own[0]) / 4; L->cl_bytes = off;
+  e = hipMemset(base, 0, off);
+  if (e == hipSuccess) e = hipMemsetD32((hipDeviceptr_t)(base + L->cl_own_off), 0x7fffffff, L->cl_own_words);
+  if (e != hipSuccess) { set_error("ud_mpm_create (cluster path): memset failed"); return UD_ERR_HIP; }
+  for (int i = 0; i < 3; ++i) { L->cl.cg[i] = (float4*)(base + o_cg[i]); L->cl.own[i] = (int*)(base + o_own[i]); }
   L->cl.bar = (unsigned*)(base + o_bar);
   L->cl.Bl = Bl;
   return UD_OK;
 }
 
+// every arena back to its rest state, asynchronously on `st`: after a device-side time-out (status bit 4) a part may have left rotating
+// grids, owner stamps, active lists or cotangent grids dirty
+int mpm_large_reset(MpmLarge* L, hipStream_t st) {
+  hipError_t e = hipSuccess;
+  if (L->arena) e = hipMemsetAsync(L->arena, 0, L->arena_bytes, st);
+  if (e == hipSuccess && L->cl_arena) {
+    e = hipMemsetAsync(L->cl_arena, 0, L->cl_bytes, st);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)((char*)L->cl_arena + L->cl_own_off), 0x7fffffff, L->cl_own_words, st);
+  }
+  if (e == hipSuccess && L->det_arena) { e = hipMemsetAsync(L->det_arena, 0, L->det_bytes, st); L->det_epoch = 0; }
+  if (e != hipSuccess) { set_error("ud_mpm_reset: %s", hipGetErrorString(e)); return UD_ERR_HIP; }
+  return UD_OK;
+}
+
 int mpm_large_plan(MpmLarge* L, int B) {
-  const MpmConst& c = L->c;
+  if (B > L->B) return -1;
   int plan = 1;
-  if (clm_envs_per_launch(L, B, clm_lanes())) plan |= 2;
-  if (ck_layout(c, B).budget > 0 && lg_two_launch_bwd(c, lg_lanes(B, c.N))) plan |= 4;
+  if (L->cl_arena && clm_envs_per_launch(L, B, clm_lanes(L))) plan |= 2;
+  if (ck_layout(L, B).budget > 0 && lg_two_launch_bwd(L, lg_lanes(L, B))) plan |= 4;
   return plan;
 }
 
@@ -2274,21 +2294,21 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,
                        float* prot_o, float* pv_o, float* pw_o, float* ckpt, int* status, hipStream_t st) {
-  int rc = reserve(L, B, st);
-  if (rc) return rc;
+  if (B > L->B) { set_error("ud_mpm_step_fwd: B=%d exceeds the handle's max_envs=%d (arenas are sized at create)", B, L->B); return UD_ERR_INVALID; }
+  int rc = UD_OK;
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N;
   const dim3 blk(256), blks(LG_SCATTER_T);
-  const int lanes = lg_lanes(B, N);                      // lanes per particle in the four particle kernels
+  const int lanes = lg_lanes(L, B);                      // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
   a.B = L->B;
   // history: in the caller's checkpoint when there is one, otherwise the handle's ping-pong pair
   float* hist = ckpt ? ckpt : L->w.hist;
-  const CkLayout ck = ck_layout(c, B);
+  const CkLayout ck = ck_layout(L, B);
   const long rec = ck.rec;
   const long stride_b = ckpt ? ck.stride : 2 * rec;
   a.hist_stride_b = stride_b;
-  a.svd_rows = (ckpt && lg_svd_rows(c, B)) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
+  a.svd_rows = (ckpt && lg_svd_rows(L, B)) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
   // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
@@ -2304,13 +2324,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   while (npow2 < N) npow2 <<= 1;
   if (c.det) {
     // deterministic forward (mpm_det.hip): the data movement around it is this file's, the arithmetic is compiled there
-    const size_t flag_b = ((size_t)B * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)B * 27 * c.Np * 4 + 255) / 256 * 256, trq_b = (size_t)B * S * 3 * 4;
-    if (B > L->det_B) {
-      if (L->det_arena) { (void)hipStreamSynchronize(st); (void)hipFree(L->det_arena); L->det_arena = nullptr; L->det_B = 0; }
-      if (hipMalloc(&L->det_arena, flag_b + pre_b + trq_b) != hipSuccess) { set_error("ud_mpm_step_fwd (deterministic): hipMalloc failed"); return UD_ERR_HIP; }
-      (void)hipMemsetAsync(L->det_arena, 0, flag_b + pre_b + trq_b, st);
-      L->det_B = B; L->det_epoch = 0;
-    }
+    const size_t flag_b = ((size_t)L->B * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)L->B * 27 * c.Np * 4 + 255) / 256 * 256;
     a.b0 = 0; a.f = 0;
     hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, B), blk, 0, st, c, 0, x, v, C, F, hist, stride_b, 1, (const int*)nullptr, 0L);
@@ -2332,11 +2346,9 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     if (e != hipSuccess) { set_error("ud_mpm_step_fwd (deterministic): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
     return UD_OK;
   }
-  const int clT = clm_lanes();
-  if (const int per = clm_envs_per_launch(L, B, clT)) {
+  const int clT = clm_lanes(L);
+  if (const int per = L->cl_arena ? std::min(clm_envs_per_launch(L, B, clT), L->cl.Bl) : 0) {
     // persistent cluster kernel: one launch runs all S substeps of `per` envs (mpm_cluster.h)
-    rc = clm_reserve(L, per, st);
-    if (rc) return rc;
     a.status = status;                                    // gck_base stays: the cluster forward writes the grid checkpoint too
     const float* last = hist + (ckpt ? (long)S * rec : (long)(S & 1) * rec);
     float* tail = ckpt ? ckpt + ck.off_tail : nullptr;
@@ -2370,40 +2382,28 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, x, v, C, F, hist, stride_b, 1, (const int*)perm, perm_stride);
   }
   // Two launches per substep: the grid op (which also retires the previous substep's cells and its own list's bits: no clear launch)
-  // and ONE particle launch, g2p(f) -> p2g(f + 1) (lg_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it -- the (m, mv) grid alternates between two arrays, the active lists between three (LargeArgs, ls3); forward
-  // kinematics of the whole step once (lg_fk_all).  UD_LG_CLEAR_LAUNCH=1 (diagnostic, read per call): the four-launch substep with
-  // lg_clear_fk in front.
-  const char* cle = getenv("UD_LG_CLEAR_LAUNCH");
-  const bool ls3 = !(cle && cle[0] == '1');
-  const char* fze = getenv("UD_LG_FUSED_FWD");          // diagnostic: 0 = p2g, grid op, g2p as three launches (ls3 only)
-  const bool fuse = ls3 && !(fze && fze[0] == '0');
-  if (ls3)
-    for (int g = 0; g < G; ++g) {
-      a.b0 = grp[g].b0; a.f = 0; a.ls3 = 1;
-      hipLaunchKernelGGL(lg_fk_all, dim3(grp[g].Bg, c.n_prim), dim3(64), 0, grp[g].s, a);
-    }
+  // and ONE particle launch, g2p(f) -> p2g(f + 1) (lg_g2p_p2g); p2g(0) opens the step, g2p(S - 1) closes it -- the (m, mv) grid
+  // alternates between two arrays, the active lists between three (LargeArgs, ls3); forward kinematics of the whole step once (lg_fk_all).
+  for (int g = 0; g < G; ++g) {
+    a.b0 = grp[g].b0; a.f = 0; a.ls3 = 1;
+    hipLaunchKernelGGL(lg_fk_all, dim3(grp[g].Bg, c.n_prim), dim3(64), 0, grp[g].s, a);
+  }
   for (int f = 0; f <= S; ++f) {
     a.f = f;
     a.hist_in = hist + (ckpt ? (long)f * rec : (long)(f & 1) * rec);
     a.hist_out = hist + (ckpt ? (long)(f + 1) * rec : (long)((f + 1) & 1) * rec);
-    a.ls3 = ls3 ? 1 : 0; a.vb = f & 1; a.ls = f % 3; a.lprev = (f + 2) % 3; a.lnext = (f + 1) % 3;
+    a.ls3 = 1; a.vb = f & 1; a.ls = f % 3; a.lprev = (f + 2) % 3; a.lnext = (f + 1) % 3;
     for (int g = 0; g < G; ++g) {
       const int Bg = grp[g].Bg;
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
       const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      if (ls3) {
-        if (f == S) { hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0); continue; }   // retires the last substep's cells: both grids all-zero again
-      } else {
-        if (f == S) { hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 0); continue; }   // restore the all-zero grid invariant
-        hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 1, 0);
-      }
-      // ls3: the p2g pass of substep f >= 1 rode behind g2p(f - 1) in lg_g2p_p2g -- two launches per substep
-      if (!fuse || f == 0) {
+      if (f == S) { hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0); continue; }   // retires the last substep's cells: both grids all-zero again
+      if (f == 0) {                                          // the p2g pass of substep f >= 1 rides behind g2p(f - 1) in lg_g2p_p2g
         if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
       }
       hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0);
-      if (fuse && f + 1 < S) {
+      if (f + 1 < S) {
         float* ho2 = hist + (ckpt ? (long)(f + 2) * rec : (long)(f & 1) * rec);
         if (lanes == 4) hipLaunchKernelGGL(lg_g2p_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, ho2); else hipLaunchKernelGGL(lg_g2p_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, ho2);
       } else {
@@ -2430,18 +2430,17 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
                        const float* lamda, const float* action, const float* gx, const float* gv, const float* gC, const float* gF,
                        const float* gppos, const float* gprot, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
                        float* grot0, float* gfric, float* gmu, float* glam, float* gaction, int* status, hipStream_t st) {
-  int rc = reserve(L, B, st);
-  if (rc) return rc;
+  if (B > L->B) { set_error("ud_mpm_step_bwd: B=%d exceeds the handle's max_envs=%d", B, L->B); return UD_ERR_INVALID; }
   const MpmConst& c = L->c;
   const int S = c.steps, N = c.N, Np = c.Np;
   const dim3 blk(256), blks(LG_SCATTER_T);
-  const int lanes = lg_lanes(B, N);                      // lanes per particle in the four particle kernels
+  const int lanes = lg_lanes(L, B);                      // lanes per particle in the four particle kernels
   LargeArgs a = base_args(L, B, psize, friction, mu, lamda, action);
-  const CkLayout ck = ck_layout(c, B);
+  const CkLayout ck = ck_layout(L, B);
   const long rec = ck.rec;
   const long stride_b = ck.stride;
   a.hist_stride_b = stride_b;
-  { const char* e = getenv("UD_LG_SVD_ROWS"); a.svd_rows = (!lg_svd_rows(c, B) || (e && e[0] == '0')) ? 0 : 1; }   // diagnostic: 0 = iterate again instead of reading the checkpointed factors
+  a.svd_rows = lg_svd_rows(L, B) ? 1 : 0;                 // the forward's SVD factors ride in the records: read, not iterated again
   // restore the grid from the checkpoint instead of recomputing p2g + grid op -- unless the caller saw the forward flag a
   // pool overflow and asks for the recomputing backward (clip bit 1)
   const bool gck = ck.budget > 0 && !(clip & 2);
@@ -2449,42 +2448,16 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
   if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
-  // Default backward = the multi-kernel path below, restoring the grid from the checkpoint that either forward wrote
-  // (measurements: mpm_cluster.h, clm_bwd_kernel).  UD_MPM_CLUSTER_BWD=1: the persistent cluster backward (recomputes the grid).
-  const char* cbw = getenv("UD_MPM_CLUSTER_BWD");
-  const int clT = clm_lanes();
-  if (const int per = (cbw && cbw[0] == '1') ? clm_envs_per_launch(L, B, clT) : 0) {
-    rc = clm_reserve(L, per, st);
-    if (rc) return rc;
-    a.gck_base = nullptr; a.status = status;
-    for (int b0 = 0; b0 < B; b0 += per) {
-      const int Bl = std::min(per, B - b0);
-      a.b0 = b0; a.f = S - 1;
-      hipLaunchKernelGGL(lg_bwd_in, dim3(Bl, c.n_prim), blk, 0, st, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
-      hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, Bl), blk, 0, st, c, b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
-      (void)hipMemsetAsync(L->cl.bar, 0, (size_t)Bl * CLM_BAR_STRIDE * sizeof(unsigned), st);
-      ClusterGrid g = L->cl;
-      g.Bl = Bl; g.W = clm_parts(c, clT);
-      const dim3 gr(clm_grid(Bl, g.W));
-      if (clT == 128) hipLaunchKernelGGL(clm_bwd_kernel<128>, gr, dim3(128), 0, st, a, g, ckpt, rec);
-      else hipLaunchKernelGGL(clm_bwd_kernel<64>, gr, dim3(64), 0, st, a, g, ckpt, rec);
-      a.f = -1;
-      const dim3 gp((N + 255) / 256, Bl);
-      if (clip) hipLaunchKernelGGL(lg_bwd_norm, gp, blk, 0, st, a);
-      hipLaunchKernelGGL(lg_bwd_out, gp, blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error("ud_mpm_step_bwd (cluster path): %s", hipGetErrorString(e)); return UD_ERR_HIP; }
-    return UD_OK;
-  }
+  // The backward is the multi-kernel path, restoring the grid from the checkpoint that either forward wrote.  (A persistent cluster
+  // backward -- recomputing the grid, or restoring it from per-part records -- was built in round 3 and measured no faster: 256 VGPRs +
+  // scratch at two waves per SIMD, and its long chains are single-wave latency either way; a three-launch form where the two-launch one
+  // does not apply was measured slower.  Both are gone: git history)
   // Two launches per reverse substep (lg_gadj_restore, lg_padj_gadj) where the backward restores the grid, four lanes work on a
   // particle and one primitive touches the grid.  Measured on 1x MI355X, 32 envs, backward ms per step, four-kernel / two-launch
   // (profiles/r03c_fused_bwd_groups.txt): rope at n_grid 128 (position control) 2.88 / 2.45 in one env group, 2.76 / 2.92 in two;
   // shape_rope (soft contact: the grid-op adjoint is the long launch and overlaps the other groups' particle launches)
   // 6.08 / 6.00 in one, 5.98 / 5.65 in two, 7.24 / 5.25 in four; pour_water (two container primitives) 1.35 / 1.61: kept on four.
-  const bool fused = gck && lg_two_launch_bwd(c, lanes);
-  const char* b3 = getenv("UD_LG_BWD3");                          // 1 = three launches where the two-launch form does not apply (measured slower: below)
-  const bool three = !fused && b3 && b3[0] == '1';
+  const bool fused = gck && lg_two_launch_bwd(L, lanes);
   LgGroup grp[MpmLarge::MAX_GROUPS];
   const int G = lg_fork(L, B, st, grp, fused ? (c.position_control ? 1 : 4) : 0);
   for (int g = 0; g < G; ++g) {
@@ -2494,7 +2467,6 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   }
   if (fused) {
     a.gpar = 1;
-    (void)hipFuncSetAttribute((const void*)lg_padj_gadj, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg_table_bytes<4>());
     for (int g = 0; g < G; ++g) {
       const int Bg = grp[g].Bg;
       hipStream_t s = grp[g].s;
@@ -2516,36 +2488,6 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       // the grid-op adjoint of substep 0) -- both grids all-zero again
       a.f = -1;
       hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
-    }
-  } else if (gck && three) {
-    // Three launches per reverse substep where the two-launch form does not apply (one lane per particle, several primitives): the
-    // restore of substep f - 1 rides beside the grid-op adjoint of f (lg_gadj_restore), the two particle kernels stay apart; the
-    // cotangent grids alternate by parity exactly as above.  Correct (tests) and NOT the default: backward ms per step, four / three
-    // launches: pour_water 1.23 / 1.59, pour_soup 3.34 / 3.46, rope at n_grid 256 5.38 / 6.44 (32 envs, 1x MI355X) -- the restore is
-    // cheaper as a launch of its own than as a block range of the grid-op adjoint's register-heavy kernel.
-    a.gpar = 1;
-    for (int g = 0; g < G; ++g) {
-      const int Bg = grp[g].Bg;
-      hipStream_t s = grp[g].s;
-      a.b0 = grp[g].b0;
-      const int nb = lg_cell_blocks(L->cap);
-      const dim3 gc2(2 * nb, Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      const dim3 gqf(gq.x + c.n_prim, Bg);
-      auto g2p_adj = [&](int f) {
-        a.f = f; a.hist_in = ckpt + (long)f * rec;
-        if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
-      };
-      a.f = S; a.hist_in = ckpt;
-      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);          // restore of substep S - 1
-      g2p_adj(S - 1);
-      for (int f = S - 1; f >= 0; --f) {
-        a.f = f; a.hist_in = ckpt + (long)f * rec;
-        hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);        // grid-op adjoint of f || restore of f - 1
-        if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gqf, blk, 0, s, a, (int)gq.x); else hipLaunchKernelGGL(lg_p2g_adj<1>, gqf, blk, 0, s, a, (int)gq.x);
-        if (f > 0) g2p_adj(f - 1);
-      }
-      a.f = -1;
-      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);          // zeroes substep 0's cotangent cells: both grids all-zero again
     }
   } else
   for (int f = S - 1; f >= -1; --f) {

@@ -147,7 +147,8 @@ class ClothSimulator:
 
         cc = _lib.ud_cloth_conf(N=self.N, gravity=float(conf.gravity), damping=float(conf.damping),
                                 dt=float(conf.dt), max_v=float(conf.max_v), small_num=float(conf.small_num),
-                                substeps=self.substeps, mode=self.mode)
+                                substeps=self.substeps, mode=self.mode, max_envs=int(batch_size),
+                                one_workgroup_per_env=int(bool(getattr(conf, "one_workgroup_per_env", False))))
         mask_u8 = np.ascontiguousarray(self.cloth_mask != 0, dtype=np.uint8)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):

@@ -114,8 +114,14 @@ class _Step(torch.autograd.Function):
 
 
 class SimpleMPMSimulator:
+    # Kernel selection of the many-workgroup path (ud_mpm_conf.tune_*: lanes, cluster, cluster_part_lanes, cluster_envs, env_groups,
+    # bwd_two_launch; include/unidom_hip.h).  Empty = the library's choice by measurement.  Copied into `self.tuning` when a simulator
+    # is built and fixed for a handle when it is created (_make_handle) -- there is no per-call switch; diagnostics and the tests set it.
+    default_tuning: dict = {}
+
     def __init__(self, conf, batch_size, use_position_control=False, device="cuda"):
         self.conf = conf
+        self.tuning = dict(type(self).default_tuning)
         self.key_global = None
         self.batch_size = batch_size
         self.ground_friction = conf.ground_friction
@@ -230,7 +236,8 @@ class SimpleMPMSimulator:
                               grid_ckpt_cells=int(self.grid_ckpt_cells), sort_particles=int(self.sort_particles),
                               prim_friction_each=(C.c_float * 4)(*(list(self.prim_friction_each) + [0.0] * 4)[:4]),
                               prim_softness_each=(C.c_float * 4)(*(list(self.prim_softness_each) + [0.0] * 4)[:4]),
-                              deterministic=int(self.deterministic))
+                              deterministic=int(self.deterministic), max_envs=int(self.batch_size),
+                              **{"tune_" + k: int(v) for k, v in self.tuning.items()})
         mat = np.ascontiguousarray(self.material, dtype=np.int32)
         hh = np.ascontiguousarray(self.h, dtype=np.float32)
         self._h = C.c_void_p()
@@ -261,7 +268,8 @@ class SimpleMPMSimulator:
         if len(self._staged) > 64:           # the oldest are long complete: look at them now, without a sync
             for h, d in self._staged[:32]:
                 if d.query() and bool((h & 6).any()):
-                    raise _lib.UnidomError("MPM cluster kernels: device-side failure flags in an earlier step (cell table overflow / time-out)")
+                    self._reset_after_failure(h)
+                    raise _lib.UnidomError("MPM cluster kernels: device-side failure flags in an earlier step (spill list overflow / time-out)")
             self._staged = self._staged[32:]
         return host, done
 
@@ -274,11 +282,19 @@ class SimpleMPMSimulator:
         host, done = staged
         done.synchronize()            # long complete by the time the backward of this step runs
         if bool((host & 6).any()):
-            raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = cell table of a part "
+            self._reset_after_failure(host)
+            raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = a part's spill list "
                                    "overflowed, 4 = a part gave up waiting for its siblings); outputs of this step are invalid")
         over = bool((host & 1).any())
         self.grid_ckpt_overflows += int(over)
         return over
+
+    def _reset_after_failure(self, flags):
+        """A part that gave up waiting (bit 4) skipped the zeroing of its cells: the handle's arenas go back to their rest state
+        (ud_mpm_reset, asynchronous on the current stream) before anything else runs on it."""
+        if bool((flags & 4).any()):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.lib().ud_mpm_reset(self._h, stream), "ud_mpm_reset")
 
     def _prof_begin(self, kind):
         if self.profile is None:
@@ -302,13 +318,17 @@ class SimpleMPMSimulator:
             done.synchronize()
             if bool((host & 6).any()):
                 self._staged = []
-                raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = cell table of a "
-                                       "part overflowed, 4 = a part gave up waiting for its siblings)")
+                self._reset_after_failure(host)
+                raise _lib.UnidomError(f"MPM cluster kernels: device-side failure flags {sorted(set(host.tolist()))} (2 = a part's spill "
+                                       "list overflowed, 4 = a part gave up waiting for its siblings)")
         self._staged = []
         if self.status_log or self._status_acc is not None:
             self._fold_status(0)
             bad = self._status_acc.item()
             self._status_acc = None
+            if bad and self._h_large:      # which bit it was is gone in the fold: a reset is cheap and always right
+                stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                _lib.check(_lib.lib().ud_mpm_reset(self._h, stream), "ud_mpm_reset")
             if bad:
                 raise _lib.UnidomError("MPM device-side capacity exceeded (UD_ERR_OVERFLOW): LDS cell table (one-workgroup path) or "
                                        "grid-checkpoint pool (conf.grid_ckpt_cells too small) -- particle cloud too spread out")
