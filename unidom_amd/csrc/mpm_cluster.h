@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64) lg_fk_all(LargeArgs a) {
 // The table is sparse (a compact part fills 40-150 of its 512 slots) and everything that follows the walk -- flush, read-back + grid op,
 // zeroing, the grid-op adjoint -- is per CELL: swept over the 512 slots, each trip of those loops cost its whole body (the grid
 // op with its primitive loads, the collide chains) for a handful of live lanes, T = 64 twice as many trips as T = 128; rocprofv3
-// counted 3 024 VALU instructions per wave and substep in the forward, half of the kernel's time (profiles/r03c_pmc_cluster.txt).
+// counted 3 024 VALU instructions per wave and substep in the forward, half of the kernel's time (a round-3 counter pass; the file was not kept).
 // One compaction pass per substep (ballot + mbcnt, one LDS add per wave and trip) leaves (key, slot) pairs; the cell loops then
 // make ceil(n / T) trips, normally one.  Every thread of the part calls this; it ends with a workgroup barrier.
 template <int T>

@@ -80,7 +80,31 @@ struct LargeArgs {
   float* hist_out;        // state at substep f + 1
   long hist_stride_b;     // floats between envs
   const float *psize, *friction, *mu, *lamda, *action;
+  // logical launch shape of the per-substep kernels: (nbx blocks per env) x (Bg envs), issued as a ONE-dimensional grid (lg_bid)
+  int nbx, Bg, xcd;
 };
+
+// Block -> (block within the env, env) of the per-substep kernels.  Workgroups are dealt round-robin over the 8 XCDs in linear order, and
+// each XCD has its own L2: with the natural (x, env) order the 13-27 blocks of one env land on all eight, and every L2 fetches the env's
+// grid lines (vel, cotangent grid) for itself -- measured on the rope at n_grid 128: ~215 of the 420 KB the backward's particle kernel
+// fetches per env and substep were those refetches (tools/pmc_large.sh; 128-B lines of eight z-neighbours x 2 grids x 8 XCDs).  With
+// xcd != 0 (Bg >= 8) ids congruent mod 8 belong to one env -- the mapping of the cluster kernels (clm_decode) -- so an env's grid lives
+// in ONE L2.  Speed and traffic only, never correctness.  Fewer than 8 envs keep the natural order (an env per XCD would idle the rest).
+struct LgB { int x, y; bool ok; };
+__device__ __forceinline__ LgB lg_bid(const LargeArgs& a) {
+  const int id = blockIdx.x;
+  LgB o;
+  if (a.xcd) {
+    const int j = id >> 3;
+    o.y = (j / a.nbx) * 8 + (id & 7);
+    o.x = j % a.nbx;
+  } else {
+    o.y = id / a.nbx;
+    o.x = id % a.nbx;
+  }
+  o.ok = o.y < a.Bg;
+  return o;
+}
 
 // ---- agent-scope accesses (persistent cluster kernels, mpm_cluster.h): sc1 loads bypass the CU's L1, sc1 stores write through
 __device__ __forceinline__ float ldc(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -304,11 +328,13 @@ __host__ __device__ constexpr int lg_cell_blocks(int cap) { return (cap + 255) /
 
 // clear the cells the previous substep touched; block 0 of each env also runs forward_kinematics (:185-194)
 __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int clear_bwd) {
-  const int b = blockIdx.y + a.b0;
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0;
   const int prev = (a.f + 1) & 1, cur = a.f & 1;   // works for f ascending (forward) and descending (backward)
   const int n = min(a.w.count[prev * a.B + b], a.cap);
   for (int u = 0;; ++u) {
-    const int t = (u * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    const int t = (u * a.nbx + lgb_.x) * 256 + threadIdx.x;
     if (t - (int)threadIdx.x >= n) break;
     if (t < n) {
       const long lin = cell_lin(a.c, a.w.list[((long)prev * a.B + b) * a.cap + t]);
@@ -317,7 +343,7 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
       if (clear_bwd) a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  if (blockIdx.x == 0) {
+  if (lgb_.x == 0) {
     const int S = a.c.steps, f = a.f, tid = threadIdx.x;
     if (tid == 0) a.w.count[cur * a.B + b] = 0;
     if (tid == 0 && a.gck_base && !clear_bwd) {   // forward: records of substep f start where those of f - 1 end
@@ -366,9 +392,11 @@ __global__ void __launch_bounds__(256) lg_clear_fk(LargeArgs a, int do_fk, int c
 // g2p of the previous substep has just produced them) and only F is read from hist_in.  Every thread of the block calls it (barriers inside).
 template <int LANES>
 __device__ __forceinline__ void lg_p2g_body(const LargeArgs& a, int store_F, const float* reg) {
+  const LgB lgb_ = lg_bid(a);
+
   constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
   const BlockTable bt = bt_make<TH>();
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   LG_STAMP_BEGIN
   bt_clear<TH>(bt);
@@ -585,7 +613,7 @@ __device__ __forceinline__ void lg_p2g_body(const LargeArgs& a, int store_F, con
 }
 
 template <int LANES>
-__global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) { lg_p2g_body<LANES>(a, store_F, nullptr); }
+__global__ void __launch_bounds__(LG_SCATTER_T) lg_p2g(LargeArgs a, int store_F) { if (!lg_bid(a).ok) return; lg_p2g_body<LANES>(a, store_F, nullptr); }
 
 // grid op over the active cells (:283-313).  to_vel: write the velocity to w.vel (backward) instead of in place
 __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, int to_vel) {
@@ -638,17 +666,19 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
   }
 }
 __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
-  const int b = blockIdx.y + a.b0;
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0;
   int n = min(a.w.count[lg_ls(a) * a.B + b], a.cap);
   if (a.ls3) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lgb_.x == 0 && threadIdx.x == 0) {
       a.w.count[a.lnext * a.B + b] = 0;                              // the list the next substep's p2g fills (nobody reads it in this launch)
       if (a.gck_base && a.f < a.c.steps) gck_idx(a, b)[a.f + 1] = gck_idx(a, b)[a.f] + n;   // records of substep f + 1 start where these end
     }
     n = max(n, min(a.w.count[a.lprev * a.B + b], a.cap));
     if (a.f >= a.c.steps) {                                           // the launch after the last substep: only the retiring
       for (int u = 0;; ++u) {
-        const int t = (u * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const int t = (u * a.nbx + lgb_.x) * 256 + threadIdx.x;
         if (t - (int)threadIdx.x >= n) break;
         if (t < min(a.w.count[a.lprev * a.B + b], a.cap))
           (a.vb ? a.w.val : a.w.val2)[(long)b * a.G + cell_lin(a.c, a.w.list[((long)a.lprev * a.B + b) * a.cap + t])] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -657,7 +687,7 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
     }
   }
   for (int u = 0;; ++u) {
-    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
     lg_grid_cell(a, b, base + threadIdx.x, to_vel);
   }
@@ -666,7 +696,9 @@ __global__ void __launch_bounds__(256) lg_grid(LargeArgs a, int to_vel) {
 // g2p + advect (:196-221, :318-328)
 template <int LANES>
 __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   if (p >= c.N) return;   // whole quads leave together
   const float* hi = a.hist_in + (long)b * a.hist_stride_b;
@@ -750,7 +782,9 @@ __global__ void __launch_bounds__(256) lg_g2p(LargeArgs a) {
 // ready by lg_grid(f); its bitmap is clean because lg_grid(f) cleared the bits of substep f's list.
 template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_p2g(LargeArgs a, float* hist_out2) {
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   float reg[15];
 #pragma unroll
@@ -1060,9 +1094,11 @@ __device__ __forceinline__ void fk_adj_block(const LargeArgs& a, long b) { fk_ad
 // g2p adjoint: scatter cotangents onto the grid velocity, keep the weight / fx partials per particle
 template <int LANES>
 __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
   constexpr int TH = LgTable<LANES>::H, TLOG = LgTable<LANES>::LOGH;
   const BlockTable bt = bt_make<TH>();
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   LG_STAMP_BEGIN
   bt_clear<TH>(bt);
@@ -1295,14 +1331,16 @@ __device__ __forceinline__ void lg_restore_tile(const LargeArgs& a, int b, int t
   a.w.gacc[(long)b * a.G + lin] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ void __launch_bounds__(256) lg_restore(LargeArgs a) {
-  const int b = blockIdx.y + a.b0, S = a.c.steps;
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0, S = a.c.steps;
   const int* idx = gck_idx(a, b);                   // the longer of the two lists this launch walks (records of f + 1 and of f)
   int n = 1;                                        // tile 0 always runs: it publishes the count
   if (a.f + 1 < S) n = max(n, min(idx[a.f + 2], a.gck_budget) - idx[a.f + 1]);
   if (a.f >= 0) n = max(n, min(idx[a.f + 1], a.gck_budget) - idx[a.f]);
   n = min(n, a.cap);
   for (int u = 0;; ++u) {
-    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
     lg_restore_tile(a, b, base + threadIdx.x);
   }
@@ -1444,10 +1482,12 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   LG_STAMP(3, 3);     // head adjoint + store
 }
 __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
   __shared__ float red[4][UD_PRIMC_NGRAD];
-  const int b = blockIdx.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+  const int b = lgb_.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
   for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
-    const int base = (u * gridDim.x + blockIdx.x) * 256;
+    const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
     lg_grid_adj_tile(a, b, base, red);
   }
@@ -1456,11 +1496,13 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
 template <int LANES>
 __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_blocks) {
-  if ((int)blockIdx.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
-    fk_adj_block(a, (long)(blockIdx.y + a.b0) * a.c.n_prim + ((int)blockIdx.x - particle_blocks));
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  if (lgb_.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
+    fk_adj_block(a, (long)(lgb_.y + a.b0) * a.c.n_prim + (lgb_.x - particle_blocks));
     return;
   }
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid / LANES, qi = gid % LANES;
   const MpmConst& c = a.c;
   // mu / lamda cotangents: summed per block in LDS, ONE global atomic per block and parameter.  (One per particle -- 7631
   // same-address atomics per env and substep on pour_soup -- serialises at the memory side: round 2 measurement below.)
@@ -1483,11 +1525,14 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   float gx[3], gv[3], gC[9], gF[9];
   // one lane per particle: loaded after the gather instead -- 24 registers the walk's loads in flight can use (243 VGPRs, two
   // waves per SIMD; ahead of it the kernel needs 278 and drops to one)
+  // Of the cotangent of state f + 1 only x's and F's rows are read: v_{f+1} and C_{f+1} are outputs of g2p, their cotangents were consumed
+  // by the g2p adjoint of this substep (the previous launch); the particle adjoint overwrites gv, gC (mpm_device.h::particle_adjoint).
+  // 12 of the 24 rows: a quarter of this kernel's bytes where the chip is full (rope at n_grid 256).
   if (LANES != 1) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = 0.f; }
 #pragma unroll
-    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+    for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = gs[(15 + d) * c.Np + p]; }
   }
   const float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
   float gw[9], gfx[3], gaff[9], gvp[3] = {0.f, 0.f, 0.f};
@@ -1581,9 +1626,9 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   if (qi == 0) {
   if (LANES == 1) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = 0.f; }
 #pragma unroll
-    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+    for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = gs[(15 + d) * c.Np + p]; }
     // Fn is formed again here (as particle_pre forms it) instead of being held across the gather: nine registers fewer there
     if (material == 2) {
       float US[9];
@@ -1666,46 +1711,61 @@ __device__ __forceinline__ void lg_restore_par(const LargeArgs& a, int b, int f,
 // blocks [0, nb): grid-op adjoint of substep a.f (none when a.f is not a substep: the first and the last launch of a step);
 // blocks [nb, 2 nb): restore of substep a.f - 1
 __global__ void __launch_bounds__(256) lg_gadj_restore(LargeArgs a, int nb) {
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
   __shared__ float red[4][UD_PRIMC_NGRAD];
-  const int b = blockIdx.y + a.b0;
-  if ((int)blockIdx.x < nb) {
+  const int b = lgb_.y + a.b0;
+  if (lgb_.x < nb) {
     if (a.f < 0 || a.f >= a.c.steps) return;
     const int n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
     for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
-      const int base = (u * nb + (int)blockIdx.x) * 256;
+      const int base = (u * nb + lgb_.x) * 256;
       if (base >= n) break;
       lg_grid_adj_tile(a, b, base, red);
     }
     return;
   }
-  lg_restore_par(a, b, a.f - 1, nb, (int)blockIdx.x - nb);
+  lg_restore_par(a, b, a.f - 1, nb, lgb_.x - nb);
 }
 
 // K2: p2g adjoint + particle adjoint of substep a.f, then the g2p adjoint of substep a.f - 1 (hist_prev = its input state; nullptr:
 // none, the last launch).  do_a == 0 (the first launch): only the g2p adjoint, of substep a.f - 1 = S - 1, cotangents from w.gstate.
 __global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_eu(2))) lg_padj_gadj(LargeArgs a, int particle_blocks, int do_a, const float* hist_prev) {
-  if ((int)blockIdx.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
-    if (do_a) fk_adj_block(a, (long)(blockIdx.y + a.b0) * a.c.n_prim + ((int)blockIdx.x - particle_blocks));
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  if (lgb_.x >= particle_blocks) {   // the last n_prim blocks of each env: FK adjoint of this substep
+    if (do_a) fk_adj_block(a, (long)(lgb_.y + a.b0) * a.c.n_prim + (lgb_.x - particle_blocks));
     return;
   }
   constexpr int TH = LgTable<4>::H, TLOG = LgTable<4>::LOGH;
   const BlockTable bt = bt_make<TH>();
-  const int b = blockIdx.y + a.b0, gid = blockIdx.x * blockDim.x + threadIdx.x, p = gid >> 2, qi = gid & 3;
+  const int b = lgb_.y + a.b0, gid = lgb_.x * blockDim.x + threadIdx.x, p = gid >> 2, qi = gid & 3;
   const MpmConst& c = a.c;
   __shared__ float s_par[2];
   if (threadIdx.x < 2) s_par[threadIdx.x] = 0.f;
   if (hist_prev) bt_clear<TH>(bt);
   __syncthreads();
   const bool live = p < c.N;
+  // What crosses a launch boundary of the cotangent state: x's and F's rows only.  v_{f+1} and C_{f+1} are outputs of g2p: their cotangents
+  // are consumed by part B (the g2p adjoint) of the launch that produced them, from registers; the particle adjoint overwrites them.  So a
+  // launch that runs part A reads 12 of the 24 rows and, while more launches follow, writes those 12; the first launch (B only) reads x, v,
+  // C (15 rows), the last one (no B) writes all 24 for lg_bwd_norm / lg_bwd_out.
   float* gs = a.w.gstate + (long)b * 24 * c.Np;
   float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, gC[9], gF[9];
 #pragma unroll
   for (int d = 0; d < 9; ++d) { gC[d] = 0.f; gF[d] = 0.f; }
   if (live) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { gx[d] = gs[d * c.Np + p]; gv[d] = gs[(3 + d) * c.Np + p]; }
+    for (int d = 0; d < 3; ++d) gx[d] = gs[d * c.Np + p];
+    if (do_a) {
 #pragma unroll
-    for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gF[d] = gs[(15 + d) * c.Np + p]; }
+      for (int d = 0; d < 9; ++d) gF[d] = gs[(15 + d) * c.Np + p];
+    } else {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gv[d] = gs[(3 + d) * c.Np + p];
+#pragma unroll
+      for (int d = 0; d < 9; ++d) gC[d] = gs[(6 + d) * c.Np + p];
+    }
   }
   // ---- A: p2g adjoint (gather) + particle adjoint of substep f: cotangent state at f + 1 -> at f ----
   if (do_a && live) {
@@ -1766,9 +1826,15 @@ __global__ void __launch_bounds__(LG_SCATTER_T) __attribute__((amdgpu_waves_per_
         atomicAdd(&s_par[1], gla_p * h);
       }
 #pragma unroll
-      for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
+      for (int d = 0; d < 3; ++d) gs[d * c.Np + p] = gx[d];
 #pragma unroll
-      for (int d = 0; d < 9; ++d) { gs[(6 + d) * c.Np + p] = gC[d]; gs[(15 + d) * c.Np + p] = gF[d]; }
+      for (int d = 0; d < 9; ++d) gs[(15 + d) * c.Np + p] = gF[d];
+      if (!hist_prev) {               // the last launch of the step: the whole cotangent state
+#pragma unroll
+        for (int d = 0; d < 3; ++d) gs[(3 + d) * c.Np + p] = gv[d];
+#pragma unroll
+        for (int d = 0; d < 9; ++d) gs[(6 + d) * c.Np + p] = gC[d];
+      }
     }
   }
   // ---- B: g2p adjoint of substep f - 1 (lg_g2p_adj<4>), its input cotangents in registers ----
@@ -2182,7 +2248,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.cap = L->cap; a.G = L->G; a.W32 = L->W32;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr; a.gpar = 0;
-  a.svd_rows = 0; a.ls3 = 0; a.vb = 0; a.ls = 0; a.lprev = 0; a.lnext = 0;
+  a.svd_rows = 0; a.ls3 = 0; a.vb = 0; a.ls = 0; a.lprev = 0; a.lnext = 0; a.nbx = 1; a.Bg = 0; a.xcd = 0;
   a.perm = nullptr; a.perm_stride = 0;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
@@ -2289,6 +2355,11 @@ int mpm_large_plan(MpmLarge* L, int B) {
   if (ck_layout(L, B).budget > 0 && lg_two_launch_bwd(L, lg_lanes(L, B))) plan |= 4;
   return plan;
 }
+
+// launch of a per-substep kernel: logical shape (NBX blocks per env) x (BG envs) as a one-dimensional grid, XCD-aware where there are
+// at least eight envs (lg_bid); `a` (the LargeArgs of the calling function) carries the shape
+#define LG_LAUNCH(K, NBX, BG, BLK, SH, ST, ...) do { a.nbx = (int)(NBX); a.Bg = (int)(BG); a.xcd = a.Bg >= 8 ? 1 : 0;                      \
+    hipLaunchKernelGGL(K, dim3(a.xcd ? 8u * (unsigned)a.nbx * (unsigned)((a.Bg + 7) / 8) : (unsigned)a.nbx * (unsigned)a.Bg), BLK, SH, ST, a, ##__VA_ARGS__); } while (0)
 
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
@@ -2398,16 +2469,16 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
       hipStream_t s = grp[g].s;
       a.b0 = grp[g].b0;
       const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
-      if (f == S) { hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0); continue; }   // retires the last substep's cells: both grids all-zero again
+      if (f == S) { LG_LAUNCH(lg_grid, gc.x, (int)gc.y, blk, 0, s, 0); continue; }   // retires the last substep's cells: both grids all-zero again
       if (f == 0) {                                          // the p2g pass of substep f >= 1 rides behind g2p(f - 1) in lg_g2p_p2g
-        if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 1); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 1);
+        if (lanes == 4) LG_LAUNCH(lg_p2g<4>, gs.x, (int)gs.y, blks, lg_table_bytes<4>(), s, 1); else LG_LAUNCH(lg_p2g<1>, gs.x, (int)gs.y, blks, lg_table_bytes<1>(), s, 1);
       }
-      hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 0);
+      LG_LAUNCH(lg_grid, gc.x, (int)gc.y, blk, 0, s, 0);
       if (f + 1 < S) {
         float* ho2 = hist + (ckpt ? (long)(f + 2) * rec : (long)(f & 1) * rec);
-        if (lanes == 4) hipLaunchKernelGGL(lg_g2p_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, ho2); else hipLaunchKernelGGL(lg_g2p_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, ho2);
+        if (lanes == 4) LG_LAUNCH(lg_g2p_p2g<4>, gs.x, (int)gs.y, blks, lg_table_bytes<4>(), s, ho2); else LG_LAUNCH(lg_g2p_p2g<1>, gs.x, (int)gs.y, blks, lg_table_bytes<1>(), s, ho2);
       } else {
-        if (lanes == 4) hipLaunchKernelGGL(lg_g2p<4>, gq, blk, 0, s, a); else hipLaunchKernelGGL(lg_g2p<1>, gq, blk, 0, s, a);
+        if (lanes == 4) LG_LAUNCH(lg_g2p<4>, gq.x, (int)gq.y, blk, 0, s); else LG_LAUNCH(lg_g2p<1>, gq.x, (int)gq.y, blk, 0, s);
       }
     }
   }
@@ -2477,17 +2548,17 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       const dim3 gk2(pb + c.n_prim, Bg);
       // prologue: restore of substep S - 1, then its g2p adjoint alone (cotangents from w.gstate)
       a.f = S; a.hist_in = ckpt;
-      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
-      hipLaunchKernelGGL(lg_padj_gadj, gk2, blks, lg_table_bytes<4>(), s, a, pb, 0, ckpt + (long)(S - 1) * rec);
+      LG_LAUNCH(lg_gadj_restore, gc2.x, (int)gc2.y, blk, 0, s, nb);
+      LG_LAUNCH(lg_padj_gadj, gk2.x, (int)gk2.y, blks, lg_table_bytes<4>(), s, pb, 0, ckpt + (long)(S - 1) * rec);
       for (int f = S - 1; f >= 0; --f) {
         a.f = f; a.hist_in = ckpt + (long)f * rec;
-        hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
-        hipLaunchKernelGGL(lg_padj_gadj, gk2, blks, lg_table_bytes<4>(), s, a, pb, 1, f > 0 ? ckpt + (long)(f - 1) * rec : nullptr);
+        LG_LAUNCH(lg_gadj_restore, gc2.x, (int)gc2.y, blk, 0, s, nb);
+        LG_LAUNCH(lg_padj_gadj, gk2.x, (int)gk2.y, blks, lg_table_bytes<4>(), s, pb, 1, f > 0 ? ckpt + (long)(f - 1) * rec : nullptr);
       }
       // lg_padj_gadj(0) consumed the cotangent cells of substep 0: "restore" of substep -2 zeroes them (those of substep 1 went beside
       // the grid-op adjoint of substep 0) -- both grids all-zero again
       a.f = -1;
-      hipLaunchKernelGGL(lg_gadj_restore, gc2, blk, 0, s, a, nb);
+      LG_LAUNCH(lg_gadj_restore, gc2.x, (int)gc2.y, blk, 0, s, nb);
     }
   } else
   for (int f = S - 1; f >= -1; --f) {
@@ -2500,18 +2571,18 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
       a.b0 = grp[g].b0;
       const dim3 gc(lg_cell_blocks(L->cap), Bg), gs((lanes * N + LG_SCATTER_T - 1) / LG_SCATTER_T, Bg), gq((lanes * N + 255) / 256, Bg);
       if (gck) {          // the dense val grid is never touched: nothing to recompute; gacc is handed back all-zero
-        hipLaunchKernelGGL(lg_restore, gc, blk, 0, s, a);
+        LG_LAUNCH(lg_restore, gc.x, (int)gc.y, blk, 0, s);
         if (f < 0) continue;
       } else {
-        hipLaunchKernelGGL(lg_clear_fk, gc, blk, 0, s, a, 0, 1);
+        LG_LAUNCH(lg_clear_fk, gc.x, (int)gc.y, blk, 0, s, 0, 1);
         if (f < 0) continue;
-        if (lanes == 4) hipLaunchKernelGGL(lg_p2g<4>, gs, blks, lg_table_bytes<4>(), s, a, 0); else hipLaunchKernelGGL(lg_p2g<1>, gs, blks, lg_table_bytes<1>(), s, a, 0);
-        hipLaunchKernelGGL(lg_grid, gc, blk, 0, s, a, 1);
+        if (lanes == 4) LG_LAUNCH(lg_p2g<4>, gs.x, (int)gs.y, blks, lg_table_bytes<4>(), s, 0); else LG_LAUNCH(lg_p2g<1>, gs.x, (int)gs.y, blks, lg_table_bytes<1>(), s, 0);
+        LG_LAUNCH(lg_grid, gc.x, (int)gc.y, blk, 0, s, 1);
       }
-      if (lanes == 4) hipLaunchKernelGGL(lg_g2p_adj<4>, gs, blks, lg_table_bytes<4>(), s, a); else hipLaunchKernelGGL(lg_g2p_adj<1>, gs, blks, lg_table_bytes<1>(), s, a);
-      hipLaunchKernelGGL(lg_grid_adj, gc, blk, 0, s, a);
+      if (lanes == 4) LG_LAUNCH(lg_g2p_adj<4>, gs.x, (int)gs.y, blks, lg_table_bytes<4>(), s); else LG_LAUNCH(lg_g2p_adj<1>, gs.x, (int)gs.y, blks, lg_table_bytes<1>(), s);
+      LG_LAUNCH(lg_grid_adj, gc.x, (int)gc.y, blk, 0, s);
       const dim3 gqf(gq.x + c.n_prim, Bg);   // + one block per primitive: the FK adjoint
-      if (lanes == 4) hipLaunchKernelGGL(lg_p2g_adj<4>, gqf, blk, 0, s, a, (int)gq.x); else hipLaunchKernelGGL(lg_p2g_adj<1>, gqf, blk, 0, s, a, (int)gq.x);
+      if (lanes == 4) LG_LAUNCH(lg_p2g_adj<4>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x); else LG_LAUNCH(lg_p2g_adj<1>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x);
     }
   }
   a.f = -1;
