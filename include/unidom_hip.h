@@ -173,15 +173,16 @@ typedef struct {
   float prim_friction_each[4], prim_softness_each[4];   /* soft contact with several primitives: friction / softness of primitive i where
                                 prim_softness_each[i] > 0 (create_primitive passes them per primitive, mpm_env.py:201-217); entries left
                                 at 0 take prim_friction / prim_softness (every reference env passes 0.1 / 666 to all of them) */
-  int deterministic;         /* != 0: ud_mpm_step_fwd sums every grid cell over the particles in index order and each particle's
-                                27 offsets in (i, j, k) order, in f32 -- the order of the reference's scatter-add on XLA's CPU
-                                backend (mpm_simulator.py:178-194) -- and g2p adds its cells in (i, j, k) order; no float atomics,
-                                IEEE arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same
-                                inputs return the same bits, and x, v, C, F equal the CPU build of the same source bit for bit
-                                (tests/test_mpm_det.py).  A test mode: one thread per touched cell walks all particles -- 13x the
-                                default forward at 67 particles, 332x at 798 (profiles/r03g_det_cost.txt).  Position control with one box primitive only
-                                (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the backward is
-                                the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
+  int deterministic;         /* != 0: ud_mpm_step_fwd sums every grid cell in the order of the reference's flattened scatter-add array
+                                (mpm_simulator.py:178-194: [27 offsets][N particles] -- offsets in (i, j, k) order, the particles of an
+                                offset in ascending index), in f32, and g2p adds its cells in (i, j, k) order; no float atomics, IEEE
+                                arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same inputs return
+                                the same bits, and x, v, C, F equal the CPU build of the same source bit for bit (tests/test_mpm_det.py).
+                                Per substep the particles are bucketed by base cell (one sort per env) and a cell walks the 27 buckets
+                                that can reach it: 3.2x the default forward at 67 particles, 5.4x at 798 (profiles/r04*_det_cost.txt; rounds
+                                2-3, every cell walking every particle: 13x / 332x).  Position control with one box primitive and at most
+                                8192 particles only (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the
+                                backward is the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
   int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
                                 grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's
                                 scratch) is allocated in ud_mpm_create for this many envs: no step call allocates or synchronises the

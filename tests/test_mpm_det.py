@@ -1,8 +1,10 @@
 """Deterministic MPM mode (ud_mpm_conf.deterministic, include/unidom_hip.h).
 
-The reference's p2g is a scatter-add that XLA's CPU backend applies in the order of the flattened (particle, offset) index array
-(mpm_simulator.py:178-194, :233-274); the fast kernels sum in the arrival order of atomics, so every other MPM comparison carries
-a tolerance.  In this mode each cell is summed by one thread in that order, in IEEE f32, and the tests below are bit-for-bit:
+The reference's p2g is a scatter-add that XLA's CPU backend applies in the order of the flattened update array, which is
+[27 offsets][N particles] (mpm_simulator.py:178-194, :259-274): a cell receives its contributions ordered by (offset, particle index).
+The fast kernels sum in the arrival order of atomics, so every other MPM comparison carries a tolerance.  In this mode each cell is summed
+in that order, in IEEE f32 -- a group of 32 lanes per cell on the device (each lane fetches one offset's bucket, the running sums pass
+through the lanes in order), one thread on the host: the same additions in the same order -- and the tests below are bit-for-bit:
   * two GPU runs of the same step are identical,
   * x, v, C, F after 70 substeps equal the CPU build of the same per-element source (oracle/csrc/mpm_det_host.cpp),
 and, on the CPU, that source is held against the independent restatement of the reference (oracle/csrc/mpm_oracle.hpp) within the

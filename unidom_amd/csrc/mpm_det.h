@@ -2,11 +2,17 @@
 // mpm_det.hip and -- compiled by the host compiler, UD_HOST_BUILD -- by the same-order CPU restatement the tests compare them
 // with bit for bit (oracle/csrc/mpm_det_host.cpp).
 //
-// What "deterministic" fixes: the reference's p2g is a scatter-add that XLA's CPU backend applies update by update, in the order
-// of the flattened (particle, 27 offsets) index array (mpm_simulator.py:178-194, :233-274); the fast kernels sum each cell in the
-// arrival order of LDS / memory atomics instead, so two runs differ in the last bits.  Here every touched cell is summed by ONE
-// thread, over the particles in index order and each particle's offsets in (i, j, k) order, in f32 -- the reference's order -- and
-// g2p adds its 27 cells in (i, j, k) order in one lane.  Nothing is accumulated through atomics.
+// What "deterministic" fixes: the reference's p2g is a scatter-add that XLA's CPU backend applies update by update, in the order of the
+// flattened update array (mpm_simulator.py:178-194, :259-274) -- and that array is [27 offsets][N particles] (`offset = idx[:, None, :]
+// .repeat(n_particles, axis=1)`, `pos_in_grid.reshape(-1, 3)`): OFFSET-major, so a cell receives its contributions ordered by (offset in
+// (i, j, k) order, then particle index).  The fast kernels sum each cell in the arrival order of LDS / memory atomics instead, so two runs
+// differ in the last bits.  Here every touched cell is summed by ONE thread in that (offset, particle) order, in f32, and g2p adds its 27
+// cells in (i, j, k) order in one lane.  Nothing is accumulated through atomics.  (Rounds 2-3 summed particle-major: also deterministic,
+// but not the order of the flattened array; no reference data can tell the two apart -- both sit 1e-6 from the recording.)
+// Cost: the particles are bucketed by base cell once per substep (sorted by (base cell, index): det_sort_kernel), so a cell walks the 27
+// buckets that can reach it -- for offset (i, j, k) the bucket of base cell (cell - (i, j, k)), its particles in ascending index -- instead
+// of all N particles (round 3: 332x the default forward at N = 798).  Particles whose stencil wraps or is cut at the domain edge (negative
+// base index, Q9; base + 2 outside `res`) are kept apart ("irregular", bucket key -1) and merged into every offset's walk by index.
 // Scope: position control, one box primitive (whip_rope's configuration); soft contact is refused at ud_mpm_create.
 // Reference lines as in mpm.hip / mpm_device.h: particle pre-pass :233-258, p2g :259-274, grid op :283-313, g2p :196-221, :318-328,
 // forward kinematics primitives.py:185-194, position control primitives.py:232-239.
@@ -69,50 +75,89 @@ __host__ __device__ inline long det_lin(const MpmConst& c, int key) {
   return ((long)ci * c.res[1] + cj) * c.res[2] + ck;
 }
 
+__host__ __device__ inline bool det_regular(const MpmConst& c, int b0, int b1, int b2) {
+  return b0 >= 0 && b1 >= 0 && b2 >= 0 && b0 + 2 < c.res[0] && b1 + 2 < c.res[1] && b2 + 2 < c.res[2];
+}
+__host__ __device__ inline long det_lin3(const MpmConst& c, int ci, int cj, int ck) { return ((long)ci * c.res[1] + cj) * c.res[2] + ck; }
+
 // particle p of one env: state at substep f (SoA record `h`: x, v, C, F rows of Np floats) -> pre[UD_DET_PRE][Np], F of substep
-// f + 1 into `hn`, and the epoch stamp on every cell its scatter or its gather will touch
-__host__ __device__ inline void det_pre_particle(const MpmConst& c, const float* h, float* hn, int p, float mu, float la, int material,
-                                                 float hard, float* pre, int* flag, int epoch) {
+// f + 1 into `hn`.  Returns the particle's bucket key: the linear index of its base cell, or -1 for an irregular particle.
+// (`store`: the device runs it in all 32 lanes of a particle's group -- same inputs, same bits -- and lets lane 0 write; q, v: the lanes'
+// own copies of what the contributions below are made of)
+__host__ __device__ inline int det_pre_particle(const MpmConst& c, const float* h, float* hn, int p, float mu, float la, int material,
+                                                float hard, float* pre, bool store, Pre& q, float* v) {
   const int Np = c.Np;
-  float x[3], v[3], Cm[9], F[9];
+  float x[3], Cm[9], F[9];
   for (int d = 0; d < 3; ++d) { x[d] = h[d * Np + p]; v[d] = h[(3 + d) * Np + p]; }
   for (int d = 0; d < 9; ++d) { Cm[d] = h[(6 + d) * Np + p]; F[d] = h[(15 + d) * Np + p]; }
-  Pre q;
   particle_pre<false>(c, x, Cm, F, mu, la, material, hard, q, nullptr);
-  for (int d = 0; d < 9; ++d) hn[(15 + d) * Np + p] = q.Fn[d];
-  for (int d = 0; d < 3; ++d) { pre[d * Np + p] = __builtin_bit_cast(float, q.base[d]); pre[(3 + d) * Np + p] = q.fx[d]; pre[(24 + d) * Np + p] = v[d]; }
-  for (int d = 0; d < 9; ++d) { pre[(6 + d) * Np + p] = q.w[d]; pre[(15 + d) * Np + p] = q.affine[d]; }
+  if (store) {
+    for (int d = 0; d < 9; ++d) hn[(15 + d) * Np + p] = q.Fn[d];
+    for (int d = 0; d < 3; ++d) { pre[d * Np + p] = __builtin_bit_cast(float, q.base[d]); pre[(3 + d) * Np + p] = q.fx[d]; pre[(24 + d) * Np + p] = v[d]; }
+    for (int d = 0; d < 9; ++d) { pre[(6 + d) * Np + p] = q.w[d]; pre[(15 + d) * Np + p] = q.affine[d]; }
+  }
+  return det_regular(c, q.base[0], q.base[1], q.base[2]) ? (int)det_lin3(c, q.base[0], q.base[1], q.base[2]) : -1;
+}
+// what particle p adds to the cell its offset (i, j, k) reaches: (m, mv xyz) -- one update of the reference's scatter-add (:178-194)
+__host__ __device__ inline void det_contrib(const MpmConst& c, const Pre& q, const float* v, int i, int j, int k, float* out4) {
+  const float weight = q.w[i * 3 + 0] * q.w[j * 3 + 1] * q.w[k * 3 + 2];
+  const float dpos[3] = {((float)i - q.fx[0]) * c.dx, ((float)j - q.fx[1]) * c.dx, ((float)k - q.fx[2]) * c.dx};
+  out4[0] = weight * c.p_mass;
+  for (int r = 0; r < 3; ++r)
+    out4[1 + r] = weight * (c.p_mass * v[r] + (q.affine[r * 3] * dpos[0] + q.affine[r * 3 + 1] * dpos[1] + q.affine[r * 3 + 2] * dpos[2]));
+}
+// the cells particle p's scatter or gather will touch, offset cidx = 0 .. 26: the scatter cell (or -1: dropped) and the gather cell (a clamped
+// gather may read a cell nobody scatters to) -- the callers stamp both into the env's touched-cell set
+__host__ __device__ inline void det_touch_base(const MpmConst& c, int b0, int b1, int b2, int cidx, long& sc_lin, long& gc_lin) {
+  const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+  const int sc = cell_scatter(c, b0 + i, b1 + j, b2 + k);
+  sc_lin = sc >= 0 ? det_lin(c, sc) : -1;
+  gc_lin = det_lin(c, cell_gather(c, b0 + i, b1 + j, b2 + k));
+}
+__host__ __device__ inline void det_touch(const MpmConst& c, const float* pre, int p, int cidx, long& sc_lin, long& gc_lin) {
+  const int Np = c.Np;
+  const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
+  const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+  const int sc = cell_scatter(c, b0 + i, b1 + j, b2 + k);
+  sc_lin = sc >= 0 ? det_lin(c, sc) : -1;
+  gc_lin = det_lin(c, cell_gather(c, b0 + i, b1 + j, b2 + k));
+}
+
+struct DetRange { int s, e; };
+// one env's particle buckets of one substep: `order` = the particle indices sorted by (bucket key, index) -- the n_irr irregular ones (key -1)
+// first; brange[base cell] = [s, e) of that cell's bucket in `order`, valid where bflag[base cell] == epoch
+struct DetBuckets { const int* order; const DetRange* brange; const int* bflag; int n_irr, epoch; };
+
+// one touched cell: (m, mv) summed in the order of the reference's flattened update array -- offsets in (i, j, k) order, the particles of an
+// offset in ascending index -- then the grid op.  contrib: [27][Np][4], det_contrib of every (offset, particle).
+__host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int ck, const float* pre, const float* contrib, const PrimF& pf,
+                                         const DetBuckets& bk, float* vo) {
+  const int Np = c.Np, key = ci | (cj << 10) | (ck << 20);
+  float m = 0.f, mv[3] = {0.f, 0.f, 0.f};
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j)
       for (int k = 0; k < 3; ++k) {
-        const int sc = cell_scatter(c, q.base[0] + i, q.base[1] + j, q.base[2] + k);
-        if (sc >= 0) flag[det_lin(c, sc)] = epoch;
-        flag[det_lin(c, cell_gather(c, q.base[0] + i, q.base[1] + j, q.base[2] + k))] = epoch;   // a clamped gather may read a cell nobody scatters to
-      }
-}
-
-// one touched cell: (m, mv) summed over the particles in index order, each particle's offsets in (i, j, k) order; then the grid op
-__host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int ck, const float* pre, const PrimF& pf, float* vo) {
-  const int Np = c.Np, key = ci | (cj << 10) | (ck << 20);
-  float m = 0.f, mv[3] = {0.f, 0.f, 0.f};
-  for (int p = 0; p < c.N; ++p) {
-    const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
-    // away from the wrap-around of negative indices the stencil is base .. base + 2 per axis: most particles leave here
-    if (b0 >= 0 && b1 >= 0 && b2 >= 0 && (ci < b0 || ci > b0 + 2 || cj < b1 || cj > b1 + 2 || ck < b2 || ck > b2 + 2)) continue;
-    float fx[3], w[9], aff[9], v[3];
-    for (int d = 0; d < 3; ++d) { fx[d] = pre[(3 + d) * Np + p]; v[d] = pre[(24 + d) * Np + p]; }
-    for (int d = 0; d < 9; ++d) { w[d] = pre[(6 + d) * Np + p]; aff[d] = pre[(15 + d) * Np + p]; }
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j)
-        for (int k = 0; k < 3; ++k) {
-          if (cell_scatter(c, b0 + i, b1 + j, b2 + k) != key) continue;
-          const float weight = w[i * 3 + 0] * w[j * 3 + 1] * w[k * 3 + 2];
-          const float dpos[3] = {((float)i - fx[0]) * c.dx, ((float)j - fx[1]) * c.dx, ((float)k - fx[2]) * c.dx};
-          m += weight * c.p_mass;
-          for (int r = 0; r < 3; ++r)
-            mv[r] += weight * (c.p_mass * v[r] + (aff[r * 3] * dpos[0] + aff[r * 3 + 1] * dpos[1] + aff[r * 3 + 2] * dpos[2]));
+        int bs = 0, be = 0;                          // the regular particles whose base cell is cell - (i, j, k)
+        const int c0 = ci - i, c1 = cj - j, c2 = ck - k;
+        if (det_regular(c, c0, c1, c2)) {
+          const long bl = det_lin3(c, c0, c1, c2);
+          if (bk.bflag[bl] == bk.epoch) { bs = bk.brange[bl].s; be = bk.brange[bl].e; }
         }
-  }
+        int ir = 0;                                  // merged, by index, with the irregular particles that reach this cell with this offset
+        while (bs < be || ir < bk.n_irr) {
+          const int pb = bs < be ? bk.order[bs] : 0x7fffffff, pi = ir < bk.n_irr ? bk.order[ir] : 0x7fffffff;
+          int p;
+          if (pb < pi) { p = pb; ++bs; }
+          else {
+            p = pi; ++ir;
+            const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
+            if (cell_scatter(c, b0 + i, b1 + j, b2 + k) != key) continue;
+          }
+          const float* q4 = contrib + ((long)(i * 9 + j * 3 + k) * Np + p) * 4;
+          m += q4[0];
+          for (int r = 0; r < 3; ++r) mv[r] += q4[1 + r];
+        }
+      }
   grid_op<false>(c, pf, ci, cj, ck, m, mv, vo, nullptr);
 }
 

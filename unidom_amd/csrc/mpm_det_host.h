@@ -19,6 +19,15 @@ struct DetArgs {
   float* vel;             // [B][G][4] grid velocity after the grid op (written at the stamped cells only)
   int* flag;              // [B][G]    epoch stamp of the cells a substep touches
   float* pre;             // [B][UD_DET_PRE][Np]
+  float* contrib;         // [B][27][Np][4] what every (offset, particle) adds to its cell: (m, mv)
+  int* bkey;              // [B][Np]   bucket key of every particle (linear index of its base cell; -1 irregular)
+  int* order;             // [B][Np]   particle indices sorted by (bucket key, index)
+  void* brange;           // [B][G]    DetRange: the bucket of a base cell in `order`
+  int* bflag;             // [B][G]    epoch stamp of the valid brange entries
+  int* nirr;              // [B]       irregular particles (the first nirr entries of `order`)
+  int* list;              // [B][cap]  touched cells of the substep (any order: every cell is summed on its own)
+  int* count;             // [B]
+  int cap;
   float* trq3;            // [B][S][3] Q6 row sums of particles 0..2
   float* trq;             // [B][S]    their sum, in a fixed order
 };

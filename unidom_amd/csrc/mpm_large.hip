@@ -2090,7 +2090,7 @@ struct MpmLarge {
   void* cl_arena = nullptr;
   size_t cl_zero_bytes = 0, cl_own_off = 0, cl_own_words = 0, cl_bytes = 0;
   void* det_arena = nullptr; // deterministic forward (mpm_det.hip): flag [B][G] int, pre [B][27][Np], trq3 [B][S][3]
-  size_t det_bytes = 0;
+  size_t det_bytes = 0, det_off[11] = {};
   int det_epoch = 0;
   bool has_liquid = false;   // some particle has material 0
   int n_cu = 0, occ_fwd[2] = {0, 0};   // CUs; resident parts per CU of the persistent forward (occupancy query), [0] 64-lane, [1] 128-lane parts
@@ -2159,9 +2159,23 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
     if (per > 0) rc = clm_reserve(L, per);
   }
   if (rc == UD_OK && c.det) {
-    const size_t flag_b = ((size_t)tune.max_envs * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)tune.max_envs * 27 * c.Np * 4 + 255) / 256 * 256, trq_b = (size_t)tune.max_envs * c.steps * 3 * 4;
-    L->det_bytes = flag_b + pre_b + trq_b;
-    if (hipMalloc(&L->det_arena, L->det_bytes) != hipSuccess || hipMemset(L->det_arena, 0, L->det_bytes) != hipSuccess) { set_error("ud_mpm_create (deterministic): hipMalloc failed"); rc = UD_ERR_HIP; }
+    if (c.N > LG_SORT_MAX) { set_error("ud_mpm_create: deterministic mode sorts an env's particles in one workgroup's LDS: n_particles <= %d", LG_SORT_MAX); rc = UD_ERR_UNSUPPORTED; }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t Bm = (size_t)tune.max_envs;
+    L->det_off[0] = take(Bm * L->G * 4);                 // flag
+    L->det_off[1] = take(Bm * 27 * c.Np * 4);            // pre
+    L->det_off[2] = take(Bm * c.steps * 3 * 4);          // trq3
+    L->det_off[3] = take(Bm * c.Np * 4);                 // bkey
+    L->det_off[4] = take(Bm * c.Np * 4);                 // order
+    L->det_off[5] = take(Bm * L->G * 8);                 // brange
+    L->det_off[6] = take(Bm * L->G * 4);                 // bflag
+    L->det_off[7] = take(Bm * 4);                        // nirr
+    L->det_off[8] = take(Bm * L->cap * 4);               // list
+    L->det_off[9] = take(Bm * 4);                        // count
+    L->det_off[10] = take(Bm * 27 * c.Np * 16);          // contrib
+    L->det_bytes = off;
+    if (rc == UD_OK && (hipMalloc(&L->det_arena, L->det_bytes) != hipSuccess || hipMemset(L->det_arena, 0, L->det_bytes) != hipSuccess)) { set_error("ud_mpm_create (deterministic): hipMalloc failed"); rc = UD_ERR_HIP; }
   }
   if (rc == UD_OK && hipDeviceSynchronize() != hipSuccess) { set_error("ud_mpm_create: device synchronisation failed"); rc = UD_ERR_HIP; }
   if (rc != UD_OK) { mpm_large_destroy(L); return nullptr; }
@@ -2395,7 +2409,6 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   while (npow2 < N) npow2 <<= 1;
   if (c.det) {
     // deterministic forward (mpm_det.hip): the data movement around it is this file's, the arithmetic is compiled there
-    const size_t flag_b = ((size_t)L->B * L->G * 4 + 255) / 256 * 256, pre_b = ((size_t)L->B * 27 * c.Np * 4 + 255) / 256 * 256;
     a.b0 = 0; a.f = 0;
     hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, B), blk, 0, st, c, 0, x, v, C, F, hist, stride_b, 1, (const int*)nullptr, 0L);
@@ -2404,7 +2417,10 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     d.ppos = L->w.ppos; d.prot = L->w.prot; d.psize = psize; d.friction = friction; d.mu = mu; d.lamda = lamda; d.action = action;
     d.hist = hist; d.rec = rec; d.stride_b = stride_b; d.pingpong = ckpt ? 0 : 1;
     d.vel = (float*)L->w.vel;
-    d.flag = (int*)L->det_arena; d.pre = (float*)((char*)L->det_arena + flag_b); d.trq3 = (float*)((char*)L->det_arena + flag_b + pre_b);
+    char* db = (char*)L->det_arena;
+    d.flag = (int*)(db + L->det_off[0]); d.pre = (float*)(db + L->det_off[1]); d.trq3 = (float*)(db + L->det_off[2]);
+    d.bkey = (int*)(db + L->det_off[3]); d.order = (int*)(db + L->det_off[4]); d.brange = (void*)(db + L->det_off[5]); d.bflag = (int*)(db + L->det_off[6]);
+    d.nirr = (int*)(db + L->det_off[7]); d.list = (int*)(db + L->det_off[8]); d.count = (int*)(db + L->det_off[9]); d.cap = L->cap; d.contrib = (float*)(db + L->det_off[10]);
     d.trq = L->w.trq;
     rc = mpm_det_forward(d, &L->det_epoch, st);
     if (rc) { set_error("ud_mpm_step_fwd (deterministic): launch failed"); return rc; }
