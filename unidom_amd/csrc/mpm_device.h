@@ -62,16 +62,24 @@ __device__ __forceinline__ void m_mul_at(const float* A, const float* B, float* 
 #define UD_FRSQ(x) __builtin_amdgcn_rsqf(x)
 #endif
 
+// One-sided Jacobi rotation of columns p, q.  With al = |a_p|^2, be = |a_q|^2, ga = a_p . a_q the textbook angle is zeta = (be - al) / (2 ga),
+// t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), c = 1 / sqrt(1 + t^2) -- with the thresholds' sqrt(al be) five transcendental instructions
+// (quarter rate) and a division chain per rotation.  The same t without forming zeta: t = sign(d g) |g| / (|d| + sqrt(d^2 + g^2)), d = be - al,
+// g = 2 ga: ONE sqrt, ONE rcp, ONE rsq; the thresholds compare squares.  The Jacobi sweeps were ~38 % of the VALU instructions of the one-lane
+// particle kernels (tools/isa_budget.py on lg_g2p_p2g<1>: 355 of 3252 static instructions, run three to four times per particle), which the
+// counters show VALU-bound at ~70 % of issue (tools/pmc_budget.sh, rope at n_grid 256); round 4, as in plb_common.h for f64.
 #define UD_JROT(p, q)                                                                                       \
   {                                                                                                         \
-    float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                      \
-    float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                      \
-    float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                      \
-    const float nrm_ = UD_FSQRT(al * be);                                                                    \
-    const bool rot = !done && fabsf(ga) > 1.5e-8f * nrm_;                                                    \
-    any_rot |= fabsf(ga) > 1e-4f * nrm_;                                                                     \
-    float zeta = (be - al) * UD_FRCP(2.f * (rot ? ga : 1.f));                                                \
-    float t = copysignf(1.f, zeta) * UD_FRCP(fabsf(zeta) + UD_FSQRT(1.f + zeta * zeta));                     \
+    const float al = a[p] * a[p] + a[3 + p] * a[3 + p] + a[6 + p] * a[6 + p];                                \
+    const float be = a[q] * a[q] + a[3 + q] * a[3 + q] + a[6 + q] * a[6 + q];                                \
+    const float ga = a[p] * a[q] + a[3 + p] * a[3 + q] + a[6 + p] * a[6 + q];                                \
+    const float ab_ = al * be, gg_ = ga * ga;                                                                \
+    const bool rot = !done && gg_ > 2.25e-16f * ab_;        /* |ga| > 1.5e-8 sqrt(al be) */                  \
+    any_rot |= gg_ > 1e-8f * ab_;                           /* |ga| > 1e-4 sqrt(al be) */                    \
+    const float g2_ = rot ? ga + ga : 1.f, d_ = be - al;                                                     \
+    const float h_ = UD_FSQRT(d_ * d_ + g2_ * g2_);                                                          \
+    float t = fabsf(g2_) * UD_FRCP(fabsf(d_) + h_);                                                          \
+    t = ((d_ < 0.f) != (g2_ < 0.f)) ? -t : t;                                                                \
     float cs = UD_FRSQ(1.f + t * t), sn = cs * t;  /* cs^2+sn^2 = 1 to round-off whatever t is */            \
     cs = rot ? cs : 1.f; sn = rot ? sn : 0.f;                                                                \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \

@@ -661,7 +661,7 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
       r[0] = make_float4(__builtin_bit_cast(float, key), mv.x, mv.y, mv.z);
       r[1] = make_float4(mv.w, vo[0], vo[1], vo[2]);
     } else if (a.status) {
-      a.status[b] = 1;   // pool exhausted: the backward of this env is invalid (UD_ERR_OVERFLOW, reported like the LDS table's)
+      atomicOr(&a.status[b], 1);   // (OR: other workgroups flag the same word) pool exhausted: the backward of this env is invalid (UD_ERR_OVERFLOW, reported like the LDS table's)
     }
   }
 }
