@@ -200,7 +200,9 @@ def test_order_v2_matches_reference_order_short_horizon():
     in f64 the two orders agree to 1e-9 over 50 substeps."""
     mask = fold_cloth1_mask()
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
-    for S, tol_x, tol_v in ((1, 5e-7, 1e-4), (5, 1e-6, 2e-4)):
+    # (two macro actions of S substeps each; 50 is the env's own robot_step: the same round-off, amplified by the stiff springs -- measured
+    # 8.6e-8 / 1.7e-7 / 1.1e-5 / 6.4e-5 on x and 1.5e-5 / 4.6e-5 / 5.3e-4 / 6.5e-3 on v at S = 1 / 5 / 20 / 50; grasp sets and primitives equal)
+    for S, tol_x, tol_v in ((1, 5e-7, 1e-4), (5, 1e-6, 2e-4), (20, 5e-5, 2e-3), (50, 3e-4, 2e-2)):
         o1, o2 = ClothOracle(mask, substeps=S), ClothOracle(mask, substeps=S, order=2)
         rng = np.random.default_rng(3)
         x, v, prim, k, mu, a = make_cloth_case(rng, 2, 2, deform=0.0005, v_scale=0.01)

@@ -52,15 +52,33 @@ __device__ __forceinline__ void plb_prepass(const PlbConst& c, double E, double 
   for (int i = 0; i < 9; ++i) q.IC[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c.dt * Cm[i];
   dm_mul(q.IC, F, q.Ft);
   if (!have_svd) dsvd3(q.Ft, q.U, q.sig, q.Vh);
-  double sum = 0;
+  // Return mapping (:133-150): the deviatoric log-strain norm against yield_stress / (2 mu).  The three logarithms are needed only by a
+  // particle that yields; whether it can is decided first from a bound that needs none: |log s| <= |s - 1| / min(s, 1) for s > 0, and the
+  // deviator's norm is at most the norm of the strains themselves, so  sum_i (|s_i - 1| / min(s_i, 1))^2 + 1e-8 <= (ys / 2 mu)^2  means
+  // "does not yield" whatever the logs are (Torus: ys / 2 mu = 0.48 -- a particle would have to be strained by a third).  Forward and
+  // adjoint run this same code on the same (checkpointed) singular values: the same decision.
+  const double ylim = ys / (2 * q.mu);
+  double bound2 = 1e-8;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { q.eps[i] = log(fmax(q.sig[i], 0.05)); sum += q.eps[i]; }
-  double nn = 0;
+  for (int i = 0; i < 3; ++i) {
+    const double sc_ = fmax(q.sig[i], 0.05);
+    const double b_ = fabs(sc_ - 1.0) * ud_rcp_nr(fmin(sc_, 1.0));
+    bound2 += b_ * b_;
+  }
+  q.yields = false; q.ehn = 0; q.dg = 0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { q.eh[i] = q.eps[i] - sum / 3; nn += q.eh[i] * q.eh[i]; }
-  q.ehn = sqrt(nn + 1e-8);
-  q.dg = q.ehn - ys / (2 * q.mu);
-  q.yields = q.dg > 0;
+  for (int i = 0; i < 3; ++i) { q.eps[i] = 0; q.eh[i] = 0; }
+  if (!(bound2 <= ylim * ylim * (1.0 - 1e-12))) {          // (the margin covers the reciprocal's last bits)
+    double sum = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q.eps[i] = log(fmax(q.sig[i], 0.05)); sum += q.eps[i]; }
+    double nn = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q.eh[i] = q.eps[i] - sum / 3; nn += q.eh[i] * q.eh[i]; }
+    q.ehn = sqrt(nn + 1e-8);
+    q.dg = q.ehn - ylim;
+    q.yields = q.dg > 0;
+  }
 #pragma unroll
   for (int i = 0; i < 9; ++i) q.nF[i] = q.Ft[i];
   q.ex[0] = 1; q.ex[1] = 1; q.ex[2] = 1;
