@@ -1,9 +1,9 @@
 #!/bin/bash
 # Every counter pass profiles/pmc_traffic.json is built from, on the final tree (its entries carry the hash of the kernel sources):
 # cloth (one workgroup per env; several), the one-workgroup MPM kernels, the many-workgroup MPM step calls, the PlasticineLab path.
-# usage (GPU box): TAG=r03 bash tools/pmc_all.sh  ->  gpurun_out/pmc_all/{pmc_traffic.json, <TAG>_pmc_large_*.csv, <TAG>_kernel_stats_*}
+# usage (GPU box): TAG=r04 bash tools/pmc_all.sh  ->  gpurun_out/pmc_all/{pmc_traffic.json, <TAG>_pmc_large_*.csv, <TAG>_kernel_stats_*}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r03}; A=gpurun_out/pmc_all; rm -rf $A; mkdir -p $A
+TAG=${TAG:-r04}; A=gpurun_out/pmc_all; rm -rf $A; mkdir -p $A
 keep() { cp $1 profiles/pmc_traffic.json; }     # the box's copy of the repo is scratch: the next tool starts from the merged file
 W=fold_cloth1 TAG=$TAG bash tools/pmc_cloth.sh > $A/cloth.log 2>&1; keep gpurun_out/pmc_cloth_fold_cloth1/pmc_traffic.json; tail -n 3 $A/cloth.log
 W=fold_tshirt TAG=$TAG bash tools/pmc_cloth.sh > $A/tshirt.log 2>&1; keep gpurun_out/pmc_cloth_fold_tshirt/pmc_traffic.json; tail -n 3 $A/tshirt.log

@@ -15,20 +15,31 @@ for NG in 64 128; do for MODE in fwd grad; do
 import csv, json, sys
 sys.path.insert(0, "tools")
 import src_hash
-tot = {}
+tot, per_k = {}, {}
 for c, f in (("FETCH_SIZE", "FETCH_SIZE"), ("WRITE_SIZE", "WRITE_SIZE"), ("SQ_WAVES", "INSTS"), ("SQ_INSTS_VALU", "INSTS"), ("SQ_INSTS_SALU", "INSTS")):
     s = 0.0
     for r in csv.DictReader(open("$O/${MODE}_${NG}_%s/p_counter_collection.csv" % f)):
-        if r["Counter_Name"] == c and "plb" in r["Kernel_Name"]:
+        if r["Counter_Name"] == c and ("plb" in r["Kernel_Name"] or "pcl_" in r["Kernel_Name"]):
             s += float(r["Counter_Value"])
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ud::", "")
+            per_k.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
     tot[c] = s
 steps = 3.0   # --warmup 1 --steps 2: a warm-up step is a whole bench step in both modes (bench.py::bench_torus)
 per_step = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / steps
 d = json.load(open("$O/pmc_traffic.json"))
 d["plb:$MODE:ngrid$NG"] = {"hbm_bytes_per_launch": per_step, "src_sha16": src_hash.sha16("plb"),
     "insts": {k: tot[k] / steps for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
-    "note": "all plb_* kernels of one bench step (8 envs x 10 env.steps x 19 substeps" + (", + loss + adjoint" if "$MODE" == "grad" else "") +
+    "note": "all plb_* / pcl_* kernels of one bench step (8 envs x 10 env.steps x 19 substeps" + (", + loss + adjoint" if "$MODE" == "grad" else "") +
             "): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 summed over the pass / its 3 bench steps; separate --pmc passes (tools/pmc_plb.sh)"}
+for k in ("pcl_fwd_kernel", "pcl_bwd_kernel"):       # the persistent kernels, per launch (= per step call): what the bench line's roofline.traffic quotes
+    if k in per_k and ("$MODE" == "grad" or k == "pcl_fwd_kernel"):
+        v = per_k[k]
+        mean = lambda c: sum(v[c]) / len(v[c]) if v.get(c) else 0.0
+        d["%s:$MODE:ngrid$NG" % k] = {"hbm_bytes_per_launch": (2 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024, "src_sha16": src_hash.sha16("pcl_"),
+            "launches_in_the_pass": len(v.get("FETCH_SIZE", [])),
+            "insts": {c: mean(c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU")},
+            "note": "mean per launch (one step call of 8 envs); 2 x FETCH_SIZE + WRITE_SIZE, KB x 1024, separate --pmc passes (tools/pmc_plb.sh)"}
+        print("%s:$MODE:ngrid$NG  %.1f MB per launch" % (k, d["%s:$MODE:ngrid$NG" % k]["hbm_bytes_per_launch"] / 1e6))
 json.dump(d, open("$O/pmc_traffic.json", "w"), indent=1)
 print("plb:$MODE:ngrid$NG  %.3f GB per bench step" % (per_step / 1e9))
 PY

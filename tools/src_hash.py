@@ -17,7 +17,8 @@ GROUPS = {   # kernel-name prefix (or "large_path:" key) -> the sources its code
     "large_path": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
     "lg_": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
     "clm_": ["mpm_large.hip", "mpm_cluster.h", "mpm_large.h", "mpm_device.h", "mpm_collide.h", "common.h"],
-    "plb": ["plb.hip", "plb_adj.hip", "plb_common.h", "common.h"],
+    "plb": ["plb.hip", "plb_adj.hip", "plb_cluster.hip", "plb_common.h", "plb_device.h", "common.h"],
+    "pcl_": ["plb.hip", "plb_adj.hip", "plb_cluster.hip", "plb_common.h", "plb_device.h", "common.h"],
 }
 
 

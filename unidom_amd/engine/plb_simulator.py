@@ -71,8 +71,10 @@ class _PlbStep(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ckpt = torch.empty((L.ud_plb_ckpt_bytes(sim._h, C.c_int(B)) // 8,), dtype=torch.float64, device=x.device)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        ev = sim._prof_begin("fwd")
         _lib.check(L.ud_plb_step_fwd(sim._h, C.c_int(B), _p(x), _p(v), _p(Cm), _p(F), _p(pp), _p(so), _p(action), _p(E), _p(nu),
                                      _p(ys), _p(xo), _p(vo), _p(Co), _p(Fo), _p(po), _p(ckpt), stream), "ud_plb_step_fwd")
+        sim._prof_end(ev)
         ctx.sim, ctx.B = sim, B
         ctx.save_for_backward(ckpt, so, action, E, nu, ys)
         return xo, vo, Co, Fo, po
@@ -91,9 +93,11 @@ class _PlbStep(torch.autograd.Function):
         ox, ov, oC, oF, op, oa = mk(B, N, 3), mk(B, N, 3), mk(B, N, 3, 3), mk(B, N, 3, 3), mk(B, P, 3), mk(B, 3)
         oE, onu, oys, ofr = mk(B), mk(B), mk(B), mk(B)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ev = sim._prof_begin("bwd")
         _lib.check(L.ud_plb_step_bwd(sim._h, C.c_int(B), _p(ckpt), _p(so), _p(action), _p(E), _p(nu), _p(ys), _p(gx), _p(gv), _p(gC),
                                      _p(gF), _p(gpp), _p(ox), _p(ov), _p(oC), _p(oF), _p(op), _p(oa), _p(oE), _p(onu), _p(oys), _p(ofr),
                                      stream), "ud_plb_step_bwd")
+        sim._prof_end(ev)
         sim.ground_friction_grad = ofr if sim.ground_friction_grad is None else sim.ground_friction_grad + ofr
         return None, ox, ov, oC, oF, op, None, oa, oE, onu, oys
 
@@ -153,6 +157,7 @@ class PlbSimulator:
             lower_bound=(C.c_double * 3)(*cfg.lower_bound), upper_bound=(C.c_double * 3)(*cfg.upper_bound),
             grid_ckpt_cells=int(self.grid_ckpt_cells), max_envs=int(batch_size), path=self.path, lanes=self.lanes, sort_every=self.sort_every)
         self._h = C.c_void_p()
+        self.profile = None    # {"fwd": [], "bwd": []}: HIP-event pairs around every step call, on its stream (bench.py)
         self.ground_friction_grad = None   # [B], accumulated by backward() (optimize_ground_friction.grad); reset it by hand
         _lib.check(_lib.lib().ud_plb_create(C.byref(cc), C.byref(self._h)), "ud_plb_create")
 
@@ -162,6 +167,18 @@ class PlbSimulator:
                 _lib.lib().ud_plb_destroy(self._h)
         except Exception:
             pass
+
+    def _prof_begin(self, kind):
+        if self.profile is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(self.device))
+        return (kind, a, b)
+
+    def _prof_end(self, ev):
+        if ev is not None:
+            ev[2].record(torch.cuda.current_stream(self.device))
+            self.profile[ev[0]].append((ev[1], ev[2]))
 
     def launch_plan(self, B=None):
         """ud_plb_launch_plan: 1 = multi-kernel path, 2 = one persistent launch per step call and direction"""
