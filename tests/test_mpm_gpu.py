@@ -1069,6 +1069,26 @@ def test_launch_plan_reports_the_kernels_a_call_runs(monkeypatch):
     assert big.launch_plan(200) == 1                                         # 200 x 798 particles: one lane per particle, neither rule applies
 
 
+@pytest.mark.parametrize("grid_ckpt_cells", [0, 2])
+def test_reset_leaves_a_healthy_handle_as_it_was(grid_ckpt_cells):
+    """ud_mpm_reset (what the mirror calls after status bit 4, a part that gave up at the env barrier) rewrites the handle's rest state --
+    barrier words, exchange grids, record counters, bitmaps.  On a healthy handle that state is already there: the step and its gradients
+    before and after a reset agree to the float-atomics spread of two plain runs (test_large_path_matches_oracle_n798 pins this handle
+    shape to the oracle)."""
+    import ctypes as C
+    from unidom_amd import _lib
+    sim, st, g, N = _scaled_case(3, 0, B=2, grid_ckpt_cells=grid_ckpt_cells)
+    assert sim.launch_plan(2) & 2                                            # the persistent cluster forward: the path with barrier words
+    a = run_hip(sim, st, g)
+    stream = C.c_void_p(torch.cuda.current_stream(sim.device).cuda_stream)
+    for _ in range(2):                                                       # idempotent
+        _lib.check(_lib.lib().ud_mpm_reset(sim._h, stream), "ud_mpm_reset")
+    b = run_hip(sim, st, g)
+    for k in a:
+        scale = max(1e-6, float(np.abs(a[k]).max()))
+        assert np.abs(a[k] - b[k]).max() <= 2e-4 * scale, k
+
+
 def test_more_envs_than_the_handle_was_created_for_is_refused():
     """Every arena is sized at ud_mpm_create (max_envs): a call with more envs returns UD_ERR_INVALID instead of growing anything."""
     from unidom_amd._lib import UnidomError
