@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cost of ud_mpm_conf.deterministic: forward ms per simulator.step, deterministic against default, 32 envs.
-    python tools/det_cost.py > profiles/r03_det_cost.txt"""
+    python tools/det_cost.py > gpurun_out/det_cost.txt   (tools/final_regression.sh copies it to profiles/<TAG>_det_cost.txt)"""
 import os
 import sys
 import time
