@@ -179,9 +179,11 @@ typedef struct {
                                 arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same inputs return
                                 the same bits, and x, v, C, F equal the CPU build of the same source bit for bit (tests/test_mpm_det.py).
                                 Per substep the particles are bucketed by base cell (one sort per env) and a cell walks the 27 buckets
-                                that can reach it: 3.2x the default forward at 67 particles, 5.4x at 798 (profiles/r04*_det_cost.txt; rounds
-                                2-3, every cell walking every particle: 13x / 332x).  Position control with one box primitive and at most
-                                8192 particles only (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the
+                                that can reach it: 3.1x the default forward at 67 particles, 5.2x at 798 (profiles/r04*_det_cost.txt; rounds
+                                2-3, every cell walking every particle: 13x / 332x).  Position control or soft contact (collide_batch of
+                                box / container primitives: its exp is a plain-IEEE polynomial in this mode so that both builds agree; a
+                                primitive's ROTATION still goes through the platform's sinf / cosf); at most 8192 particles
+                                (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the
                                 backward is the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
   int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
                                 grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's

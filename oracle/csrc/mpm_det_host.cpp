@@ -16,12 +16,15 @@
 
 extern "C" {
 
-// x, v [B][N][3], C, F [B][N][3][3] -> the same after `steps` substeps; ppos [B][S][3] / prot [B][S][4] in: the input arrays,
-// out: the rows forward kinematics leaves.  Returns 0.
+// x, v [B][N][3], C, F [B][N][3][3] -> the same after `steps` substeps; ppos [B][P][S][3] / prot [B][P][S][4] in: the input arrays,
+// out: the rows forward kinematics leaves; psize [B][P][3], action [B][6 P].  position_control != 0: one box primitive (P = 1); else
+// collide_batch of P box (sdf_kind 0) or container (1) primitives with their own friction / softness (prim_friction / prim_softness [P]).
+// Returns 0.
 int oc_mpm_det_forward(int B, int N, int n_grid, const int* res, int steps, float dt, float p_mass, float p_vol, const float* gravity,
                        const int* material, const float* hard, const float* x, const float* v, const float* Cm, const float* F,
                        float* ppos, float* prot, const float* psize, const float* friction, const float* mu, const float* lamda,
-                       const float* action, float* xo, float* vo, float* Co, float* Fo) {
+                       const float* action, float* xo, float* vo, float* Co, float* Fo, int position_control, int n_prim, int sdf_kind,
+                       const float* prim_friction, const float* prim_softness) {
   ud::MpmConst c;
   std::memset(&c, 0, sizeof(c));
   c.N = N; c.Np = (N + 15) / 16 * 16; c.n_grid = n_grid; c.steps = steps;
@@ -32,7 +35,9 @@ int oc_mpm_det_forward(int B, int N, int n_grid, const int* res, int steps, floa
   c.stress_c = (float)(-(double)dt * (double)p_vol * 4.0);
   c.dx2 = (float)(dx * dx);
   for (int d = 0; d < 3; ++d) c.dtg[d] = dt * gravity[d];
-  c.position_control = 1; c.n_prim = 1; c.det = 1;
+  c.position_control = position_control ? 1 : 0; c.n_prim = position_control ? 1 : n_prim; c.sdf_kind = sdf_kind; c.det = 1;
+  for (int ip = 0; ip < c.n_prim && ip < 4; ++ip) { c.prim_friction_each[ip] = prim_friction ? prim_friction[ip] : 0.f; c.prim_softness_each[ip] = prim_softness ? prim_softness[ip] : 0.f; }
+  const int P = c.n_prim;
   const long G = (long)res[0] * res[1] * res[2];
   const int Np = c.Np, S = steps;
   std::vector<float> h0((size_t)24 * Np), h1((size_t)24 * Np), pre((size_t)UD_DET_PRE * Np), vel((size_t)G * 4), contrib((size_t)27 * Np * 4);
@@ -40,9 +45,9 @@ int oc_mpm_det_forward(int B, int N, int n_grid, const int* res, int steps, floa
   std::vector<ud::DetRange> brange((size_t)G);
   std::vector<std::pair<unsigned, int>> keyed((size_t)N);
   for (int b = 0; b < B; ++b) {
-    float* pp = ppos + (long)b * S * 3;
-    float* pr = prot + (long)b * S * 4;
-    ud::det_fk_rows(S, action + (long)b * 6, pp, pr);
+    float* pp = ppos + (long)b * P * S * 3;
+    float* pr = prot + (long)b * P * S * 4;
+    for (int ip = 0; ip < P; ++ip) ud::det_fk_rows(S, action + ((long)b * P + ip) * 6, pp + (long)ip * S * 3, pr + (long)ip * S * 4);
     std::fill(h0.begin(), h0.end(), 0.f); std::fill(h1.begin(), h1.end(), 0.f);
     for (int p = 0; p < N; ++p) {                      // lg_pack: SoA record, nan_to_num on the way in
       for (int d = 0; d < 3; ++d) { h0[d * Np + p] = ud::nan_to_num(x[((long)b * N + p) * 3 + d]); h0[(3 + d) * Np + p] = ud::nan_to_num(v[((long)b * N + p) * 3 + d]); }
@@ -76,13 +81,12 @@ int oc_mpm_det_forward(int B, int N, int n_grid, const int* res, int steps, floa
         brange[key].e = i + 1;
       }
       const ud::DetBuckets bk{order.data(), brange.data(), bflag.data(), n_irr, epoch};
-      ud::PrimF pf;
-      ud::det_prim(S, f, pp, pr, psize + (long)b * 3, action + (long)b * 6, friction[b], pf);
+      const ud::DetPrimRows pw{f, pp, pr, psize + (long)b * P * 3, action + (long)b * P * 6, friction[b]};
       for (long lin = 0; lin < G; ++lin) {
         if (flag[lin] != epoch) continue;
         const int ck = (int)(lin % res[2]), cj = (int)((lin / res[2]) % res[1]), ci = (int)(lin / ((long)res[2] * res[1]));
         float o[3];
-        ud::det_cell(c, ci, cj, ck, pre.data(), contrib.data(), pf, bk, o);
+        ud::det_cell(c, ci, cj, ck, pre.data(), contrib.data(), pw, bk, o);
         vel[lin * 4] = o[0]; vel[lin * 4 + 1] = o[1]; vel[lin * 4 + 2] = o[2]; vel[lin * 4 + 3] = 0.f;
       }
       for (int p = 0; p < N; ++p) (void)ud::det_g2p_particle(c, h, hn, p, pre.data(), vel.data());

@@ -200,10 +200,13 @@ class MpmOracle:
         return o
 
 
-def mpm_det_forward(st, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0), material=None, hardness=None):
+def mpm_det_forward(st, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho=1.0, gravity=(0, -9.8, 0), material=None, hardness=None,
+                    position_control=True, n_prim=1, sdf_kind=0, prim_friction=None, prim_softness=None):
     """The deterministic MPM forward's own source (unidom_amd/csrc/mpm_det.h) compiled for the CPU (csrc/mpm_det_host.cpp): the
-    same-order, same-arithmetic checker of ud_mpm_conf.deterministic.  f32 only; position control, one box primitive.
-    st as MpmOracle.step_fwd takes it; returns x v C F after the step and the primitive rows forward kinematics leaves."""
+    same-order, same-arithmetic checker of ud_mpm_conf.deterministic.  f32 only; position control with one box primitive, or
+    (position_control=False) collide_batch of n_prim box (sdf_kind 0) / container (1) primitives with their own friction / softness.
+    st as MpmOracle.step_fwd takes it (primitive arrays [B, P, ...] when P > 1); returns x v C F after the step and the primitive rows
+    forward kinematics leaves."""
     f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     x, v, Cm, F = f(st["x"]), f(st["v"]), f(st["C"]), f(st["F"])
     B = x.shape[0]
@@ -217,7 +220,9 @@ def mpm_det_forward(st, N, n_grid=64, res=(32, 32, 32), steps=70, dt=1e-4, p_rho
         C.c_int(B), C.c_int(N), C.c_int(n_grid), _p(np.ascontiguousarray(res, dtype=np.int32)), C.c_int(steps), C.c_float(dt),
         C.c_float(p_vol * p_rho), C.c_float(p_vol), _p(f(gravity)), _p(mat), _p(hd), _p(x), _p(v), _p(Cm), _p(F), _p(ppos), _p(prot),
         _p(f(st["psize"])), _p(f(st["friction"])), _p(f(st["mu"])), _p(f(st["lamda"])), _p(f(st["action"])),
-        _p(o["x"]), _p(o["v"]), _p(o["C"]), _p(o["F"]))
+        _p(o["x"]), _p(o["v"]), _p(o["C"]), _p(o["F"]), C.c_int(1 if position_control else 0), C.c_int(n_prim), C.c_int(sdf_kind),
+        _p(f(np.zeros(4) if prim_friction is None else np.resize(np.asarray(prim_friction, np.float32), 4))),
+        _p(f(np.zeros(4) if prim_softness is None else np.resize(np.asarray(prim_softness, np.float32), 4))))
     assert rc == 0
     o["ppos_rows"], o["prot_rows"] = ppos, prot
     return o

@@ -102,16 +102,71 @@ def test_deterministic_mode_on_a_many_workgroup_body(demo):
         assert np.isfinite(a[key]).all() and _rel(a[key], ref[key]) < 2e-4, (key, _rel(a[key], ref[key]))
 
 
+def _soft_cases(demo):
+    """soft contact (collide_batch): a rotated box sitting in the rope (elastic and plastic rope, 20 substeps) and two upright bowls
+    (container SDF) around a liquid body -- no primitive turns during the step, so no library sin / cos enters the poses"""
+    from test_oracle_mpm import _collide_case, _two_bowl_case
+    out = []
+    for material in (1, 2):
+        st, _ = _collide_case(demo, 20, 40, material, 0, np.float32, w=(0.0, 0.0, 0.0))
+        out.append((f"box_material{material}", st, dict(steps=20, material=np.full(67, material), n_prim=1, sdf_kind=0)))
+    st, _ = _two_bowl_case(demo, 3, 40, 0, np.float32, turning=False)
+    out.append(("two_bowls_liquid", st, dict(steps=3, material=np.zeros(67, np.int64), n_prim=2, sdf_kind=1)))
+    return out
+
+
+def _soft_checker(st, kw):
+    from oracle.pyoracle import mpm_det_forward
+    P = kw["n_prim"]
+    return mpm_det_forward(st, 67, steps=kw["steps"], material=kw["material"], position_control=False, n_prim=P, sdf_kind=kw["sdf_kind"],
+                           prim_friction=[0.1] * P, prim_softness=[666.0] * P)
+
+
+def test_same_order_source_follows_the_reference_restatement_in_soft_contact(demo):
+    """collide_batch in the deterministic mode's source (mpm_collide.h compiled for the host, its exp the plain-IEEE ud_expf) against the
+    independent oracle: the usual forward tolerances of the soft-contact tests."""
+    from oracle.pyoracle import MpmOracle
+    for name, st, kw in _soft_cases(demo):
+        ref = MpmOracle(67, steps=kw["steps"], material=kw["material"], position_control=False, n_prim=kw["n_prim"],
+                        sdf="container" if kw["sdf_kind"] else "box").step_fwd(st)
+        got = _soft_checker(st, kw)
+        assert np.isfinite(got["x"]).all(), name
+        assert _rel(got["x"], ref["x"]) < 5e-6 and _rel(got["v"], ref["v"]) < 1e-4, (name, _rel(got["x"], ref["x"]), _rel(got["v"], ref["v"]))
+        assert _rel(got["C"], ref["C"]) < 1e-3 and _rel(got["F"], ref["F"]) < 5e-5, (name, _rel(got["C"], ref["C"]), _rel(got["F"], ref["F"]))
+
+
 @pytest.mark.gpu
-def test_deterministic_mode_refuses_soft_contact():
+def test_deterministic_soft_contact_is_bit_identical_to_the_same_order_checker(demo):
+    """ud_mpm_conf.deterministic with use_position_control = 0 (round 4): box and container primitives, elastic / plastic / liquid bodies.
+    Two GPU runs identical; x, v, C, F bit for bit the CPU build of the same source; the default kernels' physics to their tolerance."""
+    import torch
     from test_mpm_gpu import LegacyConf
-    from unidom_amd._lib import UnidomError
-    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
-    conf = LegacyConf()
-    conf.deterministic = 1
-    sim = SimpleMPMSimulator(conf, 1, use_position_control=False)
-    sim.n_particles = 67
-    sim.material = np.full(67, 1, np.int32)
-    sim.h = np.ones(67, np.float32)
-    with pytest.raises(UnidomError):
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator, _Step
+
+    def run(st, kw, deterministic):
+        conf = LegacyConf()
+        conf.steps = kw["steps"]
+        conf.deterministic = deterministic
+        sim = SimpleMPMSimulator(conf, 1, use_position_control=False)
+        sim.n_particles, sim.material, sim.h = 67, np.asarray(kw["material"], np.int32), np.ones(67, np.float32)
+        if kw["n_prim"] > 1:
+            sim.n_primitive, sim.sdf_kind = kw["n_prim"], "container"
         sim._make_handle()
+        t = lambda a: torch.tensor(np.asarray(a, np.float32), device=sim.device)
+        outs = []
+        for _ in range(2):
+            with torch.no_grad():
+                out = _Step.apply(sim, *[t(st[k]) for k in ("x", "v", "C", "F", "J", "ppos", "prot", "psize", "friction", "mu", "lamda", "action")])
+            sim.check_status()
+            outs.append({k: o.cpu().numpy() for k, o in zip(("x", "v", "C", "F"), out)})
+        return outs
+
+    for name, st, kw in _soft_cases(demo):
+        a, b = run(st, kw, 1)
+        chk = _soft_checker(st, kw)
+        for key in ("x", "v", "C", "F"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{name} {key}: two runs differ")
+            np.testing.assert_array_equal(a[key], chk[key], err_msg=f"{name} {key}: GPU != CPU build of the same source")
+        fast = run(st, kw, 0)[0]
+        assert _rel(a["x"], fast["x"]) < 5e-6 and _rel(a["v"], fast["v"]) < 2e-4 and _rel(a["F"], fast["F"]) < 5e-5, \
+            (name, _rel(a["x"], fast["x"]), _rel(a["v"], fast["v"]), _rel(a["F"], fast["F"]))

@@ -1249,10 +1249,6 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
     return UD_ERR_UNSUPPORTED;
   }
   // soft contact (collide_batch) runs on the many-workgroup path whatever N is: every reference env that uses it has N > 128
-  if (conf->deterministic && (!conf->use_position_control || n_prim != 1)) {
-    ud::set_error("ud_mpm_create: deterministic mode covers position control with one box primitive");
-    return UD_ERR_UNSUPPORTED;
-  }
   // the deterministic forward lives beside the many-workgroup kernels (dense grid in HBM), whatever N is
   const bool large = N > 128 || !conf->use_position_control || conf->deterministic;
   if (!large && S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }

@@ -21,6 +21,29 @@ namespace ud {
 __device__ __forceinline__ float sqrt_rte(float x) { return (float)sqrt((double)x); }
 __device__ __forceinline__ float div_rte(float a, float b) { return (float)((double)a / (double)b); }
 
+// exp for the softness falloff.  The fast kernels take the platform's expf; the deterministic mode's builds (UD_MPM_EXACT on the device,
+// UD_HOST_BUILD for the same-order CPU checker) need the SAME bits from hipcc and from the host compiler: range reduction and a degree-6
+// polynomial in plain IEEE operations (neither build contracts), scaled by an exact ldexp.  Within 2 ulp of expf on the range that reaches
+// it; results below the normal range are flushed to zero (influence 1e-38 either way).
+#if defined(UD_MPM_EXACT) || defined(UD_HOST_BUILD)
+__device__ __forceinline__ float ud_expf(float x) {
+  if (!(x < 88.7f)) return x != x ? x : INFINITY;
+  if (x < -87.f) return 0.f;
+  const float kf = rintf(x * 1.44269504f);
+  float r = x - kf * 0.693359375f;            // ln 2 in two pieces: the first has 9 significant bits, its product with |k| <= 128 is exact
+  r = r - kf * -2.12194440e-4f;
+  float p = 1.3888889e-3f;
+  p = p * r + 8.3333333e-3f;
+  p = p * r + 4.1666668e-2f;
+  p = p * r + 1.6666667e-1f;
+  p = p * r + 0.5f;
+  const float y = 1.f + (r + (r * r) * p);
+  return ldexpf(y, (int)kf);
+}
+#else
+__device__ __forceinline__ float ud_expf(float x) { return expf(x); }
+#endif
+
 struct PrimC {            // the primitive as the grid op of substep f sees it (rows f and f + 1, clamped: Q5); uniform
   float p0[3], r0[4], p1[3], r1[4], iq[4], nq, size[3], soft, mu;
   int kind;               // 0 box, 1 container (the reference's process-global set_sdf, primitives.py:26-28)
@@ -156,7 +179,7 @@ __device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const fl
     for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
     qrot_x(pc.iq, r.rel, r.loc);
     const float dist = prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2]);
-    r.e = expf(-dist * pc.soft);
+    r.e = ud_expf(-dist * pc.soft);
     r.infl = clipf(r.e, -INFINITY, 1.f);
     const float d = 1.e-6f, k = 500000.f;   // (0.5 / d)
     r.n[0] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0] + d, r.loc[1], r.loc[2]) - prim_sdf_x(pc.kind, pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2]));

@@ -13,11 +13,14 @@
 // buckets that can reach it -- for offset (i, j, k) the bucket of base cell (cell - (i, j, k)), its particles in ascending index -- instead
 // of all N particles (round 3: 332x the default forward at N = 798).  Particles whose stencil wraps or is cut at the domain edge (negative
 // base index, Q9; base + 2 outside `res`) are kept apart ("irregular", bucket key -1) and merged into every offset's walk by index.
-// Scope: position control, one box primitive (whip_rope's configuration); soft contact is refused at ud_mpm_create.
+// Scope: the forward, position control or soft contact (collide_batch of up to four box / container primitives: mpm_collide.h compiled into
+// both builds; its exp is ud_expf's plain-IEEE form there).  The rotation of a primitive goes through the platform's sinf / cosf (ocml vs glibc):
+// equal for the non-rotating primitives tested.
 // Reference lines as in mpm.hip / mpm_device.h: particle pre-pass :233-258, p2g :259-274, grid op :283-313, g2p :196-221, :318-328,
 // forward kinematics primitives.py:185-194, position control primitives.py:232-239.
 #pragma once
 #include "mpm_device.h"
+#include "mpm_collide.h"
 
 namespace ud {
 
@@ -67,6 +70,39 @@ __host__ __device__ inline void det_prim(int S, int f, const float* pp, const fl
   const float n = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-12f;
   pf.iq[0] = r0 / n; pf.iq[1] = r1 / n; pf.iq[2] = r2 / n; pf.iq[3] = r3 / n;
   pf.friction = friction;
+}
+
+// primitive ip as collide_batch sees it in substep f (load_primc_f, mpm_large.hip): rows f and f + 1 of the FK arrays, clamped (Q5)
+__host__ __device__ inline void det_primc(const MpmConst& c, int f, const float* pp, const float* pr, const float* psize3, int ip, PrimC& pc) {
+  const int S = c.steps, f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
+  for (int d = 0; d < 3; ++d) { pc.p0[d] = pp[f0 * 3 + d]; pc.p1[d] = pp[f1 * 3 + d]; pc.size[d] = psize3[d]; }
+  for (int d = 0; d < 4; ++d) { pc.r0[d] = pr[f0 * 4 + d]; pc.r1[d] = pr[f1 * 4 + d]; }
+  pc.soft = c.prim_softness_each[ip]; pc.mu = c.prim_friction_each[ip]; pc.kind = c.sdf_kind;
+  primc_finish(pc);
+}
+// the grid op of one cell (mpm_simulator.py:283-313) from its summed (m, mv): position control (grid_op) or collide_batch of each primitive
+// in turn, then ground friction and the boundary (lg_grid_cell, mpm_large.hip).  pp / pr / psize / action: the env's rows, [P][S*3] / [P][S*4] /
+// [P][3] / [6 P]
+__host__ __device__ inline void det_grid_cell(const MpmConst& c, int f, const float* pp, const float* pr, const float* psize, const float* action,
+                                              float friction, int ci, int cj, int ck, float m, const float* mv, float* vo) {
+  const int S = c.steps;
+  if (c.position_control) {
+    PrimF pf;
+    det_prim(S, f, pp, pr, psize, action, friction, pf);
+    grid_op<false>(c, pf, ci, cj, ck, m, mv, vo, nullptr);
+    return;
+  }
+  float v0[3], v1[3] = {0.f, 0.f, 0.f};
+  for (int d = 0; d < 3; ++d) v0[d] = ((m > 0.f) ? mv[d] / m : mv[d]) + c.dtg[d];
+  const float gp[3] = {(float)ci * c.dx, (float)cj * c.dx, (float)ck * c.dx};
+  for (int ip = 0; ip < c.n_prim; ++ip) {                       // primitive after primitive (mpm_simulator.py:292-294)
+    PrimC pc;
+    det_primc(c, f, pp + (long)ip * S * 3, pr + (long)ip * S * 4, psize + ip * 3, ip, pc);
+    CollideRec cr;
+    collide_cell(pc, c.dt, gp, v0, v1, cr);
+    for (int d = 0; d < 3; ++d) v0[d] = v1[d];
+  }
+  grid_tail<false>(c, friction, ci, cj, ck, v1, vo, nullptr);
 }
 
 __host__ __device__ inline long det_lin(const MpmConst& c, int key) {
@@ -130,7 +166,8 @@ struct DetBuckets { const int* order; const DetRange* brange; const int* bflag; 
 
 // one touched cell: (m, mv) summed in the order of the reference's flattened update array -- offsets in (i, j, k) order, the particles of an
 // offset in ascending index -- then the grid op.  contrib: [27][Np][4], det_contrib of every (offset, particle).
-__host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int ck, const float* pre, const float* contrib, const PrimF& pf,
+struct DetPrimRows { int f; const float *pp, *pr, *psize, *action; float friction; };   // the env's primitive rows for det_grid_cell
+__host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int ck, const float* pre, const float* contrib, const DetPrimRows& pw,
                                          const DetBuckets& bk, float* vo) {
   const int Np = c.Np, key = ci | (cj << 10) | (ck << 20);
   float m = 0.f, mv[3] = {0.f, 0.f, 0.f};
@@ -158,7 +195,7 @@ __host__ __device__ inline void det_cell(const MpmConst& c, int ci, int cj, int 
           for (int r = 0; r < 3; ++r) mv[r] += q4[1 + r];
         }
       }
-  grid_op<false>(c, pf, ci, cj, ck, m, mv, vo, nullptr);
+  det_grid_cell(c, pw.f, pw.pp, pw.pr, pw.psize, pw.action, pw.friction, ci, cj, ck, m, mv, vo);
 }
 
 // particle p: gather of the 27 cell velocities in (i, j, k) order, advection; x, v, C of substep f + 1 into `hn`.

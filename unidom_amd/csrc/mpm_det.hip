@@ -10,10 +10,11 @@
 
 namespace ud {
 
-__global__ void __launch_bounds__(64) det_fk_kernel(DetArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x, S = a.c.steps;
-  if (b >= a.B) return;
-  det_fk_rows(S, a.action + (long)b * 6, a.ppos + (long)b * S * 3, a.prot + (long)b * S * 4);
+__global__ void __launch_bounds__(64) det_fk_kernel(DetArgs a) {   // one thread per (env, primitive)
+  const long bp = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int S = a.c.steps;
+  if (bp >= (long)a.B * a.c.n_prim) return;
+  det_fk_rows(S, a.action + bp * 6, a.ppos + bp * S * 3, a.prot + bp * S * 4);
 }
 
 // pre-pass per particle; its bucket key; its 27 contributions; the cells it touches into the env's list (first toucher of a cell -- whoever
@@ -164,11 +165,10 @@ __global__ void __launch_bounds__(256) det_cells_kernel(DetArgs a, int f, int ep
       m = __shfl(tm, src); mv[0] = __shfl(tv[0], src); mv[1] = __shfl(tv[1], src); mv[2] = __shfl(tv[2], src);
     }
     if (!cell_on || o != 0) continue;
-    PrimF pf;
-    const int S = c.steps;
-    det_prim(S, f, a.ppos + (long)b * S * 3, a.prot + (long)b * S * 4, a.psize + (long)b * 3, a.action + (long)b * 6, a.friction[b], pf);
+    const int S = c.steps, P = c.n_prim;
     float vo[3];
-    grid_op<false>(c, pf, ci, cj, ck, m, mv, vo, nullptr);
+    det_grid_cell(c, f, a.ppos + (long)b * P * S * 3, a.prot + (long)b * P * S * 4, a.psize + (long)b * P * 3, a.action + (long)b * P * 6, a.friction[b],
+                  ci, cj, ck, m, mv, vo);
     float* ov = a.vel + ((long)b * a.G + lin) * 4;
     ov[0] = vo[0]; ov[1] = vo[1]; ov[2] = vo[2]; ov[3] = 0.f;
   }
@@ -203,7 +203,7 @@ int mpm_det_forward(const DetArgs& a, int* epoch, hipStream_t st) {
   int npow2 = 64;
   while (npow2 < c.N) npow2 <<= 1;
   (void)hipFuncSetAttribute((const void*)det_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, npow2 * 8);
-  hipLaunchKernelGGL(det_fk_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(det_fk_kernel, dim3((a.B * c.n_prim + 63) / 64), dim3(64), 0, st, a);
   (void)hipMemsetAsync(a.count, 0, (size_t)a.B * sizeof(int), st);
   for (int f = 0; f < S; ++f) {
     const int e = ++*epoch;
