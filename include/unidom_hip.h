@@ -183,8 +183,12 @@ typedef struct {
                                 2-3, every cell walking every particle: 13x / 332x).  Position control or soft contact (collide_batch of
                                 box / container primitives: its exp is a plain-IEEE polynomial in this mode so that both builds agree; a
                                 primitive's ROTATION still goes through the platform's sinf / cosf); at most 8192 particles
-                                (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored; the
-                                backward is the many-workgroup recomputing backward (float atomics: its bits still vary from run to run) */
+                                (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored.  ud_mpm_step_bwd of such a
+                                handle: under position control it is deterministic too -- the grid recomputed by the deterministic forward's
+                                kernels, the g2p adjoint's scatter an ordered sum per cell over (offset, particle), every per-env sum added
+                                in a fixed order: two calls return the same bits (fast-math arithmetic, so no CPU build is bit-equal to it;
+                                checked against the oracle by tolerance); under soft contact it is the recomputing backward with float
+                                atomics (its bits vary from run to run) */
   int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
                                 grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's
                                 scratch) is allocated in ud_mpm_create for this many envs: no step call allocates or synchronises the

@@ -128,7 +128,8 @@ __host__ __device__ inline int det_pre_particle(const MpmConst& c, const float* 
   for (int d = 0; d < 9; ++d) { Cm[d] = h[(6 + d) * Np + p]; F[d] = h[(15 + d) * Np + p]; }
   particle_pre<false>(c, x, Cm, F, mu, la, material, hard, q, nullptr);
   if (store) {
-    for (int d = 0; d < 9; ++d) hn[(15 + d) * Np + p] = q.Fn[d];
+    if (hn)        // (null: the deterministic backward re-runs the pre-pass on the caller's checkpoint, which it does not write)
+      for (int d = 0; d < 9; ++d) hn[(15 + d) * Np + p] = q.Fn[d];
     for (int d = 0; d < 3; ++d) { pre[d * Np + p] = __builtin_bit_cast(float, q.base[d]); pre[(3 + d) * Np + p] = q.fx[d]; pre[(24 + d) * Np + p] = v[d]; }
     for (int d = 0; d < 9; ++d) { pre[(6 + d) * Np + p] = q.w[d]; pre[(15 + d) * Np + p] = q.affine[d]; }
   }

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) det_pre_kernel(DetArgs a, int f, int epoc
   const MpmConst& c = a.c;
   if (p >= c.N) return;                                   // whole groups of 32 lanes together
   const float* h = a.hist + (long)b * a.stride_b + (long)(a.pingpong ? (f & 1) : f) * a.rec;
-  float* hn = a.hist + (long)b * a.stride_b + (long)(a.pingpong ? ((f + 1) & 1) : (f + 1)) * a.rec;
+  float* hn = a.bwd ? nullptr : a.hist + (long)b * a.stride_b + (long)(a.pingpong ? ((f + 1) & 1) : (f + 1)) * a.rec;
   float* pre = a.pre + (long)b * UD_DET_PRE * c.Np;
   Pre q;
   float v[3];
@@ -100,6 +100,9 @@ __global__ void __launch_bounds__(1024) det_sort_kernel(DetArgs a, int npow2, in
 // ascending particle index: the SAME additions in the SAME order, so the same bits.  A lane keeps up to DET_K contributions in registers;
 // a longer bucket (or irregular particles) is finished with loads inside the ordered pass.
 constexpr int DET_K = 8;
+// MODE 0: the forward's (m, mv) sums + grid op.  MODE 1 (deterministic backward): the same ordered walk over a.contrib holding the g2p adjoint's
+// contributions (x, y, z; w = 0) -- g2p GATHERS with clamped indices, so an irregular particle reaches the cell its clamped index names.
+template <int MODE>
 __global__ void __launch_bounds__(256) det_cells_kernel(DetArgs a, int f, int epoch) {
   const int b = blockIdx.y, o = threadIdx.x & 31;
   const MpmConst& c = a.c;
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256) det_cells_kernel(DetArgs a, int f, int ep
           else {
             p = pi; ++ir;
             const int b0 = __builtin_bit_cast(int, pre[p]), b1 = __builtin_bit_cast(int, pre[Np + p]), b2 = __builtin_bit_cast(int, pre[2 * Np + p]);
-            if (cell_scatter(c, b0 + i, b1 + j, b2 + k) != key) continue;
+            if ((MODE ? cell_gather(c, b0 + i, b1 + j, b2 + k) : cell_scatter(c, b0 + i, b1 + j, b2 + k)) != key) continue;
           }
           const float4 x4 = contrib[p];
           tm += x4.x; tv[0] += x4.y; tv[1] += x4.z; tv[2] += x4.w;
@@ -165,6 +168,17 @@ __global__ void __launch_bounds__(256) det_cells_kernel(DetArgs a, int f, int ep
       m = __shfl(tm, src); mv[0] = __shfl(tv[0], src); mv[1] = __shfl(tv[1], src); mv[2] = __shfl(tv[2], src);
     }
     if (!cell_on || o != 0) continue;
+    if (MODE) {
+      float* og = a.gacc + ((long)b * a.G + lin) * 4;
+      og[0] = m; og[1] = mv[0]; og[2] = mv[1]; og[3] = 0.f;
+      continue;
+    }
+    if (a.val_out) {
+      float* ov = a.val_out + ((long)b * a.G + lin) * 4;
+      ov[0] = m; ov[1] = mv[0]; ov[2] = mv[1]; ov[3] = mv[2];
+      a.keylist[(long)b * a.cap + t] = key;
+      if (t == 0) a.keycount[b] = ncell;
+    }
     const int S = c.steps, P = c.n_prim;
     float vo[3];
     det_grid_cell(c, f, a.ppos + (long)b * P * S * 3, a.prot + (long)b * P * S * 4, a.psize + (long)b * P * 3, a.action + (long)b * P * 6, a.friction[b],
@@ -196,6 +210,83 @@ __global__ void __launch_bounds__(256) det_trq_kernel(DetArgs a) {
   a.trq[e] = s;
 }
 
+// ---- deterministic backward (position control): the pieces around mpm_large.hip's g2p-adjoint / grid-op-adjoint / p2g-adjoint kernels ----------
+// cellred -> the env's friction cotangent and row f of the controlled-velocity cotangent: lane t adds cells t, t + 256, ... in ascending order,
+// thread 0 adds the 256 partial sums in lane order -- a fixed order whatever order the cells were listed in; the touched cells go back to zero.
+__global__ void __launch_bounds__(256) det_reduce_cells_kernel(DetArgs a, int f) {
+  __shared__ float4 part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float4* cr = (const float4*)a.cellred + (long)b * a.G;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long lin = tid; lin < a.G; lin += 256) { const float4 x = cr[lin]; s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w; }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 256; ++k) { tot.x += part[k].x; tot.y += part[k].y; tot.z += part[k].z; tot.w += part[k].w; }
+    a.acc[b * 4 + 0] += tot.x;
+    float* gp = a.gpv + ((long)b * a.c.steps + f) * 3;
+    gp[0] += tot.y; gp[1] += tot.z; gp[2] += tot.w;
+  }
+  const int ncell = min(a.count[b], a.cap);
+  for (int t = tid; t < ncell; t += 256) ((float4*)a.cellred)[(long)b * a.G + a.list[(long)b * a.cap + t]] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(256) det_bwd_clear_kernel(DetArgs a) {
+  const int b = blockIdx.y, ncell = min(a.count[b], a.cap);
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < ncell; t += gridDim.x * 256)
+    ((float4*)a.gacc)[(long)b * a.G + a.list[(long)b * a.cap + t]] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void __launch_bounds__(64) det_count_reset_kernel(DetArgs a) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b < a.B) a.count[b] = 0;
+}
+// pacc -> the env's mu / lamda cotangents, same fixed order over the particles; pacc zeroed again
+__global__ void __launch_bounds__(256) det_reduce_particles_kernel(DetArgs a) {
+  __shared__ float part[2][256];
+  const int b = blockIdx.x, tid = threadIdx.x, Np = a.c.Np;
+  float* pa = a.pacc + (long)b * 2 * Np;
+  float s0 = 0.f, s1 = 0.f;
+  for (int p = tid; p < a.c.N; p += 256) { s0 += pa[p]; s1 += pa[Np + p]; pa[p] = 0.f; pa[Np + p] = 0.f; }
+  part[0][tid] = s0; part[1][tid] = s1;
+  __syncthreads();
+  if (tid < 2) {
+    float tot = 0.f;
+    for (int k = 0; k < 256; ++k) tot += part[tid][k];
+    a.acc[b * 4 + 1 + tid] += tot;
+  }
+}
+
+int mpm_det_bwd_recompute(const DetArgs& a, int f, int* epoch, hipStream_t st) {
+  const MpmConst& c = a.c;
+  const dim3 blk(256), gp32((c.N * 32 + 255) / 256, a.B), gc((unsigned)std::min(128, (a.cap + 7) / 8), a.B);
+  int npow2 = 64;
+  while (npow2 < c.N) npow2 <<= 1;
+  (void)hipFuncSetAttribute((const void*)det_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, npow2 * 8);
+  const int e = ++*epoch;
+  hipLaunchKernelGGL(det_pre_kernel, gp32, blk, 0, st, a, f, e);
+  hipLaunchKernelGGL(det_sort_kernel, dim3(a.B), dim3(1024), (size_t)npow2 * 8, st, a, npow2, e);
+  hipLaunchKernelGGL(det_cells_kernel<0>, gc, blk, 0, st, a, f, e);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+int mpm_det_bwd_gcells(const DetArgs& a, int f, int epoch, hipStream_t st) {
+  const dim3 gc((unsigned)std::min(128, (a.cap + 7) / 8), a.B);
+  hipLaunchKernelGGL(det_cells_kernel<1>, gc, dim3(256), 0, st, a, f, epoch);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+int mpm_det_bwd_reduce_cells(const DetArgs& a, int f, hipStream_t st) {
+  hipLaunchKernelGGL(det_reduce_cells_kernel, dim3(a.B), dim3(256), 0, st, a, f);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+int mpm_det_bwd_clear(const DetArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(det_bwd_clear_kernel, dim3(16, a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(det_count_reset_kernel, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+int mpm_det_bwd_reduce_particles(const DetArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(det_reduce_particles_kernel, dim3(a.B), dim3(256), 0, st, a);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+
 int mpm_det_forward(const DetArgs& a, int* epoch, hipStream_t st) {
   const MpmConst& c = a.c;
   const int S = c.steps;
@@ -209,7 +300,7 @@ int mpm_det_forward(const DetArgs& a, int* epoch, hipStream_t st) {
     const int e = ++*epoch;
     hipLaunchKernelGGL(det_pre_kernel, gp32, blk, 0, st, a, f, e);
     hipLaunchKernelGGL(det_sort_kernel, dim3(a.B), dim3(1024), (size_t)npow2 * 8, st, a, npow2, e);
-    hipLaunchKernelGGL(det_cells_kernel, gc, blk, 0, st, a, f, e);
+    hipLaunchKernelGGL(det_cells_kernel<0>, gc, blk, 0, st, a, f, e);
     hipLaunchKernelGGL(det_g2p_kernel, gp, blk, 0, st, a, f);
   }
   hipLaunchKernelGGL(det_trq_kernel, dim3((a.B * S + 255) / 256), blk, 0, st, a);

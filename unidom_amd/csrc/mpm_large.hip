@@ -82,7 +82,13 @@ struct LargeArgs {
   const float *psize, *friction, *mu, *lamda, *action;
   // logical launch shape of the per-substep kernels: (nbx blocks per env) x (Bg envs), issued as a ONE-dimensional grid (lg_bid)
   int nbx, Bg, xcd;
+  // deterministic backward (ud_mpm_conf.deterministic, position control; null otherwise): every sum that an atomic would order by arrival goes
+  // to an array instead and is added up in a fixed order by a kernel of its own (mpm_det.hip)
+  float4* det_cellred;    // [B][G]      per cell: (ground friction, controlled velocity xyz) cotangents of the grid-op adjoint
+  float* det_pacc;        // [B][2][Np]  per particle: mu / lamda cotangents, accumulated over the substeps by the particle's own thread
+  float* det_normpart;    // [B][LG_NORM_PARTS] per block of lg_bwd_norm: its share of the squared norm
 };
+constexpr int LG_NORM_PARTS = 64;
 
 // Block -> (block within the env, env) of the per-substep kernels.  Workgroups are dealt round-robin over the 8 XCDs in linear order, and
 // each XCD has its own L2: with the natural (x, env) order the 13-27 blocks of one env land on all eight, and every L2 fetches the env's
@@ -1303,6 +1309,65 @@ __global__ void __launch_bounds__(LG_SCATTER_T) lg_g2p_adj(LargeArgs a) {
   LG_STAMP(1, 6);     // flush
 }
 
+// Deterministic backward: the g2p adjoint of one particle per lane with NO accumulation across particles -- what the particle adds to the cell
+// its offset (i, j, k) gathers from goes to contrib[27][Np] (x, y, z; w = 0), and mpm_det.hip sums every cell over (offset, particle) in that
+// order (det_cells_kernel<1>); the weight / fx partials are the particle's own (27 cells in (i, j, k) order) and go to the scratch as in lg_g2p_adj.
+__global__ void __launch_bounds__(256) lg_g2p_adj_det(LargeArgs a, float4* contrib) {
+  const LgB lgb_ = lg_bid(a);
+  if (!lgb_.ok) return;
+  const int b = lgb_.y + a.b0, p = lgb_.x * blockDim.x + threadIdx.x;
+  const MpmConst& c = a.c;
+  if (p >= c.N) return;
+  const float* hi = a.hist_in + (long)b * a.hist_stride_b;
+  int base[3];
+  float fx[3], w[9];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float xd = hi[d * c.Np + p];
+    base[d] = (int)(xd * c.inv_dx - 0.5f);
+    const float f = xd * c.inv_dx - (float)base[d];
+    fx[d] = f;
+    w[d] = 0.5f * ((1.5f - f) * (1.5f - f)); w[3 + d] = 0.75f - (f - 1.f) * (f - 1.f); w[6 + d] = 0.5f * ((f - 0.5f) * (f - 0.5f));
+  }
+  const float* gs = a.w.gstate + (long)b * 24 * c.Np;
+  float gnv[3], gC[9], gw[9], gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gnv[d] = gs[(3 + d) * c.Np + p] + c.dt * gs[d * c.Np + p];
+#pragma unroll
+  for (int d = 0; d < 9; ++d) { gC[d] = gs[(6 + d) * c.Np + p]; gw[d] = 0.f; }
+  const float4* vel = a.w.vel + (long)b * a.G;
+  float4* out = contrib + (long)b * 27 * c.Np + p;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 27; ++cidx) {
+    const int i = cidx / 9, j = (cidx / 3) % 3, k = cidx % 3;
+    const float wi = sel3(w, 0, i), wj = sel3(w, 1, j), wk = sel3(w, 2, k);
+    const float weight = wi * wj * wk;
+    const float dp[3] = {(float)i - fx[0], (float)j - fx[1], (float)k - fx[2]};
+    const float4 v4 = vel[cell_lin(c, cell_gather(c, base[0] + i, base[1] + j, base[2] + k))];
+    const float vv[3] = {v4.x, v4.y, v4.z};
+    float gcell[3], gwt = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float gCd = gC[r * 3] * dp[0] + gC[r * 3 + 1] * dp[1] + gC[r * 3 + 2] * dp[2];
+      gcell[r] = weight * gnv[r] + 4.f * c.inv_dx * weight * gCd;
+      gwt += vv[r] * (gnv[r] + 4.f * c.inv_dx * gCd);
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) gfx[s2] -= 4.f * c.inv_dx * weight * gC[r * 3 + s2] * vv[r];
+    }
+    out[(long)cidx * c.Np] = make_float4(gcell[0], gcell[1], gcell[2], 0.f);
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      gw[kk * 3 + 0] += (i == kk) ? gwt * wj * wk : 0.f;
+      gw[kk * 3 + 1] += (j == kk) ? gwt * wi * wk : 0.f;
+      gw[kk * 3 + 2] += (k == kk) ? gwt * wi * wj : 0.f;
+    }
+  }
+  float* ps = a.w.pscr + (long)b * 3 * c.Np + p;
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+    ps[d * c.Np] = gfx[d] + gw[0 * 3 + d] * (-(1.5f - fx[d])) + gw[1 * 3 + d] * (-2.f * (fx[d] - 1.f)) + gw[2 * 3 + d] * (fx[d] - 0.5f);
+}
+
 // grid checkpoint -> dense arrays of the backward for substep f: velocity after the grid op, zeroed cotangent, the cell list.
 // It also zeroes the cotangent cells of substep f + 1 (just consumed by its p2g adjoint), and a last call with f = -1 does
 // only that for substep 0: the handle's gacc grid is all-zero again afterwards, which the recomputing backward relies on
@@ -1380,6 +1445,14 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       load_prim(a, b, pf, pv);
       if (grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dp)) { dpv[0] = dp[0]; dpv[1] = dp[1]; dpv[2] = dp[2]; }
       lg_gacc(a, a.f)[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
+    }
+    if (a.det_cellred) {          // deterministic backward: per cell, summed in a fixed order by det_reduce_cells_kernel
+      if (live) {
+        int ci, cj, ck;
+        decode_cell(a.c, a.w.list[((long)cur * a.B + b) * a.cap + t], ci, cj, ck);
+        a.det_cellred[(long)b * a.G + ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck] = make_float4(dfric, dpv[0], dpv[1], dpv[2]);
+      }
+      return;
     }
     const float sf = wave_sum(dfric), s0 = wave_sum(dpv[0]), s1 = wave_sum(dpv[1]), s2 = wave_sum(dpv[2]);
     if ((threadIdx.x & 63) == 0) {
@@ -1648,8 +1721,13 @@ __global__ void __launch_bounds__(256, 2) lg_p2g_adj(LargeArgs a, int particle_b
   particle_adjoint<true>(c, q, kb, Cm, F, material, gw, gfx, gaff, gvp, gx, gv, gC, gF, gmu_p, gla_p);
   if (material != 0) {
     const float h = clipf(a.hard[up], 0.1f, 5.f);
-    atomicAdd(&s_par[0], gmu_p * h);
-    atomicAdd(&s_par[1], gla_p * h);
+    if (a.det_pacc) {            // deterministic backward: the particle's own running sums, reduced in a fixed order at the end of the step
+      float* pa = a.det_pacc + (long)b * 2 * c.Np;
+      pa[p] += gmu_p * h; pa[c.Np + p] += gla_p * h;
+    } else {
+      atomicAdd(&s_par[0], gmu_p * h);
+      atomicAdd(&s_par[1], gla_p * h);
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) { gs[d * c.Np + p] = gx[d]; gs[(3 + d) * c.Np + p] = gv[d]; }
@@ -2017,7 +2095,11 @@ __global__ void __launch_bounds__(256) lg_bwd_norm(LargeArgs a) {
   s2 = wave_sum(s2);
   if ((tid & 63) == 0) red[tid >> 6] = s2;
   __syncthreads();
-  if (tid == 0) atomicAdd(&a.w.acc[b * 4 + 3], (red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) {
+    const float part = (red[0] + red[1]) + (red[2] + red[3]);
+    if (a.det_normpart) a.det_normpart[b * LG_NORM_PARTS + blockIdx.x] = part;     // added up in block order by lg_bwd_out
+    else atomicAdd(&a.w.acc[b * 4 + 3], part);
+  }
 }
 
 __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* gx0, float* gv0, float* gC0, float* gF0, float* gppos0,
@@ -2026,7 +2108,12 @@ __global__ void __launch_bounds__(256) lg_bwd_out(LargeArgs a, int clip, float* 
   const int b = blockIdx.y + a.b0, S = a.c.steps, N = a.c.N, Np = a.c.Np, P = a.c.n_prim, tid = threadIdx.x;
   const int p = blockIdx.x * 256 + tid;
   const float* gs = a.w.gstate + (long)b * 24 * Np;
-  const float sn = clip ? sqrtf(a.w.acc[b * 4 + 3]) : 0.f;
+  float n2 = a.w.acc[b * 4 + 3];
+  if (a.det_normpart && clip) {
+    n2 = 0.f;
+    for (int k = 0; k < (N + 255) / 256; ++k) n2 += a.det_normpart[b * LG_NORM_PARTS + k];
+  }
+  const float sn = clip ? sqrtf(n2) : 0.f;
   const bool sc = clip && !(sn < 1.f);
   if (p < N) {
     const int up = user_index(a, b, p);
@@ -2090,7 +2177,7 @@ struct MpmLarge {
   void* cl_arena = nullptr;
   size_t cl_zero_bytes = 0, cl_own_off = 0, cl_own_words = 0, cl_bytes = 0;
   void* det_arena = nullptr; // deterministic forward (mpm_det.hip): flag [B][G] int, pre [B][27][Np], trq3 [B][S][3]
-  size_t det_bytes = 0, det_off[11] = {};
+  size_t det_bytes = 0, det_off[14] = {};
   int det_epoch = 0;
   bool has_liquid = false;   // some particle has material 0
   int n_cu = 0, occ_fwd[2] = {0, 0};   // CUs; resident parts per CU of the persistent forward (occupancy query), [0] 64-lane, [1] 128-lane parts
@@ -2106,7 +2193,7 @@ struct MpmLarge {
 // primitives: the grid kernels, not the particle kernels, carry its substep): 231 k in one group, 199-227 k from run to run in two.
 static int lg_groups(const MpmLarge* L, int B) {
   const int forced = L->t.env_groups;                             // ud_mpm_conf.tune_env_groups (diagnostics, counter passes)
-  if (!L->ev_fork) return 1;
+  if (!L->ev_fork || L->c.det) return 1;                          // (the deterministic mode runs on the caller's stream alone)
   const long particles = (long)B * L->c.N;
   int want = 1;
   if (particles <= 50000) want = L->c.n_prim >= 2 ? 1 : LG_GROUPS;     // four-lane kernels, up to 200 k lanes (two collide passes per cell: below)
@@ -2174,6 +2261,9 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
     L->det_off[8] = take(Bm * L->cap * 4);               // list
     L->det_off[9] = take(Bm * 4);                        // count
     L->det_off[10] = take(Bm * 27 * c.Np * 16);          // contrib
+    L->det_off[11] = take(Bm * L->G * 16);               // cellred (backward)
+    L->det_off[12] = take(Bm * 2 * c.Np * 4);            // pacc
+    L->det_off[13] = take(Bm * LG_NORM_PARTS * 4);       // normpart
     L->det_bytes = off;
     if (rc == UD_OK && (hipMalloc(&L->det_arena, L->det_bytes) != hipSuccess || hipMemset(L->det_arena, 0, L->det_bytes) != hipSuccess)) { set_error("ud_mpm_create (deterministic): hipMalloc failed"); rc = UD_ERR_HIP; }
   }
@@ -2258,12 +2348,13 @@ static int reserve(MpmLarge* L, int B) {
 
 static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* friction, const float* mu, const float* lamda,
                            const float* action) {
-  LargeArgs a;
+  LargeArgs a{};
   a.c = L->c; a.w = L->w; a.material = L->d_material; a.hard = L->d_hard; a.B = L->B; a.f = 0; a.cap = L->cap; a.G = L->G; a.W32 = L->W32;
   a.hist_in = nullptr; a.hist_out = nullptr; a.hist_stride_b = 0; a.b0 = 0;
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr; a.gpar = 0;
   a.svd_rows = 0; a.ls3 = 0; a.vb = 0; a.ls = 0; a.lprev = 0; a.lnext = 0; a.nbx = 1; a.Bg = 0; a.xcd = 0;
   a.perm = nullptr; a.perm_stride = 0;
+  a.det_cellred = nullptr; a.det_pacc = nullptr; a.det_normpart = nullptr;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
   return a;
@@ -2375,6 +2466,21 @@ int mpm_large_plan(MpmLarge* L, int B) {
 #define LG_LAUNCH(K, NBX, BG, BLK, SH, ST, ...) do { a.nbx = (int)(NBX); a.Bg = (int)(BG); a.xcd = a.Bg >= 8 ? 1 : 0;                      \
     hipLaunchKernelGGL(K, dim3(a.xcd ? 8u * (unsigned)a.nbx * (unsigned)((a.Bg + 7) / 8) : (unsigned)a.nbx * (unsigned)a.Bg), BLK, SH, ST, a, ##__VA_ARGS__); } while (0)
 
+// the deterministic mode's arrays (mpm_det.hip): scratch in the handle's det arena, grids shared with the default kernels
+static DetArgs lg_det_args(MpmLarge* L, int B, const float* psize, const float* friction, const float* mu, const float* lamda, const float* action) {
+  DetArgs d{};
+  d.c = L->c; d.B = B; d.G = L->G; d.material = L->d_material; d.hard = L->d_hard;
+  d.ppos = L->w.ppos; d.prot = L->w.prot; d.psize = psize; d.friction = friction; d.mu = mu; d.lamda = lamda; d.action = action;
+  d.vel = (float*)L->w.vel;
+  char* db = (char*)L->det_arena;
+  d.flag = (int*)(db + L->det_off[0]); d.pre = (float*)(db + L->det_off[1]); d.trq3 = (float*)(db + L->det_off[2]);
+  d.bkey = (int*)(db + L->det_off[3]); d.order = (int*)(db + L->det_off[4]); d.brange = (void*)(db + L->det_off[5]); d.bflag = (int*)(db + L->det_off[6]);
+  d.nirr = (int*)(db + L->det_off[7]); d.list = (int*)(db + L->det_off[8]); d.count = (int*)(db + L->det_off[9]); d.cap = L->cap; d.contrib = (float*)(db + L->det_off[10]);
+  d.cellred = (float*)(db + L->det_off[11]); d.pacc = (float*)(db + L->det_off[12]);
+  d.trq = L->w.trq;
+  return d;
+}
+
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,
@@ -2412,16 +2518,8 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
     a.b0 = 0; a.f = 0;
     hipLaunchKernelGGL(lg_prim_in, dim3(B, c.n_prim), blk, 0, st, a, ppos, prot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, B), blk, 0, st, c, 0, x, v, C, F, hist, stride_b, 1, (const int*)nullptr, 0L);
-    DetArgs d;
-    d.c = c; d.B = B; d.G = L->G; d.material = L->d_material; d.hard = L->d_hard;
-    d.ppos = L->w.ppos; d.prot = L->w.prot; d.psize = psize; d.friction = friction; d.mu = mu; d.lamda = lamda; d.action = action;
+    DetArgs d = lg_det_args(L, B, psize, friction, mu, lamda, action);
     d.hist = hist; d.rec = rec; d.stride_b = stride_b; d.pingpong = ckpt ? 0 : 1;
-    d.vel = (float*)L->w.vel;
-    char* db = (char*)L->det_arena;
-    d.flag = (int*)(db + L->det_off[0]); d.pre = (float*)(db + L->det_off[1]); d.trq3 = (float*)(db + L->det_off[2]);
-    d.bkey = (int*)(db + L->det_off[3]); d.order = (int*)(db + L->det_off[4]); d.brange = (void*)(db + L->det_off[5]); d.bflag = (int*)(db + L->det_off[6]);
-    d.nirr = (int*)(db + L->det_off[7]); d.list = (int*)(db + L->det_off[8]); d.count = (int*)(db + L->det_off[9]); d.cap = L->cap; d.contrib = (float*)(db + L->det_off[10]);
-    d.trq = L->w.trq;
     rc = mpm_det_forward(d, &L->det_epoch, st);
     if (rc) { set_error("ud_mpm_step_fwd (deterministic): launch failed"); return rc; }
     a.f = S;
@@ -2551,6 +2649,42 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     a.b0 = grp[g].b0;
     hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
+  }
+  if (c.det && c.position_control) {
+    // Deterministic backward (position control): the recomputing backward with every arrival-ordered sum replaced -- the grid of substep f comes
+    // from the deterministic forward's own kernels (ordered (m, mv) sums), the g2p adjoint's scatter is an ordered sum per cell over (offset,
+    // particle) (lg_g2p_adj_det -> det_cells_kernel<1>), the per-env cotangents of the grid-op adjoint, the mu / lamda cotangents and the clip's
+    // norm are added up in a fixed order.  One lane per particle, one stream.  Two calls on the same inputs return the same bits.
+    DetArgs d = lg_det_args(L, B, psize, friction, mu, lamda, action);
+    d.hist = const_cast<float*>(ckpt); d.rec = rec; d.stride_b = stride_b; d.pingpong = 0; d.bwd = 1;
+    d.val_out = (float*)L->w.val; d.gacc = (float*)L->w.gacc; d.acc = L->w.acc; d.gpv = L->w.gpv;
+    char* db = (char*)L->det_arena;
+    a.det_cellred = (float4*)(db + L->det_off[11]); a.det_pacc = (float*)(db + L->det_off[12]); a.det_normpart = (float*)(db + L->det_off[13]);
+    a.b0 = 0; a.gck_base = nullptr; a.svd_rows = 0; a.perm = nullptr;
+    const dim3 gc(lg_cell_blocks(L->cap), B), gq((N + 255) / 256, B), gqf(gq.x + c.n_prim, B);
+    int rc = UD_OK;
+    for (int f = S - 1; f >= 0 && rc == UD_OK; --f) {
+      a.f = f; a.hist_in = ckpt + (long)f * rec;
+      d.keylist = L->w.list + (long)(f & 1) * L->B * L->cap; d.keycount = L->w.count + (long)(f & 1) * L->B;
+      rc = mpm_det_bwd_recompute(d, f, &L->det_epoch, st);
+      {
+        hipStream_t s = st;
+        LG_LAUNCH(lg_g2p_adj_det, gq.x, (int)gq.y, blk, 0, s, (float4*)d.contrib);
+        if (rc == UD_OK) rc = mpm_det_bwd_gcells(d, f, L->det_epoch, st);
+        LG_LAUNCH(lg_grid_adj, gc.x, (int)gc.y, blk, 0, s);
+        if (rc == UD_OK) rc = mpm_det_bwd_reduce_cells(d, f, st);
+        LG_LAUNCH(lg_p2g_adj<1>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x);
+        if (rc == UD_OK) rc = mpm_det_bwd_clear(d, st);
+      }
+    }
+    if (rc == UD_OK) rc = mpm_det_bwd_reduce_particles(d, st);
+    a.f = -1;
+    const dim3 gp((N + 255) / 256, B);
+    if (clip) hipLaunchKernelGGL(lg_bwd_norm, gp, blk, 0, st, a);
+    hipLaunchKernelGGL(lg_bwd_out, gp, blk, 0, st, a, clip, gx0, gv0, gC0, gF0, gppos0, gfric, gmu, glam, gaction, grot0);
+    const hipError_t e = hipGetLastError();
+    if (rc != UD_OK || e != hipSuccess) { set_error("ud_mpm_step_bwd (deterministic): %s", rc != UD_OK ? "launch failed" : hipGetErrorString(e)); return rc != UD_OK ? rc : UD_ERR_HIP; }
+    return UD_OK;
   }
   if (fused) {
     a.gpar = 1;
