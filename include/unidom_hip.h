@@ -184,11 +184,11 @@ typedef struct {
                                 box / container primitives: its exp is a plain-IEEE polynomial in this mode so that both builds agree; a
                                 primitive's ROTATION still goes through the platform's sinf / cosf); at most 8192 particles
                                 (UD_ERR_UNSUPPORTED otherwise); grid_ckpt_cells and sort_particles are ignored.  ud_mpm_step_bwd of such a
-                                handle: under position control it is deterministic too -- the grid recomputed by the deterministic forward's
-                                kernels, the g2p adjoint's scatter an ordered sum per cell over (offset, particle), every per-env sum added
-                                in a fixed order: two calls return the same bits (fast-math arithmetic, so no CPU build is bit-equal to it;
-                                checked against the oracle by tolerance); under soft contact it is the recomputing backward with float
-                                atomics (its bits vary from run to run) */
+                                handle is deterministic too -- the grid recomputed by the deterministic forward's kernels, the g2p adjoint's
+                                scatter an ordered sum per cell over (offset, particle), every per-env sum (ground friction, controlled
+                                velocity, the collide adjoint's per-primitive cotangents, mu / lamda, the clip's norm) added in a fixed
+                                order: two calls return the same bits (fast-math arithmetic, so no CPU build is bit-equal to it; checked
+                                against the oracle by tolerance).  At most 32768 touched cells per env and substep */
   int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
                                 grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's
                                 scratch) is allocated in ud_mpm_create for this many envs: no step call allocates or synchronises the

@@ -9,7 +9,7 @@ through the lanes in order), one thread on the host: the same additions in the s
   * x, v, C, F after 70 substeps equal the CPU build of the same per-element source (oracle/csrc/mpm_det_host.cpp),
 and, on the CPU, that source is held against the independent restatement of the reference (oracle/csrc/mpm_oracle.hpp) within the
 tolerance their different SVDs leave -- the same-order checker pins order and arithmetic, the independent one the algorithm.
-Round 4: soft contact in the same mode (collide_batch compiled into both builds), and a reproducible BACKWARD under position control (two calls,
+Round 4: soft contact in the same mode (collide_batch compiled into both builds), and a reproducible BACKWARD in both contact modes (two calls,
 the same bits in every gradient; checked against the oracle by tolerance -- its arithmetic is the fast kernels')."""
 import os
 
@@ -206,3 +206,43 @@ def test_deterministic_soft_contact_is_bit_identical_to_the_same_order_checker(d
         fast = run(st, kw, 0)[0]
         assert _rel(a["x"], fast["x"]) < 5e-6 and _rel(a["v"], fast["v"]) < 2e-4 and _rel(a["F"], fast["F"]) < 5e-5, \
             (name, _rel(a["x"], fast["x"]), _rel(a["v"], fast["v"]), _rel(a["F"], fast["F"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", [True, False])
+def test_deterministic_soft_contact_backward_is_reproducible(demo, clip):
+    """The backward of a deterministic handle under soft contact: the collide adjoint's per-primitive cotangents (position, rotation, size,
+    friction) take the same route as the position-control ones -- one row per listed cell, the list sorted, added up in a fixed order.
+    Two forward + backward calls: every gradient bit-identical; the default kernels' gradients to their tolerance."""
+    from test_mpm_gpu import LegacyConf, run_hip_collide
+    from test_oracle_mpm import _collide_case, _two_bowl_case
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+
+    def make(kw, deterministic):
+        conf = LegacyConf()
+        conf.steps = kw["steps"]
+        conf.deterministic = deterministic
+        sim = SimpleMPMSimulator(conf, 1, use_position_control=False)
+        sim.n_particles, sim.material, sim.h = 67, np.asarray(kw["material"], np.int32), np.ones(67, np.float32)
+        if kw["n_prim"] > 1:
+            sim.n_primitive, sim.sdf_kind = kw["n_prim"], "container"
+        sim._make_handle()
+        return sim
+
+    cases = []
+    for material in (1, 2):
+        st, g = _collide_case(demo, 20, 40, material, 0, np.float32, w=(0.0, 0.0, 0.0))
+        cases.append((f"box_material{material}", st, g, dict(steps=20, material=np.full(67, material), n_prim=1)))
+    st, g = _two_bowl_case(demo, 3, 40, 0, np.float32, turning=False)
+    cases.append(("two_bowls_liquid", st, g, dict(steps=3, material=np.zeros(67, np.int64), n_prim=2)))
+    keys = ("x", "v", "C", "F", "gx", "gv", "gC", "gF", "gppos", "gprot", "gfriction", "gmu", "glamda", "gaction")
+    for name, st, g, kw in cases:
+        sim = make(kw, 1)
+        a, b = run_hip_collide(sim, st, g, clip), run_hip_collide(sim, st, g, clip)
+        for key in keys:
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{name} {key}: two runs differ")
+        fast = run_hip_collide(make(kw, 0), st, g, clip)
+        for key in ("gx", "gv", "gF", "gppos"):
+            fin = np.isfinite(fast[key])
+            assert (np.isfinite(a[key]) == fin).all(), (name, key)
+            assert _rel(np.where(fin, a[key], 0), np.where(fin, fast[key], 0)) < 5e-3, (name, key, _rel(np.where(fin, a[key], 0), np.where(fin, fast[key], 0)))

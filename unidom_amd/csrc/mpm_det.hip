@@ -210,26 +210,63 @@ __global__ void __launch_bounds__(256) det_trq_kernel(DetArgs a) {
   a.trq[e] = s;
 }
 
-// ---- deterministic backward (position control): the pieces around mpm_large.hip's g2p-adjoint / grid-op-adjoint / p2g-adjoint kernels ----------
-// cellred -> the env's friction cotangent and row f of the controlled-velocity cotangent: lane t adds cells t, t + 256, ... in ascending order,
-// thread 0 adds the 256 partial sums in lane order -- a fixed order whatever order the cells were listed in; the touched cells go back to zero.
-__global__ void __launch_bounds__(256) det_reduce_cells_kernel(DetArgs a, int f) {
-  __shared__ float4 part[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float4* cr = (const float4*)a.cellred + (long)b * a.G;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long lin = tid; lin < a.G; lin += 256) { const float4 x = cr[lin]; s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w; }
-  part[tid] = s;
+// ---- deterministic backward: the pieces around mpm_large.hip's g2p-adjoint / grid-op-adjoint / p2g-adjoint kernels ----------------------------
+constexpr int DET_SORT_CELLS = 32768;   // touched cells per env the list sort holds (128 KB of LDS); the pre-pass lists them in arrival order
+// the env's touched-cell list in ascending order: position t in it is what the per-cell arrays of the backward are indexed by
+__global__ void __launch_bounds__(1024) det_sort_cells_kernel(DetArgs a) {
+  extern __shared__ int det_sc[];
+  const int b = blockIdx.x, tid = threadIdx.x, n = min(min(a.count[b], a.cap), DET_SORT_CELLS);
+  int npow2 = 64;
+  while (npow2 < n) npow2 <<= 1;
+  int* list = a.list + (long)b * a.cap;
+  for (int i = tid; i < npow2; i += blockDim.x) det_sc[i] = i < n ? list[i] : 0x7fffffff;
   __syncthreads();
-  if (tid == 0) {
-    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < 256; ++k) { tot.x += part[k].x; tot.y += part[k].y; tot.z += part[k].z; tot.w += part[k].w; }
-    a.acc[b * 4 + 0] += tot.x;
-    float* gp = a.gpv + ((long)b * a.c.steps + f) * 3;
-    gp[0] += tot.y; gp[1] += tot.z; gp[2] += tot.w;
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += blockDim.x) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int ei = det_sc[i], el = det_sc[l];
+          const bool up = (i & k) == 0;
+          if ((ei > el) == up) { det_sc[i] = el; det_sc[l] = ei; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < n; i += blockDim.x) list[i] = det_sc[i];
+}
+// cellred -> the env's cotangents of substep f.  Component k: lane t adds cells t, t + 256, ... of the (sorted) list in ascending order, thread 0
+// adds the 256 partial sums in lane order -- a fixed order.
+__global__ void __launch_bounds__(256) det_reduce_cells_kernel(DetArgs a, int f) {
+  __shared__ float part[256];
+  const int b = blockIdx.x, tid = threadIdx.x, K = a.K, S = a.c.steps, P = a.c.n_prim;
+  const int n = min(min(a.count[b], a.cap), a.capc);
+  const float* cr = a.cellred + (long)b * a.capc * K;
+  const int f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int t = tid; t < n; t += 256) s += cr[(long)t * K + k];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int u = 0; u < 256; ++u) tot += part[u];
+      float* dst;
+      if (k == 0) dst = a.acc + b * 4;
+      else if (a.c.position_control) dst = a.gpv + ((long)b * S + f) * 3 + (k - 1);
+      else {
+        const int ip = (k - 1) / 18, d = (k - 1) % 18;
+        const long bp = (long)b * P + ip;
+        dst = (d < 3)    ? a.gppos + bp * S * 3 + f0 * 3 + d
+              : (d < 7)  ? a.grot + bp * S * 4 + f0 * 4 + (d - 3)
+              : (d < 10) ? a.gppos + bp * S * 3 + f1 * 3 + (d - 7)
+              : (d < 14) ? a.grot + bp * S * 4 + f1 * 4 + (d - 10)
+                         : a.gpsz + bp * 4 + (d - 14);
+      }
+      if (tot != 0.f) *dst += tot;
+    }
+    __syncthreads();
   }
-  const int ncell = min(a.count[b], a.cap);
-  for (int t = tid; t < ncell; t += 256) ((float4*)a.cellred)[(long)b * a.G + a.list[(long)b * a.cap + t]] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 __global__ void __launch_bounds__(256) det_bwd_clear_kernel(DetArgs a) {
   const int b = blockIdx.y, ncell = min(a.count[b], a.cap);
@@ -265,6 +302,8 @@ int mpm_det_bwd_recompute(const DetArgs& a, int f, int* epoch, hipStream_t st) {
   const int e = ++*epoch;
   hipLaunchKernelGGL(det_pre_kernel, gp32, blk, 0, st, a, f, e);
   hipLaunchKernelGGL(det_sort_kernel, dim3(a.B), dim3(1024), (size_t)npow2 * 8, st, a, npow2, e);
+  (void)hipFuncSetAttribute((const void*)det_sort_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DET_SORT_CELLS * 4);
+  hipLaunchKernelGGL(det_sort_cells_kernel, dim3(a.B), dim3(1024), (size_t)DET_SORT_CELLS * 4, st, a);
   hipLaunchKernelGGL(det_cells_kernel<0>, gc, blk, 0, st, a, f, e);
   return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
 }

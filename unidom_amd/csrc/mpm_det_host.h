@@ -36,17 +36,21 @@ struct DetArgs {
   int* keylist;           // [B][cap]  their keys (ci | cj << 10 | ck << 20), in the list's order
   int* keycount;          // [B]
   float* gacc;            // [B][G][4] cotangent of the grid velocity: the ordered sums of the g2p adjoint's contributions (det_gcells)
-  float* cellred;         // [B][G][4] per-cell (ground friction, controlled velocity xyz) cotangents of the grid-op adjoint, zero elsewhere
+  float* cellred;         // [B][capc][K] per listed cell, in the list's (sorted) order: what the grid-op adjoint adds to the env's cotangents --
+                          // position control: K = 4 (ground friction, controlled velocity xyz); soft contact: K = 1 + 18 n_prim (ground
+                          // friction; per primitive p0[3] r0[4] p1[3] r1[4] size[3] mu, as lg_grid_adj_tile books them)
+  int capc, K;
+  float *gppos, *grot, *gpsz;   // soft contact: the primitives' cotangent rows [B][P][S][3], [B][P][S][4], [B][P][4]
   float* pacc;            // [B][2][Np] per-particle mu / lamda cotangents, summed over the substeps by the particle's own thread
   float* acc;             // [B][4]    the env's scalars: friction, mu, lamda (, norm)
   float* gpv;             // [B][S][3] cotangent of the controlled velocity rows
 };
 
 int mpm_det_forward(const DetArgs& a, int* epoch, hipStream_t st);
-// pieces of the deterministic backward of substep f (position control), in launch order around mpm_large.hip's own kernels:
-int mpm_det_bwd_recompute(const DetArgs& a, int f, int* epoch, hipStream_t st);   // pre-pass, buckets, ordered (m, mv) sums + grid op -> vel, val_out, keylist
+// pieces of the deterministic backward of substep f, in launch order around mpm_large.hip's own kernels:
+int mpm_det_bwd_recompute(const DetArgs& a, int f, int* epoch, hipStream_t st);   // pre-pass, buckets, the cell list SORTED, ordered (m, mv) sums + grid op -> vel, val_out, keylist
 int mpm_det_bwd_gcells(const DetArgs& a, int f, int epoch, hipStream_t st);       // ordered sums of a.contrib (the g2p adjoint's contributions) -> gacc
-int mpm_det_bwd_reduce_cells(const DetArgs& a, int f, hipStream_t st);            // cellred -> acc[.][0], gpv row f, in a fixed order; cellred zeroed again
+int mpm_det_bwd_reduce_cells(const DetArgs& a, int f, hipStream_t st);            // cellred -> the env's cotangents of substep f, in a fixed order
 int mpm_det_bwd_clear(const DetArgs& a, hipStream_t st);                          // gacc of the touched cells back to zero, the list retired
 int mpm_det_bwd_reduce_particles(const DetArgs& a, hipStream_t st);               // pacc -> acc[.][1], acc[.][2] in a fixed order; pacc zeroed again
 

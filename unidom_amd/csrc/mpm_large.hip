@@ -84,7 +84,9 @@ struct LargeArgs {
   int nbx, Bg, xcd;
   // deterministic backward (ud_mpm_conf.deterministic, position control; null otherwise): every sum that an atomic would order by arrival goes
   // to an array instead and is added up in a fixed order by a kernel of its own (mpm_det.hip)
-  float4* det_cellred;    // [B][G]      per cell: (ground friction, controlled velocity xyz) cotangents of the grid-op adjoint
+  float* det_cellred;     // [B][det_capc][det_K] per listed cell (the list is sorted): what the grid-op adjoint adds to the env's cotangents --
+                          // ground friction, then the controlled velocity xyz (position control) or 18 values per primitive (soft contact)
+  int det_capc, det_K;
   float* det_pacc;        // [B][2][Np]  per particle: mu / lamda cotangents, accumulated over the substeps by the particle's own thread
   float* det_normpart;    // [B][LG_NORM_PARTS] per block of lg_bwd_norm: its share of the squared norm
 };
@@ -1447,10 +1449,9 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       lg_gacc(a, a.f)[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
     }
     if (a.det_cellred) {          // deterministic backward: per cell, summed in a fixed order by det_reduce_cells_kernel
-      if (live) {
-        int ci, cj, ck;
-        decode_cell(a.c, a.w.list[((long)cur * a.B + b) * a.cap + t], ci, cj, ck);
-        a.det_cellred[(long)b * a.G + ((long)ci * a.c.res[1] + cj) * a.c.res[2] + ck] = make_float4(dfric, dpv[0], dpv[1], dpv[2]);
+      if (live && t < a.det_capc) {
+        float* cr = a.det_cellred + ((long)b * a.det_capc + t) * 4;
+        cr[0] = dfric; cr[1] = dpv[0]; cr[2] = dpv[1]; cr[3] = dpv[2];
       }
       return;
     }
@@ -1522,6 +1523,14 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       pgv[17] = pg.mu;
     }
     LG_STAMP(3, 1);   // collide chain forward + this primitive's adjoint
+    if (a.det_cellred) {          // deterministic backward: the cell's 18 values to its row, summed in a fixed order by det_reduce_cells_kernel
+      if (live && t < a.det_capc) {
+        float* cr = a.det_cellred + ((long)b * a.det_capc + t) * a.det_K + 1 + ip * UD_PRIMC_NGRAD;
+#pragma unroll
+        for (int d = 0; d < UD_PRIMC_NGRAD; ++d) cr[d] = pgv[d];
+      }
+      continue;                   // (block-uniform)
+    }
     // this primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
 #pragma unroll
     for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
@@ -1543,7 +1552,9 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
     __syncthreads();
     LG_STAMP(3, 2);   // wave sums, barriers, the block's atomics
   }
-  {                  // one atomic per wave onto the env's friction word (see the position-control branch)
+  if (a.det_cellred) {
+    if (live && t < a.det_capc) a.det_cellred[((long)b * a.det_capc + t) * a.det_K] = dfric_cell;
+  } else {           // one atomic per wave onto the env's friction word (see the position-control branch)
     const float sf = wave_sum(dfric_cell);
     if ((threadIdx.x & 63) == 0 && sf != 0.f) atomicAdd(&a.w.acc[b * 4 + 0], sf);
   }
@@ -2261,7 +2272,7 @@ MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float
     L->det_off[8] = take(Bm * L->cap * 4);               // list
     L->det_off[9] = take(Bm * 4);                        // count
     L->det_off[10] = take(Bm * 27 * c.Np * 16);          // contrib
-    L->det_off[11] = take(Bm * L->G * 16);               // cellred (backward)
+    L->det_off[11] = take(Bm * (size_t)std::min(L->cap, 32768) * (c.position_control ? 4 : 1 + 18 * c.n_prim) * 4);   // cellred (backward)
     L->det_off[12] = take(Bm * 2 * c.Np * 4);            // pacc
     L->det_off[13] = take(Bm * LG_NORM_PARTS * 4);       // normpart
     L->det_bytes = off;
@@ -2354,7 +2365,7 @@ static LargeArgs base_args(MpmLarge* L, int B, const float* psize, const float* 
   a.gck_base = nullptr; a.gck_off_idx = 0; a.gck_off_pool = 0; a.gck_budget = 0; a.status = nullptr; a.gpar = 0;
   a.svd_rows = 0; a.ls3 = 0; a.vb = 0; a.ls = 0; a.lprev = 0; a.lnext = 0; a.nbx = 1; a.Bg = 0; a.xcd = 0;
   a.perm = nullptr; a.perm_stride = 0;
-  a.det_cellred = nullptr; a.det_pacc = nullptr; a.det_normpart = nullptr;
+  a.det_cellred = nullptr; a.det_capc = 0; a.det_K = 0; a.det_pacc = nullptr; a.det_normpart = nullptr;
   a.psize = psize; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   (void)B;
   return a;
@@ -2477,6 +2488,8 @@ static DetArgs lg_det_args(MpmLarge* L, int B, const float* psize, const float* 
   d.bkey = (int*)(db + L->det_off[3]); d.order = (int*)(db + L->det_off[4]); d.brange = (void*)(db + L->det_off[5]); d.bflag = (int*)(db + L->det_off[6]);
   d.nirr = (int*)(db + L->det_off[7]); d.list = (int*)(db + L->det_off[8]); d.count = (int*)(db + L->det_off[9]); d.cap = L->cap; d.contrib = (float*)(db + L->det_off[10]);
   d.cellred = (float*)(db + L->det_off[11]); d.pacc = (float*)(db + L->det_off[12]);
+  d.capc = std::min(L->cap, 32768); d.K = L->c.position_control ? 4 : 1 + 18 * L->c.n_prim;
+  d.gppos = L->w.gppos; d.grot = L->w.grot; d.gpsz = L->w.gpsz;
   d.trq = L->w.trq;
   return d;
 }
@@ -2650,8 +2663,8 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     hipLaunchKernelGGL(lg_bwd_in, dim3(grp[g].Bg, c.n_prim), blk, 0, grp[g].s, a, ckpt + ck.off_tail, stride_b, gppos, gprot);
     hipLaunchKernelGGL(lg_pack, dim3((N + 255) / 256, grp[g].Bg), blk, 0, grp[g].s, c, a.b0, gx, gv, gC, gF, L->w.gstate, (long)24 * Np, 0, a.perm, a.perm_stride);
   }
-  if (c.det && c.position_control) {
-    // Deterministic backward (position control): the recomputing backward with every arrival-ordered sum replaced -- the grid of substep f comes
+  if (c.det) {
+    // Deterministic backward: the recomputing backward with every arrival-ordered sum replaced -- the grid of substep f comes
     // from the deterministic forward's own kernels (ordered (m, mv) sums), the g2p adjoint's scatter is an ordered sum per cell over (offset,
     // particle) (lg_g2p_adj_det -> det_cells_kernel<1>), the per-env cotangents of the grid-op adjoint, the mu / lamda cotangents and the clip's
     // norm are added up in a fixed order.  One lane per particle, one stream.  Two calls on the same inputs return the same bits.
@@ -2659,7 +2672,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     d.hist = const_cast<float*>(ckpt); d.rec = rec; d.stride_b = stride_b; d.pingpong = 0; d.bwd = 1;
     d.val_out = (float*)L->w.val; d.gacc = (float*)L->w.gacc; d.acc = L->w.acc; d.gpv = L->w.gpv;
     char* db = (char*)L->det_arena;
-    a.det_cellred = (float4*)(db + L->det_off[11]); a.det_pacc = (float*)(db + L->det_off[12]); a.det_normpart = (float*)(db + L->det_off[13]);
+    a.det_cellred = d.cellred; a.det_capc = d.capc; a.det_K = d.K; a.det_pacc = (float*)(db + L->det_off[12]); a.det_normpart = (float*)(db + L->det_off[13]);
     a.b0 = 0; a.gck_base = nullptr; a.svd_rows = 0; a.perm = nullptr;
     const dim3 gc(lg_cell_blocks(L->cap), B), gq((N + 255) / 256, B), gqf(gq.x + c.n_prim, B);
     int rc = UD_OK;
