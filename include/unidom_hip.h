@@ -188,7 +188,7 @@ typedef struct {
                                 scatter an ordered sum per cell over (offset, particle), every per-env sum (ground friction, controlled
                                 velocity, the collide adjoint's per-primitive cotangents, mu / lamda, the clip's norm) added in a fixed
                                 order: two calls return the same bits (fast-math arithmetic, so no CPU build is bit-equal to it; checked
-                                against the oracle by tolerance).  At most 32768 touched cells per env and substep */
+                                against the oracle by tolerance).  At most 32768 touched cells per env and substep (status[b] = 1 beyond) */
   int max_envs;              /* the largest B any call on this handle will pass (>= 1).  Every arena of the many-workgroup path (dense
                                 grids, active lists, cotangent grids, the persistent forward's rotating grids, the deterministic mode's
                                 scratch) is allocated in ud_mpm_create for this many envs: no step call allocates or synchronises the

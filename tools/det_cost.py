@@ -17,7 +17,7 @@ def main():
     from test_mpm_gpu import LegacyConf, ScaledConf, _scaled_case, run_hip
     from test_mpm_det import _det_sim
     B = 32
-    print("# forward only (no checkpoint), %d envs, ms per ud_mpm_step_fwd call; 1x MI355X" % B)
+    print("# forward only (no checkpoint), %d envs, ms per ud_mpm_step_fwd call; then forward + backward per simulator.step pair; 1x MI355X" % B)
     for name in ("whip_rope N=67 res 32^3, 70 substeps", "rope at n_grid 128 N=798 res 64^3, 70 substeps"):
         row = []
         for det in (0, 1):
@@ -37,15 +37,20 @@ def main():
                 class Conf(ScaledConf):
                     deterministic = det
                 sim, st, _, N = _scaled_case(70, 0, B=B, conf_cls=Conf)
-            for _ in range(2):
-                run_hip(sim, st)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                run_hip(sim, st)
-            torch.cuda.synchronize()
-            row.append((time.perf_counter() - t0) / 5 * 1e3)
-        print("%-55s default %8.2f ms   deterministic %8.2f ms   x%.1f" % (name, row[0], row[1], row[1] / row[0]))
+            rng = np.random.default_rng(1)
+            g = dict(gx=rng.normal(size=(B, N, 3)), gv=rng.normal(size=(B, N, 3)), gC=rng.normal(size=(B, N, 3, 3)) * 0.01,
+                     gF=rng.normal(size=(B, N, 3, 3)) * 0.1, gppos=rng.normal(size=(B, 70, 3)))
+            for gg in (None, g):
+                for _ in range(2):
+                    run_hip(sim, st, g=gg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    run_hip(sim, st, g=gg)
+                torch.cuda.synchronize()
+                row.append((time.perf_counter() - t0) / 5 * 1e3)
+        print("%-55s default %8.2f ms   deterministic %8.2f ms   x%.1f" % (name, row[0], row[2], row[2] / row[0]))
+        print("%-55s default %8.2f ms   deterministic %8.2f ms   x%.1f" % ("   ... forward with checkpoint + backward (host copies in both)", row[1], row[3], row[3] / row[1]))
 
 
 if __name__ == "__main__":

@@ -2,7 +2,8 @@
 // default correctly rounded f32 divide / sqrt (Makefile), so that its arithmetic is the IEEE arithmetic the host compiler gives the
 // same source (oracle/csrc/mpm_det_host.cpp) -- the rest of the MPM path keeps its fast-math build.
 // Four launches per substep: pre-pass + touched-cell list (one thread per particle), bucket sort (one workgroup per env), cell sums + grid op
-// (one thread per touched cell, walking the 27 buckets that reach it), gather (one thread per particle); cost in DESIGN.md 3.2.
+// (a group of 32 lanes per touched cell, walking the 27 buckets that reach it), gather (one thread per particle); cost in DESIGN.md 3.2.
+// Below them: the pieces of the deterministic BACKWARD that are sums over particles or cells (mpm_large.hip drives it and keeps the arithmetic).
 #include <algorithm>
 
 #include "mpm_det.h"
@@ -243,6 +244,7 @@ __global__ void __launch_bounds__(256) det_reduce_cells_kernel(DetArgs a, int f)
   const int n = min(min(a.count[b], a.cap), a.capc);
   const float* cr = a.cellred + (long)b * a.capc * K;
   const int f0 = min(max(f, 0), S - 1), f1 = min(max(f + 1, 0), S - 1);
+  if (tid == 0 && a.status && min(a.count[b], a.cap) > min(a.capc, DET_SORT_CELLS)) atomicOr(&a.status[b], 1);
   for (int k = 0; k < K; ++k) {
     float s = 0.f;
     for (int t = tid; t < n; t += 256) s += cr[(long)t * K + k];

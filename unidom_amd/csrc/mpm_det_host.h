@@ -41,6 +41,7 @@ struct DetArgs {
                           // friction; per primitive p0[3] r0[4] p1[3] r1[4] size[3] mu, as lg_grid_adj_tile books them)
   int capc, K;
   float *gppos, *grot, *gpsz;   // soft contact: the primitives' cotangent rows [B][P][S][3], [B][P][S][4], [B][P][4]
+  int* status;            // [B] or null: 1 is OR-ed in when an env touches more cells than the sorted list holds (its gradients are then incomplete)
   float* pacc;            // [B][2][Np] per-particle mu / lamda cotangents, summed over the substeps by the particle's own thread
   float* acc;             // [B][4]    the env's scalars: friction, mu, lamda (, norm)
   float* gpv;             // [B][S][3] cotangent of the controlled velocity rows

@@ -3,11 +3,12 @@
 // kernels per substep.  Same arithmetic (shared device functions, mpm_device.h) and the same C ABI as mpm.hip.
 //
 // Per substep the forward runs  grid op (+ retiring the previous substep's cells) -> [g2p -> p2g of the next substep] (two launches:
-// lg_grid, lg_g2p_p2g; round 3 -- rounds 1-2: clear+FK -> p2g -> grid op -> g2p, still there behind UD_LG_CLEAR_LAUNCH=1), or, for
+// lg_grid, lg_g2p_p2g; round 3 -- rounds 1-2: clear+FK -> p2g -> grid op -> g2p, four launches), or, for
 // solids with one primitive below the chip-filling size, ONE persistent launch per step call (mpm_cluster.h); the backward either
 // clear -> p2g (recompute) -> grid op (recompute) -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint in extra blocks)
 // or, with the grid checkpoint,  restore -> g2p-adjoint -> grid-op adjoint -> p2g-adjoint (+ FK adjoint), which for four lanes per
-// particle and one primitive is two launches (lg_gadj_restore, lg_padj_gadj); ud_mpm_conf.deterministic: mpm_det.hip:
+// particle and one primitive is two launches (lg_gadj_restore, lg_padj_gadj); ud_mpm_conf.deterministic: the forward is mpm_det.hip's, the
+// backward this file's kernels with every arrival-ordered sum replaced by an ordered one (the `c.det` branch of mpm_large_step_bwd):
 //   * p2g scatters with global_atomic_add_f32 into one float4 (m, mv) per cell and marks cells in a bitmap
 //     (one bit per cell); the first toucher appends the cell to the env's ACTIVE LIST, so the grid op and the clear of
 //     the next substep visit only touched cells (never the 32^3..128^3 dense volume the reference sweeps ~10x);
@@ -2670,7 +2671,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
     // norm are added up in a fixed order.  One lane per particle, one stream.  Two calls on the same inputs return the same bits.
     DetArgs d = lg_det_args(L, B, psize, friction, mu, lamda, action);
     d.hist = const_cast<float*>(ckpt); d.rec = rec; d.stride_b = stride_b; d.pingpong = 0; d.bwd = 1;
-    d.val_out = (float*)L->w.val; d.gacc = (float*)L->w.gacc; d.acc = L->w.acc; d.gpv = L->w.gpv;
+    d.val_out = (float*)L->w.val; d.gacc = (float*)L->w.gacc; d.acc = L->w.acc; d.gpv = L->w.gpv; d.status = status;
     char* db = (char*)L->det_arena;
     a.det_cellred = d.cellred; a.det_capc = d.capc; a.det_K = d.K; a.det_pacc = (float*)(db + L->det_off[12]); a.det_normpart = (float*)(db + L->det_off[13]);
     a.b0 = 0; a.gck_base = nullptr; a.svd_rows = 0; a.perm = nullptr;
