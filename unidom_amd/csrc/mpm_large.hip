@@ -1425,6 +1425,9 @@ __device__ __forceinline__ float4 cell_mass_momentum(const LargeArgs& a, int b, 
 }
 
 // grid-op adjoint over the active cells
+// DET (a template parameter, so that the default kernels' code and registers stay what they were: 163 VGPRs = three waves per SIMD; with the
+// branch at run time the kernel took 181 and pour_water's grid-op adjoint 29 us instead of 20): the deterministic backward's variant.
+template <bool DET>
 __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int tile_base, float (*red)[UD_PRIMC_NGRAD]) {
   const int t = tile_base + threadIdx.x;
   const int cur = a.f & 1;
@@ -1449,7 +1452,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       if (grid_op_adjoint(a.c, pf, ci, cj, ck, mv.x, mvv, g, gmm, dfric, dp)) { dpv[0] = dp[0]; dpv[1] = dp[1]; dpv[2] = dp[2]; }
       lg_gacc(a, a.f)[(long)b * a.G + lin] = make_float4(g[0], g[1], g[2], gmm);
     }
-    if (a.det_cellred) {          // deterministic backward: per cell, summed in a fixed order by det_reduce_cells_kernel
+    if (DET) {                    // deterministic backward: per cell, summed in a fixed order by det_reduce_cells_kernel
       if (live && t < a.det_capc) {
         float* cr = a.det_cellred + ((long)b * a.det_capc + t) * 4;
         cr[0] = dfric; cr[1] = dpv[0]; cr[2] = dpv[1]; cr[3] = dpv[2];
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       pgv[17] = pg.mu;
     }
     LG_STAMP(3, 1);   // collide chain forward + this primitive's adjoint
-    if (a.det_cellred) {          // deterministic backward: the cell's 18 values to its row, summed in a fixed order by det_reduce_cells_kernel
+    if (DET) {                    // deterministic backward: the cell's 18 values to its row, summed in a fixed order by det_reduce_cells_kernel
       if (live && t < a.det_capc) {
         float* cr = a.det_cellred + ((long)b * a.det_capc + t) * a.det_K + 1 + ip * UD_PRIMC_NGRAD;
 #pragma unroll
@@ -1553,7 +1556,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
     __syncthreads();
     LG_STAMP(3, 2);   // wave sums, barriers, the block's atomics
   }
-  if (a.det_cellred) {
+  if (DET) {
     if (live && t < a.det_capc) a.det_cellred[((long)b * a.det_capc + t) * a.det_K] = dfric_cell;
   } else {           // one atomic per wave onto the env's friction word (see the position-control branch)
     const float sf = wave_sum(dfric_cell);
@@ -1566,7 +1569,8 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   }
   LG_STAMP(3, 3);     // head adjoint + store
 }
-__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
+template <bool DET>
+__device__ __forceinline__ void lg_grid_adj_body(const LargeArgs& a) {
   const LgB lgb_ = lg_bid(a);
   if (!lgb_.ok) return;
   __shared__ float red[4][UD_PRIMC_NGRAD];
@@ -1574,9 +1578,11 @@ __global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) {
   for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
     const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
-    lg_grid_adj_tile(a, b, base, red);
+    lg_grid_adj_tile<DET>(a, b, base, red);
   }
 }
+__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) { lg_grid_adj_body<false>(a); }
+__global__ void __launch_bounds__(256) lg_grid_adj_det(LargeArgs a) { lg_grid_adj_body<true>(a); }
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
 template <int LANES>
@@ -1811,7 +1817,7 @@ __global__ void __launch_bounds__(256) lg_gadj_restore(LargeArgs a, int nb) {
     for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
       const int base = (u * nb + lgb_.x) * 256;
       if (base >= n) break;
-      lg_grid_adj_tile(a, b, base, red);
+      lg_grid_adj_tile<false>(a, b, base, red);
     }
     return;
   }
@@ -2685,7 +2691,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
         hipStream_t s = st;
         LG_LAUNCH(lg_g2p_adj_det, gq.x, (int)gq.y, blk, 0, s, (float4*)d.contrib);
         if (rc == UD_OK) rc = mpm_det_bwd_gcells(d, f, L->det_epoch, st);
-        LG_LAUNCH(lg_grid_adj, gc.x, (int)gc.y, blk, 0, s);
+        LG_LAUNCH(lg_grid_adj_det, gc.x, (int)gc.y, blk, 0, s);
         if (rc == UD_OK) rc = mpm_det_bwd_reduce_cells(d, f, st);
         LG_LAUNCH(lg_p2g_adj<1>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x);
         if (rc == UD_OK) rc = mpm_det_bwd_clear(d, st);
