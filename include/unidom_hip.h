@@ -179,7 +179,7 @@ typedef struct {
                                 arithmetic (no FMA contraction, correctly rounded divide / sqrt).  Two calls on the same inputs return
                                 the same bits, and x, v, C, F equal the CPU build of the same source bit for bit (tests/test_mpm_det.py).
                                 Per substep the particles are bucketed by base cell (one sort per env) and a cell walks the 27 buckets
-                                that can reach it: 3.1x the default forward at 67 particles, 5.2x at 798 (profiles/r04*_det_cost.txt; rounds
+                                that can reach it: 3.1x the default forward at 67 particles, 5.3x at 798 (profiles/r04*_det_cost.txt; rounds
                                 2-3, every cell walking every particle: 13x / 332x).  Position control or soft contact (collide_batch of
                                 box / container primitives: its exp is a plain-IEEE polynomial in this mode so that both builds agree; a
                                 primitive's ROTATION still goes through the platform's sinf / cosf); at most 8192 particles
