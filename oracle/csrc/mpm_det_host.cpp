@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE.  The same-order checker of the deterministic MPM forward (ud_mpm_conf.deterministic): the device's own
-// per-element source -- unidom_amd/csrc/mpm_det.h and mpm_device.h -- compiled by the host compiler (UD_HOST_BUILD: no HIP, IEEE
+// per-element source -- unidom_amd/csrc/mpm_det.h, mpm_device.h and (soft contact) mpm_collide.h -- compiled by the host compiler (UD_HOST_BUILD: no HIP, IEEE
 // arithmetic, -ffp-contract=off) and driven by plain loops in the order the kernels of mpm_det.hip define: per substep every
 // particle's pre-pass, the particles bucketed by base cell (sorted by (bucket key, index)), every touched cell summed over the 27
 // offsets in (i, j, k) order and each offset's bucket in ascending particle index, every particle's gather in (i, j, k) order.
