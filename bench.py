@@ -80,10 +80,12 @@ def bench_selftest(args, rank, world, device):
         (pol(x) ** 2).sum().backward()
         sync.step()
 
+    grouped = dist.is_initialized()     # world > 1, or a one-rank group joined on purpose (UNIDOM_DIST_JOIN_SINGLE=1: the RCCL smoke test)
+
     def barrier():
         if device.type == "cuda":
             torch.cuda.synchronize(device)
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -96,16 +98,21 @@ def bench_selftest(args, rank, world, device):
     barrier()
     dt_rank = time.perf_counter() - t0
     tm = torch.tensor([dt_rank], device=device, dtype=torch.float64)
-    if world > 1:
+    if grouped:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     ranks = rank_report(world, device, dt_rank, None, sync)
     flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
     same = torch.ones((), device=device)
-    if world > 1:
+    probe_ok = None
+    if grouped:
         lo, hi = flat.clone(), flat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         same = (lo == hi).all().float()
+        probe = torch.arange(1, 1025, device=device, dtype=torch.float32) * (1 + rank)      # known answer: sum over ranks = i * W (W + 1) / 2
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+        probe_ok = bool((probe == torch.arange(1, 1025, device=device, dtype=torch.float32) * (world * (world + 1) // 2)).all().item())
+    ar_ms = sync.allreduce_ms()
     if rank == 0:
         print(json.dumps({"metric": "selftest_updates_per_sec", "value": world * args.steps / float(tm[0]), "unit": "updates/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tm[0]) / args.steps * 1e3,
@@ -113,8 +120,11 @@ def bench_selftest(args, rank, world, device):
                           "config": {"workload": "selftest (no simulator): policy gradient all-reduce + Adam"},
                           "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                           "allreduce_bytes_per_update": sync.n_params * 4 if world > 1 else 0,
-                          "replicas_identical": bool(same.item()), **ranks}), flush=True)
-    if world > 1:
+                          "replicas_identical": bool(same.item()),
+                          "collective": {"backend": dist.get_backend() if grouped else None, "device": str(device), "known_answer_allreduce_ok": probe_ok,
+                                         "gradient_allreduces_timed": len(ar_ms), "gradient_allreduce_ms_mean": float(np.mean(ar_ms)) if ar_ms else None,
+                                         "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}, **ranks}), flush=True)
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -256,10 +266,14 @@ def host_cores():
     return n
 
 
-def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
+def cpu_baseline(sample_envs=4, ep_len=EP_LEN, gpu_order=2):
     """Oracle (CPU restatement, NOT JAX-CPU), rebuilt here with -O3 -march=native, timed on the host cores: forward + adjoint
-    of the headline workload (4 envs x ep_len step_diffs) on min(4, nproc) threads (`value`), the same on ONE thread, and
-    nproc envs on nproc threads (all cores busy).  The oracle is only the thing timed here, never the product path."""
+    of the headline workload (4 envs x ep_len step_diffs) on min(4, nproc) threads, the same on ONE thread, and nproc envs on
+    nproc threads (all cores busy) -- in BOTH operation orders the restatement has: order 1 = the reference's literal order
+    (cloth_simulator.py:264-268: k*r/len*(len-L0)/L0, 48 IEEE divisions + 10 sqrt per particle-substep), order 2 = the
+    re-associated order "v2" the default GPU forward runs (8 divisions).  `value` is the order the GPU leg of this line ran
+    (`gpu_order`), so the stated baseline is like for like; the other order sits beside it under `reference_order` / `v2_order`.
+    The oracle is only the thing timed here, never the product path."""
     from oracle import pyoracle
     from tests.conftest import fold_cloth1_mask, make_cloth_case
     build = "-O3 -march=native built on this host"
@@ -267,40 +281,51 @@ def cpu_baseline(sample_envs=4, ep_len=EP_LEN):
         pyoracle.use_native()
     except Exception as e:      # no compiler on this host: time the portable build that travelled with the repo, and say so
         build = f"-O3 baseline x86-64 (the native rebuild failed: {type(e).__name__})"
-    orc = pyoracle.ClothOracle(fold_cloth1_mask())
     nproc = host_cores()
 
-    def run(envs, threads, reps):
-        rng = np.random.default_rng(0)
-        x, v, prim, k, mu, actions = make_cloth_case(rng, envs, MACRO, deform=0.0005, v_scale=0.01)
-        actions *= 0.2
-        g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
-        t0 = time.time()
-        for _ in range(reps):
-            orc.rollout_fwd(x, v, prim, k, mu, actions, nthreads=threads)
-        t_f = time.time() - t0
-        t0 = time.time()
-        for _ in range(reps):
-            orc.rollout_bwd(x, v, prim, k, mu, actions, g[0], g[1], g[2], normalize=True, nthreads=threads)
-        t_b = time.time() - t0
-        return envs * reps * MACRO * SUBSTEPS, t_f, t_b
+    def legs(order):
+        orc = pyoracle.ClothOracle(fold_cloth1_mask(), order=order)
 
-    threads = min(sample_envs, nproc)
-    n, t_f, t_b = run(sample_envs, threads, ep_len)
-    n1, t_f1, t_b1 = run(1, 1, ep_len)
-    nn, t_fn, t_bn = run(nproc, nproc, ep_len)
-    return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port",
-            "sample": f"CPU restatement (C++ {build}, f32, reference op order, no FMA contraction; not "
-                      f"JAX-CPU) on a SYNTHETIC cloth state (tests/conftest.make_cloth_case: deformed lattice + a lifting macro-action sequence, "
-                      f"not the env state the GPU leg runs; the work per substep does not depend on the data): "
-                      f"{sample_envs} envs x {ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint "
-                      f"{t_b:.2f}s; the adjoint call recomputes the forward states itself (it keeps no checkpoint), so its time "
-                      f"includes one more forward; OpenMP over envs ({threads} threads; substeps are sequential)",
-            "fwd_only_value": n / t_f,
-            "one_thread": {"value": n1 / (t_f1 + t_b1), "fwd_only_value": n1 / t_f1, "cores": 1, "sample": f"1 env x {ep_len} step_diff"},
-            "all_cores": {"value": nn / (t_fn + t_bn), "fwd_only_value": nn / t_fn, "cores": nproc,
-                          "sample": f"{nproc} envs x {ep_len} step_diff on {nproc} threads = the cores this job may use (affinity mask and cgroup quota; "
-                                    f"the box shows {os.cpu_count()} logical CPUs); more envs than the headline workload has"}}
+        def run(envs, threads, reps):
+            rng = np.random.default_rng(0)
+            x, v, prim, k, mu, actions = make_cloth_case(rng, envs, MACRO, deform=0.0005, v_scale=0.01)
+            actions *= 0.2
+            g = [rng.normal(size=a.shape).astype(np.float32) for a in (x, v, prim)]
+            t0 = time.time()
+            for _ in range(reps):
+                orc.rollout_fwd(x, v, prim, k, mu, actions, nthreads=threads)
+            t_f = time.time() - t0
+            t0 = time.time()
+            for _ in range(reps):
+                orc.rollout_bwd(x, v, prim, k, mu, actions, g[0], g[1], g[2], normalize=True, nthreads=threads)
+            t_b = time.time() - t0
+            return envs * reps * MACRO * SUBSTEPS, t_f, t_b
+
+        threads = min(sample_envs, nproc)
+        n, t_f, t_b = run(sample_envs, threads, ep_len)
+        n1, t_f1, t_b1 = run(1, 1, ep_len)
+        nn, t_fn, t_bn = run(nproc, nproc, ep_len)
+        name = {1: "the reference's literal operation order (cloth_simulator.py:257-337 as written)",
+                2: "operation order v2 (the reference's formulas re-associated, what the default GPU forward runs)"}[order]
+        return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port", "order": order,
+                "sample": f"CPU restatement (C++ {build}, f32, {name}, no FMA contraction; not "
+                          f"JAX-CPU) on a SYNTHETIC cloth state (tests/conftest.make_cloth_case: deformed lattice + a lifting macro-action sequence, "
+                          f"not the env state the GPU leg runs; the work per substep does not depend on the data): "
+                          f"{sample_envs} envs x {ep_len} step_diff x {MACRO * SUBSTEPS} substeps, forward {t_f:.2f}s + adjoint "
+                          f"{t_b:.2f}s; the adjoint call recomputes the forward states itself (it keeps no checkpoint), so its time "
+                          f"includes one more forward; OpenMP over envs ({threads} threads; substeps are sequential)",
+                "fwd_only_value": n / t_f,
+                "one_thread": {"value": n1 / (t_f1 + t_b1), "fwd_only_value": n1 / t_f1, "cores": 1, "sample": f"1 env x {ep_len} step_diff"},
+                "all_cores": {"value": nn / (t_fn + t_bn), "fwd_only_value": nn / t_fn, "cores": nproc,
+                              "sample": f"{nproc} envs x {ep_len} step_diff on {nproc} threads = the cores this job may use (affinity mask and cgroup quota; "
+                                        f"the box shows {os.cpu_count()} logical CPUs); more envs than the headline workload has"}}
+
+    out = legs(gpu_order)
+    other = 1 if gpu_order == 2 else 2
+    out["value_is"] = (f"order {gpu_order}: the operation order of the GPU leg's forward (`value` of this line); "
+                       f"the order-{other} figure is under `{'reference_order' if other == 1 else 'v2_order'}`")
+    out["reference_order" if other == 1 else "v2_order"] = legs(other)
+    return out
 
 
 def cpu_baseline_tshirt(env, st, sample_envs=4, macro=4):
@@ -310,8 +335,9 @@ def cpu_baseline_tshirt(env, st, sample_envs=4, macro=4):
     pyoracle, build = _oracle_native()
     conf = env.conf
     mask = env.cloth_mask.cpu().numpy() if hasattr(env.cloth_mask, "cpu") else np.asarray(env.cloth_mask)
+    order = 1 if (getattr(conf, "kernel_mode", 0) == 1 or getattr(conf, "one_workgroup_per_env", False)) else 2   # what the GPU leg runs
     orc = pyoracle.ClothOracle(mask, N=int(conf.N), gravity=float(conf.gravity), damping=float(conf.damping), dt=float(conf.dt),
-                               max_v=float(conf.max_v), small_num=float(conf.small_num), substeps=SUBSTEPS)
+                               max_v=float(conf.max_v), small_num=float(conf.small_num), substeps=SUBSTEPS, order=order)
     npy = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy()[:sample_envs])
     x, v = npy(st.x), npy(st.v)
     prim = np.stack([npy(st.primitive0), npy(st.primitive1)], 1)
@@ -331,7 +357,8 @@ def cpu_baseline_tshirt(env, st, sample_envs=4, macro=4):
     t_b = time.time() - t0
     n = sample_envs * macro * SUBSTEPS
     return {"value": n / (t_f + t_b), "unit": "substeps/s", "cores": threads, "kind": "port", "fwd_only_value": n / t_f,
-            "sample": f"CPU restatement (C++ {build}, f32, reference op order; not JAX-CPU): {sample_envs} envs x {macro} macro actions x {SUBSTEPS} substeps of the env's "
+            "order": order,
+            "sample": f"CPU restatement (C++ {build}, f32, operation order {order} = the order the GPU leg of this line runs ({'v2, re-associated' if order == 2 else 'reference, literal'}); not JAX-CPU): {sample_envs} envs x {macro} macro actions x {SUBSTEPS} substeps of the env's "
                       f"reset state (P={x.shape[1]}), forward {t_f:.2f}s + adjoint (with its own forward recompute) {t_b:.2f}s, OpenMP over envs ({threads} threads)"}
 
 
@@ -592,6 +619,7 @@ def bench_torus(args, rank, world, device):
         else:
             for _ in range(inner):
                 st = sim.step(st, action)
+    sim.check_status()                         # a part of the persistent kernels that gave up in the warm-up would poison every later step (NaN)
     sim.profile = {"fwd": [], "bwd": []}      # HIP events around every step call, on its stream
     sync()
     t0 = time.perf_counter()
@@ -604,6 +632,7 @@ def bench_torus(args, rank, world, device):
     sync()
     dt = time.perf_counter() - t0
     prof, sim.profile = sim.profile, None
+    sim.check_status()                         # ... and a line must never be a rate over NaN state: raises if any part timed out in the timed region
     tm = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -1017,7 +1046,8 @@ def main():
                     help="MPM workloads, diagnostics only: ud_mpm_conf.tune_* of every simulator this run builds (lanes, cluster, cluster_part_lanes, "
                          "cluster_envs, env_groups, bwd_two_launch), e.g. --tune env_groups=1 for counter passes that attribute per kernel")
     ap.add_argument("--kernel-mode", type=int, default=0,
-                    help="cloth kernel family (include/unidom_hip.h): 0 default (bit-exact forward), 1 strict, 2 fast-math")
+                    help="cloth kernel family (include/unidom_hip.h): 0 default (v2-order forward, bit-exact vs the restatement of that order), "
+                         "1 reference-order forward + literal adjoint, 2 fast-math, 3 reference-order forward + restructured adjoint")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(sys.argv[1:])              # never returns; nothing above has touched a GPU
@@ -1113,16 +1143,43 @@ def main():
         sync()
         dt_fwd = time.perf_counter() - tf0
 
-    t_max = torch.tensor([dt, dt_fwd], device=device, dtype=torch.float64)
+    # the same update in the reference's LITERAL operation order (ud_cloth_conf.mode 3: cloth_simulator.py:257-337 as written, forward
+    # bit-exact vs the restatement of that order + the restructured adjoint), timed exactly like the headline -- reported beside it
+    ref_line, dt_ref, k_ms_ref = None, float("nan"), {}
+    if args.kernel_mode == 0:
+        conf3 = DefaultConf()
+        conf3.kernel_mode = 3
+        if para:
+            env3 = env_functions["fold_cloth1_para"](batch_size=NUM_ENVS_PER_GPU, conf=conf3, aux_reward=True, stiffness=1300,
+                                                     eval_min_max_stiff=[10, 1800], device=device)
+        else:
+            env3 = env_functions["fold_cloth1"](batch_size=NUM_ENVS_PER_GPU, conf=conf3, seed=0, aux_reward=True, device=device)
+        assert env3.simulator.mode == 3
+        learner3 = APG(env3, EP_LEN, learning_rate=1e-4, max_gradient_norm=0.3, seed=0)
+        _, state3 = env3.reset(key_env)
+        for _ in range(args.warmup):
+            learner3.minimize(state3)
+        env3.simulator.profile = {"fwd": [], "bwd": []}
+        sync()
+        tr0 = time.perf_counter()
+        for _ in range(args.steps):
+            learner3.minimize(state3)
+        sync()
+        dt_ref = time.perf_counter() - tr0
+        k_ms_ref = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in env3.simulator.profile.items() if v}
+        env3.simulator.profile = None
+
+    t_max = torch.tensor([dt, dt_fwd, dt_ref], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt, dt_fwd = float(t_max[0]), float(t_max[1])
+    dt, dt_fwd, dt_ref = float(t_max[0]), float(t_max[1]), float(t_max[2])
 
     if rank == 0:
         units = world * NUM_ENVS_PER_GPU * EP_LEN * MACRO * SUBSTEPS * args.steps
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
-        kname = {"fwd": {0: "cloth_rollout_fwd_v2_kernel", 1: "cloth_rollout_fwd_kernel", 2: "cloth_rollout_fwd_fast_kernel"}[args.kernel_mode],
+        kname = {"fwd": {0: "cloth_rollout_fwd_v2_kernel", 1: "cloth_rollout_fwd_kernel", 2: "cloth_rollout_fwd_fast_kernel",
+                         3: "cloth_rollout_fwd_kernel"}[args.kernel_mode],
                  "bwd": "cloth_rollout_bwd_kernel" if args.kernel_mode == 1 else "cloth_rollout_bwd_fast_kernel"}[dom]
         per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
@@ -1136,7 +1193,8 @@ def main():
                                    "ep_len=3, 40 macro x 50 substeps per step_diff",
                        "kernel_mode": args.kernel_mode,
                        "order": {0: "v2 (the reference's formulas re-associated; bit-exact vs the CPU restatement of the same order)",
-                                 1: "reference (literal operation order)", 2: "v2 fast-math"}[args.kernel_mode],
+                                 1: "reference (literal operation order), literal six-reduction adjoint", 2: "v2 fast-math",
+                                 3: "reference (literal operation order; bit-exact vs the CPU restatement of that order) + restructured adjoint"}[args.kernel_mode],
                        "num_envs_per_gpu": NUM_ENVS_PER_GPU, "ep_len": EP_LEN, "substeps_per_step": units // args.steps,
                        "parallelism": f"env-sharded dp{world}, 1 RCCL all-reduce of {learner.n_params} f32 per update"},
             "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
@@ -1149,13 +1207,23 @@ def main():
                                  "about this kernel -- see `issue` (instruction issue on the busy CUs) and `saturation`",
                          "issue": issue_roof(kname, k_ms[dom], 8 * NUM_ENVS_PER_GPU, NUM_ENVS_PER_GPU, MACRO * SUBSTEPS)},
         }
+        if args.kernel_mode == 0:
+            out["reference_order"] = {
+                "value": units / dt_ref, "unit": "substeps/s", "ms_per_step": dt_ref / args.steps * 1e3, "kernel_ms": k_ms_ref, "kernel_mode": 3,
+                "kernels": {"fwd": "cloth_rollout_fwd_kernel<512>", "bwd": "cloth_rollout_bwd_fast_kernel"},
+                "note": "the SAME update (same policy seed, same reset key, same steps / warm-up, same barrier-bracketed timing) with the cloth forward in the "
+                        "reference's literal operation order (cloth_simulator.py:264-268 k*r/len*(len-L0)/L0 and the friction block :281-306 as written, "
+                        "IEEE divide / sqrt, no FMA contraction): bit-exact against ClothOracle(order=1) over a whole step_diff incl. the grasp set of every "
+                        "substep (tests/test_cloth_gpu.py::test_reference_order_*); the adjoint is the restructured one of the headline, reading this "
+                        "forward's checkpoints.  The CPU figure in the same order: cpu_baseline.reference_order"}
         out.update(ranks)
         if graph_line is not None:
             out["hip_graph"] = graph_line
         if not args.no_saturation:
             out["saturation"] = saturation_probe(env, device)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sample_envs=min(NUM_ENVS_PER_GPU, max(4, host_cores())))
+            out["cpu_baseline"] = cpu_baseline(sample_envs=min(NUM_ENVS_PER_GPU, max(4, host_cores())),
+                                               gpu_order=1 if args.kernel_mode in (1, 3) else 2)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -68,6 +68,11 @@ typedef struct {
                     *    of that order) AND reference-order adjoint (six reductions per substep);
                     * 2: v2 structure with fast-math (v_rsq, FMA) forward + restructured adjoint (f32 round-off
                     *    differences, which this stiff system amplifies over long rollouts -- see DESIGN.md).
+                    * 3: forward in the reference's literal f32 operation order (mode 1's forward kernel: k*r/len*(len-L0)/L0,
+                    *    cloth_simulator.py:264-268, and the friction block :281-306 as written; bit-identical to the CPU
+                    *    restatement of THAT order) + the restructured adjoint of modes 0 / 2 (it reads the same checkpoint
+                    *    records and re-derives the grasp sets from them).  Bodies of at most 512 particles
+                    *    (UD_ERR_UNSUPPORTED above).
                     * Bodies above 1024 particles: modes 0 / 2 run the v2-order forward and the restructured adjoint on
                     *    SEVERAL workgroups per env (512 particles each, halo positions / force cotangents / block sums handed
                     *    over through HBM every substep; forward still bit-identical to the v2 restatement); mode 1 runs the
@@ -318,7 +323,9 @@ int ud_plb_launch_plan(const ud_plb* h, int B);
 /* Persistent path only: a workgroup that waits for a sibling longer than ~seconds gives up, its env's outputs are NaN and a device-side
  * counter is raised.  This call SYNCHRONISES `stream`, returns the number of such workgroups since the previous call (0 = none, also on
  * the multi-kernel path; ud_last_error() holds the text otherwise) and, when it is not 0, puts the handle's exchange arena back into its
- * rest state so that later calls are valid again.  The step calls themselves stay asynchronous and return UD_OK. */
+ * rest state so that later calls are valid again.  The step calls themselves stay asynchronous and return UD_OK.  Between a time-out
+ * and the poll that clears it the handle is POISONED: every persistent launch sees the raised counter at entry, touches neither barrier
+ * words nor exchange grids and writes NaN to all its outputs -- a time-out can never turn into finite-but-wrong results of later steps. */
 int ud_plb_poll_timeouts(ud_plb* h, void* stream);
 /* One env.step for B independent envs (float64 device arrays): x, v [B,N,3]; C, F [B,N,3,3]; prim_pos
  * [B,n_primitives,3]; softness [B,n_primitives]; action [B,3]; E, nu, yield_stress [B]. */

@@ -13,6 +13,45 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def run_rccl_child(timeout=900):
+    """One rank of `python -m torch.distributed.run ... bench.py --workload selftest` with the nccl (= RCCL) backend as a CHILD process:
+    the driver's own N-rank command line at N = 1.  Must be started by a process that has not initialised the GPU (a GPU-initialised
+    parent must not fork + exec on this pool) -- pytest_sessionstart below does it before any test runs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "UNIDOM_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["UNIDOM_DIST_JOIN_SINGLE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "selftest"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        return {"rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr[-4000:]}
+    except subprocess.TimeoutExpired as e:
+        return {"rc": None, "stdout": (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""),
+                "stderr": f"timed out after {timeout}s"}
+
+
+def pytest_sessionstart(session):
+    """-m gpu runs only: start the RCCL child of tests/test_distributed_gpu.py now, while this process has not touched the GPU
+    (torch.cuda.device_count() does not initialise it on this image; is_available() would)."""
+    session.config._rccl_child = None
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:
+        return
+    session.config._rccl_child = run_rccl_child()
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

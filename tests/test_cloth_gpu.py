@@ -246,6 +246,87 @@ def test_config3_launch_shape_32_envs_full_step_diff_matches_oracle():
             assert _rel(hb, ob_) < 1e-2, (key, b, _rel(hb, ob_))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# mode 3: forward in the reference's LITERAL operation order (cloth_simulator.py:257-337 as written: k*r/len*(len-L0)/L0,
+# the whole friction block) + the restructured adjoint.  The forward must equal the reference-order restatement bit for
+# bit -- grasp sets included -- over a whole step_diff; the adjoint reads that forward's checkpoints.
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def rsim():
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    return ClothSimulator(Conf(), 4, lambda x, v, i, j: v, fold_cloth1_mask(), mode=3)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_reference_order_fwd_with_fast_adjoint_short(rsim, oracle, normalize):
+    rng = np.random.default_rng(301)
+    B, T = 3, 2
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    g = _grads(rng, B, T, x.shape[1])
+    o = oracle.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    ob = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], g["gx_list"], g["gv_list"],
+                            g["gprim_list"], normalize=normalize)
+    h = _run_hip(rsim, x, v, prim, k, mu, actions, g=g, normalize=normalize)
+    assert o["grasp"].sum() > 0
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert _rel(h[key], ob[key]) < 1e-3, (key, _rel(h[key], ob[key]))
+
+
+def test_reference_order_full_step_diff_4_envs(rsim, oracle):
+    """The headline's launch shape (fold_cloth1, 4 envs, 40 x 50 substeps) in the reference's own operation order: forward bit for
+    bit against ClothOracle(order=1) incl. the grasp set of every substep; adjoint within the default mode's 5e-3."""
+    rng = np.random.default_rng(8)
+    B, T = 4, 40
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T, deform=0.0005, v_scale=0.01)
+    actions *= 0.2
+    g = _grads(rng, B, T, x.shape[1], lists=False)
+    o = oracle.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True, nthreads=4)
+    ob = oracle.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], normalize=True, nthreads=4)
+    h = _run_hip(rsim, x, v, prim, k, mu, actions, g=g)
+    assert o["grasp"].sum() > 0
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert np.isfinite(h[key]).all(), key
+        assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))
+
+
+def test_reference_order_full_step_diff_32_envs():
+    """config 3's launch shape (32 envs, per-env stiffness from [1000, 1600]) in the reference's operation order."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    B, T = 32, 40
+    sim = ClothSimulator(Conf(), B, lambda x, v, i, j: v, fold_cloth1_mask(), mode=3)
+    orc = ClothOracle(fold_cloth1_mask())
+    rng = np.random.default_rng(34)
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T, deform=0.0005, v_scale=0.01)
+    actions *= 0.2
+    k = rng.uniform(1000, 1600, size=B).astype(np.float32)
+    g = _grads(rng, B, T, x.shape[1], lists=False)
+    o = orc.rollout_fwd(x, v, prim, k, mu, actions, want_grasp=True, nthreads=8)
+    ob = orc.rollout_bwd(x, v, prim, k, mu, actions, g["gx"], g["gv"], g["gprim"], normalize=True, nthreads=8)
+    h = _run_hip(sim, x, v, prim, k, mu, actions, g=g, want_lists=False)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+    for key in ("gx", "gv", "gprim", "gactions", "gk", "gmu"):
+        assert np.isfinite(h[key]).all(), key
+        assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))
+
+
+def test_reference_order_mode_refuses_bodies_above_512_particles():
+    from unidom_amd import _lib
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+    mask = np.zeros((80, 80), np.float32)
+    mask[10:40, 10:40] = 1          # 900 particles
+    with pytest.raises(_lib.UnidomError, match="512"):
+        ClothSimulator(Conf(), 1, lambda x, v, i, j: v, mask, mode=3)
+
+
 @pytest.mark.parametrize("r0,r1", [(1.7, -0.1), (0.0, 3.0e19), (0.2, float("inf")), (float("nan"), 0.05)])
 def test_default_mode_grasp_radius_edge_cases(dsim, oracle2, r0, r1):
     """The kernels replace sqrt(s) <= radius by s <= T(radius) with T found once per launch for the first substep's radius and

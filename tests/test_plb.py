@@ -279,10 +279,11 @@ def test_loss_twin_known_answers():
     assert abs(float(total) - d0 ** 2) < 1e-15
 
 
-def _hip_sim(N, B, quality=0.5, grid_ckpt_cells=None, path=0, lanes=0, sort_every=0):
+def _hip_sim(N, B, quality=0.5, grid_ckpt_cells=None, path=0, lanes=0, sort_every=0, substeps=0):
     from unidom_amd.engine.plb_simulator import PlbConf as HipConf, PlbSimulator
     cfg = HipConf()
     cfg.quality = quality
+    cfg.substeps = substeps
     cfg.n_particles = N
     cfg.path, cfg.lanes, cfg.sort_every = path, lanes, sort_every
     if grid_ckpt_cells is not None:
@@ -322,6 +323,7 @@ def test_hip_step_adjoint_matches_torch_twin(low, path, lanes=0):
     hloss = sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w))
     sim.ground_friction_grad = None
     hloss.backward()
+    sim.check_status()
     for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
         got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
         assert np.isfinite(got).all(), name
@@ -332,6 +334,42 @@ def test_hip_step_adjoint_matches_torch_twin(low, path, lanes=0):
     if low:
         assert np.abs(ref).max() > 0          # the friction branch really ran
     assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()[1]) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", [2, 1])
+def test_hip_negative_yield_stress_follows_the_return_mapping(path):
+    """yield_stress <= 0 (g_ys is an exposed gradient: an optimiser can push it there): dg = |dev log-strain| - ys / 2 mu is then positive
+    for every particle and the reference's return mapping (mpm_simulator.py:133-150) yields everywhere.  The kernels decide "cannot yield"
+    from a squared bound without taking logarithms; that shortcut must not fire for a negative limit.  Forward 1e-9 / every leaf 1e-6
+    against the twin, which has no such shortcut."""
+    import torch
+    torch.set_num_threads(8)
+    B, N = 3, 300
+    sim = _hip_sim(N, B, path=path)
+    conf = PlbConf(quality=0.5, n_particles=N)
+    x, v, Cm, F, prim, soft, act, E, nu, ys = _small_case(B, N, 3, low=True)
+    ys = np.array([-20.0, 1762.2, -500.0])
+    F = np.eye(3)[None, None] + (F - np.eye(3)) * 0.05          # nearly undeformed: the bound of the shortcut is tiny, only the sign of ys makes these yield
+    case = (x, v, Cm, F, prim, soft, act, E, nu, ys)
+    rng = np.random.default_rng(10)
+    w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
+    leaves, out, loss = _twin_step(conf, case, conf.ground_friction, w)
+    loss.backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
+    s = sim.reset()._replace(x=hl["x"], v=hl["v"], C=hl["C"], F=hl["F"], prim_pos=hl["prim"], softness=T(soft, False), E=hl["E"], nu=hl["nu"],
+                             yield_stress=hl["ys"])
+    s1 = sim.step(s, hl["act"])
+    for o, t, name in zip(out, (s1.x, s1.v, s1.C, s1.F, s1.prim_pos), "xvCFp"):
+        assert _rel(t.detach().cpu().numpy(), o.detach().numpy()) < 1e-9, name
+    sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w)).backward()
+    sim.check_status()
+    for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
+        got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
+        assert np.isfinite(got).all(), name
+        assert _rel(got, ref) < 1e-6, (name, _rel(got, ref))
+    assert (np.abs(leaves["ys"].grad.numpy()[[0, 2]]) > 0).all()      # the negative-limit envs really went through the mapping
 
 
 @pytest.mark.gpu
@@ -382,6 +420,62 @@ def test_hip_step_adjoint_at_the_benched_configuration():
         assert np.isfinite(got).all(), name
         assert _rel(got[pick], ref) < 1e-6, (name, _rel(got[pick], ref))
     assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()[1]) > 0
+
+
+@pytest.mark.gpu
+def test_hip_step_adjoint_at_n_grid_128_the_other_benched_configuration():
+    """bench.py --workload torus --plb-grad --n-grid 128 (BASELINE config 5's "128^3 grid": quality 2, dt 5e-5): N = 1000, 8 envs in one
+    launch, the kernels ud_plb_create picks by itself (persistent path: 8 x 32 parts, 1024-slot cell tables at about one particle per
+    cell, per-part cell records, the three-buffer ring of exchange grids).  The twin's tape of 39 dense 128^3 substeps does not fit in
+    memory, and the launch shape -- not the horizon -- is what this grid adds, so ud_plb_conf.substeps is cut to 4 on both sides
+    (set_action divides the action by the same count: G/engine/primitive/primive_base.py:185-192).  Two of the eight envs are followed
+    by torch.autograd through the twin: forward 1e-9, every leaf 1e-6 relative -- the tolerances of the n_grid-32 / 64 tests."""
+    import torch
+    torch.set_num_threads(8)
+    B, N, S, pick = 8, 1000, 4, [1, 6]
+    sim = _hip_sim(N, B, quality=2.0, substeps=S)
+    assert (sim.n_grid, sim.substeps) == (128, S) and abs(sim.dt - 5e-5) < 1e-18 and sim.launch_plan() == 2
+
+    class Short(PlbConf):
+        substeps = S
+    conf = Short(quality=2.0, n_particles=N)
+    assert (conf.n_grid, conf.substeps) == (128, S)
+    rng = np.random.default_rng(22)
+    x = torus_particles(1000)[None].repeat(B, 0) + rng.normal(size=(B, N, 3)) * 1e-4
+    x[:, :, 1] -= x[:, :, 1].min(1, keepdims=True) - 1.2 / 128      # foot of the column on the floor: ground friction + boundary zeroing
+    v = rng.normal(size=(B, N, 3)) * 0.05
+    v[:, :, 1] -= 0.2
+    Cm = rng.normal(size=(B, N, 3, 3)) * 0.5
+    F = np.eye(3)[None, None] + rng.normal(size=(B, N, 3, 3)) * 0.02
+    prim = np.stack([x[:, 7], np.repeat(np.array([[0.5, 0.55, 0.5]]), B, 0)], 1)
+    soft = np.full((B, 2), 666.0)
+    act = rng.uniform(-0.002, 0.002, size=(B, 3)) * np.array([1.0, 0.3, 1.0])   # over 4 substeps instead of 39: same per-substep travel as 0.01-0.02 per env.step
+    E = rng.uniform(3e3, 6e3, size=B)
+    nu = rng.uniform(0.25, 0.4, size=B)
+    ys = np.array([1762.2, 30.0, 1762.2, 200.0, 1762.2, 50.0, 30.0, 1762.2])      # env 1 and 6 yield almost everywhere / in part
+    w = [rng.normal(size=s) for s in ((B, N, 3), (B, N, 3), (B, N, 3, 3), (B, N, 3, 3), (B, 2, 3))]
+    sub = lambda a: np.ascontiguousarray(np.asarray(a)[pick])
+    case = tuple(sub(a) for a in (x, v, Cm, F, prim, soft, act, E, nu, ys))
+    leaves, out, loss = _twin_step(conf, case, conf.ground_friction, [sub(wi) for wi in w])
+    loss.backward()
+    T = lambda a, r=True: torch.tensor(np.asarray(a, np.float64), device=sim.device, requires_grad=r)
+    hl = dict(x=T(x), v=T(v), C=T(Cm), F=T(F), prim=T(prim), act=T(act), E=T(E), nu=T(nu), ys=T(ys))
+    s = sim.reset()._replace(x=hl["x"], v=hl["v"], C=hl["C"], F=hl["F"], prim_pos=hl["prim"], softness=T(soft, False), E=hl["E"],
+                             nu=hl["nu"], yield_stress=hl["ys"])
+    s1 = sim.step(s, hl["act"])
+    for o, t, name in zip(out, (s1.x, s1.v, s1.C, s1.F, s1.prim_pos), "xvCFp"):
+        assert torch.isfinite(t).all(), name
+        assert _rel(t.detach().cpu().numpy()[pick], o.detach().numpy()) < 1e-9, name
+    sim.ground_friction_grad = None
+    sum((t * T(wi, False)).sum() for t, wi in zip((s1.x, s1.v, s1.C, s1.F, s1.prim_pos), w)).backward()
+    sim.check_status()
+    for name in ("x", "v", "C", "F", "prim", "act", "E", "nu", "ys"):
+        got, ref = hl[name].grad.cpu().numpy(), leaves[name].grad.numpy()
+        assert np.isfinite(got).all(), name
+        assert _rel(got[pick], ref) < 1e-6, (name, _rel(got[pick], ref))
+    gfr, rfr = sim.ground_friction_grad.cpu().numpy()[pick], leaves["fric"].grad.numpy()
+    assert np.abs(rfr).max() > 0 and _rel(gfr, rfr) < 1e-6, (gfr, rfr)          # the friction branch really ran
+    assert np.abs(leaves["act"].grad.numpy()).max() > 0 and np.abs(leaves["ys"].grad.numpy()).max() > 0
 
 
 @pytest.mark.gpu

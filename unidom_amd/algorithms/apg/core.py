@@ -120,7 +120,7 @@ class GradSync:
         scale = torch.where(g_norm < self.max_gradient_norm, torch.ones_like(g_norm),
                             self.max_gradient_norm / g_norm)                 # apg.py:260-267 (per device, BEFORE the mean)
         g.mul_(scale)
-        if dist.is_initialized() and dist.get_world_size() > 1:              # apg.py:235 lax.pmean
+        if dist.is_initialized():                                            # apg.py:235 lax.pmean (a one-rank group reduces too: the identity)
             if self.profile is not None:
                 cuda = g.device.type == "cuda"
                 t0 = torch.cuda.Event(enable_timing=True) if cuda else time.perf_counter()
@@ -334,7 +334,9 @@ def init_distributed(gpus: int):
     N-rank flow on a one-GPU box (RCCL refuses two ranks on one device; gloo stages the gradient through the host)."""
     import os
     backend = os.environ.get("UNIDOM_DIST_BACKEND", "nccl")
-    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # UNIDOM_DIST_JOIN_SINGLE=1 (tests/test_distributed_gpu.py): join the group even when WORLD_SIZE is 1 -- the one-GPU box's way to
+    # load RCCL, bind the device and run the update's collective once before the first multi-GPU run
+    if "RANK" in os.environ and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("UNIDOM_DIST_JOIN_SINGLE") == "1"):
         if backend == "gloo":
             if not dist.is_initialized():
                 dist.init_process_group(backend="gloo")

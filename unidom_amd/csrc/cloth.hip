@@ -893,7 +893,7 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
       L0[(size_t)l * Pp + p] = fmaxf(ol, 1e-12f);                               // :63
       nbr[(size_t)l * Pp + p] = mask[ji * N + jj] ? pid[ji * N + jj] : -1;      // :276
     }
-  auto* h = new ud_cloth;
+  auto* h = new ud_cloth();
   h->c.gdt = (float)((double)conf->gravity * (double)conf->dt);
   h->c.g = conf->gravity;
   h->c.dt = conf->dt;
@@ -914,7 +914,11 @@ int ud_cloth_create(const ud_cloth_conf* conf, const uint8_t* mask, ud_cloth** o
     h->cl_H = (H >= 64 && H <= ud::CL_HMAX && h->cl_W <= 8) ? H : 0;
   }
   h->mode = conf->mode;
-  if (h->mode < 0 || h->mode > 2) { ud::set_error("ud_cloth_create: mode must be 0, 1 or 2"); delete h; return UD_ERR_INVALID; }
+  if (h->mode < 0 || h->mode > 3) { ud::set_error("ud_cloth_create: mode must be 0, 1, 2 or 3"); delete h; return UD_ERR_INVALID; }
+  if (h->mode == 3 && Pp > 512) {   // the restructured adjoint of bodies above 512 particles belongs to the several-workgroup (v2-order) kernels
+    ud::set_error("ud_cloth_create: mode 3 (reference-order forward + restructured adjoint) covers bodies of at most 512 particles, P=%d", P);
+    delete h; return UD_ERR_UNSUPPORTED;
+  }
   if (conf->max_envs < 1) { ud::set_error("ud_cloth_create: max_envs = %d (handle-owned scratch is sized at create: give the largest B any call will pass)", conf->max_envs); delete h; return UD_ERR_INVALID; }
   h->max_envs = conf->max_envs;
   h->one_wg = conf->one_workgroup_per_env != 0;
@@ -998,7 +1002,7 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
     ud::set_error("ud_cloth_rollout_fwd: null argument"); return UD_ERR_INVALID;
   }
   if (B < 1 || T < 1 || B > h->max_envs) { ud::set_error("ud_cloth_rollout_fwd: B=%d T=%d (max_envs=%d)", B, T, h->max_envs); return UD_ERR_INVALID; }
-  ud::ClothFwdArgs a;
+  ud::ClothFwdArgs a{};
   a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
   a.x = x; a.v = v; a.prim = prim; a.k = stiffness; a.mu = mu; a.actions = actions;
   a.x_out = x_out; a.v_out = v_out; a.prim_out = prim_out; a.x_list = x_list; a.v_list = v_list;
@@ -1007,7 +1011,7 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
   if (cloth_use_cluster(h, B)) {
     const int per = cloth_cluster_envs(h, B);
     for (int b0 = 0; b0 < B; b0 += per) {
-      ud::ClusterArgs q;
+      ud::ClusterArgs q{};
       const int rc = cloth_cluster_arena(h, std::min(per, B - b0), (hipStream_t)stream, &q);
       if (rc != UD_OK) return rc;
       q.b0 = b0;
@@ -1019,7 +1023,7 @@ int ud_cloth_rollout_fwd(ud_cloth* h, int B, int T, const float* x, const float*
     ud::cloth_launch_fwd_fast(a, (hipStream_t)stream);
   else if (h->mode == 0 && h->c.Pp <= 512)
     ud::cloth_launch_fwd_v2(a, (hipStream_t)stream);
-  else if (h->c.Pp <= 512)
+  else if (h->c.Pp <= 512)   // modes 1 and 3: the reference's literal operation order (same checkpoint records as the other forwards)
     hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<512>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(ud::cloth_rollout_fwd_kernel<1024>, dim3(B), dim3(h->c.Pp), shmem, (hipStream_t)stream, a);
@@ -1037,7 +1041,7 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
     ud::set_error("ud_cloth_rollout_bwd: null argument"); return UD_ERR_INVALID;
   }
   if (B < 1 || T < 1 || B > h->max_envs) { ud::set_error("ud_cloth_rollout_bwd: B=%d T=%d (max_envs=%d)", B, T, h->max_envs); return UD_ERR_INVALID; }
-  ud::ClothBwdArgs a;
+  ud::ClothBwdArgs a{};
   a.c = h->c; a.nbr = h->d_nbr; a.L0 = h->d_L0; a.B = B; a.T = T;
   a.ckpt = (const float*)ckpt; a.k = stiffness; a.mu = mu; a.actions = actions;
   a.g_x = g_x; a.g_v = g_v; a.g_prim = g_prim; a.g_x_list = g_x_list; a.g_v_list = g_v_list;
@@ -1047,7 +1051,7 @@ int ud_cloth_rollout_bwd(ud_cloth* h, int B, int T, const void* ckpt, const floa
   if (cloth_use_cluster(h, B)) {
     const int per = cloth_cluster_envs(h, B);
     for (int b0 = 0; b0 < B; b0 += per) {
-      ud::ClusterArgs q;
+      ud::ClusterArgs q{};
       const int rc = cloth_cluster_arena(h, std::min(per, B - b0), (hipStream_t)stream, &q);
       if (rc != UD_OK) return rc;
       q.b0 = b0;

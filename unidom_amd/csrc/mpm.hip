@@ -1253,7 +1253,7 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   const bool large = N > 128 || !conf->use_position_control || conf->deterministic;
   if (!large && S * 3 > 256) { ud::set_error("ud_mpm_create: steps=%d too large for the in-LDS primitive arrays", S); return UD_ERR_UNSUPPORTED; }
   if (conf->res[0] > 1024 || conf->res[1] > 1024 || conf->res[2] > 1024) { ud::set_error("ud_mpm_create: res > 1024"); return UD_ERR_UNSUPPORTED; }
-  auto* h = new ud_mpm;
+  auto* h = new ud_mpm();
   ud::MpmConst& c = h->c;
   c.N = N; c.Np = (N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.steps = S;
   for (int d = 0; d < 3; ++d) c.res[d] = conf->res[d];
@@ -1354,7 +1354,7 @@ int ud_mpm_step_fwd(ud_mpm* h, int B, const float* x, const float* v, const floa
     return ud::mpm_large_step_fwd(h->large, B, x, v, C, F, J, prim_position, prim_rotation, prim_size, friction, mu, lamda, action,
                                   x_out, v_out, C_out, F_out, J_out, prim_position_out, prim_rotation_out, prim_v_out, prim_w_out,
                                   (float*)ckpt, status, (hipStream_t)stream);
-  ud::MpmFwdArgs a;
+  ud::MpmFwdArgs a{};
   a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B;
   a.x = x; a.v = v; a.C = C; a.F = F; a.J = J; a.ppos = prim_position; a.prot = prim_rotation; a.psize = prim_size;
   a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
@@ -1382,7 +1382,7 @@ int ud_mpm_step_bwd(ud_mpm* h, int B, const void* ckpt, const float* prim_size, 
                                   g_friction, g_mu, g_lamda, g_action, status, (hipStream_t)stream);
   // one-workgroup path = position control: no cotangent reaches the rotation array
   if (g_prim_rotation0) UD_HIP_CHECK(hipMemsetAsync(g_prim_rotation0, 0, (size_t)B * h->c.n_prim * h->c.steps * 4 * sizeof(float), (hipStream_t)stream));
-  ud::MpmBwdArgs a;
+  ud::MpmBwdArgs a{};
   a.c = h->c; a.material = h->d_material; a.hard = h->d_hard; a.B = B; a.ckpt = (const float*)ckpt;
   a.psize = prim_size; a.friction = friction; a.mu = mu; a.lamda = lamda; a.action = action;
   a.gx = g_x; a.gv = g_v; a.gC = g_C; a.gF = g_F; a.gppos = g_prim_position; a.clip = clip;

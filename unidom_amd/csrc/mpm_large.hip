@@ -2227,7 +2227,7 @@ static int clm_envs_per_launch(const MpmLarge* L, int B, int T);
 static int clm_reserve(MpmLarge* L, int Bl);
 
 MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid, const LgTune& tune) {
-  auto* L = new MpmLarge;
+  auto* L = new MpmLarge();
   L->c = c; L->t = tune; L->d_material = d_material; L->d_hard = d_hard; L->has_liquid = has_liquid;
   L->G = (long)c.res[0] * c.res[1] * c.res[2];
   L->cap = (int)std::min<long>(L->G, (long)54 * c.N);
@@ -2314,7 +2314,7 @@ static bool lg_svd_rows(const MpmLarge* L, int B) { return !L->c.det && lg_lanes
 struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int budget; };
 static CkLayout ck_layout(const MpmLarge* L, int B) {
   const MpmConst& c = L->c;
-  CkLayout k;
+  CkLayout k{};
   const long S = c.steps;
   k.rec = (long)(24 + (lg_svd_rows(L, B) ? UD_SVD_ROWS : 0)) * c.Np;      // state rows + (four-lane regime) the SVD factors of the substep's F
   k.off_tail = (S + 1) * k.rec;

@@ -463,7 +463,7 @@ int plb_reserve(ud_plb* h, int B, bool multi_kernel) {
 
 // caller-owned checkpoint of one step call: hist[B][S+1][24][Np] | pos[B][S+1][np][3] | perm[B][Np] (int) | grid checkpoint
 PlbCkOff plb_ckpt_layout(const ud::PlbConst& c, int B) {
-  PlbCkOff k;
+  PlbCkOff k{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   k.hist = take((size_t)B * (c.S + 1) * 24 * c.Np * 8);
@@ -497,7 +497,7 @@ int ud_plb_create(const ud_plb_conf* conf, ud_plb** out) {
   if (conf->path < 0 || conf->path > 2 || !(conf->lanes == 0 || conf->lanes == 1 || conf->lanes == 4 || conf->lanes == 8)) {
     ud::set_error("ud_plb_create: path = %d (0 auto, 1 multi-kernel, 2 persistent), lanes = %d (0 auto, 1, 4, 8)", conf->path, conf->lanes); return UD_ERR_INVALID;
   }
-  auto* h = new ud_plb;
+  auto* h = new ud_plb();
   ud::PlbConst& c = h->c;
   c.N = conf->n_particles; c.Np = (c.N + 15) / 16 * 16; c.n_grid = conf->n_grid; c.S = conf->substeps; c.np = conf->n_primitives;
   c.dt = conf->dt; c.dx = 1.0 / conf->n_grid; c.inv_dx = (double)conf->n_grid;
@@ -588,7 +588,7 @@ int ud_plb_step_fwd(ud_plb* h, int B, const double* x, const double* v, const do
   if (h->cl.per > 0)
     return plb_cluster_step_fwd(h, B, x, v, C, F, prim_pos, softness, action, E, nu, yield_stress, x_out, v_out, C_out, F_out, prim_pos_out,
                                 sorted ? (const int*)h->order : (const int*)nullptr, ckpt, st);
-  ud::PlbArgs a;
+  ud::PlbArgs a{};
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.slots = 2; a.hs_in = 0; a.hs_out = 1; a.lb = 0; a.ls = 0; a.lprev = 1; a.lnext = 1; a.hs_out2 = 0; a.epoch2 = 0;
   a.ck_skip = 0; a.w.gck_cnt = nullptr; a.w.gck_lin = nullptr; a.w.gck_val = nullptr; a.w.svd = nullptr;

@@ -530,7 +530,7 @@ int ud_plb_step_bwd(ud_plb* h, int B, const void* ckpt, const double* softness, 
   if (h->cl.per > 0)
     return plb_cluster_step_bwd(h, B, ckpt, softness, action, E, nu, yield_stress, g_x, g_v, g_C, g_F, g_prim_pos, g_x0, g_v0, g_C0, g_F0,
                                 g_prim_pos0, g_action, g_E, g_nu, g_yield_stress, g_ground_friction, st);
-  ud::PlbArgs a;
+  ud::PlbArgs a{};
   a.c = h->c; a.w = h->w; a.B = h->B; a.Bcall = B; a.f = 0; a.epoch = 0; a.cap = h->cap; a.G = h->G;
   a.softness = softness; a.E = E; a.nu = nu; a.ys = yield_stress;
   plb_bind_ckpt(a, h->c, B, const_cast<void*>(ckpt));

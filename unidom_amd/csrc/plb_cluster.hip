@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
   __shared__ unsigned short s_slist[PCL_REC];
   __shared__ double s_val[4 * PCL_H];              // component-major (m, mv) sums of the part; after the read-back: m | v_out xyz of the env
   __shared__ double s_pos[(PCL_SMAX + 1) * 6];
-  __shared__ int s_dead, s_n;
+  __shared__ int s_dead, s_n, s_poison;
   int bl, w;
   pcl_decode(a.W, bl, w);
   if (bl >= a.Bl) return;
@@ -209,7 +209,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
   const int b = a.b0 + bl, tid = threadIdx.x, p = w * PCL_PP + (tid >> 3), qi = tid & 7;
   const bool live = p < c.N;
   const int S = c.S;
-  if (tid == 0) s_dead = 0;
+  // a time-out nobody has polled yet (ud_plb_poll_timeouts) leaves barrier words and exchange grids of its env dirty: until the poll has
+  // reset them, every launch on the handle declines to run -- its parts touch no barrier, no grid, and every output is NaN
+  if (tid == 0) { s_dead = 0; s_poison = __hip_atomic_load(a.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
   pcl_trajectory(a, b, s_pos, (a.keep && w == 0) ? a.ck.pos + (long)b * (S + 1) * c.np * 3 : nullptr);
   const int up = live ? (a.order ? a.order[(long)b * c.Np + p] : p) : 0;
   double x[3] = {0, 0, 0}, v[3] = {0, 0, 0}, Cm[9], F[9];
@@ -227,8 +229,8 @@ __global__ void __launch_bounds__(PCL_T) pcl_fwd_kernel(const PclArgs a) {
   const double* soft = a.softness + b * c.np;
   unsigned* bar = a.bar + (long)bl * PCL_BAR_STRIDE;
   int nprev = 0;
-  bool alive = true;
   __syncthreads();
+  bool alive = s_poison == 0;
   PCL_STAMP_BEGIN
   PCL_STAMP(0, 0);                                              // prologue: trajectory, state loads
   for (int f = 0; f < S && alive; ++f) {
@@ -407,7 +409,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
   __shared__ double s_frac[PCL_H];
   __shared__ double s_pos[(PCL_SMAX + 1) * 6];
   __shared__ double s_red[3][PCL_T / 64];
-  __shared__ int s_dead;
+  __shared__ int s_dead, s_poison;
   int bl, w;
   pcl_decode(a.W, bl, w);
   if (bl >= a.Bl) return;
@@ -415,7 +417,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
   const int b = a.b0 + bl, tid = threadIdx.x, p = w * PCL_PP + (tid >> 3), qi = tid & 7;
   const bool live = p < c.N;
   const int S = c.S;
-  if (tid == 0) s_dead = 0;
+  // a time-out nobody has polled yet (ud_plb_poll_timeouts) leaves barrier words and exchange grids of its env dirty: until the poll has
+  // reset them, every launch on the handle declines to run -- its parts touch no barrier, no grid, and every output is NaN
+  if (tid == 0) { s_dead = 0; s_poison = __hip_atomic_load(a.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
   for (int e = tid; e < (S + 1) * c.np * 3; e += PCL_T) s_pos[e] = a.ck.pos[(long)b * (S + 1) * c.np * 3 + e];
   const int up = live ? a.ck.perm[(long)b * c.Np + p] : 0;
   // cotangent of state f + 1, in registers for the whole launch (every lane of the octet holds the particle's)
@@ -436,9 +440,9 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
   double* gpar = a.gpar + (long)bl * 4;
   double accE = 0, accNu = 0, accYs = 0;
   int nprev = 0;
-  bool alive = true;
   unsigned phase = 0;
   __syncthreads();
+  bool alive = s_poison == 0;
   PCL_STAMP_BEGIN
   PCL_STAMP(1, 0);
   for (int f = S - 1; f >= 0 && alive; --f) {
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(PCL_T) pcl_bwd_kernel(const PclArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct PclCkOff { size_t hist, pos, perm, svd, rec_cnt, rec_meta, rec_val, total; };
 static PclCkOff pcl_ckpt_layout(const ud::PlbConst& c, int W, int B) {
-  PclCkOff k;
+  PclCkOff k{};
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   k.hist = take((size_t)B * (c.S + 1) * 24 * c.Np * 8);

@@ -68,7 +68,9 @@ __device__ __forceinline__ void plb_prepass(const PlbConst& c, double E, double 
   q.yields = false; q.ehn = 0; q.dg = 0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) { q.eps[i] = 0; q.eh[i] = 0; }
-  if (!(bound2 <= ylim * ylim * (1.0 - 1e-12))) {          // (the margin covers the reciprocal's last bits)
+  // ys <= 0 (an optimiser may push it there: g_ys is an exposed gradient): dg = ehn - ylim > 0 always, every particle yields -- the
+  // squared comparison must not see that case
+  if (!(ylim > 0 && bound2 <= ylim * ylim * (1.0 - 1e-12))) {          // (the margin covers the reciprocal's last bits)
     double sum = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { q.eps[i] = log(fmax(q.sig[i], 0.05)); sum += q.eps[i]; }

@@ -133,7 +133,8 @@ class ClothSimulator:
         self.last_grasp = None
         # kernel family (include/unidom_hip.h ud_cloth_conf.mode): 0 (default) forward in operation order "v2" (the reference's
         # formulas re-associated; bit-identical to the CPU restatement of the same order) + restructured adjoint, 1 forward
-        # and adjoint in the reference's literal operation order, 2 fast-math v2 forward + restructured adjoint
+        # and adjoint in the reference's literal operation order, 2 fast-math v2 forward + restructured adjoint, 3 forward in
+        # the reference's literal operation order (cloth_simulator.py:257-337 as written) + restructured adjoint
         self.mode = int(getattr(conf, "kernel_mode", 0) if mode is None else mode)
         self.profile = None                  # bench.py: {"fwd": [...], "bwd": [...]} lists of (start, end) events
         self._suction_col = torch.tensor([[False, False, False, True] * 2], device=self.device)   # columns robot_step leaves unscaled

@@ -140,7 +140,8 @@ class PlbSimulator:
         self.n_grid = int(128 * quality)
         self.dx, self.inv_dx = 1 / self.n_grid, float(self.n_grid)
         self.dt = 0.5e-4 / quality
-        self.substeps = int(2e-3 // self.dt)
+        # :32 (float floor-division); `cfg.substeps` overrides it (ud_plb_conf.substeps is a handle constant): short horizons for tests
+        self.substeps = int(getattr(cfg, "substeps", 0)) or int(2e-3 // self.dt)
         self.p_vol = (self.dx * 0.5) ** 2
         self.p_mass = self.p_vol * 1
         self.n_primitive = len(cfg.prim_radius)
