@@ -1044,7 +1044,7 @@ def main():
     ap.add_argument("--plb-grad", action="store_true", help="torus only: forward with checkpoints + loss + adjoint instead of the forward rollout")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
                     help="MPM workloads, diagnostics only: ud_mpm_conf.tune_* of every simulator this run builds (lanes, cluster, cluster_part_lanes, "
-                         "cluster_envs, env_groups, bwd_two_launch), e.g. --tune env_groups=1 for counter passes that attribute per kernel")
+                         "cluster_envs, env_groups, bwd_two_launch, collide_records), e.g. --tune env_groups=1 for counter passes that attribute per kernel")
     ap.add_argument("--kernel-mode", type=int, default=0,
                     help="cloth kernel family (include/unidom_hip.h): 0 default (v2-order forward, bit-exact vs the restatement of that order), "
                          "1 reference-order forward + literal adjoint, 2 fast-math, 3 reference-order forward + restructured adjoint")

@@ -210,6 +210,10 @@ typedef struct {
   int tune_env_groups;       /* > 0: this many stream groups on the multi-kernel path (1 = everything on the caller's stream) */
   int tune_bwd_two_launch;   /* backward with the grid checkpoint: 0 = two launches per reverse substep where they apply (four lanes, one
                                 primitive); -1 = always the four-kernel sequence */
+  int tune_collide_records;  /* soft contact with the grid checkpoint: 0 = the forward's grid op leaves exp(-dist * softness) and the
+                                finite-difference normal of every cell and primitive beside the checkpoint and the grid-op adjoint reads them
+                                (16 B per cell, primitive and substep each way; same bits as evaluating the SDFs again); -1 = the adjoint
+                                evaluates the SDFs again (7 per cell and primitive, three passes for two primitives) */
 } ud_mpm_conf;
 
 /* material, hardness: host arrays [n_particles] (SimpleMPMSimulator.material / .h, mpm_simulator.py:117-122) */

@@ -318,6 +318,40 @@ def test_reference_order_full_step_diff_32_envs():
         assert _rel(h[key], ob[key]) < 5e-3, (key, _rel(h[key], ob[key]))
 
 
+@pytest.mark.parametrize("case", ["tiny_coordinates", "stiffness_below_window", "stiffness_above_window", "huge_velocity"])
+def test_reference_order_fast_path_falls_back_outside_its_operand_windows(oracle, case):
+    """Mode 3's forward takes its divisions and square roots from in-range exact sequences and tracks every operand (csrc/cloth_ref.hip); a
+    wave in which a lane leaves a window repeats the substep with the literal code.  Inputs that force that -- coordinates of 1e-30 and
+    denormals (link components far below 2^-36), a stiffness outside [2^-8, 2^24) (the whole env on the literal code), velocities of
+    1e30 (friction operands beyond 2^100) -- must still give the reference-order restatement's bits, grasp sets included."""
+    from unidom_amd.engine.cloth_simulator import ClothSimulator
+
+    class C(Conf):
+        substeps = 7
+    sim = ClothSimulator(C(), 3, lambda x, v, i, j: v, fold_cloth1_mask(), mode=3)
+    from oracle.pyoracle import ClothOracle
+    orc = ClothOracle(fold_cloth1_mask(), substeps=7)
+    rng = np.random.default_rng(77)
+    B, T = 3, 3
+    x, v, prim, k, mu, actions = make_cloth_case(rng, B, T)
+    if case == "tiny_coordinates":
+        x[0, 100:140, 0] = np.float32(1e-30) * rng.uniform(1, 2, 40).astype(np.float32)       # neighbours differ by ~1e-30
+        x[1, 5:70, 1] = np.float32(3e-39) * np.arange(1, 66, dtype=np.float32)                 # denormal heights: r_y denormal
+        x[2, 300:310, 2] = 0.0
+    elif case == "stiffness_below_window":
+        k[:] = [1e-4, 900.0, 2.0 ** -9]
+    elif case == "stiffness_above_window":
+        k[:] = [3e7, 900.0, 2.0 ** 24]
+    else:
+        v[0, 17] = [1e30, 0.0, -1e30]
+        v[2, 200:264, 0] = 3e28
+    o = orc.rollout_fwd(x, v, prim, k, mu, actions, want_lists=True, want_grasp=True)
+    h = _run_hip(sim, x, v, prim, k, mu, actions)
+    np.testing.assert_array_equal(h["grasp"], o["grasp"])
+    for key in ("x", "v", "prim", "x_list", "v_list", "prim_list"):
+        np.testing.assert_array_equal(h[key], o[key], err_msg=key)
+
+
 def test_reference_order_mode_refuses_bodies_above_512_particles():
     from unidom_amd import _lib
     from unidom_amd.engine.cloth_simulator import ClothSimulator

@@ -7,7 +7,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = "unidom_amd/csrc"
 GROUPS = {   # kernel-name prefix (or "large_path:" key) -> the sources its code is compiled from
-    "cloth": ["cloth.hip", "cloth_v2.hip", "cloth_fast.hip", "cloth_cluster_fwd.hip", "cloth_cluster_bwd.hip", "cloth_cluster.h", "cloth_v2_force.h",
+    "cloth": ["cloth.hip", "cloth_ref.hip", "cloth_ref_order.h", "cloth_v2.hip", "cloth_fast.hip", "cloth_cluster_fwd.hip", "cloth_cluster_bwd.hip", "cloth_cluster.h", "cloth_v2_force.h",
               "cloth_fast_adj.h", "cloth_common.h", "exact_math.h", "common.h"],
     "chamfer": ["env_glue.hip", "common.h"],
     "pnp": ["env_glue.hip", "common.h"],

@@ -42,7 +42,8 @@ class ud_mpm_conf(C.Structure):
                 ("n_primitive", C.c_int), ("sdf_kind", C.c_int), ("grid_ckpt_cells", C.c_int), ("sort_particles", C.c_int),
                 ("prim_friction_each", C.c_float * 4), ("prim_softness_each", C.c_float * 4), ("deterministic", C.c_int),
                 ("max_envs", C.c_int), ("tune_lanes", C.c_int), ("tune_cluster", C.c_int), ("tune_cluster_part_lanes", C.c_int),
-                ("tune_cluster_envs", C.c_int), ("tune_env_groups", C.c_int), ("tune_bwd_two_launch", C.c_int)]
+                ("tune_cluster_envs", C.c_int), ("tune_env_groups", C.c_int), ("tune_bwd_two_launch", C.c_int),
+                ("tune_collide_records", C.c_int)]
 
 
 class ud_plb_conf(C.Structure):

@@ -77,6 +77,8 @@ struct GraspThr {
 };
 
 void cloth_launch_fwd_v2(const ClothFwdArgs& a, hipStream_t stream);
+bool cloth_ref_fast_ok(const ClothConst& c);                                   // cloth_ref.hip: the mode-3 forward's per-launch checks
+void cloth_launch_fwd_ref(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_fwd_fast(const ClothFwdArgs& a, hipStream_t stream);
 void cloth_launch_bwd_fast(const ClothBwdArgs& a, hipStream_t stream);
 

@@ -31,6 +31,49 @@ __device__ __forceinline__ float rcp_rn_inrange(float d) {
   return __builtin_fmaf(e3, r, q);
 }
 
+// a / d for 2^-40 <= |d| <= 2^40 and a == 0 or 2^-60 <= |a| <= 2^60: hipcc's own IEEE expansion of f32 division (AMDGPU LowerFDIV32:
+// rcp, two FMAs refining it, the quotient, residual / correction twice) without v_div_scale / v_div_fmas exponent scaling and without
+// v_div_fixup -- inside the range none of them changes a bit (tools/check_exact_div.hip: random, near-halfway and edge operands against
+// the compiler's division on an MI355X).  The refined reciprocal depends on d alone: several numerators over one denominator share it
+// (div_prep once, div_rn_prepped per numerator: 5 instructions + the zero select instead of ~11 each).  +-0 / d keeps IEEE's sign.
+__device__ __forceinline__ float div_prep(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_rn_prepped(float a, float d, float rd) {
+  const float q0 = a * rd;
+  float e = __builtin_fmaf(-d, q0, a);
+  float q = __builtin_fmaf(e, rd, q0);
+  e = __builtin_fmaf(-d, q, a);
+  q = __builtin_fmaf(e, rd, q);
+  return (a == 0.0f) ? q0 : q;          // (+-0) * rd is the correctly signed zero; the FMA chain would return +0
+}
+// the same without the select: a zero numerator returns +0 whatever its sign (callers that only add the quotient to a running sum or
+// subtract it from one do not see the difference).  Also checked for |a| in [2^-100, 2^100), |d| in [2^-24, 2^24) (check_exact_div 33 100 24):
+// what the sequence needs is a normal quotient and residuals above the denormal floor, not these particular windows.
+__device__ __forceinline__ float div_rn_prepped_nz(float a, float d, float rd) {
+  float q = a * rd;
+  float e = __builtin_fmaf(-d, q, a);
+  q = __builtin_fmaf(e, rd, q);
+  e = __builtin_fmaf(-d, q, a);
+  return __builtin_fmaf(e, rd, q);
+}
+__device__ __forceinline__ bool div_den_inrange(float d) { return __builtin_fabsf(d) >= 0x1p-40f && __builtin_fabsf(d) <= 0x1p40f; }   // false for NaN
+__device__ __forceinline__ bool div_num_inrange(float a) { return __builtin_fabsf(a) <= 0x1p60f && (__builtin_fabsf(a) >= 0x1p-60f || a == 0.0f); }
+// correctly rounded a / d for ANY operands: the in-range sequence where it applies, the f64 route otherwise (53 >= 2 * 24 + 2 bits: the
+// second rounding is innocuous) -- a rarely taken branch.  `rd` / `dok` = div_prep(d) / div_den_inrange(d), shared by the numerators of one d.
+__device__ __forceinline__ float div_rn_shared(float a, float d, float rd, bool dok) {
+  if (__builtin_expect(dok && div_num_inrange(a), 1)) return div_rn_prepped(a, d, rd);
+  return (float)((double)a / (double)d);
+}
+__device__ __forceinline__ float div_rn(float a, float d) { return div_rn_shared(a, d, div_prep(d), div_den_inrange(d)); }
+// correctly rounded sqrt for ANY argument
+__device__ __forceinline__ float sqrt_rn(float x) {
+  if (__builtin_expect(x >= 0x1p-96f, 1)) return sqrt_rn_inrange(x);      // (false for NaN, zero, negatives, tiny arguments)
+  return (float)__builtin_sqrt((double)x);
+}
+
 // The same two functions on a pair of values (v_pk_fma_f32 for the residual corrections; IEEE per component).
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i2 __attribute__((ext_vector_type(2)));

@@ -1306,7 +1306,7 @@ int ud_mpm_create(const ud_mpm_conf* conf, const int* material, const float* har
   h->max_envs = conf->max_envs;
   if (large) {
     const ud::LgTune tune{conf->max_envs, conf->tune_lanes, conf->tune_cluster, conf->tune_cluster_part_lanes, conf->tune_cluster_envs,
-                          conf->tune_env_groups, conf->tune_bwd_two_launch};
+                          conf->tune_env_groups, conf->tune_bwd_two_launch, conf->tune_collide_records};
     h->large = ud::mpm_large_create(h->c, h->d_material, h->d_hard, has_liquid, tune);
     if (!h->large) { (void)hipFree(h->d_material); (void)hipFree(h->d_hard); delete h; return UD_ERR_HIP; }
   }

@@ -11,15 +11,69 @@
 // correctly rounded division / square root, in the reference's operation order; the rest follows the file's flags.
 #pragma once
 #include "mpm_device.h"
+#ifndef UD_HOST_BUILD
+#include "exact_math.h"
+#endif
 
 namespace ud {
 
-// correctly rounded f32 sqrt / divide whatever the file's -f[no-]hip-fp32-correctly-rounded-divide-sqrt setting:
-// through f64 (53 >= 2*24 + 2 bits, so the second rounding is innocuous)
-// (building the whole file with correctly rounded f32 divide / sqrt instead was measured: same speed within noise on
-// pour_water, shape_rope and the scaled ropes -- these roots are not what the grid kernels wait for)
+// Correctly rounded f32 sqrt / divide whatever the file's -f[no-]hip-fp32-correctly-rounded-divide-sqrt setting, as a policy of the
+// SDF / collide code below:
+//   CMath<false>  through f64 (53 >= 2*24 + 2 bits, so the second rounding is innocuous): right for ANY operands.  The host build (the
+//                 deterministic mode's same-order CPU checker) has only this one.
+//   CMath<true>   (device, round 5) exact_math.h's in-range f32 sequences -- the compiler's own IEEE expansions minus their exponent
+//                 scaling: the same bits inside the stated windows (tools/check_exact_math.hip, tools/check_exact_div.hip) at about a
+//                 third of the issue slots of the f64 route (v_cvt + v_rsq_f64 / v_rcp_f64 + ~8 half-rate f64 FMAs + v_cvt per root or
+//                 quotient: 592 of lg_grid's 1750 static VALU instructions were f64).  It never branches: every operand goes into a
+//                 RangeTrack (min of the sqrt arguments, min / max of the denominators, max and frexp-exponent range of the numerators --
+//                 one or two instructions each), and collide_cell asks ONCE per cell whether any lane of the wave left a window; if so
+//                 the wave runs the geometry again on the f64 route (same bits for the lanes that were in range).  So the result is the
+//                 correctly rounded one for any operands, and the common case pays no per-operation branch (a guarded sqrt / divide at
+//                 each of the 47 sites cost as many scalar instructions as it saved vector ones).
+// Quotients over one denominator share its refined reciprocal (Den).
+struct RangeTrack {
+  float smin, dmin, dmax, amax;
+  int emin, emax;
+  __device__ __forceinline__ void init() { smin = INFINITY; dmin = INFINITY; dmax = 0.f; amax = 0.f; emin = 0; emax = 0; }
+  // NaN operands slip through every test below on purpose: the in-range sequences return NaN for them, as IEEE does
+  __device__ __forceinline__ bool bad() const {
+    return !(smin >= 0x1p-96f) || !(dmin >= 0x1p-40f) || !(dmax <= 0x1p40f) || !(amax < 0x1p60f) || emin < -59 || emax > 60;
+  }
+};
+template <bool FAST> struct CMath;
+template <> struct CMath<false> {
+  struct Den { float d; };
+  static __device__ __forceinline__ float sqrt_(float x, RangeTrack&) { return (float)sqrt((double)x); }
+  static __device__ __forceinline__ float sqrt_floor(float x, RangeTrack&) { return (float)sqrt((double)x); }
+  static __device__ __forceinline__ Den den(float d, RangeTrack&) { return Den{d}; }
+  static __device__ __forceinline__ float div(float a, const Den& q, RangeTrack&) { return (float)((double)a / (double)q.d); }
+};
+#ifndef UD_HOST_BUILD
+template <> struct CMath<true> {
+  struct Den { float d, rd; };
+  static __device__ __forceinline__ float sqrt_(float x, RangeTrack& t) { t.smin = fminf(t.smin, x); return sqrt_rn_inrange(x); }
+  // x = (a sum of squares) + 1e-12f: never below 1e-12 > 2^-96 (or NaN / inf, which the in-range sequence handles) -- nothing to track
+  static __device__ __forceinline__ float sqrt_floor(float x, RangeTrack&) { return sqrt_rn_inrange(x); }
+  static __device__ __forceinline__ Den den(float d, RangeTrack& t) {
+    t.dmin = fminf(t.dmin, __builtin_fabsf(d)); t.dmax = fmaxf(t.dmax, __builtin_fabsf(d));
+    return Den{d, div_prep(d)};
+  }
+  static __device__ __forceinline__ float div(float a, const Den& q, RangeTrack& t) {
+    const int e = __builtin_amdgcn_frexp_expf(a);          // 0 for +-0 (and for inf / NaN: amax catches inf)
+    t.emin = min(t.emin, e); t.emax = max(t.emax, e); t.amax = fmaxf(t.amax, __builtin_fabsf(a));
+    return div_rn_prepped(a, q.d, q.rd);
+  }
+};
+__device__ __forceinline__ float sqrt_rte(float x) { return sqrt_rn(x); }            // one-off sites (primc_finish): guarded per call
+struct DivDen { float d, rd; bool ok; };
+__device__ __forceinline__ DivDen div_den(float d) { return DivDen{d, div_prep(d), div_den_inrange(d)}; }
+__device__ __forceinline__ float div_rte(float a, const DivDen& q) { return div_rn_shared(a, q.d, q.rd, q.ok); }
+#else
 __device__ __forceinline__ float sqrt_rte(float x) { return (float)sqrt((double)x); }
-__device__ __forceinline__ float div_rte(float a, float b) { return (float)((double)a / (double)b); }
+struct DivDen { float d; };
+__device__ __forceinline__ DivDen div_den(float d) { return DivDen{d}; }
+__device__ __forceinline__ float div_rte(float a, const DivDen& q) { return (float)((double)a / (double)q.d); }
+#endif
 
 // exp for the softness falloff.  The fast kernels take the platform's expf; the deterministic mode's builds (UD_MPM_EXACT on the device,
 // UD_HOST_BUILD for the same-order CPU checker) need the SAME bits from hipcc and from the host compiler: range reduction and a degree-6
@@ -57,8 +111,9 @@ __device__ __forceinline__ void primc_finish(PrimC& pc) {   // inv_trans_batch :
 #pragma clang fp contract(off)
   const float c0 = pc.r0[0], c1 = -pc.r0[1], c2 = -pc.r0[2], c3 = -pc.r0[3];
   pc.nq = sqrt_rte(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3) + 1e-12f;
-  pc.iq[0] = div_rte(c0, pc.nq); pc.iq[1] = div_rte(c1, pc.nq);
-  pc.iq[2] = div_rte(c2, pc.nq); pc.iq[3] = div_rte(c3, pc.nq);
+  const DivDen dn = div_den(pc.nq);
+  pc.iq[0] = div_rte(c0, dn); pc.iq[1] = div_rte(c1, dn);
+  pc.iq[2] = div_rte(c2, dn); pc.iq[3] = div_rte(c3, dn);
 }
 
 __device__ __forceinline__ void qrot_x(const float* q, const float* v, float* o) {  // :95-102, no contraction
@@ -70,12 +125,13 @@ __device__ __forceinline__ void qrot_x(const float* q, const float* v, float* o)
   o[2] = v[2] + 2.f * (q[0] * uv2 + w2);
 }
 
-__device__ __forceinline__ float box_sdf_x(const float* size, float p0, float p1, float p2) {  // box.py:6-18
+template <bool FAST>
+__device__ __forceinline__ float box_sdf_x(const float* size, float p0, float p1, float p2, RangeTrack& t) {  // box.py:6-18
 #pragma clang fp contract(off)
   const float q0 = clipf(fabsf(p0) - size[0], 0.f, INFINITY);
   const float q1 = clipf(fabsf(p1) - size[1], 0.f, INFINITY);
   const float q2 = clipf(fabsf(p2) - size[2], 0.f, INFINITY);
-  const float out = sqrt_rte(q0 * q0 + q1 * q1 + q2 * q2 + 1e-12f);
+  const float out = CMath<FAST>::sqrt_floor(q0 * q0 + q1 * q1 + q2 * q2 + 1e-12f, t);
   float tmp = q1 > q2 ? q1 : q2;
   tmp = q0 > tmp ? q0 : tmp;
   tmp = clipf(tmp, -INFINITY, 0.f);
@@ -106,15 +162,16 @@ __device__ __forceinline__ void box_sdf_bwd(const float* size, float p0, float p
 }
 
 // container.py:8-16 -- cut hollow sphere, size = (r, h, t)
-__device__ __forceinline__ float container_sdf_x(const float* size, float p0, float p1, float p2) {
+template <bool FAST>
+__device__ __forceinline__ float container_sdf_x(const float* size, float p0, float p1, float p2, RangeTrack& tr) {
 #pragma clang fp contract(off)
   const float r = size[0], h = size[1], t = size[2];
-  const float w = sqrt_rte(r * r - h * h);
-  const float q0 = sqrt_rte(p0 * p0 + p2 * p2 + 1e-12f), q1 = p1;
+  const float w = CMath<FAST>::sqrt_(r * r - h * h, tr);
+  const float q0 = CMath<FAST>::sqrt_floor(p0 * p0 + p2 * p2 + 1e-12f, tr), q1 = p1;
   const bool mask = h * q0 < w * q1;
   const float d0 = q0 - w, d1 = q1 - h;
-  const float val1 = sqrt_rte(d0 * d0 + d1 * d1 + 1e-12f) - t;
-  const float val2 = fabsf(sqrt_rte(q0 * q0 + q1 * q1 + 1e-12f) - r) - t;
+  const float val1 = CMath<FAST>::sqrt_floor(d0 * d0 + d1 * d1 + 1e-12f, tr) - t;
+  const float val2 = fabsf(CMath<FAST>::sqrt_floor(q0 * q0 + q1 * q1 + 1e-12f, tr) - r) - t;
   return mask ? val1 : val2;
 }
 
@@ -142,9 +199,10 @@ __device__ __forceinline__ void container_sdf_bwd(const float* size, float p0, f
 #ifndef UD_DIAG_BOX_ONLY
 #define UD_DIAG_BOX_ONLY 0   // timing-only diagnostic build (never shipped): drop the container branch at every SDF call site
 #endif
-__device__ __forceinline__ float prim_sdf_x(int kind, const float* size, float p0, float p1, float p2) {
-  if (UD_DIAG_BOX_ONLY) return box_sdf_x(size, p0, p1, p2);
-  return kind == 1 ? container_sdf_x(size, p0, p1, p2) : box_sdf_x(size, p0, p1, p2);
+template <bool FAST>
+__device__ __forceinline__ float prim_sdf_x(int kind, const float* size, float p0, float p1, float p2, RangeTrack& t) {
+  if (UD_DIAG_BOX_ONLY) return box_sdf_x<FAST>(size, p0, p1, p2, t);
+  return kind == 1 ? container_sdf_x<FAST>(size, p0, p1, p2, t) : box_sdf_x<FAST>(size, p0, p1, p2, t);
 }
 __device__ __forceinline__ void prim_sdf_bwd(int kind, const float* size, float p0, float p1, float p2, float gout, float* gp, float* gsize) {
   if (UD_DIAG_BOX_ONLY) { box_sdf_bwd(size, p0, p1, p2, gout, gp, gsize); return; }
@@ -171,29 +229,48 @@ struct CollideRec {
   bool flag;
 };
 
-// collide_batch (:154-182) for the cell at world position gp: v -> vo
-__device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const float* gp, const float* v, float* vo, CollideRec& r) {
-  {
+// the part of collide_batch that sees the SDF (:156-166): local position, distance -> influence, finite-difference normal, collider velocity.
+// rec != nullptr (the backward, round 5): the seven SDF evaluations are not repeated -- `rec` = (e, n[3]) is what the forward's grid op
+// computed for this cell and primitive and left beside the grid checkpoint (the same bits), everything else follows from it.
+template <bool FAST>
+__device__ __forceinline__ void collide_geom(const PrimC& pc, float dt, const float* gp, CollideRec& r, RangeTrack& t, const float* rec = nullptr) {
 #pragma clang fp contract(off)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
-    qrot_x(pc.iq, r.rel, r.loc);
-    const float dist = prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2]);
+  for (int a = 0; a < 3; ++a) r.rel[a] = gp[a] - pc.p0[a];
+  qrot_x(pc.iq, r.rel, r.loc);
+  if (rec) {
+    r.e = rec[0]; r.n[0] = rec[1]; r.n[1] = rec[2]; r.n[2] = rec[3];
+  } else {
+    const float dist = prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2], t);
     r.e = ud_expf(-dist * pc.soft);
-    r.infl = clipf(r.e, -INFINITY, 1.f);
     const float d = 1.e-6f, k = 500000.f;   // (0.5 / d)
-    r.n[0] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0] + d, r.loc[1], r.loc[2]) - prim_sdf_x(pc.kind, pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2]));
-    r.n[1] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1] + d, r.loc[2]) - prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1] + (-d), r.loc[2]));
-    r.n[2] = k * (prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + d) - prim_sdf_x(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + (-d)));
-    r.len = sqrt_rte(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + 1e-12f);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) r.nl[a] = div_rte(r.n[a], r.len);
-    qrot_x(pc.r0, r.nl, r.D);
-    float np_[3];
-    qrot_x(pc.r1, r.loc, np_);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) r.cv[a] = div_rte((np_[a] + pc.p1[a]) - gp[a], dt);
+    r.n[0] = k * (prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0] + d, r.loc[1], r.loc[2], t) - prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0] + (-d), r.loc[1], r.loc[2], t));
+    r.n[1] = k * (prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0], r.loc[1] + d, r.loc[2], t) - prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0], r.loc[1] + (-d), r.loc[2], t));
+    r.n[2] = k * (prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + d, t) - prim_sdf_x<FAST>(pc.kind, pc.size, r.loc[0], r.loc[1], r.loc[2] + (-d), t));
   }
+  r.infl = clipf(r.e, -INFINITY, 1.f);
+  r.len = CMath<FAST>::sqrt_floor(r.n[0] * r.n[0] + r.n[1] * r.n[1] + r.n[2] * r.n[2] + 1e-12f, t);
+  const typename CMath<FAST>::Den dl = CMath<FAST>::den(r.len, t);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) r.nl[a] = CMath<FAST>::div(r.n[a], dl, t);
+  qrot_x(pc.r0, r.nl, r.D);
+  float np_[3];
+  qrot_x(pc.r1, r.loc, np_);
+  const typename CMath<FAST>::Den dd = CMath<FAST>::den(dt, t);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) r.cv[a] = CMath<FAST>::div((np_[a] + pc.p1[a]) - gp[a], dd, t);
+}
+
+// collide_batch (:154-182) for the cell at world position gp: v -> vo
+__device__ __forceinline__ void collide_cell(const PrimC& pc, float dt, const float* gp, const float* v, float* vo, CollideRec& r, const float* rec = nullptr) {
+  RangeTrack t;
+#ifdef UD_HOST_BUILD
+  collide_geom<false>(pc, dt, gp, r, t, rec);
+#else
+  t.init();
+  collide_geom<true>(pc, dt, gp, r, t, rec);
+  if (__builtin_amdgcn_ballot_w64(t.bad()) != 0) collide_geom<false>(pc, dt, gp, r, t, rec);   // wave-uniform and rare: an operand outside the in-range windows
+#endif
 #pragma unroll
   for (int a = 0; a < 3; ++a) r.iv[a] = v[a] - r.cv[a];
   r.nc = r.iv[0] * r.D[0] + r.iv[1] * r.D[1] + r.iv[2] * r.D[2];

@@ -14,6 +14,7 @@ struct LgTune {
   int cluster_envs;        // > 0: at most this many envs per persistent launch (tests: several launches per call)
   int env_groups;          // > 0: this many stream groups on the multi-kernel path
   int bwd_two_launch;      // backward with the grid checkpoint: 0 two launches per substep where they apply, -1 always the four-kernel sequence
+  int collide_records;     // soft contact + grid checkpoint: 0 the grid op records (e, n) per cell and primitive for the adjoint, -1 the adjoint evaluates the SDFs again
 };
 MpmLarge* mpm_large_create(const MpmConst& c, const int* d_material, const float* d_hard, bool has_liquid, const LgTune& tune);   // has_liquid: some particle has material 0; nullptr = an allocation failed (ud_last_error)
 void mpm_large_destroy(MpmLarge* L);

@@ -71,6 +71,9 @@ struct LargeArgs {
   // p2g + grid op again.  gck_idx[f] = first record of substep f ([S+1] ints per env), pool holds gck_budget records.
   float* gck_base;        // = checkpoint base (env stride hist_stride_b); nullptr = off
   long gck_off_idx, gck_off_pool;
+  long gck_off_crec;      // soft contact, multi-kernel forward (round 5): beside every grid-checkpoint record, one float4 (e, n[3]) per primitive =
+                          // exp(-dist * softness) and the finite-difference normal of collide_batch for that cell; 0 = none.  The grid-op adjoint reads
+                          // them instead of evaluating seven SDFs per cell and primitive three times over (collide_geom).
   int gck_budget;
   int* status;
   // spatial order (ud_mpm_conf.sort_particles): slot p of the SoA history holds the caller's particle perm[p]; nullptr = as given
@@ -138,6 +141,7 @@ __device__ __forceinline__ int user_index(const LargeArgs& a, int b, int p) { re
 
 __device__ __forceinline__ int* gck_idx(const LargeArgs& a, int b) { return (int*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_idx); }
 __device__ __forceinline__ float4* gck_pool(const LargeArgs& a, int b) { return (float4*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_pool); }
+__device__ __forceinline__ float4* gck_crec(const LargeArgs& a, int b) { return (float4*)(a.gck_base + (long)b * a.hist_stride_b + a.gck_off_crec); }
 
 __device__ __forceinline__ void touch(const LargeArgs& a, int b, int key, long lin) {
   const unsigned bit = 1u << (lin & 31);
@@ -650,12 +654,19 @@ __device__ __forceinline__ void lg_grid_cell(const LargeArgs& a, int b, int t, i
 #pragma unroll
     for (int d = 0; d < 3; ++d) v0[d] = ((mv.x > 0.f) ? mvv[d] / mv.x : mvv[d]) + a.c.dtg[d];
     const float gp[3] = {(float)ci * a.c.dx, (float)cj * a.c.dx, (float)ck * a.c.dx};
+    // collide records for the backward (gck_off_crec): this cell's row sits at the position of its grid-checkpoint record
+    float4* crec = nullptr;
+    if (!to_vel && a.gck_base && a.gck_off_crec) {
+      const int pos = gck_idx(a, b)[a.f] + t;
+      if (pos < a.gck_budget) crec = gck_crec(a, b) + (long)pos * a.c.n_prim;
+    }
 #pragma unroll 1
     for (int ip = 0; ip < a.c.n_prim; ++ip) {                       // primitive after primitive (mpm_simulator.py:292-294)
       PrimC pc;
       load_primc(a, b, ip, pc);
       CollideRec cr;
       collide_cell(pc, a.c.dt, gp, v0, v1, cr);
+      if (crec) crec[ip] = make_float4(cr.e, cr.n[0], cr.n[1], cr.n[2]);
 #pragma unroll
       for (int d = 0; d < 3; ++d) v0[d] = v1[d];
     }
@@ -1427,7 +1438,9 @@ __device__ __forceinline__ float4 cell_mass_momentum(const LargeArgs& a, int b, 
 // grid-op adjoint over the active cells
 // DET (a template parameter, so that the default kernels' code and registers stay what they were: 163 VGPRs = three waves per SIMD; with the
 // branch at run time the kernel took 181 and pour_water's grid-op adjoint 29 us instead of 20): the deterministic backward's variant.
-template <bool DET>
+// REC (a template parameter for the same reason): the forward left (e, n) of every cell and primitive beside the grid checkpoint
+// (LargeArgs::gck_off_crec) -- the collide chain is re-run from those instead of from the SDFs.
+template <bool DET, bool REC = false>
 __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int tile_base, float (*red)[UD_PRIMC_NGRAD]) {
   const int t = tile_base + threadIdx.x;
   const int cur = a.f & 1;
@@ -1507,7 +1520,13 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
 #pragma unroll 1
       for (int j = 0; j <= ip; ++j) {
         load_primc(a, b, j, pc);
-        collide_cell(pc, a.c.dt, gp, vi, v1, cr);
+        if (REC) {
+          const float4 r4 = gck_crec(a, b)[(long)(gck_idx(a, b)[a.f] + t) * P + j];
+          const float rec[4] = {r4.x, r4.y, r4.z, r4.w};
+          collide_cell(pc, a.c.dt, gp, vi, v1, cr, rec);
+        } else {
+          collide_cell(pc, a.c.dt, gp, vi, v1, cr);
+        }
         if (j < ip) { vi[0] = v1[0]; vi[1] = v1[1]; vi[2] = v1[2]; }
       }
       if (ip == P - 1) {         // v1 = velocity after the last primitive: ground friction + boundary, reversed first
@@ -1536,10 +1555,17 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
       continue;                   // (block-uniform)
     }
     // this primitive's cotangents: wave sums, then one set of atomics per block onto rows f and f + 1 (clamped)
-#pragma unroll
-    for (int d = 0; d < UD_PRIMC_NGRAD; ++d) {
-      const float sum = wave_sum(pgv[d]);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = sum;
+    {   // 16 of the 18 values in two transposed butterflies (eight wave totals per pass: common.h), the last two one by one
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      const float va[8] = {pgv[0], pgv[1], pgv[2], pgv[3], pgv[4], pgv[5], pgv[6], pgv[7]};
+      const float vb[8] = {pgv[8], pgv[9], pgv[10], pgv[11], pgv[12], pgv[13], pgv[14], pgv[15]};
+      const float wa = wave_sum8_t(va, lane), wb = wave_sum8_t(vb, lane);
+      const float s16 = wave_sum(pgv[16]), s17 = wave_sum(pgv[17]);
+      if ((lane & 0x2C) == 0) {                       // lanes 0-3 and 16-19 hold the totals of values 0-3 and 4-7 of a pass
+        const int j = ((lane >> 2) & 4) | (lane & 3);
+        red[wv][j] = wa; red[wv][8 + j] = wb;
+      }
+      if (lane == 0) { red[wv][16] = s16; red[wv][17] = s17; }
     }
     __syncthreads();
     if (threadIdx.x < UD_PRIMC_NGRAD) {
@@ -1569,7 +1595,7 @@ __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int 
   }
   LG_STAMP(3, 3);     // head adjoint + store
 }
-template <bool DET>
+template <bool DET, bool REC = false>
 __device__ __forceinline__ void lg_grid_adj_body(const LargeArgs& a) {
   const LgB lgb_ = lg_bid(a);
   if (!lgb_.ok) return;
@@ -1578,10 +1604,14 @@ __device__ __forceinline__ void lg_grid_adj_body(const LargeArgs& a) {
   for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
     const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
-    lg_grid_adj_tile<DET>(a, b, base, red);
+    lg_grid_adj_tile<DET, REC>(a, b, base, red);
   }
 }
-__global__ void __launch_bounds__(256) lg_grid_adj(LargeArgs a) { lg_grid_adj_body<false>(a); }
+// amdgpu_waves_per_eu(3): at most 168 VGPRs.  These kernels run a few thousand dependent instructions per cell on launches of ~2 waves per
+// SIMD; at 169+ registers a SIMD holds two waves instead of three and pour_water's grid-op adjoint takes 29 us instead of 20 (round 4's "cliff")
+#define LG_W3 __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(256) LG_W3 lg_grid_adj(LargeArgs a) { lg_grid_adj_body<false>(a); }
+__global__ void __launch_bounds__(256) LG_W3 lg_grid_adj_rec(LargeArgs a) { lg_grid_adj_body<false, true>(a); }
 __global__ void __launch_bounds__(256) lg_grid_adj_det(LargeArgs a) { lg_grid_adj_body<true>(a); }
 
 // p2g adjoint (gather) + particle pre-pass adjoint: cotangent state at substep f+1 -> at substep f (in place)
@@ -1806,7 +1836,7 @@ __device__ __forceinline__ void lg_restore_par(const LargeArgs& a, int b, int f,
 }
 // blocks [0, nb): grid-op adjoint of substep a.f (none when a.f is not a substep: the first and the last launch of a step);
 // blocks [nb, 2 nb): restore of substep a.f - 1
-__global__ void __launch_bounds__(256) lg_gadj_restore(LargeArgs a, int nb) {
+__global__ void __launch_bounds__(256) LG_W3 lg_gadj_restore(LargeArgs a, int nb) {
   const LgB lgb_ = lg_bid(a);
   if (!lgb_.ok) return;
   __shared__ float red[4][UD_PRIMC_NGRAD];
@@ -2311,7 +2341,16 @@ static int lg_lanes(const MpmLarge* L, int B);
 // (rope at n_grid 256: 250 k -> 225-246 k substeps/s with them) -- so the record layout depends on the envs of the call, which
 // ud_mpm_ckpt_bytes, the forward and the backward all know.
 static bool lg_svd_rows(const MpmLarge* L, int B) { return !L->c.det && lg_lanes(L, B) == 4; }
-struct CkLayout { long rec, off_tail, off_idx, off_pool, off_perm, stride; int budget; };
+struct CkLayout { long rec, off_tail, off_idx, off_pool, off_crec, off_perm, stride; int budget; };
+static int clm_envs_per_launch(const MpmLarge* L, int B, int T);
+static int clm_lanes(const MpmLarge* L);
+// collide records beside the grid checkpoint: soft contact, grid checkpoint on, and the multi-kernel forward (the one whose grid op is
+// lg_grid) serves this call shape -- forward, backward and ud_mpm_ckpt_bytes decide it from the handle and B alike
+static bool lg_crec(const MpmLarge* L, int B) {
+  const MpmConst& c = L->c;
+  if (c.position_control || c.det || c.gck <= 0 || L->t.collide_records < 0) return false;
+  return !(L->cl_arena && clm_envs_per_launch(L, B, clm_lanes(L)) > 0);
+}
 static CkLayout ck_layout(const MpmLarge* L, int B) {
   const MpmConst& c = L->c;
   CkLayout k{};
@@ -2324,7 +2363,8 @@ static CkLayout ck_layout(const MpmLarge* L, int B) {
   k.off_pool = k.off_idx + nidx;
   const long budget = c.gck > 0 ? S * (long)c.gck * c.N : 0;   // records per env and launch: gck cells per particle and substep on average
   k.budget = (int)std::min<long>(budget, 0x7fffffff / 2);
-  k.off_perm = k.off_pool + (long)k.budget * 8;                // [Np] ints: the spatial order of this launch (sort_particles)
+  k.off_crec = k.off_pool + (long)k.budget * 8;                // [budget][n_prim] float4 (lg_crec), or empty
+  k.off_perm = k.off_crec + (lg_crec(L, B) ? (long)k.budget * 4 * c.n_prim : 0);   // [Np] ints: the spatial order of this launch (sort_particles)
   k.stride = k.off_perm + (c.sort ? (long)c.Np : 0);
   return k;
 }
@@ -2522,6 +2562,7 @@ int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const
   a.svd_rows = (ckpt && lg_svd_rows(L, B)) ? 1 : 0;       // the SVD factors ride in the checkpoint's records (ck_layout), for the backward
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);   // before the launches: lg_grid may flag an env
   if (ckpt && ck.budget > 0) { a.gck_base = ckpt; a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; a.status = status; }
+  if (a.gck_base && lg_crec(L, B)) a.gck_off_crec = ck.off_crec;
   // spatial order of this launch: into the checkpoint (the backward needs the same one) or the handle's arena
   const bool sort = c.sort && N <= LG_SORT_MAX;
   int* perm = nullptr;
@@ -2651,6 +2692,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
   const bool gck = ck.budget > 0 && !(clip & 2);
   clip &= 1;
   if (gck) { a.gck_base = const_cast<float*>(ckpt); a.gck_off_idx = ck.off_idx; a.gck_off_pool = ck.off_pool; a.gck_budget = ck.budget; }
+  if (gck && lg_crec(L, B)) a.gck_off_crec = ck.off_crec;
   if (c.sort && N <= LG_SORT_MAX) { a.perm = (const int*)(ckpt + ck.off_perm); a.perm_stride = stride_b; }   // the forward's order
   if (status) (void)hipMemsetAsync(status, 0, (size_t)B * sizeof(int), st);
   // The backward is the multi-kernel path, restoring the grid from the checkpoint that either forward wrote.  (A persistent cluster
@@ -2750,7 +2792,7 @@ int mpm_large_step_bwd(MpmLarge* L, int B, const float* ckpt, const float* psize
         LG_LAUNCH(lg_grid, gc.x, (int)gc.y, blk, 0, s, 1);
       }
       if (lanes == 4) LG_LAUNCH(lg_g2p_adj<4>, gs.x, (int)gs.y, blks, lg_table_bytes<4>(), s); else LG_LAUNCH(lg_g2p_adj<1>, gs.x, (int)gs.y, blks, lg_table_bytes<1>(), s);
-      LG_LAUNCH(lg_grid_adj, gc.x, (int)gc.y, blk, 0, s);
+      if (a.gck_off_crec) LG_LAUNCH(lg_grid_adj_rec, gc.x, (int)gc.y, blk, 0, s); else LG_LAUNCH(lg_grid_adj, gc.x, (int)gc.y, blk, 0, s);
       const dim3 gqf(gq.x + c.n_prim, Bg);   // + one block per primitive: the FK adjoint
       if (lanes == 4) LG_LAUNCH(lg_p2g_adj<4>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x); else LG_LAUNCH(lg_p2g_adj<1>, gqf.x, (int)gqf.y, blk, 0, s, (int)gq.x);
     }

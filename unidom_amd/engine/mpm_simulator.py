@@ -115,7 +115,7 @@ class _Step(torch.autograd.Function):
 
 class SimpleMPMSimulator:
     # Kernel selection of the many-workgroup path (ud_mpm_conf.tune_*: lanes, cluster, cluster_part_lanes, cluster_envs, env_groups,
-    # bwd_two_launch; include/unidom_hip.h).  Empty = the library's choice by measurement.  Copied into `self.tuning` when a simulator
+    # bwd_two_launch, collide_records; include/unidom_hip.h).  Empty = the library's choice by measurement.  Copied into `self.tuning` when a simulator
     # is built and fixed for a handle when it is created (_make_handle) -- there is no per-call switch; diagnostics and the tests set it.
     default_tuning: dict = {}
 
