@@ -419,6 +419,19 @@ def touched_cells(x, n_grid=64):
     return len(cells)
 
 
+def device_active_cells(sim, run_once, device):
+    """G_act of SURVEY.md 8(d) as the DEVICE counted it: one more (untimed) forward + backward with the simulator keeping a reference to its
+    checkpoint, then ud_mpm_ckpt_cells = the grid-checkpoint records of that step call per env / substeps.  0.0 where the handle keeps no grid
+    checkpoint (one workgroup per env): the host count of the input state stands then.  (The host count is taken on ONE env's input state; the
+    device count is the mean over all envs and all substeps of a step call, during which a pushed rope or a poured liquid spreads.)"""
+    sim.keep_last_ckpt = True
+    run_once()
+    torch.cuda.synchronize(device)
+    g = sim.active_cells_per_substep()
+    sim.keep_last_ckpt, sim._last_ckpt = False, None
+    return g
+
+
 def bench_whip_rope(args, rank, world, device, name="whip_rope"):
     """Secondary lines: the APG update (policy, ep_len x step_diff, loss, backward, clip, Adam) on an MPM env, 32 envs per GPU,
     ep_len 3.  whip_rope: N=67, res 32^3, 70 substeps/step, one workgroup per env.  pour_water: 702 liquid particles, two bowls
@@ -485,7 +498,8 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
     if rank == 0:
         S, N = env.conf.steps, env.simulator.n_particles
         units = world * B * ep * S * args.steps
-        g_act = touched_cells(state.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
+        g_host = touched_cells(state.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
+        g_act = device_active_cells(env.simulator, lambda: learner.minimize(state), device) or g_host
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
         per_sub = (192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act)
@@ -507,6 +521,7 @@ def bench_whip_rope(args, rank, world, device, name="whip_rope"):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world, learner.n_params),
             "config": {"workload": f"{name} (MLS-MPM, N={N}, res {'x'.join(str(r) for r in env.conf.res)}, {S} substeps/step) APG loss+grad+update: "
                                    f"{B} envs per GPU, ep_len={ep}" + (", the update replayed as one HIP graph" if graphed else ""), "touched_cells": g_act,
+                       "touched_cells_host_count_of_one_input_state": g_host,
                        "hip_graph": graphed},
             "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator, B) if env.simulator.n_primitive > 1 or N > 128 else
                          ("mpm_step_fwd_kernel" if dom == "fwd" else ("mpm_step_bwd_ws_kernel" if N <= 96 else "mpm_step_bwd_kernel")),
@@ -742,7 +757,8 @@ def bench_mpm_scaled(args, rank, world, device):
             sto = dict(x=npy(x), v=npy(v), C=npy(Cm), F=npy(F), J=npy(J), ppos=npy(ppos), prot=npy(prot), psize=npy(psize), friction=npy(fr).reshape(-1),
                        mu=npy(mu).reshape(-1), lamda=npy(la).reshape(-1), action=npy(act))
             cpu = cpu_baseline_mpm(sim, conf, sto, 8 if N < 2000 else 2, 2 if N < 2000 else 1, f"the bench's own inputs (rope seeded at n_grid {ng})")
-        g_act = touched_cells(st0.x.detach().cpu().numpy(), ng)
+        g_host = touched_cells(st0.x.detach().cpu().numpy(), ng)
+        g_act = device_active_cells(sim, one, device) or g_host
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
         per_launch = B * S * ((192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act))
@@ -752,7 +768,8 @@ def bench_mpm_scaled(args, rank, world, device):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"whip_rope rope seeded at n_grid={ng} (N={N}, res {ng // 2}^3, {S} substeps/step), "
-                                   f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act},
+                                   f"simulator.step forward+adjoint, {B} envs per GPU; scaling stress test", "touched_cells": g_act,
+                       "touched_cells_host_count_of_one_input_state": g_host},
             "roofline": {"bound": "hbm", "kernel": lg_label(dom, sim, B),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(f"large_path:whip_rope_ngrid{ng}:{dom}") if B == 32 else None,
@@ -1000,7 +1017,8 @@ def bench_shape_rope(args, rank, world, device):
     if rank == 0:
         units = world * B * T * S * args.steps
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_shape_rope(env, st, act)
-        g_act = touched_cells(st.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
+        g_host = touched_cells(st.x[0].detach().cpu().numpy() + 0.0, env.conf.n_grid)
+        g_act = device_active_cells(sim, one, device) or g_host
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in vv])) for k, vv in prof.items() if vv}
         dom = max(k_ms, key=k_ms.get)
         per_launch = B * S * ((192 * N + 56 * g_act) if dom == "fwd" else (288 * N + 112 * g_act))
@@ -1010,7 +1028,8 @@ def bench_shape_rope(args, rank, world, device):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", **dist_info(world),
             "config": {"workload": f"shape_rope (MLS-MPM plastic rope N={N}, res 64x6x64, soft contact, {T} x {S} substeps/env.step) "
-                                   f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act},
+                                   f"step_diff + backward to the push action, {B} envs per GPU", "touched_cells": g_act,
+                       "touched_cells_host_count_of_one_input_state": g_host},
             "roofline": {"bound": "hbm", "kernel": lg_label(dom, env.simulator, B),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(f"large_path:shape_rope:{dom}") if B == 32 else None,

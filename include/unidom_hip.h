@@ -231,6 +231,11 @@ size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B);
  * the grid from the checkpoint (grid_ckpt_cells > 0), takes two launches per substep, else four (six when it recomputes).
  * Negative: bad arguments. */
 int ud_mpm_launch_plan(const ud_mpm* h, int B);
+/* Measurement aid (bench.py's algorithmic-byte count, tools/traffic_table.py): cells[b] = the number of grid-checkpoint records env b's forward
+ * left in `ckpt` = its active grid cells summed over the substeps of that step call (SURVEY 8(d)'s G_act, per substep, is cells[b] / substeps).
+ * `cells`: device array of B ints, written asynchronously on `stream`.  Handles without a grid checkpoint (one workgroup per env,
+ * grid_ckpt_cells = 0, deterministic mode) write 0.  Same B as the forward that wrote `ckpt`. */
+int ud_mpm_ckpt_cells(const ud_mpm* h, int B, const void* ckpt, int* cells, void* stream);
 /* Puts every handle-owned arena back into its rest state, asynchronously on `stream` (no host synchronisation).  For the one case in which
  * a step call can leave them dirty: status bit 4 of the persistent forward (a workgroup gave up waiting for its siblings and skipped
  * the zeroing of its cells).  Until then later calls on the handle would sum into stale cells.  The Python mirror calls it when its

@@ -339,6 +339,32 @@ def _scaled_case(S, seed, B=1, grid_ckpt_cells=0, conf_cls=ScaledConf):
     return sim, st, {k: v.astype(np.float32) for k, v in g.items()}, N
 
 
+def test_ckpt_cells_counts_the_active_cells_of_a_step(large_path):
+    """ud_mpm_ckpt_cells (bench.py's G_act, tools/traffic_table.py): the grid-checkpoint records of a step call per env.  One substep of the
+    rope at n_grid 128 from rest: the records are exactly the cells the 27-point stencils of its particles reach inside `res`
+    (mpm_simulator.py:178-194: scatter drops what lies outside), counted on the host; a handle without a grid checkpoint reports 0."""
+    import ctypes as C
+    from unidom_amd import _lib
+    S = 1
+    sim, st, g, N = _scaled_case(S, 5, B=3, grid_ckpt_cells=2)
+    sim.keep_last_ckpt = True
+    run_hip(sim, st, g=g)
+    conf = ScaledConf()
+    base = (st["x"][0] * np.float32(conf.n_grid) - np.float32(0.5)).astype(np.int32)
+    cells = {(b[0] + i, b[1] + j, b[2] + k) for b in base for i in range(3) for j in range(3) for k in range(3)}
+    cells = {c for c in cells if all(0 <= c[d] < conf.res[d] for d in range(3))}
+    assert sim.active_cells_per_substep() == float(len(cells)) and len(cells) > 300
+    ckpt, B = sim._last_ckpt
+    out = torch.full((B,), -1, dtype=torch.int32, device=ckpt.device)
+    stream = C.c_void_p(torch.cuda.current_stream(ckpt.device).cuda_stream)
+    _lib.check(_lib.lib().ud_mpm_ckpt_cells(sim._h, C.c_int(B), _lib.ptr(ckpt), _lib.ptr(out), stream), "ud_mpm_ckpt_cells")
+    assert out.tolist() == [len(cells)] * B
+    sim0, st0, g0, _ = _scaled_case(S, 5, B=3, grid_ckpt_cells=0)
+    sim0.keep_last_ckpt = True
+    run_hip(sim0, st0, g=g0)
+    assert sim0.active_cells_per_substep() == 0.0
+
+
 def _tune(monkeypatch, **kw):
     """Kernel selection of every SimpleMPMSimulator built from here on in this test (ud_mpm_conf.tune_*, fixed at ud_mpm_create)."""
     from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator

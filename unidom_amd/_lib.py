@@ -18,7 +18,7 @@ SYMBOLS = [
     "ud_last_error", "ud_version",
     "ud_cloth_create", "ud_cloth_destroy", "ud_cloth_num_particles", "ud_cloth_ckpt_bytes", "ud_cloth_launch_envs", "ud_cloth_poll_timeouts",
     "ud_cloth_rollout_fwd", "ud_cloth_rollout_bwd",
-    "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_launch_plan", "ud_mpm_reset", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
+    "ud_mpm_create", "ud_mpm_destroy", "ud_mpm_ckpt_bytes", "ud_mpm_ckpt_cells", "ud_mpm_launch_plan", "ud_mpm_reset", "ud_mpm_step_fwd", "ud_mpm_step_bwd",
     "ud_plb_create", "ud_plb_destroy", "ud_plb_launch_plan", "ud_plb_poll_timeouts", "ud_plb_step_fwd", "ud_plb_ckpt_bytes", "ud_plb_step_bwd", "ud_plb_loss_fwd", "ud_plb_loss_bwd",
     "ud_chamfer_fwd", "ud_chamfer_bwd", "ud_cloth_pnp_fwd", "ud_cloth_pnp_bwd",
     "ud_mpm_focus_fwd", "ud_mpm_focus_bwd", "ud_mpm_finish_fwd", "ud_mpm_finish_bwd",

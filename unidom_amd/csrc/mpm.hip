@@ -1333,6 +1333,12 @@ size_t ud_mpm_ckpt_bytes(const ud_mpm* h, int B) {
   return (size_t)B * ((size_t)h->c.steps * 24 * h->c.Np + (size_t)h->c.steps * 10) * sizeof(float);
 }
 
+int ud_mpm_ckpt_cells(const ud_mpm* h, int B, const void* ckpt, int* cells, void* stream) {
+  if (!h || !ckpt || !cells || B < 1) { ud::set_error("ud_mpm_ckpt_cells: bad argument"); return UD_ERR_INVALID; }
+  if (h->large) return ud::mpm_large_ckpt_cells(h->large, B, (const float*)ckpt, cells, (hipStream_t)stream);
+  return hipMemsetAsync(cells, 0, (size_t)B * sizeof(int), (hipStream_t)stream) == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+
 int ud_mpm_launch_plan(const ud_mpm* h, int B) {
   if (!h || B < 1) return -1;
   return h->large ? ud::mpm_large_plan(h->large, B) : 0;

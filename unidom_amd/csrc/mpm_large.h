@@ -21,6 +21,7 @@ void mpm_large_destroy(MpmLarge* L);
 int mpm_large_reset(MpmLarge* L, hipStream_t st);   // every arena back to its rest state (after a device-side time-out)
 size_t mpm_large_ckpt_bytes(const MpmLarge* L, int B);
 int mpm_large_plan(MpmLarge* L, int B);   // ud_mpm_launch_plan's bits for a call with B envs
+int mpm_large_ckpt_cells(const MpmLarge* L, int B, const float* ckpt, int* cells, hipStream_t st);   // ud_mpm_ckpt_cells
 int mpm_large_step_fwd(MpmLarge* L, int B, const float* x, const float* v, const float* C, const float* F, const float* J,
                        const float* ppos, const float* prot, const float* psize, const float* friction, const float* mu,
                        const float* lamda, const float* action, float* xo, float* vo, float* Co, float* Fo, float* Jo, float* ppos_o,

@@ -2511,6 +2511,18 @@ int mpm_large_reset(MpmLarge* L, hipStream_t st) {
   return UD_OK;
 }
 
+__global__ void lg_ckpt_cells(const float* ckpt, long stride_b, long off_idx, int S, int B, int* cells) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) cells[b] = ((const int*)(ckpt + (long)b * stride_b + off_idx))[S];     // gck_idx(b)[S]: one past the last record of the step
+}
+int mpm_large_ckpt_cells(const MpmLarge* L, int B, const float* ckpt, int* cells, hipStream_t st) {
+  if (B > L->B) { set_error("ud_mpm_ckpt_cells: B=%d exceeds the handle's max_envs=%d", B, L->B); return UD_ERR_INVALID; }
+  const CkLayout ck = ck_layout(L, B);
+  if (ck.budget <= 0) return hipMemsetAsync(cells, 0, (size_t)B * sizeof(int), st) == hipSuccess ? UD_OK : UD_ERR_HIP;
+  hipLaunchKernelGGL(lg_ckpt_cells, dim3((B + 63) / 64), dim3(64), 0, st, ckpt, ck.stride, ck.off_idx, L->c.steps, B, cells);
+  return hipGetLastError() == hipSuccess ? UD_OK : UD_ERR_HIP;
+}
+
 int mpm_large_plan(MpmLarge* L, int B) {
   if (B > L->B) return -1;
   int plan = 1;

@@ -78,6 +78,8 @@ class _Step(torch.autograd.Function):
         else:
             sim.status_log.append(status)
         ctx.sim, ctx.B = sim, B
+        if sim.keep_last_ckpt:                 # measurement aid (active_cells_per_substep): off by default, a checkpoint can be gigabytes
+            sim._last_ckpt = (ckpt, B)
         ctx.save_for_backward(ckpt, psize, friction, mu, lamda, action)
         if sim.use_position_control:
             ctx.mark_non_differentiable(Jo, pro, pvo, pwo)
@@ -122,6 +124,7 @@ class SimpleMPMSimulator:
     def __init__(self, conf, batch_size, use_position_control=False, device="cuda"):
         self.conf = conf
         self.tuning = dict(type(self).default_tuning)
+        self.keep_last_ckpt, self._last_ckpt = False, None
         self.key_global = None
         self.batch_size = batch_size
         self.ground_friction = conf.ground_friction
@@ -307,6 +310,17 @@ class SimpleMPMSimulator:
         if ev is not None:
             ev[2].record(torch.cuda.current_stream(self.device))
             self.profile[ev[0]].append((ev[1], ev[2]))
+
+    def active_cells_per_substep(self):
+        """Mean over envs and substeps of the active grid cells the last forward with gradients enabled recorded in its checkpoint
+        (ud_mpm_ckpt_cells; set `keep_last_ckpt = True` before that forward); 0.0 for handles without a grid checkpoint.  Synchronises."""
+        if self._last_ckpt is None or self._last_ckpt[0] is None:
+            return 0.0
+        ckpt, B = self._last_ckpt
+        cells = torch.empty((B,), dtype=torch.int32, device=ckpt.device)
+        stream = C.c_void_p(torch.cuda.current_stream(ckpt.device).cuda_stream)
+        _lib.check(_lib.lib().ud_mpm_ckpt_cells(self._h, C.c_int(B), _lib.ptr(ckpt), _lib.ptr(cells), stream), "ud_mpm_ckpt_cells")
+        return float(cells.double().mean().item()) / float(self.conf.steps)
 
     def launch_plan(self, B):
         """ud_mpm_launch_plan: 0 = one workgroup per env; bit 0 many-workgroup path, bit 1 persistent forward, bit 2 two-launch backward"""
