@@ -126,7 +126,7 @@ def main():
     if "lg_gadj_restore" in k:
         # K1(f): blocks [0, nb) grid-op adjoint of substep f, blocks [nb, 2 nb) restore of substep f - 1
         rd = [("restore: checkpoint records (key, m, mv, v) 32 B / cell", 32 * C, "stream"),
-              ("restore: record keys of substep f + 2 (zeroing their cotangent cells) 4 of 32 B / cell, whole lines", 32 * C, "stream"),
+              ("restore: cell list of substep f + 2 (zeroing its cotangent cells) 4 B / cell", 4 * C, "stream"),
               ("grid-op adjoint: cell list 4 B + record (m, mv) 32 B / cell", 36 * C, "stream"),
               ("grid-op adjoint: cotangent cells 16 B / cell, one 128-B line per touched line", 128 * L, "gather")]
         wr = [("restore: cell list 4 B / cell", 4 * C, "stream"),
@@ -161,7 +161,7 @@ def main():
     print(f"\nper reverse substep (both launches): designed {tot_d / 1e6:.2f} MB, counters {tot_c / 1e6:.2f} MB ({100 * tot_d / tot_c:.0f} % accounted); "
           f"SURVEY 8(d) algorithmic 288 N + 112 G_act = {alg / 1e6:.2f} MB -> counters / algorithmic = {tot_c / alg:.2f}")
     over = [("SVD factor rows read back instead of iterated again", svd * rowB),
-            ("grid-checkpoint records: restore + grid-op adjoint read them where the algorithmic count has one 16-B grid read each", (32 + 32 + 36) * C - 2 * 16 * C),
+            ("grid-checkpoint records: restore + grid-op adjoint read them where the algorithmic count has one 16-B grid read each", (32 + 4 + 36) * C - 2 * 16 * C),
             ("128-B line granularity of the three grid gathers against 16 B per touched cell", 3 * 128 * L - 3 * 16 * C),
             ("spatial order, fx cotangent scratch written and read back (4-B rows), rows rounded out to 128-B lines", 7 * rowB + 24 * (rowB - 4 * Pn)),
             ("32-B sector granularity of the scattered cell writes and the per-block atomics beyond one per cell", 3 * (32 * S32 - 16 * C) + 12 * (flush_cells - C))]

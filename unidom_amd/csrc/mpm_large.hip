@@ -135,6 +135,9 @@ __device__ __forceinline__ long cell_lin(const MpmConst& c, int key) {
 __device__ __forceinline__ int lg_ls(const LargeArgs& a) { return a.ls3 ? a.ls : (a.f & 1); }
 __device__ __forceinline__ float4* lg_val(const LargeArgs& a) { return (a.ls3 && a.vb) ? a.w.val2 : a.w.val; }
 __device__ __forceinline__ float4* lg_gacc(const LargeArgs& a, int f) { return (a.gpar && (f & 1)) ? a.w.val : a.w.gacc; }
+// active-list slot of substep f in the backward: two slots alternating with f; three in the fused (two-launch) backward, so that the keys of
+// substep f + 2 are still there when the restore of f zeroes that substep's cotangent cells (4 B per cell instead of the 32-B record lines)
+__device__ __forceinline__ int lg_bslot(const LargeArgs& a, int f) { return a.gpar ? ((f % 3) + 3) % 3 : (f & 1); }
 
 // caller's index of the particle in slot p
 __device__ __forceinline__ int user_index(const LargeArgs& a, int b, int p) { return a.perm ? a.perm[(long)b * a.perm_stride + p] : p; }
@@ -1443,7 +1446,7 @@ __device__ __forceinline__ float4 cell_mass_momentum(const LargeArgs& a, int b, 
 template <bool DET, bool REC = false>
 __device__ __forceinline__ void lg_grid_adj_tile(const LargeArgs& a, int b, int tile_base, float (*red)[UD_PRIMC_NGRAD]) {
   const int t = tile_base + threadIdx.x;
-  const int cur = a.f & 1;
+  const int cur = lg_bslot(a, a.f);
   const bool live = t < min(a.w.count[cur * a.B + b], a.cap);
   if (a.c.position_control) {
     // The friction and controlled-velocity cotangents are per ENV: one atomic per cell put every ground-layer cell of an env on
@@ -1600,7 +1603,7 @@ __device__ __forceinline__ void lg_grid_adj_body(const LargeArgs& a) {
   const LgB lgb_ = lg_bid(a);
   if (!lgb_.ok) return;
   __shared__ float red[4][UD_PRIMC_NGRAD];
-  const int b = lgb_.y + a.b0, n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+  const int b = lgb_.y + a.b0, n = min(a.w.count[lg_bslot(a, a.f) * a.B + b], a.cap);
   for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
     const int base = (u * a.nbx + lgb_.x) * 256;
     if (base >= n) break;
@@ -1805,12 +1808,12 @@ __device__ __forceinline__ void lg_restore_par_tile(const LargeArgs& a, int b, i
   if (f + 2 < S) {                                  // cells of substep f + 2, same buffer: consumed by its p2g adjoint
     const int first = idx[f + 2], n = min(min(idx[f + 3], a.gck_budget) - first, a.cap);
     if (t < n) {
-      const int key = __builtin_bit_cast(int, gck_pool(a, b)[(long)(first + t) * 2].x);
+      const int key = a.w.list[((long)lg_bslot(a, f + 2) * a.B + b) * a.cap + t];      // written by the restore of f + 2 (three launches ago), slot not reused since
       lg_gacc(a, f)[(long)b * a.G + cell_lin(a.c, key)] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (f < 0) return;
-  const int cur = f & 1;
+  const int cur = lg_bslot(a, f);
   const int first = idx[f], n = min(min(idx[f + 1], a.gck_budget) - first, a.cap);
   if (t == 0) a.w.count[cur * a.B + b] = max(n, 0);
   if (t >= n) return;
@@ -1843,7 +1846,7 @@ __global__ void __launch_bounds__(256) LG_W3 lg_gadj_restore(LargeArgs a, int nb
   const int b = lgb_.y + a.b0;
   if (lgb_.x < nb) {
     if (a.f < 0 || a.f >= a.c.steps) return;
-    const int n = min(a.w.count[(a.f & 1) * a.B + b], a.cap);
+    const int n = min(a.w.count[lg_bslot(a, a.f) * a.B + b], a.cap);
     for (int u = 0;; ++u) {          // block-uniform trip count: the tiles' reductions hold barriers
       const int base = (u * nb + lgb_.x) * 256;
       if (base >= n) break;
@@ -2088,7 +2091,7 @@ __global__ void __launch_bounds__(256) lg_bwd_in(LargeArgs a, const float* ck_ta
   if (threadIdx.x < 4) a.w.gpsz[bp * 4 + threadIdx.x] = 0.f;
   if (ip != 0) return;
   if (threadIdx.x < 4) a.w.acc[b * 4 + threadIdx.x] = 0.f;
-  if (threadIdx.x < 2) a.w.count[threadIdx.x * a.B + b] = 0;
+  if (threadIdx.x < 3) a.w.count[threadIdx.x * a.B + b] = 0;      // (three list slots in the fused backward: lg_bslot)
 }
 
 // backward epilogue: set_action adjoint, norm_grad_state clip (the whole cotangent state of an env scaled to norm 1 when above),
