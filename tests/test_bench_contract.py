@@ -17,7 +17,7 @@ def test_bench_cli_accepts_the_driver_arguments():
 
 
 def test_committed_headline_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02g_bench_line_fold_cloth1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r05b_bench_line_fold_cloth1.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
@@ -33,6 +33,12 @@ def test_committed_headline_line_has_the_contract_keys():
     assert line["value"] > cpu["value"]          # not a target, but a GPU line slower than the CPU port would be a regression
     assert cpu["one_thread"]["cores"] == 1 and cpu["all_cores"]["cores"] >= cpu["cores"] and "-O3" in cpu["sample"]
     assert line["n_ranks_seen"] == 1 and line["allreduce_bytes_per_update"] == 0 and line["config"]["order"].startswith("v2")
+    # round 5: the same update in the reference's literal operation order beside `value`, and the CPU restatement timed in BOTH orders
+    # (`value` = the order the GPU leg ran: like for like)
+    ro = line["reference_order"]
+    assert ro["kernel_mode"] == 3 and 0 < ro["value"] < line["value"] and ro["kernel_ms"]["fwd"] > roof["kernel_ms"]["fwd"]
+    assert cpu["order"] == 2 and cpu["reference_order"]["order"] == 1 and 0 < cpu["reference_order"]["value"] < ro["value"]
+    assert "order 2" in cpu["value_is"] and "literal operation order" in cpu["reference_order"]["sample"]
 
 
 def test_bench_gpus_2_launches_its_own_ranks_gloo():
