@@ -73,6 +73,10 @@ def lib():
             raise UnidomError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(or `make -C {CSRC}`). There is no fallback path.")
+        # torch first: its wheel carries its own libamdhip64 / libhsa-runtime64, the library links /opt/rocm's.  Loaded in this order the
+        # library's HIP calls resolve to the runtime torch has already brought in (one runtime per process: device pointers and streams
+        # are torch's); loaded the other way round the process holds two runtimes and the second one finds "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         L.ud_last_error.restype = C.c_char_p
         L.ud_version.restype = C.c_char_p
