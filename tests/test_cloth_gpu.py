@@ -453,7 +453,8 @@ def test_fast_mode_long_rollout_is_sane(fsim):
 # ---------------------------------------------------------------------------------------------------------
 # generality: a non-rectangular mask whose particle count is not a multiple of the wave size
 # ---------------------------------------------------------------------------------------------------------
-def test_disk_mask_ragged_particle_count():
+@pytest.mark.parametrize("mode,order", [(0, 2), (3, 1)])
+def test_disk_mask_ragged_particle_count(mode, order):
     from oracle.pyoracle import ClothOracle
     from unidom_amd.engine.cloth_simulator import ClothSimulator
     from conftest import cloth_reset_x
@@ -462,8 +463,8 @@ def test_disk_mask_ragged_particle_count():
     mask = (((ii - 40) ** 2 + (jj - 37) ** 2) <= 9.3 ** 2).astype(np.float32)
     P = int(mask.sum())
     assert P % 64 != 0 and 200 < P < 512
-    sim = ClothSimulator(Conf(), 3, lambda x, v, i, j: v, mask)
-    orc = ClothOracle(mask, order=2)
+    sim = ClothSimulator(Conf(), 3, lambda x, v, i, j: v, mask, mode=mode)
+    orc = ClothOracle(mask, order=order)
     assert sim.n_particles == orc.P == P
     rng = np.random.default_rng(5)
     x, v, prim, k, mu, actions = make_cloth_case(rng, 3, 3, P_x=cloth_reset_x(N, mask), deform=0.0005, v_scale=0.01)
