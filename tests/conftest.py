@@ -37,7 +37,7 @@ def run_rccl_child(timeout=900):
 
 
 def pytest_sessionstart(session):
-    """-m gpu runs only: start the RCCL child of tests/test_distributed_gpu.py now, while this process has not touched the GPU
+    """-m gpu runs only: start the RCCL child of tests/test_z_rccl_gpu.py now, while this process has not touched the GPU
     (torch.cuda.device_count() does not initialise it on this image; is_available() would)."""
     session.config._rccl_child = None
     expr = session.config.getoption("markexpr", "") or ""

@@ -6,7 +6,8 @@ tests/test_bench_contract.py).  What gloo cannot show -- the RCCL library loads,
 with HSA_ENABLE_IPC_MODE_LEGACY=0, a collective on device memory completes and the group shuts down -- is what this test adds, with
 the driver's own command line at N = 1: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --workload selftest`.
 The child is started by tests/conftest.py::pytest_sessionstart BEFORE this process touches the GPU (a GPU-initialised process must
-not fork + exec on this pool).  It proves nothing about N > 1 scaling."""
+not fork + exec on this pool).  It proves nothing about N > 1 scaling.  (The file name sorts last on purpose: under `pytest -x` a
+failure here -- the one test that depends on the box's RCCL set-up rather than on this repo's kernels -- must not hide the parity tests.)"""
 import json
 
 import pytest

@@ -334,7 +334,7 @@ def init_distributed(gpus: int):
     N-rank flow on a one-GPU box (RCCL refuses two ranks on one device; gloo stages the gradient through the host)."""
     import os
     backend = os.environ.get("UNIDOM_DIST_BACKEND", "nccl")
-    # UNIDOM_DIST_JOIN_SINGLE=1 (tests/test_distributed_gpu.py): join the group even when WORLD_SIZE is 1 -- the one-GPU box's way to
+    # UNIDOM_DIST_JOIN_SINGLE=1 (tests/test_z_rccl_gpu.py): join the group even when WORLD_SIZE is 1 -- the one-GPU box's way to
     # load RCCL, bind the device and run the update's collective once before the first multi-GPU run
     if "RANK" in os.environ and (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("UNIDOM_DIST_JOIN_SINGLE") == "1"):
         if backend == "gloo":
