@@ -19,6 +19,8 @@ def test_rccl_single_rank_group_runs_the_update_collective(request):
     child = getattr(request.config, "_rccl_child", None)
     if child is None:
         import torch
+        if torch.cuda.device_count() < 1:
+            pytest.skip("no GPU")
         if torch.cuda.is_initialized():
             pytest.skip("run with -m gpu: the RCCL child must be started before this process initialises the GPU (tests/conftest.py)")
         from conftest import run_rccl_child
