@@ -825,6 +825,32 @@ def test_pour_soup_reset_step_matches_oracle_and_grad():
 
 
 @pytest.mark.gpu
+def test_pour_water_gradient_with_and_without_collide_records(monkeypatch):
+    """ud_mpm_conf.tune_collide_records: by default the forward's grid op leaves exp(-dist * softness) and the finite-difference normal of
+    every cell and primitive beside the grid checkpoint and the grid-op adjoint (lg_grid_adj_rec) re-runs the collide chain from them; with
+    -1 the adjoint evaluates the seven SDFs per cell and primitive again (lg_grid_adj).  The records are the bits the SDFs would give, so
+    one env.step of pour_water (two container bowls, 23 substeps) must return the same action gradient either way -- up to the order of the
+    float atomics both paths share (1e-5 relative); the forward does not read the records (two forwards differ only by the arrival order of
+    the p2g atomics: an ulp here and there)."""
+    from unidom_amd.engine.mpm_simulator import SimpleMPMSimulator
+    from unidom_amd.envs.registration import env_functions
+    got = {}
+    for rec in (0, -1):
+        monkeypatch.setattr(SimpleMPMSimulator, "default_tuning", {"collide_records": rec})
+        env = env_functions["pour_water"](batch_size=2, seed=1)
+        _, st = env.reset(np.array([0, 7], np.uint32))
+        a = torch.tensor([[0.8, 0.3, -0.5, 0.6, -0.2, 0.3], [-0.4, 0.0, 0.9, -0.5, 0.4, 0.1]], device=env.device, requires_grad=True)
+        _, reward, _, info = env.step_diff(a, st)
+        reward.sum().backward()
+        env.simulator.check_status()
+        assert env.simulator.tuning == {"collide_records": rec}
+        got[rec] = (info["state"].x.detach().cpu().numpy(), a.grad.cpu().numpy())
+    np.testing.assert_allclose(got[0][0], got[-1][0], rtol=0, atol=2e-7)
+    g0, g1 = got[0][1], got[-1][1]
+    assert np.isfinite(g0).all() and np.abs(g0).max() > 0
+    assert np.abs(g0 - g1).max() <= 1e-5 * np.abs(g1).max(), (g0, g1)
+
+
 def test_pour_soup_step_matches_oracle_with_one_lane_kernels(monkeypatch):
     """bench.py's pour_soup workload (32 envs x 7631 particles) runs the one-lane-per-particle kernels of the many-workgroup path;
     at the two envs the oracle can follow the four-lane ones would run.  tune_lanes = 1 (ud_mpm_conf, fixed at create) puts the same
