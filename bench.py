@@ -1198,7 +1198,7 @@ def main():
         k_ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in prof.items() if v}
         dom = max(k_ms, key=k_ms.get)
         kname = {"fwd": {0: "cloth_rollout_fwd_v2_kernel", 1: "cloth_rollout_fwd_kernel", 2: "cloth_rollout_fwd_fast_kernel",
-                         3: "cloth_rollout_fwd_kernel"}[args.kernel_mode],
+                         3: "cloth_rollout_fwd_ref_kernel"}[args.kernel_mode],
                  "bwd": "cloth_rollout_bwd_kernel" if args.kernel_mode == 1 else "cloth_rollout_bwd_fast_kernel"}[dom]
         per_launch = NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dom == "bwd" else BYTES_FWD)
         achieved = per_launch / (k_ms[dom] * 1e-3) / 1e9
@@ -1229,7 +1229,13 @@ def main():
         if args.kernel_mode == 0:
             out["reference_order"] = {
                 "value": units / dt_ref, "unit": "substeps/s", "ms_per_step": dt_ref / args.steps * 1e3, "kernel_ms": k_ms_ref, "kernel_mode": 3,
-                "kernels": {"fwd": "cloth_rollout_fwd_kernel<512>", "bwd": "cloth_rollout_bwd_fast_kernel"},
+                "kernels": {"fwd": "cloth_rollout_fwd_ref_kernel", "bwd": "cloth_rollout_bwd_fast_kernel"},
+                "roofline": (lambda dk, kn: {"bound": "hbm", "kernel": kn, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "achieved": NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dk == "bwd" else BYTES_FWD) / (k_ms_ref[dk] * 1e-3) / 1e9,
+                                             "frac": NUM_ENVS_PER_GPU * MACRO * SUBSTEPS * (BYTES_BWD if dk == "bwd" else BYTES_FWD) / (k_ms_ref[dk] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "traffic": pmc_traffic(kn) if NUM_ENVS_PER_GPU == 4 else None,
+                                             "issue": issue_roof(kn, k_ms_ref[dk], 8 * NUM_ENVS_PER_GPU, NUM_ENVS_PER_GPU, MACRO * SUBSTEPS)})(
+                    max(k_ms_ref, key=k_ms_ref.get), {"fwd": "cloth_rollout_fwd_ref_kernel", "bwd": "cloth_rollout_bwd_fast_kernel"}[max(k_ms_ref, key=k_ms_ref.get)]) if k_ms_ref else None,
                 "note": "the SAME update (same policy seed, same reset key, same steps / warm-up, same barrier-bracketed timing) with the cloth forward in the "
                         "reference's literal operation order (cloth_simulator.py:264-268 k*r/len*(len-L0)/L0 and the friction block :281-306 as written, "
                         "IEEE divide / sqrt, no FMA contraction): bit-exact against ClothOracle(order=1) over a whole step_diff incl. the grasp set of every "
