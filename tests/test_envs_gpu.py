@@ -316,6 +316,36 @@ def test_unfold_cloth1_reset_folds_and_step_matches_oracle():
     assert torch.isfinite(reward).all()
 
 
+def test_fold_cloth1_step_diff_in_the_reference_operation_order_matches_its_oracle():
+    """The env surface with `conf.kernel_mode = 3` (what bench.py's `reference_order` leg runs): one full step_diff of fold_cloth1 -- the env's own
+    reset state, pick-and-place macro actions from get_pnp_actions, 40 x 50 substeps -- against the CPU restatement in the reference's literal
+    operation order (cloth_simulator.py:257-337 as written): final x / v bit for bit; the reward's gradient reaches the action."""
+    from oracle.pyoracle import ClothOracle
+    from unidom_amd.envs.basic import _fused
+    from unidom_amd.envs.fold_cloth1_env import DefaultConf
+    from unidom_amd.envs.registration import env_functions
+    conf = DefaultConf()
+    conf.kernel_mode = 3
+    env = env_functions["fold_cloth1"](batch_size=3, conf=conf, seed=0, aux_reward=True)
+    assert env.simulator.mode == 3
+    _, st = env.reset(np.array([0, 5], np.uint32))
+    actions = torch.tensor([[0.45, 0.0, 0.5, 0.6, 0.0, 0.55], [0.5, 0.0, 0.45, 0.4, 0.0, 0.6], [0.55, 0.0, 0.6, 0.45, 0.0, 0.4]],
+                           device=env.device, requires_grad=True)
+    _, reward, _, info = env.step_diff(actions, st)
+    reward.sum().backward()
+    assert torch.isfinite(actions.grad).all() and float(actions.grad.abs().sum()) > 0
+    macro = _fused.pnp_and_contact(actions.detach(), st.primitive0, st.x)[0].cpu().numpy()
+    orc = ClothOracle(np.asarray(env.cloth_mask), order=1)
+    prim = torch.stack([st.primitive0, st.primitive1], 1).cpu().numpy()
+    ref = orc.rollout_fwd(st.x.cpu().numpy(), st.v.cpu().numpy(), prim, st.stiffness.float().cpu().numpy(), st.mu.cpu().numpy(), macro, nthreads=3)
+    np.testing.assert_array_equal(info["state"].x.detach().cpu().numpy(), ref["x"])
+    np.testing.assert_array_equal(info["state"].v.detach().cpu().numpy(), ref["v"])
+    # ... and the default order gives ANOTHER trajectory from the same inputs (the two orders are two samples of a chaotic system: DESIGN.md 3.1)
+    ref2 = ClothOracle(np.asarray(env.cloth_mask), order=2).rollout_fwd(st.x.cpu().numpy(), st.v.cpu().numpy(), prim, st.stiffness.float().cpu().numpy(),
+                                                                        st.mu.cpu().numpy(), macro, nthreads=3)
+    assert not np.array_equal(ref2["x"], ref["x"])
+
+
 def test_shape_rope_seeding_and_push_matches_oracle():
     """shape_rope (shape_rope_env.py:153-174): 582 plastic particles reproduce the reference's goal.npy lattice; one
     env.step pushes the rope through collide_batch -- the first scanned `step`s agree with the CPU oracle driven with
