@@ -7,7 +7,6 @@ mkdir -p ../../gpurun_in build/abl
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
 for A in "$@"; do
   ( /opt/rocm/bin/hipcc $FLAGS -DUD_MPM_ABLATE=$A -c mpm_large.hip -o build/abl/mpm_large_$A.o &&
-    /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o ../../gpurun_in/lib_abl$A.so build/capi.o build/cloth.o build/cloth_v2.o build/cloth_cluster_fwd.o build/cloth_cluster_bwd.o build/mpm.o \
-      build/abl/mpm_large_$A.o build/plb.o build/plb_adj.o build/cloth_fast.o build/env_glue.o && echo built $A ) &
+    /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o ../../gpurun_in/lib_abl$A.so $(ls build/*.o | grep -v "build/mpm_large.o") build/abl/mpm_large_$A.o && echo built $A ) &
 done
 wait
