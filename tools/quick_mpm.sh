@@ -21,7 +21,7 @@ d = json.load(open("$O/bench_line_$name.json"))
 print("$name", round(d["value"]), "%.2f ms" % d["ms_per_step"], "frac %.4f" % d["roofline"]["frac"], d["roofline"].get("kernel_ms"), "traffic", d["roofline"].get("traffic"))
 PY
   if [ -n "$KS" ]; then
-    rm -rf $O/ks_$name; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ks_$name -o p -f csv -- python3 bench.py $args --no-cpu-baseline > $O/ks_$name.log 2>&1 \
+    rm -rf $O/ks_$name; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ks_$name -o p -f csv -- python3 bench.py $args --no-cpu-baseline $EXTRA > $O/ks_$name.log 2>&1 \
       && cp $O/ks_$name/p_kernel_stats.csv $O/kernel_stats_$name.csv && rm -rf $O/ks_$name && head -12 $O/kernel_stats_$name.csv | cut -d, -f1-4
   fi
 done
