@@ -13,7 +13,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def run_rccl_child(timeout=900):
+def run_rccl_child(timeout=420):
     """One rank of `python -m torch.distributed.run ... bench.py --workload selftest` with the nccl (= RCCL) backend as a CHILD process:
     the driver's own N-rank command line at N = 1.  Must be started by a process that has not initialised the GPU (a GPU-initialised
     parent must not fork + exec on this pool) -- pytest_sessionstart below does it before any test runs."""
